@@ -1,0 +1,57 @@
+"""Shared pytest plumbing: the `gpu` marker, golden-fixture loading, and the path to the repo root."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLDEN = ROOT/'tests'/'golden'
+if str(ROOT) not in sys.path: sys.path.insert(0, str(ROOT))
+
+TRAIN_CASES = ['train_kbr_24x32', 'train_kbr_96x128', 'train_learnK_n4_40x56', 'train_mean_n1_s1_33x47',
+               'train_min_noauto_25x38', 'train_l1_automask_24x32', 'train_bigmotion_24x32']
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name: str) -> dict:
+    """Load a fixture as {key: torch tensor | python scalar}."""
+    out = {}
+    with np.load(GOLDEN/f'{name}.npz', allow_pickle=False) as z:
+        for k in z.files:
+            a = z[k]
+            if a.dtype.kind in 'US': out[k] = str(a)
+            elif k.startswith('meta_') and a.ndim == 0: out[k] = a.item()
+            else: out[k] = torch.from_numpy(a.copy())
+    return out
+
+
+def case_inputs(g: dict, device='cpu', dtype=torch.float32, requires_grad=True):
+    """Rebuild the leaves of a `train_*` fixture.  Returns (leaves, static) dicts of tensors on `device`."""
+    scales = [int(s) for s in g['meta_scales']]
+    leaves = {f'disp_{s}': g[f'in_disp_{s}'].to(device, dtype).clone() for s in scales}
+    leaves['aa'] = g['in_aa'].to(device, dtype).clone()
+    leaves['t'] = g['in_t'].to(device, dtype).clone()
+    if g['meta_learn_K']:
+        leaves['fs'] = g['in_fs'].to(device, dtype).clone()
+        leaves['cs'] = g['in_cs'].to(device, dtype).clone()
+    if requires_grad:
+        for v in leaves.values(): v.requires_grad_(True)
+    static = {'imgs': g['in_imgs'].to(device, dtype), 'supp_imgs': g['in_supp_imgs'].to(device, dtype),
+              'K': g['in_K'].to(device, dtype), 'noise': g['in_noise'].to(device, dtype) if 'in_noise' in g else None,
+              'scales': scales, 'supp_idxs': [int(i) for i in g['meta_supp_idxs']]}
+    return leaves, static
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache: cache[name] = load_golden(name)
+        return cache[name]
+    return get

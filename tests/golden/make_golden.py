@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the view-synthesis loss hot path by IMPORTING the reference.
+
+Runs ONLY in the build container (needs /root/reference); never on the GPU box.  The reference has no
+tests of its own for this path, so these fixtures are the parity pins: seeded inputs plus
+the outputs/gradients the reference's own code produces for them.
+
+    PYTHONPATH=/root/reference python tests/golden/make_golden.py
+
+Reference entry points driven here (all paths relative to /root/reference):
+  * src/core/trainer.py:280-348  MonoDepthModule.forward_postprocess  (upsample + to_depth + Ts stacking)
+  * src/core/trainer.py:350-472  MonoDepthModule.forward_loss         (handlers.image_recon / disp_smooth)
+  * src/tools/geometry.py:353-391 ViewSynth.forward, :181-209 T_from_AAt, :62-90 to_scaled/to_inv
+  * src/losses/photometric.py:54-88 PhotoError, src/losses/reconstruction.py:79-96 compute_photo
+  * src/regularizers/smooth.py:51-97 SmoothReg
+  * src/networks/pose.py:60-73 PoseNet.build_K (+ geometry.py:249-263 resize_K)
+
+The fixture files hold data only (inputs + expected outputs); no reference source text is stored.
+"""
+import importlib.abc
+import importlib.machinery
+import math
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path('/root/reference')
+OUT = Path(__file__).resolve().parent
+
+
+# --------------------------------------------------------------------------------------------------
+# Import shim: the reference imports several third-party packages at module scope that are absent in
+# this image and never executed on the loss path.  Hand out empty placeholder modules for them.
+# --------------------------------------------------------------------------------------------------
+_ABSENT = ('cv2', 'skimage', 'kornia', 'timm', 'torchmetrics', 'pytorch_lightning', 'wandb', 'lmdb', 'h5py',
+           'torchvision', 'lightning', 'tensorboard', 'albumentations', 'mmcv')
+
+
+class _Placeholder(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith('__'): raise AttributeError(name)
+        cls = type(name, (), {'__init__': lambda self, *a, **k: None,
+                              '__class_getitem__': classmethod(lambda c, i: c)})
+        setattr(self, name, cls)
+        return cls
+
+
+class _AbsentFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split('.')[0] in _ABSENT:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+
+    def create_module(self, spec): return _Placeholder(spec.name)
+
+    def exec_module(self, module): pass
+
+
+def import_reference():
+    if not REF.is_dir(): raise SystemExit('reference checkout not found; fixtures can only be regenerated in the build container')
+    sys.meta_path.insert(0, _AbsentFinder())
+    sys.path.insert(0, str(REF))
+    import src  # noqa: F401
+    from src.core import handlers
+    from src.core.trainer import MonoDepthModule
+    from src.losses import PhotoError, ReconstructionLoss
+    from src.networks.pose import PoseNet
+    from src.regularizers import SmoothReg
+    from src.tools import ViewSynth, T_from_AAt, resize_K, to_inv, to_scaled
+    from src.utils import MultiLevelTimer
+    return types.SimpleNamespace(**locals())
+
+
+# --------------------------------------------------------------------------------------------------
+# Synthetic inputs (also restated in slowtv_monodepth_amd/synthetic.py; kept independent here)
+# --------------------------------------------------------------------------------------------------
+def texture(g, b, h, w, shift=(0.0, 0.0)):
+    """Smooth multi-sinusoid RGB texture in [0, 1] + 5% uniform noise, optionally shifted by (dx, dy) pixels."""
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    xs, ys = xs + shift[0], ys + shift[1]
+    img = torch.zeros(b, 3, h, w)
+    for _ in range(6):
+        fx, fy = (torch.rand(2, generator=g)*0.35 + 0.02).tolist()
+        ph = (torch.rand(b, 3, 1, 1, generator=g)*2*math.pi)
+        amp = torch.rand(b, 3, 1, 1, generator=g)
+        img += amp*torch.sin(fx*xs + fy*ys + ph)
+    img = (img - img.amin(dim=(2, 3), keepdim=True))/(img.amax(dim=(2, 3), keepdim=True) - img.amin(dim=(2, 3), keepdim=True))
+    img = 0.95*img + 0.05*torch.rand(b, 3, h, w, generator=g)
+    return img.clamp(0, 1)
+
+
+def make_inputs(seed, b, h, w, n, scales, pose_scale=0.01, learn_K=False, flat_patch=False):
+    g = torch.Generator().manual_seed(seed)
+    st = g.get_state()
+    imgs = texture(g, b, h, w)
+    supp = []
+    for i in range(n):
+        g.set_state(st)  # same texture, shifted
+        dx = float(2 + i)*(1 if i % 2 else -1)
+        s_img = texture(g, b, h, w, shift=(dx, 0.5*dx))
+        supp.append(s_img)
+    supp = torch.stack(supp)
+    if flat_patch:  # saturated region -> exact ties between warped and static error (automask noise matters)
+        imgs[:, :, : h//3, : w//3] = 1.0
+        supp[:, :, :, : h//3 + 2, : w//3 + 2] = 1.0
+    g.manual_seed(seed + 1)
+    disp = {s: (0.05 + 0.9*torch.rand(b, 1, max(h >> s, 1), max(w >> s, 1), generator=g)) for s in scales}
+    aa = pose_scale*torch.randn(n, b, 3, generator=g)
+    t = pose_scale*10*torch.randn(n, b, 3, generator=g)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
+    K = K[None].repeat(b, 1, 1)
+    out = dict(imgs=imgs, supp_imgs=supp, disp=disp, aa=aa, t=t, K=K)
+    if learn_K:
+        out['fs'] = torch.tensor([0.58, 1.92])[None].repeat(b, 1)*(1 + 0.1*torch.randn(b, 2, generator=g))
+        out['cs'] = torch.tensor([0.5, 0.5])[None].repeat(b, 1) + 0.05*torch.randn(b, 2, generator=g)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+def run_trainer_case(R, name, *, seed, b, h, w, n, scales, supp_idxs, loss_kw, smooth_kw, min_depth, max_depth,
+                     always_fwd_pose=True, learn_K=False, pose_scale=0.01, flat_patch=False, w_smooth=0.001):
+    inp = make_inputs(seed, b, h, w, n, scales, pose_scale=pose_scale, learn_K=learn_K, flat_patch=flat_patch)
+    leaves = {f'disp_{s}': d.clone().requires_grad_(True) for s, d in inp['disp'].items()}
+    aa = inp['aa'].clone().requires_grad_(True)
+    t = inp['t'].clone().requires_grad_(True)
+    leaves.update(aa=aa, t=t)
+
+    Ts = R.T_from_AAt(aa=aa.flatten(0, 1), t=t.flatten(0, 1)).unflatten(0, (n, b))
+    fwd = {'disp': {s: leaves[f'disp_{s}'] for s in scales}}
+    for i, T in zip(supp_idxs, Ts):
+        fwd[f'T_{i}'] = T.inverse() if (always_fwd_pose and i < 0) else T
+
+    y = {'imgs': inp['imgs'], 'supp_imgs': inp['supp_imgs'], 'K': inp['K']}
+    if learn_K:
+        fs = inp['fs'].clone().requires_grad_(True); cs = inp['cs'].clone().requires_grad_(True)
+        leaves.update(fs=fs, cs=cs)
+        fwd['K'] = R.resize_K(R.PoseNet.build_K(fs, cs), (h, w))
+    x = {'imgs': inp['imgs'], 'supp_idxs': torch.tensor(supp_idxs)}
+
+    crit_recon = R.ReconstructionLoss(**loss_kw)
+    losses = {'img_recon': crit_recon}
+    weights = {'img_recon': torch.tensor(1.0)}
+    if smooth_kw is not None:
+        losses['disp_smooth'] = R.SmoothReg(**smooth_kw)
+        weights['disp_smooth'] = torch.tensor(w_smooth)
+
+    if min_depth or max_depth: to_depth = lambda d: R.to_scaled(d, min_depth, max_depth)[1]
+    else: to_depth = R.to_inv
+
+    ns = types.SimpleNamespace(losses=losses, weights=weights, synth=R.ViewSynth((h, w)),
+                               timer=R.MultiLevelTimer(name='golden'), to_depth=to_depth)
+
+    # Record the tie-break noise drawn inside apply_automask (reconstruction.py:72).
+    noise_log = []
+    orig = torch.randn_like
+
+    def rec(tensor, *a, **k):
+        out = orig(tensor, *a, **k); noise_log.append(out.clone()); return out
+
+    torch.manual_seed(seed + 7)
+    torch.randn_like = rec
+    try:
+        fwd = R.MonoDepthModule.forward_postprocess(ns, fwd, x, y)
+        loss, ld = R.MonoDepthModule.forward_loss(ns, fwd, x, y)
+    finally:
+        torch.randn_like = orig
+    loss.backward()
+
+    rec_ = {'meta_b': b, 'meta_h': h, 'meta_w': w, 'meta_n': n, 'meta_scales': np.array(scales),
+            'meta_supp_idxs': np.array(supp_idxs), 'meta_always_fwd_pose': int(always_fwd_pose),
+            'meta_min_depth': float(min_depth or 0), 'meta_max_depth': float(max_depth or 0),
+            'meta_learn_K': int(learn_K), 'meta_w_smooth': float(w_smooth if smooth_kw is not None else -1),
+            'meta_loss_name': str(loss_kw.get('loss_name', 'ssim')), 'meta_use_min': int(loss_kw.get('use_min', False)),
+            'meta_use_automask': int(loss_kw.get('use_automask', False)),
+            'meta_use_edges': int((smooth_kw or {}).get('use_edges', False))}
+    rec_.update({f'in_{k}': v for k, v in inp.items() if k != 'disp'})
+    rec_.update({f'in_disp_{s}': d for s, d in inp['disp'].items()})
+    if noise_log: rec_['in_noise'] = noise_log[0]
+    rec_.update({f'out_depth_up_{s}': v for s, v in fwd['depth_up'].items()})
+    rec_.update({f'out_disp_up_{s}': v for s, v in fwd['disp_up'].items()})
+    rec_['out_Ts'] = fwd['Ts']
+    if learn_K: rec_['out_K'] = fwd['K']
+    rec_['out_loss'] = loss
+    for k, v in ld.items(): rec_[f'out_{k}'] = v
+    for k, v in leaves.items(): rec_[f'grad_{k}'] = v.grad
+
+    # Finer-grained intermediates from the class-level reference modules (all scales).
+    with torch.no_grad():
+        S = len(scales)
+        depths = torch.stack([fwd['depth_up'][s] for s in scales]).flatten(0, 1)  # (S*b,1,h,w)
+        Ks = fwd.get('K', y['K'])
+        warp_all, errs = [], []
+        for i in range(n):
+            wi = ns.synth(input=inp['supp_imgs'][i].repeat(S, 1, 1, 1), depth=depths,
+                          T=fwd['Ts'][i].repeat(S, 1, 1), K=Ks.repeat(S, 1, 1))
+            warp_all.append(wi)
+        rec_['mid_warp'] = torch.stack([w_[0] for w_ in warp_all])  # (n,S*b,3,h,w)
+        rec_['mid_depth_warp'] = torch.stack([w_[1] for w_ in warp_all])
+        rec_['mid_mask_valid'] = torch.stack([w_[2] for w_ in warp_all])
+        rec_['mid_err_warp'] = crit_recon.compute_photo(rec_['mid_warp'], inp['imgs'].repeat(S, 1, 1, 1))  # (S*b,1,h,w)
+        rec_['mid_err_static'] = crit_recon.compute_photo(inp['supp_imgs'], inp['imgs'])  # (b,1,h,w), no noise
+    save(name, rec_)
+    print(f'{name}: loss={loss.item():.8f}  ' + ' '.join(f'{k}={v.item():.6f}' for k, v in ld.items() if v.ndim == 0))
+
+
+def run_op_cases(R):
+    """Stand-alone operator vectors: ViewSynth, PhotoError, SmoothReg, T_from_AAt, to_scaled/to_inv."""
+    g = torch.Generator().manual_seed(1234)
+    b, h, w, c = 3, 20, 28, 5
+    feat = torch.rand(b, c, h, w, generator=g).requires_grad_(True)
+    depth = (0.5 + 20*torch.rand(b, 1, h, w, generator=g)).requires_grad_(True)
+    aa = (0.05*torch.randn(b, 3, generator=g)).requires_grad_(True)
+    t = (0.5*torch.randn(b, 3, generator=g)); t[0, 2] = -3.0  # push some points behind the z clamp
+    t.requires_grad_(True)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(b, 1, 1)
+    K = (K*(1 + 0.05*torch.rand(b, 4, 4, generator=g))).requires_grad_(True)
+    T = R.T_from_AAt(aa, t)
+    warp, dwarp, valid = R.ViewSynth((h, w))(feat, depth, T, K)
+    gw = torch.randn(warp.shape, generator=g)
+    gd = torch.randn(dwarp.shape, generator=g)
+    ((warp*gw).sum() + (dwarp*gd).sum()).backward()
+    save('op_view_synth', dict(in_input=feat, in_depth=depth, in_aa=aa, in_t=t, in_K=K, in_gw=gw, in_gd=gd,
+                               out_T=T, out_warp=warp, out_depth_warp=dwarp, out_mask_valid=valid,
+                               grad_input=feat.grad, grad_depth=depth.grad, grad_aa=aa.grad, grad_t=t.grad, grad_K=K.grad))
+
+    pred = torch.rand(4, 3, 17, 23, generator=g).requires_grad_(True)
+    tgt = (pred.detach() + 0.2*torch.randn(4, 3, 17, 23, generator=g)).clamp(0, 1)
+    tgt[0] = pred.detach()[0]  # identical pair -> zero error, exercises the clamp at 0
+    err = R.PhotoError()(pred, tgt)
+    ge = torch.randn(err.shape, generator=g)
+    (err*ge).sum().backward()
+    save('op_photo_error', dict(in_pred=pred, in_target=tgt, in_ge=ge, out_err=err, grad_pred=pred.grad))
+
+    for use_edges in (True, False):
+        disp = (0.05 + 0.9*torch.rand(3, 1, 12, 20, generator=g)).requires_grad_(True)
+        img = texture(g, 3, 12, 20)
+        l, ld = R.SmoothReg(use_edges=use_edges)(disp, img)
+        l.backward()
+        save(f'op_smooth_edges{int(use_edges)}', dict(in_disp=disp, in_img=img, out_loss=l, out_disp_grad=ld['disp_grad'],
+                                                       out_image_grad=ld['image_grad'], grad_disp=disp.grad))
+
+    aa = torch.randn(6, 3, generator=g); aa[0] = 0; aa[1] *= 1e-4; aa[2] *= 3
+    t = torch.randn(6, 3, generator=g)
+    aa.requires_grad_(True); t.requires_grad_(True)
+    T = R.T_from_AAt(aa, t)
+    gT = torch.randn(T.shape, generator=g)
+    (T*gT).sum().backward()
+    save('op_T_from_AAt', dict(in_aa=aa, in_t=t, in_gT=gT, out_T=T, grad_aa=aa.grad, grad_t=t.grad))
+
+    d = torch.rand(2, 1, 6, 9, generator=g); d[0, 0, 0, 0] = 0.0; d[0, 0, 0, 1] = 1.0
+    sd, dep = R.to_scaled(d, 0.1, 100)
+    sd2, dep2 = R.to_scaled(d, 0.01, None)
+    save('op_to_depth', dict(in_disp=d, out_scaled_disp=sd, out_depth=dep, out_scaled_disp_nomax=sd2, out_depth_nomax=dep2,
+                             out_inv=R.to_inv(d)))
+
+
+def save(name, rec):
+    arrs = {}
+    for k, v in rec.items():
+        if isinstance(v, torch.Tensor): v = v.detach().cpu().numpy()
+        arrs[k] = np.asarray(v)
+    np.savez_compressed(OUT/f'{name}.npz', **arrs)
+
+
+def main():
+    torch.set_num_threads(8)
+    R = import_reference()
+    kbr = dict(loss_kw=dict(loss_name='ssim', use_min=True, use_automask=True), smooth_kw=dict(use_edges=True),
+               min_depth=0.1, max_depth=100)
+    # cfg-1-shaped miniature of the headline configuration
+    run_trainer_case(R, 'train_kbr_24x32', seed=42, b=2, h=24, w=32, n=2, scales=[0, 1, 2, 3], supp_idxs=[-1, 1], **kbr)
+    # larger, always_fwd_pose False (kbr), ties in a saturated patch
+    run_trainer_case(R, 'train_kbr_96x128', seed=195, b=1, h=96, w=128, n=2, scales=[0, 1, 2, 3], supp_idxs=[-1, 1],
+                     always_fwd_pose=False, flat_patch=True, **kbr)
+    # learned intrinsics (cfg 4 family), 4 supports (cfg 5 family), 2 scales, bigger motion
+    run_trainer_case(R, 'train_learnK_n4_40x56', seed=335, b=2, h=40, w=56, n=4, scales=[0, 1], supp_idxs=[-2, -1, 1, 2],
+                     learn_K=True, pose_scale=0.03, **kbr)
+    # mean-reprojection, no automask, single support / single scale, no depth range (to_inv), plain smoothness
+    run_trainer_case(R, 'train_mean_n1_s1_33x47', seed=7, b=3, h=33, w=47, n=1, scales=[0], supp_idxs=[1],
+                     loss_kw=dict(loss_name='ssim', use_min=False, use_automask=False), smooth_kw=dict(use_edges=False),
+                     min_depth=None, max_depth=None)
+    # min without automask; l1 photometric; odd sizes
+    run_trainer_case(R, 'train_min_noauto_25x38', seed=11, b=2, h=25, w=38, n=3, scales=[0, 1, 2], supp_idxs=[-1, 1, 2],
+                     loss_kw=dict(loss_name='ssim', use_min=True, use_automask=False), smooth_kw=None, min_depth=0.1, max_depth=100)
+    run_trainer_case(R, 'train_l1_automask_24x32', seed=13, b=2, h=24, w=32, n=2, scales=[0, 2], supp_idxs=[-1, 1],
+                     loss_kw=dict(loss_name='l1', use_min=True, use_automask=True), smooth_kw=dict(use_edges=True),
+                     min_depth=0.1, max_depth=100)
+    # large motion: z clamp / border clamp active
+    run_trainer_case(R, 'train_bigmotion_24x32', seed=21, b=2, h=24, w=32, n=2, scales=[0, 1], supp_idxs=[-1, 1],
+                     pose_scale=0.15, **kbr)
+    run_op_cases(R)
+
+
+if __name__ == '__main__':
+    main()

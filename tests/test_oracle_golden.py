@@ -1,0 +1,122 @@
+"""Pin the CPU oracle (`oracle/view_synth_oracle.py`) to the vectors produced by the reference itself."""
+import pytest
+import torch
+
+from conftest import TRAIN_CASES, case_inputs
+from oracle import view_synth_oracle as O
+
+
+def build_pose_and_K(g, leaves, static, mod=O):
+    """What `MonoDepthModule.forward` does after the nets (src/core/trainer.py:250-262) + Ts stacking (:347)."""
+    n, b = leaves['aa'].shape[:2]
+    Ts = mod.T_from_AAt(leaves['aa'].flatten(0, 1), leaves['t'].flatten(0, 1)).unflatten(0, (n, b))
+    if g['meta_always_fwd_pose']:
+        Ts = torch.stack([torch.linalg.inv(T) if i < 0 else T for i, T in zip(static['supp_idxs'], Ts)])
+    h, w = static['imgs'].shape[-2:]
+    K = mod.resize_K(mod.build_K(leaves['fs'], leaves['cs']), (h, w)) if g['meta_learn_K'] else static['K']
+    return Ts, K
+
+
+def run_oracle(g, aten=False, dtype=torch.float32):
+    leaves, static = case_inputs(g, dtype=dtype)
+    Ts, K = build_pose_and_K(g, leaves, static)
+    disps = {s: leaves[f'disp_{s}'] for s in static['scales']}
+    loss, out = O.loss_path(
+        disps, static['imgs'], static['supp_imgs'], Ts, K,
+        min_depth=g['meta_min_depth'] or None, max_depth=g['meta_max_depth'] or None,
+        loss_name=g['meta_loss_name'], use_min=bool(g['meta_use_min']), use_automask=bool(g['meta_use_automask']),
+        use_edges=bool(g['meta_use_edges']), w_smooth=g['meta_w_smooth'] if g['meta_w_smooth'] >= 0 else None,
+        noise=static['noise'], aten=aten)
+    loss.backward()
+    return loss, out, leaves, Ts, K
+
+
+@pytest.mark.parametrize('aten', [False, True])
+@pytest.mark.parametrize('name', TRAIN_CASES)
+def test_loss_path_matches_reference(golden, name, aten):
+    g = golden(name)
+    loss, out, leaves, Ts, K = run_oracle(g, aten=aten)
+    S, b = len(g['meta_scales']), g['meta_b']
+
+    torch.testing.assert_close(Ts, g['out_Ts'], rtol=1e-5, atol=1e-6)
+    for s in g['meta_scales'].tolist():
+        torch.testing.assert_close(out['depth_up'][s], g[f'out_depth_up_{s}'], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loss.detach(), g['out_loss'], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(out['loss_img_recon'].detach(), g['out_loss_img_recon'], rtol=2e-6, atol=1e-7)
+    if 'out_loss_disp_smooth' in g:
+        torch.testing.assert_close(out['loss_disp_smooth'].detach(), g['out_loss_disp_smooth'], rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(out['disp_grad'].detach(), g['out_disp_grad'], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out['image_grad'], g['out_image_grad'], rtol=1e-5, atol=1e-6)
+    # Warp: the explicit gather differs from ATen's weights by rounding only.
+    torch.testing.assert_close(out['supp_imgs_warp'].detach(), g['out_supp_imgs_warp'], rtol=0, atol=2e-5)
+    torch.testing.assert_close(out['full']['warp'].detach(), g['mid_warp'], rtol=0, atol=2e-5)
+    # SSIM amplifies 1e-6 warp rounding differences in low-variance windows: per-pixel 1e-4, mean much tighter.
+    ew = out['full']['err_warp'].detach().flatten(0, 1)
+    torch.testing.assert_close(ew, g['mid_err_warp'], rtol=0, atol=(2e-6 if aten else 1e-4))
+    torch.testing.assert_close(ew.mean(), g['mid_err_warp'].mean(), rtol=1e-5, atol=0)
+    if 'out_automask' in g:
+        mism = (out['automask'] != g['out_automask']).float().mean().item()
+        assert mism <= 2e-3, f'automask differs on {mism:.2%} of pixels'
+    for k, v in leaves.items():
+        ref = g[f'grad_{k}']
+        scale = ref.abs().max().clamp(min=1e-12)
+        err = (v.grad - ref).abs().max()/scale
+        assert err < 2e-4, f'grad {k}: rel-to-max error {err:.3e}'
+
+
+def test_view_synth_operator(golden):
+    g = golden('op_view_synth')
+    feat = g['in_input'].clone().requires_grad_(True); depth = g['in_depth'].clone().requires_grad_(True)
+    aa = g['in_aa'].clone().requires_grad_(True); t = g['in_t'].clone().requires_grad_(True)
+    K = g['in_K'].clone().requires_grad_(True)
+    T = O.T_from_AAt(aa, t)
+    warp, dwarp, valid = O.view_synth(feat, depth, T, K)
+    torch.testing.assert_close(T, g['out_T'], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(warp, g['out_warp'], rtol=0, atol=2e-5)
+    torch.testing.assert_close(dwarp, g['out_depth_warp'], rtol=1e-5, atol=1e-5)
+    assert (valid != g['out_mask_valid']).float().mean() < 2e-3
+    ((warp*g['in_gw']).sum() + (dwarp*g['in_gd']).sum()).backward()
+    for name, leaf in dict(input=feat, depth=depth, aa=aa, t=t, K=K).items():
+        ref = g[f'grad_{name}']
+        err = (leaf.grad - ref).abs().max()/ref.abs().max()
+        assert err < 2e-4, f'{name}: {err:.3e}'
+
+
+def test_photo_error_operator(golden):
+    g = golden('op_photo_error')
+    pred = g['in_pred'].clone().requires_grad_(True)
+    err = O.photo_error(pred, g['in_target'])
+    torch.testing.assert_close(err, g['out_err'], rtol=1e-5, atol=1e-6)
+    (err*g['in_ge']).sum().backward()
+    torch.testing.assert_close(pred.grad, g['grad_pred'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('edges', [0, 1])
+def test_smooth_operator(golden, edges):
+    g = golden(f'op_smooth_edges{edges}')
+    disp = g['in_disp'].clone().requires_grad_(True)
+    l, ld = O.smooth_reg(disp, g['in_img'], use_edges=bool(edges))
+    torch.testing.assert_close(l, g['out_loss'], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ld['disp_grad'], g['out_disp_grad'], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ld['image_grad'], g['out_image_grad'], rtol=1e-5, atol=1e-6)
+    l.backward()
+    torch.testing.assert_close(disp.grad, g['grad_disp'], rtol=1e-4, atol=1e-7)
+
+
+def test_pose_and_depth_conversions(golden):
+    g = golden('op_T_from_AAt')
+    aa = g['in_aa'].clone().requires_grad_(True); t = g['in_t'].clone().requires_grad_(True)
+    T = O.T_from_AAt(aa, t)
+    torch.testing.assert_close(T, g['out_T'], rtol=1e-5, atol=1e-6)
+    (T*g['in_gT']).sum().backward()
+    torch.testing.assert_close(aa.grad, g['grad_aa'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(t.grad, g['grad_t'], rtol=1e-6, atol=1e-7)
+
+    g = golden('op_to_depth')
+    sd, dep = O.to_scaled(g['in_disp'], 0.1, 100)
+    torch.testing.assert_close(sd, g['out_scaled_disp']); torch.testing.assert_close(dep, g['out_depth'])
+    sd, dep = O.to_scaled(g['in_disp'], 0.01, None)
+    torch.testing.assert_close(sd, g['out_scaled_disp_nomax']); torch.testing.assert_close(dep, g['out_depth_nomax'])
+    torch.testing.assert_close(O.to_inv(g['in_disp']), g['out_inv'])
+    with pytest.raises(ValueError): O.to_scaled(g['in_disp'], 0.0, 100)
+    with pytest.raises(ValueError): O.to_scaled(g['in_disp'], 1.0, 0.5)
