@@ -1,0 +1,115 @@
+/* smd_hotpath.h — C ABI of the MI355X (gfx950) view-synthesis loss hot path.
+ *
+ * This is the drop-in boundary for the ONE path this repository accelerates: the self-supervised
+ * view-synthesis loss of jspenmar/slowtv_monodepth.  The reference has no FFI of its own (it is pure
+ * Python on ATen), so each entry point below names the reference Python interface it replaces; the
+ * ctypes binding a maintainer would add to the reference is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers to contiguous fp32 (or uint8 where stated) arrays in the
+ *     reference's own layouts (NCHW images, row-major 4x4 matrices).  Inputs are const; the library
+ *     never allocates, frees or retains a pointer; the caller (PyTorch) owns every buffer.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Nothing synchronises.
+ *   - Return value: 0 on success, negative on error (SMD_E_*); smd_last_error() returns the message
+ *     for the calling thread.
+ *   - Symbols: b batch, n support frames, S scales, (h, w) image size.  Every (S,b,...) tensor is
+ *     scale-major, matching the `torch.stack(list(depths.values()))` of src/core/handlers.py:48.
+ */
+#ifndef SMD_HOTPATH_H
+#define SMD_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMD_ABI_VERSION 1
+
+#define SMD_OK 0
+#define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
+#define SMD_E_LAUNCH (-2)      /* hipLaunch / hipGetLastError failure */
+#define SMD_E_WORKSPACE (-3)   /* workspace too small: call the matching *_workspace_bytes() */
+
+/* flags for smd_image_recon_* / smd_recon_reduce_* */
+#define SMD_USE_MIN 0x1        /* ReconstructionLoss(use_min=True): min over supports, else mean (reconstruction.py:43-44) */
+#define SMD_USE_AUTOMASK 0x2   /* ReconstructionLoss(use_automask=True) (reconstruction.py:59-77) */
+#define SMD_LOSS_L1 0x4        /* loss_name='l1' (DenseL1Error) instead of 'ssim' (PhotoError 0.85/0.15) */
+#define SMD_NEED_K_GRAD 0x8    /* backward also emits dL/dK and dL/dK_inv (learned intrinsics) */
+#define SMD_USE_EDGES 0x10     /* SmoothReg(use_edges=True) (smooth.py:91-94) */
+
+#define SMD_MAX_SCALES 8
+#define SMD_MAX_SUPPORTS 8
+#define SMD_SEL_MASKED 255     /* value of `sel` where automasking removed the pixel */
+
+const char* smd_last_error(void);
+int smd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K0 — upsample + disparity->depth.  Replaces, per scale, `ops.interpolate_like(disp, imgs, 'bilinear')`
+ * followed by `to_scaled(.., min, max)[1]` or `to_inv` (src/core/trainer.py:316-321, src/tools/ops.py:311-314,
+ * src/tools/geometry.py:62-90).
+ *   disp[s]        : (b,1,hs[s],ws[s])  sigmoid disparity of scale s (host array of S device pointers)
+ *   depth_up       : (S,b,h,w) out     depth
+ *   disp_up        : (S,b,h,w) out or NULL — the upsampled (un-scaled) disparity (`fwd['disp_up']`)
+ *   min_depth/max_depth <= 0 mean "not set" (both unset -> to_inv of the raw disparity).
+ * Backward: (depth_up, g_depth_up) (S,b,h,w) -> g_disp[s] (b,1,hs,ws), overwritten.  Needs only the forward's
+ * OUTPUT (d depth/d d = -depth^2 on the pass-through branch), not the low-resolution disparity. */
+int smd_disp_to_depth_fwd(const float* const* disp, const int* hs, const int* ws, int S, int b, int h, int w,
+                          float min_depth, float max_depth, float* depth_up, float* disp_up, void* stream);
+int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int w, float min_depth, float max_depth,
+                          const float* depth_up, const float* g_depth_up, float* const* g_disp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused image reconstruction.  Replaces `handlers.image_recon(crit, synth, depths, None, imgs, supp_imgs, Ts, Ks)`
+ * (src/core/handlers.py:14-67) = ViewSynth.forward (src/tools/geometry.py:366-391) + ReconstructionLoss.forward
+ * (src/losses/reconstruction.py:98-126) + PhotoError (src/losses/photometric.py:54-88), without materialising
+ * the (n,S*b,...) expansions, point clouds, grids or warped images.
+ *   depth   (S,b,h,w)    tgt (b,3,h,w)    supp (n,b,3,h,w)    T (n,b,4,4)    K, K_inv (b,4,4)
+ *   noise   (S,b,h,w) or NULL: the `randn_like` draw of reconstruction.py:72; NULL -> counter-based
+ *           in-kernel Gaussian keyed by `seed` (statistically equivalent tie-break, different stream)
+ *   err     (S,b,h,w) out: per-pixel error after min/mean-reprojection and automasking
+ *   sel     (S,b,h,w) out uint8: winning support index, or SMD_SEL_MASKED where the static error won
+ *   loss    (1) out: mean of err  (= `loss_img_recon`)
+ *   warp0   (n,b,3,h,w) out or NULL: warped supports of scale 0 (`loss_dict['supp_imgs_warp']`)
+ *   workspace: smd_image_recon_workspace_bytes() bytes of scratch (fwd and bwd may share it).
+ * Backward (loss is the only differentiable output):
+ *   g_loss  (1) device scalar dL/dloss
+ *   g_depth (S,b,h,w) out;  g_T (n,b,4,4) out (row 3 zero);  g_K, g_Kinv (b,4,4) out or NULL
+ *           (required iff SMD_NEED_K_GRAD; only the 3x3 / 2x3 blocks the path reads are non-zero). */
+size_t smd_image_recon_workspace_bytes(int b, int n, int S, int h, int w);
+int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
+                        const float* K_inv, const float* noise, uint64_t seed, float* err, uint8_t* sel, float* loss,
+                        float* warp0, void* workspace, size_t workspace_bytes,
+                        int b, int n, int S, int h, int w, int flags, void* stream);
+int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
+                        const float* K_inv, const uint8_t* sel, const float* g_loss,
+                        float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
+                        int b, int n, int S, int h, int w, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Edge-aware disparity smoothness over all scales.  Replaces `handlers.disp_smooth(crit, disps, imgs)`
+ * (src/core/handlers.py:262-281) = per scale SmoothReg.forward (src/regularizers/smooth.py:71-97) on the
+ * bilinearly resized image, then mean_s(loss_s / 2^s).  use_laplacian/use_blur are not part of this path.
+ *   disp[s] (b,1,hs,ws)   img (b,3,h,w)   scale_keys[s]: the dictionary key of scale s (loss_s is divided by 2^key;
+ *   NULL -> key = s)
+ *   loss (1) out;  stats (S,b,2) out: per (scale, sample) {mean disparity, un-normalised edge sum E} kept for backward
+ *   disp_grad, image_grad: (b,1,hs[0],ws[0]) out or NULL (aux maps of the first scale, smooth.py:86,89)
+ * Backward: g_disp[s] (b,1,hs,ws) out. */
+size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int b);
+int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
+                        const float* img, int h, int w, int flags, float* loss, float* stats, float* disp_grad, float* image_grad,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
+                        const float* img, int h, int w, int flags, const float* stats, const float* g_loss,
+                        float* const* g_disp, void* stream);
+
+/* Debug/self-test: out[l] = {value held by lane l-1, value held by lane l+1} for in[l] = l (64 lanes).
+ * Used by the GPU tests to pin the cross-lane primitive the stencil kernels rely on. */
+int smd_debug_lane_shift(float* out_left, float* out_right, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMD_HOTPATH_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of the C ABI in `include/smd_hotpath.h` (built in-tree as `slowtv_monodepth_amd/libsmd_hotpath.so`).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is raised.
+The library is plain `extern "C"` (raw device pointers + sizes + a stream handle); PyTorch is only used by the
+callers in `functional.py` to own the device buffers and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+__all__ = ['lib', 'call', 'lib_path', 'FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError']
+
+_HERE = Path(__file__).resolve().parent
+lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
+
+FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10}
+SEL_MASKED = 255
+MAX_SCALES = 8
+MAX_SUPPORTS = 8
+
+_vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+
+# name -> (restype, argtypes); kept in the order of include/smd_hotpath.h
+PROTOTYPES = {
+    'smd_last_error': (C.c_char_p, []),
+    'smd_abi_version': (_i, []),
+    'smd_disp_to_depth_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    'smd_disp_to_depth_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    'smd_image_recon_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'smd_image_recon_fwd': (_i, [_vp]*7 + [_u64] + [_vp]*5 + [_sz] + [_i]*6 + [_vp]),
+    'smd_image_recon_bwd': (_i, [_vp]*13 + [_sz] + [_i]*6 + [_vp]),
+    'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
+    'smd_disp_smooth_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'smd_disp_smooth_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'smd_debug_lane_shift': (_i, [_vp, _vp, _vp]),
+}
+
+
+class HotpathError(RuntimeError):
+    """A call into libsmd_hotpath.so returned a negative status."""
+
+
+def _load() -> C.CDLL:
+    if not lib_path.is_file():
+        raise ImportError(
+            f'{lib_path} not found: the HIP hot path is not built. Run `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C slowtv_monodepth_amd/csrc`). There is no CPU/PyTorch fallback for this path.')
+    handle = C.CDLL(str(lib_path))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if handle.smd_abi_version() != 1: raise ImportError(f'ABI version mismatch in {lib_path}')
+    return handle
+
+
+lib = _load()
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point; map SMD_E_INVALID to ValueError (the reference's exception type for bad
+    arguments) and everything else to HotpathError."""
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.smd_last_error().decode()
+        if rc == -1: raise ValueError(f'{name}: {msg}')
+        raise HotpathError(f'{name} failed ({rc}): {msg}')
+
+
+def ptr_array(ptrs):
+    return (C.c_void_p*len(ptrs))(*ptrs)
+
+
+def int_array(vals):
+    return (C.c_int*len(vals))(*[int(v) for v in vals])

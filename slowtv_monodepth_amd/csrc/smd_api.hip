@@ -1,0 +1,220 @@
+// smd_api.hip — the extern "C" boundary (include/smd_hotpath.h): argument validation, workspace carving, launches.
+// No torch types, no allocation, no synchronisation; every launch goes to the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "smd_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(hipError_t e, const char* what) {
+  if (e != hipSuccess) return fail(SMD_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return SMD_OK;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct StripPlan { int rh, nsx, nsy; };
+
+StripPlan plan(int b, int S, int h, int w, int cols) {
+  StripPlan p;
+  p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
+  p.nsx = smd::ceil_div(w, cols);
+  p.nsy = smd::ceil_div(h, p.rh);
+  return p;
+}
+
+int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil_div(h, 8); }
+
+struct ReconWs { float* e_static; float* loss_partial; float* pose_partial; size_t bytes; };
+
+ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
+  ReconWs r;
+  size_t off = 0;
+  char* p = (char*)base;
+  r.e_static = (float*)(p + off); off += align256((size_t)b*h*w*sizeof(float));
+  r.loss_partial = (float*)(p + off); off += align256((size_t)S*b*max_strips(h, w, smd::kFwdCols)*sizeof(float));
+  r.pose_partial = (float*)(p + off); off += align256((size_t)n*b*S*max_strips(h, w, smd::kBwdCols)*smd::kPoseSums*sizeof(float));
+  r.bytes = off;
+  return r;
+}
+
+int check_dims(int b, int n, int S, int h, int w) {
+  if (b < 1 || n < 1 || S < 1 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes b=%d n=%d S=%d h=%d w=%d (need h, w >= 2)", b, n, S, h, w);
+  if (n > SMD_MAX_SUPPORTS) return fail(SMD_E_INVALID, "n=%d exceeds SMD_MAX_SUPPORTS=%d", n, SMD_MAX_SUPPORTS);
+  if (S > 65535 || b > 65535) return fail(SMD_E_INVALID, "b or S exceeds the grid limit");
+  if ((size_t)S*b*h*w >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "S*b*h*w must stay below 2^32");
+  return SMD_OK;
+}
+
+int fill_scales(smd::ScaleSet& sc, const float* const* p, float* const* g, const int* hs, const int* ws, const int* keys, int S) {
+  if (S < 1 || S > SMD_MAX_SCALES) return fail(SMD_E_INVALID, "S=%d outside [1, %d]", S, SMD_MAX_SCALES);
+  if (!hs || !ws) return fail(SMD_E_INVALID, "null scale-size arrays");
+  memset(&sc, 0, sizeof(sc));
+  sc.S = S;
+  for (int s = 0; s < S; ++s) {
+    if (hs[s] < 1 || ws[s] < 1) return fail(SMD_E_INVALID, "scale %d has empty size %dx%d", s, hs[s], ws[s]);
+    sc.p[s] = p ? p[s] : nullptr;
+    sc.g[s] = g ? g[s] : nullptr;
+    sc.hs[s] = hs[s]; sc.ws[s] = ws[s];
+    sc.key[s] = keys ? keys[s] : s;
+  }
+  return SMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* smd_last_error(void) { return g_err; }
+int smd_abi_version(void) { return SMD_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+int smd_disp_to_depth_fwd(const float* const* disp, const int* hs, const int* ws, int S, int b, int h, int w,
+                          float min_depth, float max_depth, float* depth_up, float* disp_up, void* stream) {
+  if (!disp || !depth_up) return fail(SMD_E_INVALID, "null pointer");
+  if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");
+  if ((min_depth > 0.f || max_depth > 0.f) && !(min_depth > 0.f)) return fail(SMD_E_INVALID, "Min depth must be greater than 0. (%g)", min_depth);
+  if (max_depth > 0.f && max_depth < min_depth) return fail(SMD_E_INVALID, "Max depth must be greater than min. (%g vs. %g)", max_depth, min_depth);
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, disp, nullptr, hs, ws, nullptr, S)) return rc;
+  for (int s = 0; s < S; ++s) if (!disp[s]) return fail(SMD_E_INVALID, "null disparity pointer for scale %d", s);
+  return check_launch(smd::launch_disp_to_depth_fwd(sc, b, h, w, min_depth, max_depth, depth_up, disp_up, (hipStream_t)stream), "disp_to_depth_fwd");
+}
+
+int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int w, float min_depth, float max_depth,
+                          const float* depth_up, const float* g_depth_up, float* const* g_disp, void* stream) {
+  if (!depth_up || !g_depth_up || !g_disp) return fail(SMD_E_INVALID, "null pointer");
+  if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, nullptr, g_disp, hs, ws, nullptr, S)) return rc;
+  for (int s = 0; s < S; ++s) if (!g_disp[s]) return fail(SMD_E_INVALID, "null gradient pointer for scale %d", s);
+  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth_up, (hipStream_t)stream), "disp_to_depth_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t smd_image_recon_workspace_bytes(int b, int n, int S, int h, int w) {
+  if (b < 1 || n < 1 || S < 1 || h < 2 || w < 2) return 0;
+  return carve_recon(nullptr, b, n, S, h, w).bytes;
+}
+
+int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
+                        const float* K_inv, const float* noise, uint64_t seed, float* err, uint8_t* sel, float* loss,
+                        float* warp0, void* workspace, size_t workspace_bytes,
+                        int b, int n, int S, int h, int w, int flags, void* stream) {
+  if (int rc = check_dims(b, n, S, h, w)) return rc;
+  if (!depth || !tgt || !supp || !T || !K || !K_inv || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  ReconWs ws = carve_recon(workspace, b, n, S, h, w);
+  if (workspace_bytes < ws.bytes) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  hipStream_t st = (hipStream_t)stream;
+
+  smd::ReconFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tgt = tgt; a.supp = supp; a.T = T; a.K = K; a.Kinv = K_inv;
+  a.b = b; a.n = n; a.h = h; a.w = w;
+  a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
+  a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
+  a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
+
+  if (flags & SMD_USE_AUTOMASK) {  // identity error, once per sample (scale independent)
+    smd::ReconFwdArgs id = a;
+    id.S = 1; id.err = ws.e_static; id.sel = nullptr; id.partial = nullptr;
+    id.flags = flags & (SMD_USE_MIN | SMD_LOSS_L1);
+    for (int i0 = 0; i0 < n; i0 += 2) {
+      const int ni = (n - i0 >= 2) ? 2 : 1;
+      id.i0 = i0; id.first_pass = (i0 == 0); id.last_pass = (i0 + ni >= n);
+      if (int rc = check_launch(smd::launch_recon_fwd(id, ni, false, st), "identity error")) return rc;
+    }
+  }
+  a.depth = depth; a.S = S; a.err = err; a.sel = sel; a.partial = ws.loss_partial; a.warp0 = warp0;
+  a.e_static = ws.e_static; a.noise = noise; a.flags = flags;
+  for (int i0 = 0; i0 < n; i0 += 2) {
+    const int ni = (n - i0 >= 2) ? 2 : 1;
+    a.i0 = i0; a.first_pass = (i0 == 0); a.last_pass = (i0 + ni >= n);
+    if (int rc = check_launch(smd::launch_recon_fwd(a, ni, true, st), "image_recon_fwd")) return rc;
+  }
+  const int count = S*b*pl.nsx*pl.nsy;
+  return check_launch(smd::launch_sum_partials(ws.loss_partial, count, 1.0/((double)S*b*h*w), loss, st), "loss reduction");
+}
+
+int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
+                        const float* K_inv, const uint8_t* sel, const float* g_loss,
+                        float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
+                        int b, int n, int S, int h, int w, int flags, void* stream) {
+  if (int rc = check_dims(b, n, S, h, w)) return rc;
+  if (!depth || !tgt || !supp || !T || !K || !K_inv || !sel || !g_loss || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if ((flags & SMD_NEED_K_GRAD) && (!g_K || !g_Kinv)) return fail(SMD_E_INVALID, "SMD_NEED_K_GRAD requires g_K and g_Kinv");
+  if (n >= SMD_SEL_MASKED) return fail(SMD_E_INVALID, "too many supports");
+  ReconWs ws = carve_recon(workspace, b, n, S, h, w);
+  if (workspace_bytes < ws.bytes) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  hipStream_t st = (hipStream_t)stream;
+
+  smd::ReconBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.depth = depth; a.tgt = tgt; a.supp = supp; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
+  a.g_depth = g_depth; a.pose_partial = ws.pose_partial;
+  a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
+  a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
+  const StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
+  a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
+  if (int rc = check_launch(smd::launch_recon_bwd(a, st), "image_recon_bwd")) return rc;
+  return check_launch(smd::launch_pose_finalize(ws.pose_partial, S*pl.nsx*pl.nsy, T, K, K_inv, g_T,
+                                                (flags & SMD_NEED_K_GRAD) ? g_K : nullptr, (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr,
+                                                b, n, st), "pose finalize");
+}
+
+// ------------------------------------------------------------------------------------------------
+static int smooth_chunks(const int* hs, const int* ws, int S) {
+  int maxpix = 0;
+  for (int s = 0; s < S; ++s) maxpix = hs[s]*ws[s] > maxpix ? hs[s]*ws[s] : maxpix;
+  return smd::ceil_div(maxpix, 2048);
+}
+
+size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int b) {
+  if (!hs || !ws || S < 1 || S > SMD_MAX_SCALES || b < 1) return 0;
+  return align256((size_t)S*b*smooth_chunks(hs, ws, S)*sizeof(float));
+}
+
+int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
+                        const float* img, int h, int w, int flags, float* loss, float* stats, float* disp_grad, float* image_grad,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!disp || !img || !loss || !stats || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, disp, nullptr, hs, ws, scale_keys, S)) return rc;
+  for (int s = 0; s < S; ++s) if (!disp[s]) return fail(SMD_E_INVALID, "null disparity pointer for scale %d", s);
+  const size_t need = smd_disp_smooth_workspace_bytes(hs, ws, S, b);
+  if (workspace_bytes < need) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  return check_launch(smd::launch_smooth_fwd(sc, b, img, h, w, flags, loss, stats, disp_grad, image_grad, (float*)workspace,
+                                             (hipStream_t)stream), "disp_smooth_fwd");
+}
+
+int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
+                        const float* img, int h, int w, int flags, const float* stats, const float* g_loss,
+                        float* const* g_disp, void* stream) {
+  if (!disp || !img || !stats || !g_loss || !g_disp) return fail(SMD_E_INVALID, "null pointer");
+  if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, disp, g_disp, hs, ws, scale_keys, S)) return rc;
+  for (int s = 0; s < S; ++s) if (!disp[s] || !g_disp[s]) return fail(SMD_E_INVALID, "null pointer for scale %d", s);
+  return check_launch(smd::launch_smooth_bwd(sc, b, img, h, w, flags, stats, g_loss, (hipStream_t)stream), "disp_smooth_bwd");
+}
+
+int smd_debug_lane_shift(float* out_left, float* out_right, void* stream) {
+  if (!out_left || !out_right) return fail(SMD_E_INVALID, "null pointer");
+  return check_launch(smd::launch_debug_lane_shift(out_left, out_right, (hipStream_t)stream), "debug_lane_shift");
+}
+
+}  // extern "C"

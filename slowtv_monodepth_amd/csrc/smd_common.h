@@ -1,0 +1,177 @@
+// smd_common.h — device-side building blocks shared by the gfx950 kernels of the view-synthesis loss path.
+//
+// Written for CDNA4 only: wave64, DPP wave shifts for the horizontal stencil taps, SGPR-resident camera
+// constants, unaligned 8-byte gathers from the planar (NCHW) support frames.  No LDS is needed by the fused
+// kernels: one wave owns a 64-column strip and streams down the rows, so the 3x3 windows live in registers
+// (horizontal taps = neighbouring lanes, vertical taps = forward-accumulated row sums).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smd {
+
+constexpr float kEps32 = 1.1920929e-07f;  // torch.finfo(float32).eps  (src/tools/ops.py:63-66)
+constexpr float kC1 = 1e-4f;              // SSIM eps1 = 0.01^2        (src/losses/photometric.py:30)
+constexpr float kC2 = 9e-4f;              // SSIM eps2 = 0.03^2        (src/losses/photometric.py:31)
+constexpr float kWSsim = 0.85f;           // PhotoError(weight_ssim)   (src/losses/reconstruction.py:38)
+constexpr float kZMin = 0.1f;             // z.clamp(min=0.1)          (src/tools/geometry.py:341)
+constexpr int kWave = 64;
+
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load that is only 4-byte aligned
+
+// ---------------------------------------------------------------------------------------------
+// Cross-lane neighbours (DPP wave shifts; one VALU op each, no LDS traffic).
+//   lane_left(x)[l]  = x[l-1]  (0 for lane 0)
+//   lane_right(x)[l] = x[l+1]  (0 for lane 63)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_left(float x) {
+#ifdef SMD_NO_DPP
+  float v = __shfl_up(x, 1, 64);
+  return (threadIdx.x & 63) == 0 ? 0.f : v;
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+#endif
+}
+__device__ __forceinline__ float lane_right(float x) {
+#ifdef SMD_NO_DPP
+  float v = __shfl_down(x, 1, 64);
+  return (threadIdx.x & 63) == 63 ? 0.f : v;
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+#endif
+}
+
+// Weighted horizontal 3-tap: q + wl*q[l-1] + wr*q[l+1].  With (wl, wr) = reflect_weights() this is the
+// ReflectionPad2d(1) + 3-wide box sum of src/losses/photometric.py:27-28 along x.
+__device__ __forceinline__ float hsum3(float q, float wl, float wr) {
+  return fmaf(wr, lane_right(q), fmaf(wl, lane_left(q), q));
+}
+
+// Reflection-padded 3-tap weights for position i in [0, n): neighbour i-1 has weight `lo`, i+1 has `hi`.
+//   i == 0   : window {-1->1, 0, 1}     -> lo 0, hi 2
+//   i == n-1 : window {n-2, n-1, n->n-2} -> lo 2, hi 0
+__device__ __forceinline__ void reflect_weights(int i, int n, float& lo, float& hi) {
+  lo = (i == 0) ? 0.f : ((i == n - 1) ? 2.f : 1.f);
+  hi = (i == n - 1) ? 0.f : ((i == 0) ? 2.f : 1.f);
+}
+// Adjoint of the above (weights with which position i RECEIVES from coefficient maps at i-1 / i+1):
+//   from i-1: reflect hi-weight of (i-1) = 2 if i-1 == 0;  from i+1: reflect lo-weight of (i+1) = 2 if i+1 == n-1.
+__device__ __forceinline__ void reflect_weights_adj(int i, int n, float& lo, float& hi) {
+  lo = (i == 0) ? 0.f : ((i == 1) ? 2.f : 1.f);
+  hi = (i == n - 1) ? 0.f : ((i == n - 2) ? 2.f : 1.f);
+  if (n == 2) { lo = (i == 1) ? 2.f : 0.f; hi = (i == 0) ? 2.f : 0.f; }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-(support, sample) camera constants, folded so that a pixel costs 6 FMAs + 1 rcp + 2 mul:
+//   [hx hy hz]^T = H * (u, v, 1)^T          H rows 0,1 = K[:2,:3] * R * Kinv3,  row 2 = (R * Kinv3)[2]
+//   (nx, ny, Yz) = D * (hx, hy, hz) + (a0, a1, tz)     a = K[:2,:3] * t
+//   (px, py) = (nx, ny) / max(Yz, 0.1)
+// which equals K[:, :3, :3] @ ((T @ [D * Kinv3 @ pix; 1])[:3] / z.clamp(eps).clamp(0.1)) of
+// src/tools/geometry.py:312-316, :386, :339-341 up to fp32 re-association.
+// ---------------------------------------------------------------------------------------------
+struct Cam {
+  float H[9];
+  float a0, a1, tz;
+};
+
+__device__ __forceinline__ void make_cam(Cam& c, const float* __restrict__ T, const float* __restrict__ K,
+                                         const float* __restrict__ Ki) {
+  float M[9];  // R * Kinv3
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      M[r*3 + q] = T[r*4 + 0]*Ki[0*4 + q] + T[r*4 + 1]*Ki[1*4 + q] + T[r*4 + 2]*Ki[2*4 + q];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    c.H[0*3 + q] = K[0]*M[q] + K[1]*M[3 + q] + K[2]*M[6 + q];
+    c.H[1*3 + q] = K[4]*M[q] + K[5]*M[3 + q] + K[6]*M[6 + q];
+    c.H[2*3 + q] = M[6 + q];
+  }
+  c.a0 = K[0]*T[3] + K[1]*T[7] + K[2]*T[11];
+  c.a1 = K[4]*T[3] + K[5]*T[7] + K[6]*T[11];
+  c.tz = T[11];
+}
+
+// Bilinear, border-clamped 4-tap gather setup (grid_sample(bilinear, border, align_corners=False)).
+struct Taps {
+  int off;        // iy*w + ix of the north-west tap (ix <= w-2, iy <= h-2 so the 2x2 block is in range)
+  float fx, fy;   // fractional weights of the east / south taps
+  float mx, my;   // d(clamped coord)/d(unclamped coord): 1 strictly inside (0, size-1), else 0
+};
+
+__device__ __forceinline__ Taps make_taps(float sx, float sy, int h, int w) {
+  Taps t;
+  const float xmax = (float)(w - 1), ymax = (float)(h - 1);
+  t.mx = (sx > 0.f && sx < xmax) ? 1.f : 0.f;
+  t.my = (sy > 0.f && sy < ymax) ? 1.f : 0.f;
+  // NaN-safe clamp (fmaxf/fminf drop NaNs -> 0), then split into integer and fractional parts.
+  float cx = fminf(fmaxf(sx, 0.f), xmax), cy = fminf(fmaxf(sy, 0.f), ymax);
+  float x0 = fminf(floorf(cx), xmax - 1.f), y0 = fminf(floorf(cy), ymax - 1.f);
+  t.fx = cx - x0; t.fy = cy - y0;
+  t.off = (int)y0*w + (int)x0;
+  return t;
+}
+
+__device__ __forceinline__ float bilerp(const float* __restrict__ plane, const Taps& t, int w, float& ddx, float& ddy) {
+  f2u n = *(const f2u*)(plane + t.off);
+  f2u s = *(const f2u*)(plane + t.off + w);
+  float top = fmaf(t.fx, n.y - n.x, n.x), bot = fmaf(t.fx, s.y - s.x, s.x);
+  ddx = fmaf(t.fy, (s.y - s.x) - (n.y - n.x), n.y - n.x);  // d/dfx
+  ddy = bot - top;                                          // d/dfy
+  return fmaf(t.fy, bot - top, top);
+}
+__device__ __forceinline__ float bilerp(const float* __restrict__ plane, const Taps& t, int w) {
+  f2u n = *(const f2u*)(plane + t.off);
+  f2u s = *(const f2u*)(plane + t.off + w);
+  float top = fmaf(t.fx, n.y - n.x, n.x), bot = fmaf(t.fx, s.y - s.x, s.x);
+  return fmaf(t.fy, bot - top, top);
+}
+
+// SSIM error of one channel from the nine-tap window sums (already divided by 9 where noted).
+//   mx = E[x], exx = E[x^2], exy = E[xy];  my = E[y], cy1 = my^2 + C1, cy2 = var(y) + C2
+__device__ __forceinline__ float ssim_err(float mx, float exx, float exy, float my, float cy1, float cy2) {
+  float sx = exx - mx*mx, sxy = exy - mx*my;
+  float num = fmaf(2.f*mx, my, kC1)*fmaf(2.f, sxy, kC2);
+  float den = fmaf(mx, mx, cy1)*(sx + cy2);
+  float v = fmaf(-0.5f, num*__builtin_amdgcn_rcpf(den), 0.5f);
+  return fminf(fmaxf(v, 0.f), 1.f);
+}
+
+// Partials of the (unclamped) SSIM error e = (1 - num/den)/2 w.r.t. the window means (E[x], E[x^2], E[xy]);
+// zero where the clamp(0, 1) of photometric.py:50 is active.
+__device__ __forceinline__ void ssim_err_grad(float mx, float exx, float exy, float my, float cy1, float cy2,
+                                              float& d_mx, float& d_exx, float& d_exy) {
+  float sx = exx - mx*mx, sxy = exy - mx*my;
+  float a1 = fmaf(2.f*mx, my, kC1), a2 = fmaf(2.f, sxy, kC2);
+  float b1 = fmaf(mx, mx, cy1), b2 = sx + cy2;
+  float rden = __builtin_amdgcn_rcpf(b1*b2);
+  float val = a1*a2*rden;
+  float e = fmaf(-0.5f, val, 0.5f);
+  float pass = (e >= 0.f && e <= 1.f) ? -0.5f : 0.f;  // de/dval, gated by the clamp
+  // dval/dmx  (treating mx, exx, exy as independent): [2 my (a2 - a1) - 2 mx val (b2 - b1)] / den
+  d_mx = pass*(2.f*my*(a2 - a1) - 2.f*mx*val*(b2 - b1))*rden;
+  d_exx = pass*(-val*b1)*rden;       // dval/dexx = -val / b2
+  d_exy = pass*(2.f*a1)*rden;        // dval/dexy = 2 a1 / den
+}
+
+// Counter-based Gaussian for the automask tie-break when the caller supplies no noise tensor.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float gauss_noise(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx) {
+  uint32_t a = hash32(idx ^ seed_lo), b = hash32(a ^ seed_hi ^ 0x9e3779b9U);
+  float u1 = (float)(a >> 8)*(1.0f/16777216.0f) + (0.5f/16777216.0f);
+  float u2 = (float)(b >> 8)*(1.0f/16777216.0f);
+  return sqrtf(-2.f*__logf(u1))*__cosf(6.2831853f*u2);
+}
+
+}  // namespace smd

@@ -1,0 +1,110 @@
+// smd_kernels.h — argument blocks and host-side launchers shared between the kernel translation units and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/smd_hotpath.h"
+
+namespace smd {
+
+// A wave owns a strip of 64 lanes = 64 consecutive columns; the outer 1 (forward) or 2 (backward) lanes on each
+// side are halo (their stencil results are incomplete), so a strip advances by 62 / 60 columns.
+constexpr int kFwdCols = 62;
+constexpr int kBwdCols = 60;
+constexpr int kWavesPerBlock = 4;
+constexpr int kPoseSums = 12;  // accumulated d/d(H[9], a0, a1, tz) per (support, sample)
+
+struct ScaleSet {  // the multi-scale disparity pyramid, passed by value
+  const float* p[SMD_MAX_SCALES];
+  float* g[SMD_MAX_SCALES];
+  int hs[SMD_MAX_SCALES];
+  int ws[SMD_MAX_SCALES];
+  int key[SMD_MAX_SCALES];  // dictionary key of the scale (the `s` of `loss_s / 2**s`, src/core/handlers.py:279)
+  int S;
+};
+
+struct ReconFwdArgs {
+  const float* depth;     // (S,b,h,w); unused when WARP == false
+  const float* tgt;       // (b,3,h,w)
+  const float* supp;      // (n,b,3,h,w)
+  const float* T;         // (n,b,4,4)
+  const float* K;         // (b,4,4)
+  const float* Kinv;      // (b,4,4)
+  const float* e_static;  // (b,h,w) identity error (automask) or null
+  const float* noise;     // (S,b,h,w) or null
+  float* err;             // (S,b,h,w) running / final error
+  uint8_t* sel;           // (S,b,h,w) running / final selection (may be null for the identity pass)
+  float* partial;         // [S*b*nstrips] per-wave loss sums (last pass only)
+  float* warp0;           // (n,b,3,h,w) or null
+  int b, n, S, h, w;
+  int i0;                 // first support handled by this launch
+  int flags;
+  int rh;                 // rows per strip
+  int nsx, nsy;           // strips per image in x / y
+  float wscale, hscale;   // w/(w-1), h/(h-1)
+  uint32_t seed_lo, seed_hi;
+  int first_pass, last_pass;
+};
+
+struct ReconBwdArgs {
+  const float* depth; const float* tgt; const float* supp; const float* T; const float* K; const float* Kinv;
+  const uint8_t* sel;
+  const float* g_loss;    // device scalar
+  float* g_depth;         // (S,b,h,w)
+  float* pose_partial;    // [n*b][S*nstrips][kPoseSums]
+  int b, n, S, h, w;
+  int flags;
+  int rh, nsx, nsy;
+  float wscale, hscale;
+};
+
+// launchers (return hipError_t from hipGetLastError after the launch)
+hipError_t launch_recon_fwd(const ReconFwdArgs& a, int ni, bool warp, hipStream_t st);
+hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st);
+hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st);
+hipError_t launch_pose_finalize(const float* pose_partial, int entries, const float* T, const float* K, const float* Kinv,
+                                float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st);
+
+hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
+                                    float* depth_up, float* disp_up, hipStream_t st);
+hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
+                                    const float* depth_up, const float* g_depth_up, hipStream_t st);
+
+hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
+                             float* disp_grad, float* image_grad, float* ws_sums, hipStream_t st);
+hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
+                             const float* g_loss, hipStream_t st);
+
+hipError_t launch_view_synth_fwd(const float* input, const float* depth, const float* T, const float* K, const float* Kinv,
+                                 float* warp, float* depth_warp, uint8_t* mask_valid, int B, int C, int h, int w, hipStream_t st);
+hipError_t launch_view_synth_bwd(const float* input, const float* depth, const float* T, const float* K, const float* Kinv,
+                                 const float* g_warp, const float* g_depth_warp, float* g_input, float* g_depth,
+                                 float* g_T, float* g_K, float* g_Kinv, float* ws, int B, int C, int h, int w, hipStream_t st);
+hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int h, int w, int flags, hipStream_t st);
+hipError_t launch_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred,
+                                  int N, int h, int w, int flags, hipStream_t st);
+hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed,
+                                   float* err, uint8_t* sel, float* loss, float* ws, int n, int B, int h, int w, int flags,
+                                   hipStream_t st);
+hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w,
+                                   int flags, hipStream_t st);
+hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
+
+inline int ceil_div(int a, int b) { return (a + b - 1)/b; }
+
+// Rows per strip: enough strips to give every SIMD several waves, few enough that the halo rows stay cheap.
+inline int pick_rows_per_strip(int b, int S, int h, int w, int cols, int halo) {
+  const int nsx = ceil_div(w, cols);
+  const long target_waves = 1024L*4;  // 256 CUs x 4 SIMDs x 4 waves
+  int best = 8;
+  for (int rh = 64; rh >= 8; rh -= 4) {
+    long waves = (long)nsx*ceil_div(h, rh)*b*S;
+    best = rh;
+    if (waves >= target_waves) break;
+  }
+  (void)halo;
+  return best;
+}
+
+}  // namespace smd

@@ -1,0 +1,285 @@
+// smd_recon_bwd.hip — hand-written adjoint of the fused view-synthesis photometric loss (gfx950).
+//
+// Same wave-strip streaming structure as the forward (smd_recon_fwd.hip) with a three-stage software pipeline
+// per row step j (60 interior columns, 2 halo lanes per side, rows r0-2 .. r1+1):
+//   stage A (row j)   : re-synthesise the warped pixel x and its bilinear partials dx/dsx, dx/dsy; horizontal
+//                       3-tap sums; roll the vertical accumulators -> window statistics of row j-1 complete
+//   stage B (row j-1) : SSIM partials d e/d(E[x], E[x^2], E[xy]) times the upstream gradient routed by `sel`
+//                       (min-reprojection / automask), box-summed with the ADJOINT reflection weights
+//                       (avg_pool2d + reflection_pad2d backward) -> complete for row j-2
+//   stage C (row j-2) : dL/dx -> dL/d(sx, sy) (zero where the border clamp is active) -> projective chain rule
+//                       -> dL/d depth (written once per pixel) and twelve per-lane sums dL/d(H, a) that a tiny
+//                       epilogue kernel turns into dL/dT, dL/dK and dL/dK^-1.
+// Nothing is re-read from HBM except the inputs themselves; no intermediate tensor of the forward is stored.
+#include "smd_common.h"
+#include "smd_kernels.h"
+
+namespace smd {
+
+__global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int strip = blockIdx.x*kWavesPerBlock + wid;
+  const int nstrips = a.nsx*a.nsy;
+  if (strip >= nstrips) return;
+  const int sxi = strip % a.nsx, syi = strip/a.nsx;
+  const int bi = blockIdx.y, s = blockIdx.z;
+  const int h = a.h, w = a.w;
+  const int c0 = sxi*kBwdCols;
+  const int r0 = syi*a.rh, r1 = min(r0 + a.rh, h);
+
+  const int u = c0 - 2 + lane;
+  const bool col_ok = (u >= 0) && (u < w);
+  const int uc = min(max(u, 0), w - 1);
+  const bool interior = (lane >= 2) && (lane < 2 + kBwdCols) && (u < w);
+  float wl, wr, wla, wra;
+  reflect_weights(uc, w, wl, wr);
+  reflect_weights_adj(uc, w, wla, wra);
+  if (!col_ok) { wl = wr = wla = wra = 0.f; }
+  const float uf = (float)u;
+
+  const bool use_min = a.flags & SMD_USE_MIN;
+  const bool l1_only = a.flags & SMD_LOSS_L1;
+  const size_t hw = (size_t)h*w;
+  const float w_ssim = l1_only ? 0.f : kWSsim/3.f;
+  const float w_l1 = l1_only ? 1.f/3.f : (1.f - kWSsim)/3.f;
+  float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
+  if (!use_min) gscale /= (float)a.n;
+  const float ninth = 1.f/9.f;
+
+  const float* tgt_b = a.tgt + (size_t)bi*3*hw;
+  const float* depth_sb = a.depth + ((size_t)s*a.b + bi)*hw;
+  const uint8_t* sel_sb = a.sel + ((size_t)s*a.b + bi)*hw;
+  float* gd_sb = a.g_depth + ((size_t)s*a.b + bi)*hw;
+
+  for (int i = 0; i < a.n; ++i) {
+    Cam cm;
+    make_cam(cm, a.T + ((size_t)i*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16);
+    const float* splane = a.supp + ((size_t)i*a.b + bi)*3*hw;
+
+    float ay1[3][2] = {}, ay0[3][2] = {};      // vertical accumulators of {y, y^2}
+    float ax1[3][3] = {}, ax0[3][3] = {};      // ... of {x, x^2, xy}
+    float ac1[3][3] = {}, ac0[3][3] = {};      // ... of the coefficient maps {A, B, C} (adjoint weights)
+    float x1[3] = {}, x2[3] = {};              // warped pixel of rows j-1, j-2
+    float gx1[3] = {}, gx2[3] = {}, gy1[3] = {}, gy2[3] = {};  // dx/dpx, dx/dpy (clamp mask and grid scale folded in)
+    float psum[kPoseSums] = {};
+
+    const int jstart = max(r0 - 2, 0);
+    for (int j = jstart; j <= r1 + 1; ++j) {
+      // ================= stage A: row j =================
+      float hy[3][2] = {}, hxs[3][3] = {};
+      float x0[3] = {}, gx0[3] = {}, gy0[3] = {};
+      if (j < h) {
+        const float D = col_ok ? depth_sb[(size_t)j*w + uc] : 0.f;
+        const float vf = (float)j;
+        float hx = fmaf(cm.H[0], uf, fmaf(cm.H[1], vf, cm.H[2]));
+        float hyy = fmaf(cm.H[3], uf, fmaf(cm.H[4], vf, cm.H[5]));
+        float hz = fmaf(cm.H[6], uf, fmaf(cm.H[7], vf, cm.H[8]));
+        float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hyy, cm.a1), yz = fmaf(D, hz, cm.tz);
+        float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
+        float sx = fmaf(nx*rz, a.wscale, -0.5f), sy = fmaf(ny*rz, a.hscale, -0.5f);
+        Taps tp = make_taps(sx, sy, h, w);
+        const float kx = tp.mx*a.wscale, ky = tp.my*a.hscale;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float y = col_ok ? tgt_b[(size_t)c*hw + (size_t)j*w + uc] : 0.f;
+          float ddx, ddy;
+          float x = bilerp(splane + (size_t)c*hw, tp, w, ddx, ddy);
+          x = col_ok ? x : 0.f;
+          x0[c] = x; gx0[c] = ddx*kx; gy0[c] = ddy*ky;
+          if (!l1_only) {
+            hy[c][0] = hsum3(y, wl, wr); hy[c][1] = hsum3(y*y, wl, wr);
+            hxs[c][0] = hsum3(x, wl, wr); hxs[c][1] = hsum3(x*x, wl, wr); hxs[c][2] = hsum3(x*y, wl, wr);
+          }
+        }
+      }
+
+      // ================= stage B: row p = j-1 =================
+      const int p = j - 1;
+      float hc[3][3] = {};
+      if (!l1_only && p >= max(r0 - 1, 0) && p <= min(r1, h - 1)) {
+        float lo_p, hi_p;
+        reflect_weights(p, h, lo_p, hi_p);
+        const uint8_t sl = col_ok ? sel_sb[(size_t)p*w + uc] : (uint8_t)SMD_SEL_MASKED;
+        const bool active = use_min ? (sl == (uint8_t)i) : (sl != (uint8_t)SMD_SEL_MASKED);
+        const float g = (active && col_ok) ? gscale*w_ssim : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float my = fmaf(hi_p, hy[c][0], ay1[c][0])*ninth, eyy = fmaf(hi_p, hy[c][1], ay1[c][1])*ninth;
+          float cy1 = fmaf(my, my, kC1), cy2 = (eyy - my*my) + kC2;
+          float mx = fmaf(hi_p, hxs[c][0], ax1[c][0])*ninth;
+          float exx = fmaf(hi_p, hxs[c][1], ax1[c][1])*ninth;
+          float exy = fmaf(hi_p, hxs[c][2], ax1[c][2])*ninth;
+          float dmx, dexx, dexy;
+          ssim_err_grad(mx, exx, exy, my, cy1, cy2, dmx, dexx, dexy);
+          hc[c][0] = hsum3(g*dmx, wla, wra);
+          hc[c][1] = hsum3(g*dexx, wla, wra);
+          hc[c][2] = hsum3(g*dexy, wla, wra);
+        }
+      }
+
+      // ================= stage C: row q = j-2 =================
+      const int q = j - 2;
+      if (q >= r0 && q < r1) {
+        float lo_q, hi_q;
+        reflect_weights_adj(q, h, lo_q, hi_q);
+        const uint8_t sl = col_ok ? sel_sb[(size_t)q*w + uc] : (uint8_t)SMD_SEL_MASKED;
+        const bool active = use_min ? (sl == (uint8_t)i) : (sl != (uint8_t)SMD_SEL_MASKED);
+        const float gl = (active && col_ok) ? gscale*w_l1 : 0.f;
+        float gpx = 0.f, gpy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float y = col_ok ? tgt_b[(size_t)c*hw + (size_t)q*w + uc] : 0.f;
+          float d = x2[c] - y;
+          float gxc = gl*((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+          if (!l1_only) {
+            float SA = fmaf(hi_q, hc[c][0], ac1[c][0]), SB = fmaf(hi_q, hc[c][1], ac1[c][1]), SC = fmaf(hi_q, hc[c][2], ac1[c][2]);
+            gxc += ninth*(SA + 2.f*x2[c]*SB + y*SC);
+          }
+          gpx = fmaf(gxc, gx2[c], gpx);
+          gpy = fmaf(gxc, gy2[c], gpy);
+        }
+        // projective chain rule at (q, u): recompute the cheap geometry
+        const float D = col_ok ? depth_sb[(size_t)q*w + uc] : 0.f;
+        const float vf = (float)q;
+        float hx = fmaf(cm.H[0], uf, fmaf(cm.H[1], vf, cm.H[2]));
+        float hyy = fmaf(cm.H[3], uf, fmaf(cm.H[4], vf, cm.H[5]));
+        float hz = fmaf(cm.H[6], uf, fmaf(cm.H[7], vf, cm.H[8]));
+        float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hyy, cm.a1), yz = fmaf(D, hz, cm.tz);
+        float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
+        float gnx = gpx*rz, gny = gpy*rz;
+        float gz = (yz >= kZMin) ? -(gpx*nx + gpy*ny)*rz*rz : 0.f;
+        if (!interior) { gnx = 0.f; gny = 0.f; gz = 0.f; }
+        float gD = fmaf(gnx, hx, fmaf(gny, hyy, gz*hz));
+        if (interior) {
+          float* gp = gd_sb + (size_t)q*w + u;
+          if (i == 0) *gp = gD; else *gp += gD;
+        }
+        float dnx = gnx*D, dny = gny*D, dz = gz*D;
+        psum[0] = fmaf(dnx, uf, psum[0]); psum[1] = fmaf(dnx, vf, psum[1]); psum[2] += dnx;
+        psum[3] = fmaf(dny, uf, psum[3]); psum[4] = fmaf(dny, vf, psum[4]); psum[5] += dny;
+        psum[6] = fmaf(dz, uf, psum[6]);  psum[7] = fmaf(dz, vf, psum[7]);  psum[8] += dz;
+        psum[9] += gnx; psum[10] += gny; psum[11] += gz;
+      }
+
+      // ================= roll =================
+      float lo_n, hi_n, lo_na, hi_na;
+      reflect_weights(min(j + 1, h - 1), h, lo_n, hi_n);
+      if (j + 1 >= h) lo_n = 0.f;
+      reflect_weights_adj(min(max(p + 1, 0), h - 1), h, lo_na, hi_na);  // weight of coefficient row p in out(p+1)
+      if (p + 1 >= h || p < 0) lo_na = 0.f;
+      if (!l1_only) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) { ay1[c][k] = ay0[c][k] + hy[c][k]; ay0[c][k] = lo_n*hy[c][k]; }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            ax1[c][k] = ax0[c][k] + hxs[c][k]; ax0[c][k] = lo_n*hxs[c][k];
+            ac1[c][k] = ac0[c][k] + hc[c][k];  ac0[c][k] = lo_na*hc[c][k];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        x2[c] = x1[c]; x1[c] = x0[c];
+        gx2[c] = gx1[c]; gx1[c] = gx0[c];
+        gy2[c] = gy1[c]; gy1[c] = gy0[c];
+      }
+    }
+
+    // per-wave pose partials
+    float* pp = a.pose_partial + (((size_t)i*a.b + bi)*((size_t)a.S*nstrips) + (size_t)s*nstrips + strip)*kPoseSums;
+#pragma unroll
+    for (int k = 0; k < kPoseSums; ++k) {
+      float tot = wave_sum(psum[k]);
+      if (lane == 0) pp[k] = tot;
+    }
+  }
+}
+
+hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
+  dim3 grid(ceil_div(a.nsx*a.nsy, kWavesPerBlock), a.b, a.S), block(64*kWavesPerBlock);
+  hipLaunchKernelGGL(k_recon_bwd, grid, block, 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue: sum the per-wave partials of dL/d(H, a0, a1, tz) and push them through
+//   H[0:2] = K2 * M,  H[2] = M[2],  M = R * Ki3,  (a0, a1) = K2 * t,  tz = t[2]
+// to dL/dT (n,b,4,4), dL/dK (b,4,4), dL/dKinv (b,4,4).  One block per sample; fp64 accumulation.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pose_finalize(const float* __restrict__ pose_partial, int entries,
+                                                       const float* __restrict__ T, const float* __restrict__ K,
+                                                       const float* __restrict__ Kinv, float* g_T, float* g_K, float* g_Kinv,
+                                                       int b, int n) {
+  __shared__ double red[256];
+  __shared__ double tot[kPoseSums];
+  const int bi = blockIdx.x;
+  double gK[6] = {0, 0, 0, 0, 0, 0}, gKi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const float* pp = pose_partial + ((size_t)i*b + bi)*(size_t)entries*kPoseSums;
+    for (int k = 0; k < kPoseSums; ++k) {
+      double acc = 0.0;
+      for (int e = threadIdx.x; e < entries; e += 256) acc += (double)pp[(size_t)e*kPoseSums + k];
+      red[threadIdx.x] = acc;
+      __syncthreads();
+      for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) tot[k] = red[0];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float* Tm = T + ((size_t)i*b + bi)*16;
+      const float* Km = K + (size_t)bi*16;
+      const float* Ki = Kinv + (size_t)bi*16;
+      double R[9], t[3], K2[6], Ki3[9], M[9];
+      for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { R[r*3 + c] = Tm[r*4 + c]; Ki3[r*3 + c] = Ki[r*4 + c]; } t[r] = Tm[r*4 + 3]; }
+      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) K2[r*3 + c] = Km[r*4 + c];
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r*3 + c] = R[r*3]*Ki3[c] + R[r*3 + 1]*Ki3[3 + c] + R[r*3 + 2]*Ki3[6 + c];
+      const double* gH = tot;          // 3x3
+      const double ga[2] = {tot[9], tot[10]};
+      const double gtz = tot[11];
+      double gM[9];
+      for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c) gM[m*3 + c] = K2[m]*gH[c] + K2[3 + m]*gH[3 + c];
+      for (int c = 0; c < 3; ++c) gM[6 + c] += gH[6 + c];
+      for (int r = 0; r < 2; ++r) for (int m = 0; m < 3; ++m)
+        gK[r*3 + m] += gH[r*3]*M[m*3] + gH[r*3 + 1]*M[m*3 + 1] + gH[r*3 + 2]*M[m*3 + 2] + ga[r]*t[m];
+      double gt[3];
+      for (int m = 0; m < 3; ++m) gt[m] = K2[m]*ga[0] + K2[3 + m]*ga[1];
+      gt[2] += gtz;
+      float* gTo = g_T + ((size_t)i*b + bi)*16;
+      for (int r = 0; r < 3; ++r) {
+        for (int m = 0; m < 3; ++m)
+          gTo[r*4 + m] = (float)(gM[r*3]*Ki3[m*3] + gM[r*3 + 1]*Ki3[m*3 + 1] + gM[r*3 + 2]*Ki3[m*3 + 2]);
+        gTo[r*4 + 3] = (float)gt[r];
+      }
+      for (int c = 0; c < 4; ++c) gTo[12 + c] = 0.f;
+      for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c)
+        gKi[m*3 + c] += R[m]*gM[c] + R[3 + m]*gM[3 + c] + R[6 + m]*gM[6 + c];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (g_K) {
+      float* o = g_K + (size_t)bi*16;
+      for (int k = 0; k < 16; ++k) o[k] = 0.f;
+      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) o[r*4 + c] = (float)gK[r*3 + c];
+    }
+    if (g_Kinv) {
+      float* o = g_Kinv + (size_t)bi*16;
+      for (int k = 0; k < 16; ++k) o[k] = 0.f;
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[r*4 + c] = (float)gKi[r*3 + c];
+    }
+  }
+}
+
+hipError_t launch_pose_finalize(const float* pose_partial, int entries, const float* T, const float* K, const float* Kinv,
+                                float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(256), 0, st, pose_partial, entries, T, K, Kinv, g_T, g_K, g_Kinv, b, n);
+  return hipGetLastError();
+}
+
+}  // namespace smd

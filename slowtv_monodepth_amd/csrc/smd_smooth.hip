@@ -1,0 +1,191 @@
+// smd_smooth.hip — edge-aware disparity smoothness over the whole scale pyramid, forward and adjoint.
+//
+// Restates `handlers.disp_smooth` (src/core/handlers.py:262-281): per scale s, resize the target image to the
+// disparity's size (bilinear, align_corners=False), `SmoothReg.forward` (src/regularizers/smooth.py:71-97) with
+// `ops.mean_normalize` (src/tools/ops.py:279-286) and `compute_grad` (smooth.py:12-30), then mean_s(loss_s / 2^s).
+// All scales run in one launch per phase (the reference issues ~170 launches here).
+//
+// Per image the loss is E/N with E = sum_edges w|dhat_p - dhat_q|, dhat = d / max(mean(d), eps).  E is 1-homogeneous
+// in dhat, so sum_p (dE/ddhat_p) dhat_p = E and the mean-normalisation term of the adjoint needs only (mean, E):
+//   dL/dd_q = g_s/N * [ G_q / m  -  [mean >= eps] * E / (m * hs*ws) ],   G_q = dE/ddhat_q.
+#include "smd_common.h"
+#include "smd_kernels.h"
+
+namespace smd {
+
+constexpr int kSmoothChunk = 2048;  // pixels per block in the main pass
+
+__device__ __forceinline__ void src_index_s(int dst, float scale, int n_in, int& i0, int& i1, float& l1) {
+  float src = fmaxf(scale*((float)dst + 0.5f) - 0.5f, 0.f);
+  i0 = min((int)src, n_in - 1);
+  i1 = min(i0 + 1, n_in - 1);
+  l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+}
+
+// Bilinearly resized target image at low-res pixel (v, u), three channels.
+__device__ __forceinline__ void img_at(const float* __restrict__ img, int h, int w, int hs, int ws, int v, int u, float out[3]) {
+  if (hs == h && ws == w) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = img[(size_t)c*h*w + (size_t)v*w + u];
+    return;
+  }
+  int y0, y1, x0, x1; float ly, lx;
+  src_index_s(v, (float)h/(float)hs, h, y0, y1, ly);
+  src_index_s(u, (float)w/(float)ws, w, x0, x1, lx);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* p = img + (size_t)c*h*w;
+    float p00 = p[(size_t)y0*w + x0], p01 = p[(size_t)y0*w + x1], p10 = p[(size_t)y1*w + x0], p11 = p[(size_t)y1*w + x1];
+    out[c] = (1.f - ly)*((1.f - lx)*p00 + lx*p01) + ly*((1.f - lx)*p10 + lx*p11);
+  }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// Phase 1: mean disparity per (scale, sample).  One block per image (all images are small and L2 resident).
+__global__ __launch_bounds__(256) void k_smooth_mean(const ScaleSet sc, int b, float* __restrict__ stats) {
+  __shared__ float red[4];
+  const int s = blockIdx.y, bi = blockIdx.x;
+  const int n = sc.hs[s]*sc.ws[s];
+  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += d[i];
+  float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) stats[((size_t)s*b + bi)*2 + 0] = tot/(float)n;
+}
+
+// Phase 2: per-block partial of E for its chunk of pixels; optional aux maps for scale index 0.
+__global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
+                                                     const float* __restrict__ stats, float* __restrict__ partial, int max_chunks,
+                                                     float* __restrict__ disp_grad, float* __restrict__ image_grad) {
+  __shared__ float red[4];
+  const int s = blockIdx.z, bi = blockIdx.y, chunk = blockIdx.x;
+  const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
+  if (chunk*kSmoothChunk >= n) return;
+  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
+  const float* __restrict__ im = img + (size_t)bi*3*h*w;
+  const float inv_m = 1.f/fmaxf(stats[((size_t)s*b + bi)*2], kEps32);
+  const bool edges = flags & SMD_USE_EDGES;
+  float acc = 0.f;
+  for (int k = 0; k < kSmoothChunk/256; ++k) {
+    const int pix = chunk*kSmoothChunk + k*256 + threadIdx.x;
+    if (pix < n) {
+      const int v = pix/ws, u = pix - v*ws;
+      const float dc = d[pix]*inv_m;
+      float gx = 0.f, gy = 0.f, ax = 0.f, ay = 0.f;
+      float ic[3];
+      img_at(im, h, w, hs, ws, v, u, ic);
+      if (u < ws - 1) {
+        gx = fabsf(dc - d[pix + 1]*inv_m);
+        float ir[3]; img_at(im, h, w, hs, ws, v, u + 1, ir);
+        ax = (fabsf(ic[0] - ir[0]) + fabsf(ic[1] - ir[1]) + fabsf(ic[2] - ir[2]))*(1.f/3.f);
+      }
+      if (v < hs - 1) {
+        gy = fabsf(dc - d[pix + ws]*inv_m);
+        float ib[3]; img_at(im, h, w, hs, ws, v + 1, u, ib);
+        ay = (fabsf(ic[0] - ib[0]) + fabsf(ic[1] - ib[1]) + fabsf(ic[2] - ib[2]))*(1.f/3.f);
+      }
+      if (s == 0 && disp_grad) disp_grad[(size_t)bi*n + pix] = sqrtf(fmaxf(gx*gx + gy*gy, kEps32));
+      if (s == 0 && image_grad) image_grad[(size_t)bi*n + pix] = sqrtf(fmaxf(ax*ax + ay*ay, kEps32));
+      acc += edges ? (gx*__expf(-ax) + gy*__expf(-ay)) : (gx + gy);
+    }
+  }
+  float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[((size_t)s*b + bi)*max_chunks + chunk] = tot;
+}
+
+// Phase 3: E per image -> stats[...,1]; loss = mean_s( 2^-scale_s * sum_b E / (b*hs*ws) ).  `sc.key[s]` is the
+// dictionary key of the scale (handlers.py:279 divides by 2**key).
+__global__ __launch_bounds__(64) void k_smooth_finalize(const ScaleSet sc, int b, const float* __restrict__ partial, int max_chunks,
+                                                        float* __restrict__ stats, float* __restrict__ loss) {
+  double total = 0.0;
+  for (int s = 0; s < sc.S; ++s) {
+    const int n = sc.hs[s]*sc.ws[s];
+    const int chunks = (n + kSmoothChunk - 1)/kSmoothChunk;
+    double es = 0.0;
+    for (int bi = 0; bi < b; ++bi) {
+      double e = 0.0;
+      for (int c = threadIdx.x; c < chunks; c += 64) e += (double)partial[((size_t)s*b + bi)*max_chunks + c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+      if (threadIdx.x == 0) stats[((size_t)s*b + bi)*2 + 1] = (float)e;
+      es += e;
+    }
+    total += es/((double)b*n)*exp2(-(double)sc.key[s]);
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(total/sc.S);
+}
+
+hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
+                             float* disp_grad, float* image_grad, float* ws_sums, hipStream_t st) {
+  int maxpix = 0;
+  for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
+  const int max_chunks = ceil_div(maxpix, kSmoothChunk);
+  hipLaunchKernelGGL(k_smooth_mean, dim3(b, sc.S), dim3(256), 0, st, sc, b, stats);
+  hipLaunchKernelGGL(k_smooth_main, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, ws_sums, max_chunks,
+                     disp_grad, image_grad);
+  hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(64), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
+                                                    const float* __restrict__ stats, const float* __restrict__ g_loss) {
+  const int s = blockIdx.z, bi = blockIdx.y;
+  const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
+  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
+  float* __restrict__ gd = sc.g[s] + (size_t)bi*n;
+  const float* __restrict__ im = img + (size_t)bi*3*h*w;
+  const float mean = stats[((size_t)s*b + bi)*2], E = stats[((size_t)s*b + bi)*2 + 1];
+  const float m = fmaxf(mean, kEps32), inv_m = 1.f/m;
+  const bool edges = flags & SMD_USE_EDGES;
+  const float gs = g_loss[0]*exp2f(-(float)sc.key[s])/((float)sc.S*(float)b*(float)n);
+  const float mean_term = (mean >= kEps32) ? E*inv_m/(float)n : 0.f;
+  for (int pix = blockIdx.x*256 + threadIdx.x; pix < n; pix += gridDim.x*256) {
+    const int v = pix/ws, u = pix - v*ws;
+    const float dc = d[pix]*inv_m;
+    float ic[3];
+    if (edges) img_at(im, h, w, hs, ws, v, u, ic);
+    float G = 0.f;
+    auto sgn = [](float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); };
+    auto wgt = [&](const float a[3], const float bb[3]) {
+      return __expf(-(fabsf(a[0] - bb[0]) + fabsf(a[1] - bb[1]) + fabsf(a[2] - bb[2]))*(1.f/3.f));
+    };
+    if (u < ws - 1) {
+      float wgt_ = 1.f;
+      if (edges) { float io[3]; img_at(im, h, w, hs, ws, v, u + 1, io); wgt_ = wgt(ic, io); }
+      G += wgt_*sgn(dc - d[pix + 1]*inv_m);
+    }
+    if (u > 0) {
+      float wgt_ = 1.f;
+      if (edges) { float io[3]; img_at(im, h, w, hs, ws, v, u - 1, io); wgt_ = wgt(io, ic); }
+      G -= wgt_*sgn(d[pix - 1]*inv_m - dc);
+    }
+    if (v < hs - 1) {
+      float wgt_ = 1.f;
+      if (edges) { float io[3]; img_at(im, h, w, hs, ws, v + 1, u, io); wgt_ = wgt(ic, io); }
+      G += wgt_*sgn(dc - d[pix + ws]*inv_m);
+    }
+    if (v > 0) {
+      float wgt_ = 1.f;
+      if (edges) { float io[3]; img_at(im, h, w, hs, ws, v - 1, u, io); wgt_ = wgt(io, ic); }
+      G -= wgt_*sgn(d[pix - ws]*inv_m - dc);
+    }
+    gd[pix] = gs*(G*inv_m - mean_term);
+  }
+}
+
+hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
+                             const float* g_loss, hipStream_t st) {
+  int maxpix = 0;
+  for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
+  hipLaunchKernelGGL(k_smooth_bwd, dim3(min(ceil_div(maxpix, 256), 256), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, g_loss);
+  return hipGetLastError();
+}
+
+}  // namespace smd

@@ -1,0 +1,190 @@
+"""`torch.autograd.Function`s around the C ABI (`include/smd_hotpath.h`).
+
+PyTorch's role here is plumbing only: it owns the device buffers, provides the current HIP stream and carries
+the hand-written backward kernels in its autograd graph.  Every function validates its inputs on the host and
+raises the exception types the reference raises (`ValueError`) before any launch; there is no fallback path —
+CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import FLAGS, call, int_array, ptr_array
+
+__all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'lane_shift_selftest', 'recon_flags']
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(name: str, t: torch.Tensor, shape=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor): raise TypeError(f'{name} must be a Tensor, got {type(t)}')
+    if not t.is_cuda: raise RuntimeError(f'{name} must live on the GPU: the view-synthesis hot path has no CPU implementation')
+    if t.dtype != torch.float32: raise TypeError(f'{name} must be float32 (the loss path is fp32 only), got {t.dtype}')
+    if shape is not None and tuple(t.shape) != tuple(shape): raise ValueError(f'{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
+    return t.contiguous()
+
+
+def recon_flags(loss_name: str = 'ssim', use_min: bool = False, use_automask: bool = False) -> int:
+    if loss_name not in ('ssim', 'l1'): raise NotImplementedError(f"fused image reconstruction supports loss_name 'ssim'|'l1', not {loss_name!r}")
+    return (FLAGS['use_min'] if use_min else 0) | (FLAGS['use_automask'] if use_automask else 0) | (FLAGS['loss_l1'] if loss_name == 'l1' else 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+class _DispToDepth(torch.autograd.Function):
+    """K0: per-scale bilinear upsample + `to_scaled`/`to_inv` (src/core/trainer.py:316-321)."""
+
+    @staticmethod
+    def forward(ctx, size, min_depth, max_depth, want_disp_up, *disps):
+        h, w = size
+        b = disps[0].shape[0]
+        disps = [_check(f'disp[{i}]', d) for i, d in enumerate(disps)]
+        for d in disps:
+            if d.ndim != 4 or d.shape[0] != b or d.shape[1] != 1: raise ValueError(f'disparities must be (b,1,hs,ws), got {tuple(d.shape)}')
+        S = len(disps)
+        hs, ws = [d.shape[2] for d in disps], [d.shape[3] for d in disps]
+        depth_up = torch.empty((S, b, 1, h, w), device=disps[0].device, dtype=torch.float32)
+        disp_up = torch.empty_like(depth_up) if want_disp_up else None
+        call('smd_disp_to_depth_fwd', ptr_array([d.data_ptr() for d in disps]), int_array(hs), int_array(ws), S, b, h, w,
+             float(min_depth or 0), float(max_depth or 0), depth_up.data_ptr(), disp_up.data_ptr() if want_disp_up else None, _stream())
+        ctx.save_for_backward(depth_up)
+        ctx.meta = (hs, ws, S, b, h, w, float(min_depth or 0), float(max_depth or 0))
+        if want_disp_up:
+            ctx.mark_non_differentiable(disp_up)
+            return depth_up, disp_up
+        return depth_up, None
+
+    @staticmethod
+    def backward(ctx, g_depth_up, _g_disp_up):
+        (depth_up,) = ctx.saved_tensors
+        hs, ws, S, b, h, w, mn, mx = ctx.meta
+        g_depth_up = _check('grad(depth_up)', g_depth_up)
+        g_disps = [torch.empty((b, 1, hs[s], ws[s]), device=depth_up.device, dtype=torch.float32) for s in range(S)]
+        call('smd_disp_to_depth_bwd', int_array(hs), int_array(ws), S, b, h, w, mn, mx, depth_up.data_ptr(), g_depth_up.data_ptr(),
+             ptr_array([g.data_ptr() for g in g_disps]), _stream())
+        return (None, None, None, None, *g_disps)
+
+
+def disp_to_depth(disps, size, min_depth=None, max_depth=None, want_disp_up=False):
+    """disps: sequence of (b,1,hs,ws) -> depth_up (S,b,1,h,w) [, disp_up (S,b,1,h,w)] in one launch."""
+    if min_depth is not None and min_depth <= 0: raise ValueError(f'Min depth must be greater than 0. ({min_depth})')
+    if max_depth and min_depth and max_depth < min_depth: raise ValueError(f'Max depth must be greater than min. ({max_depth} vs. {min_depth})')
+    return _DispToDepth.apply(tuple(int(x) for x in size), min_depth, max_depth, bool(want_disp_up), *disps)
+
+
+# ---------------------------------------------------------------------------------------------------
+class _ImageRecon(torch.autograd.Function):
+    """Fused `handlers.image_recon` (src/core/handlers.py:14-67)."""
+
+    @staticmethod
+    def forward(ctx, depth, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp):
+        S, b, h, w = depth.shape  # always 4-D here: `image_recon_fused` squeezes the channel dim as an autograd view
+        n = supp.shape[0]
+        depth = _check('depth', depth, (S, b, h, w)); tgt = _check('imgs', tgt, (b, 3, h, w))
+        supp = _check('supp_imgs', supp, (n, b, 3, h, w)); T = _check('Ts', T, (n, b, 4, 4))
+        K = _check('Ks', K, (b, 4, 4)); K_inv = _check('K_inv', K_inv, (b, 4, 4))
+        if noise is not None: noise = _check('noise', noise.reshape(S, b, h, w), (S, b, h, w))
+        dev = depth.device
+        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32)
+        sel = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.uint8)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        warp0 = torch.empty((n, b, 3, h, w), device=dev, dtype=torch.float32) if want_warp else None
+        nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        call('smd_image_recon_fwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
+             noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
+             warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, int(flags), _stream())
+        ctx.save_for_backward(depth, tgt, supp, T, K, K_inv, sel)
+        ctx.meta = (b, n, S, h, w, int(flags))
+        ctx.need_k = bool(ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
+        ctx.mark_non_differentiable(err, sel)
+        if want_warp: ctx.mark_non_differentiable(warp0)
+        return loss, err, sel, warp0
+
+    @staticmethod
+    def backward(ctx, g_loss, *_):
+        depth, tgt, supp, T, K, K_inv, sel = ctx.saved_tensors
+        b, n, S, h, w, flags = ctx.meta
+        dev = depth.device
+        g_loss = g_loss.to(torch.float32).contiguous()
+        g_depth = torch.empty((S, b, h, w), device=dev, dtype=torch.float32)
+        g_T = torch.empty((n, b, 4, 4), device=dev, dtype=torch.float32)
+        g_K = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
+        g_Ki = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
+        if ctx.need_k: flags |= FLAGS['need_k_grad']
+        nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        call('smd_image_recon_bwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
+             sel.data_ptr(), g_loss.data_ptr(), g_depth.data_ptr(), g_T.data_ptr(),
+             g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
+             ws.data_ptr(), nbytes, b, n, S, h, w, flags, _stream())
+        return g_depth, None, None, g_T, (g_K if ctx.needs_input_grad[4] else None), (g_Ki if ctx.needs_input_grad[5] else None), None, None, None, None
+
+
+def image_recon_fused(depth, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int, noise=None, seed: int = 0, want_warp: bool = False):
+    """depth (S,b,1,h,w)|(S,b,h,w); returns (loss, err (S,b,1,h,w), sel uint8 (S,b,1,h,w), warp0 (n,b,3,h,w)|None).
+
+    `K_inv=None` inverts `Ks` with torch (differentiable), as `ViewSynth.forward` does (src/tools/geometry.py:383)."""
+    if K_inv is None: K_inv = torch.linalg.inv(Ks)
+    was5 = depth.ndim == 5
+    d4 = depth.squeeze(2) if was5 else depth
+    return _ImageRecon.apply(d4, imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp)
+
+
+# ---------------------------------------------------------------------------------------------------
+class _DispSmooth(torch.autograd.Function):
+    """Fused `handlers.disp_smooth` (src/core/handlers.py:262-281) over every scale."""
+
+    @staticmethod
+    def forward(ctx, img, flags, keys, want_aux, *disps):
+        b, _, h, w = img.shape
+        img = _check('imgs', img, (b, 3, h, w))
+        disps = [_check(f'disp[{i}]', d) for i, d in enumerate(disps)]
+        for d in disps:
+            if d.ndim != 4 or d.shape[0] != b or d.shape[1] != 1: raise ValueError(f'disparities must be (b,1,hs,ws), got {tuple(d.shape)}')
+        S = len(disps)
+        hs, ws = [d.shape[2] for d in disps], [d.shape[3] for d in disps]
+        dev = img.device
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        stats = torch.empty((S, b, 2), device=dev, dtype=torch.float32)
+        aux = want_aux and keys[0] == 0
+        dg = torch.empty((b, 1, hs[0], ws[0]), device=dev, dtype=torch.float32) if aux else None
+        ig = torch.empty((b, 1, hs[0], ws[0]), device=dev, dtype=torch.float32) if aux else None
+        hs_a, ws_a, keys_a = int_array(hs), int_array(ws), int_array(keys)
+        nbytes = _lib.lib.smd_disp_smooth_workspace_bytes(hs_a, ws_a, S, b)
+        wsp = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+        call('smd_disp_smooth_fwd', ptr_array([d.data_ptr() for d in disps]), hs_a, ws_a, keys_a, S, b, img.data_ptr(), h, w, int(flags),
+             loss.data_ptr(), stats.data_ptr(), dg.data_ptr() if aux else None, ig.data_ptr() if aux else None,
+             wsp.data_ptr(), nbytes, _stream())
+        ctx.save_for_backward(img, stats, *disps)
+        ctx.meta = (hs, ws, list(keys), S, b, h, w, int(flags))
+        if aux: ctx.mark_non_differentiable(dg, ig)
+        return loss, dg, ig
+
+    @staticmethod
+    def backward(ctx, g_loss, *_):
+        img, stats, *disps = ctx.saved_tensors
+        hs, ws, keys, S, b, h, w, flags = ctx.meta
+        g_loss = g_loss.to(torch.float32).contiguous()
+        g_disps = [torch.empty_like(d) for d in disps]
+        call('smd_disp_smooth_bwd', ptr_array([d.data_ptr() for d in disps]), int_array(hs), int_array(ws), int_array(keys), S, b,
+             img.data_ptr(), h, w, flags, stats.data_ptr(), g_loss.data_ptr(), ptr_array([g.data_ptr() for g in g_disps]), _stream())
+        return (None, None, None, None, *g_disps)
+
+
+def disp_smooth_fused(disps: dict, imgs, *, use_edges: bool = False, want_aux: bool = True):
+    """disps {key: (b,1,hs,ws)} -> (loss, disp_grad|None, image_grad|None); aux maps are those of key 0."""
+    keys = [int(k) for k in disps.keys()]
+    flags = FLAGS['use_edges'] if use_edges else 0
+    return _DispSmooth.apply(imgs, flags, keys, want_aux, *disps.values())
+
+
+# ---------------------------------------------------------------------------------------------------
+def lane_shift_selftest(device='cuda'):
+    """Returns (left, right): left[l] = l-1 (0 at lane 0), right[l] = l+1 (0 at lane 63) if the DPP wave shifts that the
+    stencil kernels rely on behave as documented."""
+    left = torch.empty(64, device=device, dtype=torch.float32); right = torch.empty_like(left)
+    call('smd_debug_lane_shift', left.data_ptr(), right.data_ptr(), _stream())
+    return left, right

@@ -1,0 +1,2 @@
+from .photometric import *  # noqa: F401,F403
+from .reconstruction import *  # noqa: F401,F403
