@@ -69,6 +69,8 @@ int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int
  *   depth   (S,b,h,w)    tgt (b,3,h,w)    supp (n,b,3,h,w)    T (n,b,4,4)    K, K_inv (b,4,4)
  *   noise   (S,b,h,w) or NULL: the `randn_like` draw of reconstruction.py:72; NULL -> counter-based
  *           in-kernel Gaussian keyed by `seed` (statistically equivalent tie-break, different stream)
+ *   supp_packed (n,b,h,w,4) out: the supports repacked as RGBX texels (smd_packed_supports_bytes() bytes); the
+ *           forward fills it and the caller keeps it for the backward (aligned 16-byte bilinear taps)
  *   err     (S,b,h,w) out: per-pixel error after min/mean-reprojection and automasking
  *   sel     (S,b,h,w) out uint8: winning support index, or SMD_SEL_MASKED where the static error won
  *   loss    (1) out: mean of err  (= `loss_img_recon`)
@@ -79,11 +81,12 @@ int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int
  *   g_depth (S,b,h,w) out;  g_T (n,b,4,4) out (row 3 zero);  g_K, g_Kinv (b,4,4) out or NULL
  *           (required iff SMD_NEED_K_GRAD; only the 3x3 / 2x3 blocks the path reads are non-zero). */
 size_t smd_image_recon_workspace_bytes(int b, int n, int S, int h, int w);
+size_t smd_packed_supports_bytes(int b, int n, int h, int w);
 int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
-                        const float* K_inv, const float* noise, uint64_t seed, float* err, uint8_t* sel, float* loss,
+                        const float* K_inv, const float* noise, uint64_t seed, float* supp_packed, float* err, uint8_t* sel, float* loss,
                         float* warp0, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream);
-int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
+int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_packed, const float* T, const float* K,
                         const float* K_inv, const uint8_t* sel, const float* g_loss,
                         float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream);
@@ -104,6 +107,16 @@ int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, 
 int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
                         const float* img, int h, int w, int flags, const float* stats, const float* g_loss,
                         float* const* g_disp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel timing hooks for bench.py: while enabled, every call of the named entry point records a HIP event pair
+ * around its DOMINANT kernel (the fused strip kernel; not the identity-error pass or the scalar reductions) on
+ * the caller's stream.  smd_profile_collect() waits for the recorded events and returns their durations in ms.
+ * which: 0 = smd_image_recon_fwd, 1 = smd_image_recon_bwd.  Not thread-safe; one device. */
+#define SMD_PROF_RECON_FWD 0
+#define SMD_PROF_RECON_BWD 1
+int smd_profile_enable(int which, int capacity);
+int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out);
 
 /* Debug/self-test: out[l] = {value held by lane l-1, value held by lane l+1} for in[l] = l (64 lanes).
  * Used by the GPU tests to pin the cross-lane primitive the stencil kernels rely on. */

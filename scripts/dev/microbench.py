@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Kernel-level timing of the fused forward / backward at a BASELINE shape, for tuning (run on the GPU box).
+usage: microbench.py [cfg2|cfg4|cfg5] [iters]   — honours the SMD_* tuning env vars."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from slowtv_monodepth_amd import functional as F, _lib
+from slowtv_monodepth_amd.synthetic import make_batch
+name = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+b, h, w, supp = {'cfg2': (12, 192, 640, (-1, 1)), 'cfg4': (12, 384, 640, (-1, 1)), 'cfg5': (12, 384, 640, (-2, -1, 1, 2))}[name]
+S, n = 4, len(supp)
+dev = 'cuda'
+_, y, _ = make_batch(b, h, w, supp, seed=42, device=dev)
+g = torch.Generator(device=dev).manual_seed(0)
+import torch.nn.functional as Fn
+rough = os.environ.get('MB_ROUGH', '0') == '1'   # 1: per-pixel random disparity (incoherent gathers, worst case)
+def mk(s):
+    hs, ws = h >> s, w >> s
+    if rough: return 0.05 + 0.9*torch.rand(b, 1, hs, ws, device=dev, generator=g)
+    low = 0.2 + 0.6*torch.rand(b, 1, 4, 10, device=dev, generator=g)   # smooth field, like a network's output
+    return Fn.interpolate(low, size=(hs, ws), mode='bilinear', align_corners=False) + 0.01*torch.rand(b, 1, hs, ws, device=dev, generator=g)
+disps = [mk(s).requires_grad_(True) for s in range(S)]
+T = torch.eye(4, device=dev).repeat(n, b, 1, 1); T[..., :3, 3] = 0.05*torch.randn(n, b, 3, device=dev, generator=g); T.requires_grad_(True)
+flags = F.recon_flags('ssim', True, True)
+def step():
+    depth_up, _ = F.disp_to_depth(disps, (h, w), 0.1, 100)
+    loss, err, sel, _ = F.image_recon_fused(depth_up, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, seed=1)
+    lsm, _, _ = F.disp_smooth_fused({s: d for s, d in enumerate(disps)}, y['imgs'], use_edges=True, want_aux=False)
+    (loss + 0.001*lsm).backward()
+    return loss
+for _ in range(3): step()
+torch.cuda.synchronize()
+_lib.lib.smd_profile_enable(0, iters); _lib.lib.smd_profile_enable(1, iters)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters): l = step()
+e1.record(); torch.cuda.synchronize()
+def col(which):
+    buf = (C.c_float*iters)(); k = C.c_int(0)
+    _lib.lib.smd_profile_collect(which, buf, iters, C.byref(k)); v = sorted(buf[i] for i in range(k.value))
+    return v[len(v)//2]*1e3, v[0]*1e3
+f, fb = col(0); bw, bb = col(1)
+B = b*h*w*(S*9 + 12*(1 + n))
+tag = ' '.join(f'{k}={v}' for k, v in os.environ.items() if k.startswith('SMD_'))
+print(f'{name} [{tag}] fwd med {f:.1f} us (min {fb:.1f}) = {B/f/1e3:.0f} GB/s | bwd med {bw:.1f} us (min {bb:.1f}) = {B/bw/1e3:.0f} GB/s | '
+      f'whole loss path fwd+bwd {e0.elapsed_time(e1)/iters*1e3:.0f} us/iter | loss {l.item():.6f}')

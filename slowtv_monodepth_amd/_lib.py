@@ -10,6 +10,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
+import torch  # noqa: F401  MUST precede the CDLL below: the library binds to the HIP runtime torch has already loaded
+
 __all__ = ['lib', 'call', 'lib_path', 'FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError']
 
 _HERE = Path(__file__).resolve().parent
@@ -29,11 +31,14 @@ PROTOTYPES = {
     'smd_disp_to_depth_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     'smd_disp_to_depth_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     'smd_image_recon_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
-    'smd_image_recon_fwd': (_i, [_vp]*7 + [_u64] + [_vp]*5 + [_sz] + [_i]*6 + [_vp]),
+    'smd_packed_supports_bytes': (_sz, [_i, _i, _i, _i]),
+    'smd_image_recon_fwd': (_i, [_vp]*7 + [_u64] + [_vp]*6 + [_sz] + [_i]*6 + [_vp]),
     'smd_image_recon_bwd': (_i, [_vp]*13 + [_sz] + [_i]*6 + [_vp]),
     'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_disp_smooth_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'smd_disp_smooth_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'smd_profile_enable': (_i, [_i, _i]),
+    'smd_profile_collect': (_i, [_i, _vp, _i, _vp]),
     'smd_debug_lane_shift': (_i, [_vp, _vp, _vp]),
 }
 

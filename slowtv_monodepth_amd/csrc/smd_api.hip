@@ -2,6 +2,7 @@
 // No torch types, no allocation, no synchronisation; every launch goes to the caller's stream.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "smd_kernels.h"
@@ -27,12 +28,32 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct StripPlan { int rh, nsx, nsy; };
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// Tuning knobs (read per call; unset = built-in heuristics): SMD_FWD_RH / SMD_BWD_RH rows per strip, SMD_FWD_NI supports
+// held in registers per forward pass (1 or 2).
 StripPlan plan(int b, int S, int h, int w, int cols) {
   StripPlan p;
   p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
+  const int ov = env_int(cols == smd::kFwdCols ? "SMD_FWD_RH" : "SMD_BWD_RH", 0);
+  if (ov >= 1) p.rh = ov;
   p.nsx = smd::ceil_div(w, cols);
   p.nsy = smd::ceil_div(h, p.rh);
   return p;
+}
+
+// ---- optional event-pair recording around the dominant kernels (bench.py roofline measurement) ----
+struct ProfSlot { hipEvent_t* ev = nullptr; int cap = 0, used = 0; };
+ProfSlot g_prof[2];
+
+void prof_mark(int which, hipStream_t st, bool begin) {
+  ProfSlot& p = g_prof[which];
+  if (!p.ev || p.used >= p.cap) return;
+  if (begin) hipEventRecord(p.ev[2*p.used], st);
+  else { hipEventRecord(p.ev[2*p.used + 1], st); ++p.used; }
 }
 
 int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil_div(h, 8); }
@@ -109,52 +130,66 @@ size_t smd_image_recon_workspace_bytes(int b, int n, int S, int h, int w) {
   return carve_recon(nullptr, b, n, S, h, w).bytes;
 }
 
+size_t smd_packed_supports_bytes(int b, int n, int h, int w) {
+  if (b < 1 || n < 1 || h < 2 || w < 2) return 0;
+  return (size_t)n*b*h*w*4*sizeof(float);
+}
+
 int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
-                        const float* K_inv, const float* noise, uint64_t seed, float* err, uint8_t* sel, float* loss,
+                        const float* K_inv, const float* noise, uint64_t seed, float* supp_packed, float* err, uint8_t* sel, float* loss,
                         float* warp0, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
-  if (!depth || !tgt || !supp || !T || !K || !K_inv || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (!depth || !tgt || !supp || !T || !K || !K_inv || !supp_packed || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if ((size_t)n*b*h*w*16 >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "n*b*h*w*16 must stay below 2^32");
   ReconWs ws = carve_recon(workspace, b, n, S, h, w);
   if (workspace_bytes < ws.bytes) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
   hipStream_t st = (hipStream_t)stream;
+  if (int rc = check_launch(smd::launch_pack_supports(supp, supp_packed, n*b, h, w, st), "pack supports")) return rc;
 
   smd::ReconFwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.tgt = tgt; a.supp = supp; a.T = T; a.K = K; a.Kinv = K_inv;
+  a.tgt = tgt; a.supp_pk = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv;
   a.b = b; a.n = n; a.h = h; a.w = w;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
+  a.variant = env_int("SMD_FWD_VARIANT", 1);
 
   if (flags & SMD_USE_AUTOMASK) {  // identity error, once per sample (scale independent)
     smd::ReconFwdArgs id = a;
+    const StripPlan ipl = plan(b, 1, h, w, smd::kFwdCols);  // one "scale" only: shorter strips keep the chip full
+    id.rh = ipl.rh; id.nsx = ipl.nsx; id.nsy = ipl.nsy;
     id.S = 1; id.err = ws.e_static; id.sel = nullptr; id.partial = nullptr;
     id.flags = flags & (SMD_USE_MIN | SMD_LOSS_L1);
-    for (int i0 = 0; i0 < n; i0 += 2) {
-      const int ni = (n - i0 >= 2) ? 2 : 1;
+    const int id_max = env_int("SMD_FWD_NI", 2) >= 2 ? 2 : 1;
+    for (int i0 = 0; i0 < n; i0 += id_max) {
+      const int ni = (n - i0 >= id_max) ? id_max : 1;
       id.i0 = i0; id.first_pass = (i0 == 0); id.last_pass = (i0 + ni >= n);
       if (int rc = check_launch(smd::launch_recon_fwd(id, ni, false, st), "identity error")) return rc;
     }
   }
   a.depth = depth; a.S = S; a.err = err; a.sel = sel; a.partial = ws.loss_partial; a.warp0 = warp0;
   a.e_static = ws.e_static; a.noise = noise; a.flags = flags;
-  for (int i0 = 0; i0 < n; i0 += 2) {
-    const int ni = (n - i0 >= 2) ? 2 : 1;
+  const int ni_max = env_int("SMD_FWD_NI", 2) >= 2 ? 2 : 1;
+  for (int i0 = 0; i0 < n; i0 += ni_max) {
+    const int ni = (n - i0 >= ni_max) ? ni_max : 1;
     a.i0 = i0; a.first_pass = (i0 == 0); a.last_pass = (i0 + ni >= n);
+    if (i0 == 0) prof_mark(SMD_PROF_RECON_FWD, st, true);
     if (int rc = check_launch(smd::launch_recon_fwd(a, ni, true, st), "image_recon_fwd")) return rc;
+    if (a.last_pass) prof_mark(SMD_PROF_RECON_FWD, st, false);
   }
   const int count = S*b*pl.nsx*pl.nsy;
   return check_launch(smd::launch_sum_partials(ws.loss_partial, count, 1.0/((double)S*b*h*w), loss, st), "loss reduction");
 }
 
-int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
+int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_packed, const float* T, const float* K,
                         const float* K_inv, const uint8_t* sel, const float* g_loss,
                         float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
-  if (!depth || !tgt || !supp || !T || !K || !K_inv || !sel || !g_loss || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (!depth || !tgt || !supp_packed || !T || !K || !K_inv || !sel || !g_loss || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if ((flags & SMD_NEED_K_GRAD) && (!g_K || !g_Kinv)) return fail(SMD_E_INVALID, "SMD_NEED_K_GRAD requires g_K and g_Kinv");
   if (n >= SMD_SEL_MASKED) return fail(SMD_E_INVALID, "too many supports");
   ReconWs ws = carve_recon(workspace, b, n, S, h, w);
@@ -163,13 +198,15 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp,
 
   smd::ReconBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.depth = depth; a.tgt = tgt; a.supp = supp; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
+  a.depth = depth; a.tgt = tgt; a.supp_pk = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
   a.g_depth = g_depth; a.pose_partial = ws.pose_partial;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   const StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
+  prof_mark(SMD_PROF_RECON_BWD, st, true);
   if (int rc = check_launch(smd::launch_recon_bwd(a, st), "image_recon_bwd")) return rc;
+  prof_mark(SMD_PROF_RECON_BWD, st, false);
   return check_launch(smd::launch_pose_finalize(ws.pose_partial, S*pl.nsx*pl.nsy, T, K, K_inv, g_T,
                                                 (flags & SMD_NEED_K_GRAD) ? g_K : nullptr, (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr,
                                                 b, n, st), "pose finalize");
@@ -210,6 +247,35 @@ int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, 
   if (int rc = fill_scales(sc, disp, g_disp, hs, ws, scale_keys, S)) return rc;
   for (int s = 0; s < S; ++s) if (!disp[s] || !g_disp[s]) return fail(SMD_E_INVALID, "null pointer for scale %d", s);
   return check_launch(smd::launch_smooth_bwd(sc, b, img, h, w, flags, stats, g_loss, (hipStream_t)stream), "disp_smooth_bwd");
+}
+
+int smd_profile_enable(int which, int capacity) {
+  if (which < 0 || which > 1 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
+  ProfSlot& p = g_prof[which];
+  for (int i = 0; i < 2*p.cap; ++i) hipEventDestroy(p.ev[i]);
+  delete[] p.ev;
+  p = ProfSlot();
+  if (capacity == 0) return SMD_OK;
+  p.ev = new hipEvent_t[2*capacity];
+  for (int i = 0; i < 2*capacity; ++i)
+    if (hipEventCreate(&p.ev[i]) != hipSuccess) return fail(SMD_E_LAUNCH, "hipEventCreate failed");
+  p.cap = capacity;
+  return SMD_OK;
+}
+
+int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out) {
+  if (which < 0 || which > 1 || !ms_out || !n_out) return fail(SMD_E_INVALID, "bad profile arguments");
+  ProfSlot& p = g_prof[which];
+  int n = 0;
+  for (int i = 0; i < p.used && n < max_out; ++i) {
+    if (hipEventSynchronize(p.ev[2*i + 1]) != hipSuccess) return fail(SMD_E_LAUNCH, "hipEventSynchronize failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.ev[2*i], p.ev[2*i + 1]) != hipSuccess) return fail(SMD_E_LAUNCH, "hipEventElapsedTime failed");
+    ms_out[n++] = ms;
+  }
+  p.used = 0;
+  *n_out = n;
+  return SMD_OK;
 }
 
 int smd_debug_lane_shift(float* out_left, float* out_right, void* stream) {

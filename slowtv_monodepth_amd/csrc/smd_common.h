@@ -18,6 +18,7 @@ constexpr float kZMin = 0.1f;             // z.clamp(min=0.1)          (src/tool
 constexpr int kWave = 64;
 
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load that is only 4-byte aligned
+typedef float f4 __attribute__((ext_vector_type(4)));               // one RGBX texel of a repacked support frame
 
 // ---------------------------------------------------------------------------------------------
 // Cross-lane neighbours (DPP wave shifts; one VALU op each, no LDS traffic).
@@ -76,6 +77,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // which equals K[:, :3, :3] @ ((T @ [D * Kinv3 @ pix; 1])[:3] / z.clamp(eps).clamp(0.1)) of
 // src/tools/geometry.py:312-316, :386, :339-341 up to fp32 re-association.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float uniform(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
 struct Cam {
   float H[9];
   float a0, a1, tz;
@@ -98,6 +103,11 @@ __device__ __forceinline__ void make_cam(Cam& c, const float* __restrict__ T, co
   c.a0 = K[0]*T[3] + K[1]*T[7] + K[2]*T[11];
   c.a1 = K[4]*T[3] + K[5]*T[7] + K[6]*T[11];
   c.tz = T[11];
+  // The inputs are wave-uniform but fp math runs on the VALU: pin the results into SGPRs so that the twelve constants
+  // per support do not occupy vector registers for the whole kernel.
+#pragma unroll
+  for (int q = 0; q < 9; ++q) c.H[q] = uniform(c.H[q]);
+  c.a0 = uniform(c.a0); c.a1 = uniform(c.a1); c.tz = uniform(c.tz);
 }
 
 // Bilinear, border-clamped 4-tap gather setup (grid_sample(bilinear, border, align_corners=False)).
@@ -134,6 +144,10 @@ __device__ __forceinline__ float bilerp(const float* __restrict__ plane, const T
   float top = fmaf(t.fx, n.y - n.x, n.x), bot = fmaf(t.fx, s.y - s.x, s.x);
   return fmaf(t.fy, bot - top, top);
 }
+
+// Uniform base + 32-bit lane offset: lets the compiler use the saddr form (no 64-bit VALU address arithmetic).
+__device__ __forceinline__ float ld1(const float* base, unsigned idx) { return *(const float*)((const char*)base + (size_t)(idx*4u)); }
+__device__ __forceinline__ f4 ld4(const float* base, unsigned texel) { return *(const f4*)((const char*)base + (size_t)(texel*16u)); }
 
 // SSIM error of one channel from the nine-tap window sums (already divided by 9 where noted).
 //   mx = E[x], exx = E[x^2], exy = E[xy];  my = E[y], cy1 = my^2 + C1, cy2 = var(y) + C2

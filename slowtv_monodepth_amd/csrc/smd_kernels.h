@@ -27,7 +27,7 @@ struct ScaleSet {  // the multi-scale disparity pyramid, passed by value
 struct ReconFwdArgs {
   const float* depth;     // (S,b,h,w); unused when WARP == false
   const float* tgt;       // (b,3,h,w)
-  const float* supp;      // (n,b,3,h,w)
+  const float* supp_pk;   // (n,b,h,w,4) supports repacked as RGBX texels (16-byte aligned gathers)
   const float* T;         // (n,b,4,4)
   const float* K;         // (b,4,4)
   const float* Kinv;      // (b,4,4)
@@ -45,10 +45,11 @@ struct ReconFwdArgs {
   float wscale, hscale;   // w/(w-1), h/(h-1)
   uint32_t seed_lo, seed_hi;
   int first_pass, last_pass;
+  int variant;            // code-generation variant of the hot instantiation (tuning)
 };
 
 struct ReconBwdArgs {
-  const float* depth; const float* tgt; const float* supp; const float* T; const float* K; const float* Kinv;
+  const float* depth; const float* tgt; const float* supp_pk; const float* T; const float* K; const float* Kinv;
   const uint8_t* sel;
   const float* g_loss;    // device scalar
   float* g_depth;         // (S,b,h,w)
@@ -62,6 +63,7 @@ struct ReconBwdArgs {
 // launchers (return hipError_t from hipGetLastError after the launch)
 hipError_t launch_recon_fwd(const ReconFwdArgs& a, int ni, bool warp, hipStream_t st);
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st);
+hipError_t launch_pack_supports(const float* supp, float* supp_pk, int nb, int h, int w, hipStream_t st);
 hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st);
 hipError_t launch_pose_finalize(const float* pose_partial, int entries, const float* T, const float* K, const float* Kinv,
                                 float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st);

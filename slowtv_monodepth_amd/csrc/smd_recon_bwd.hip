@@ -2,9 +2,10 @@
 //
 // Same wave-strip streaming structure as the forward (smd_recon_fwd.hip) with a three-stage software pipeline
 // per row step j (60 interior columns, 2 halo lanes per side, rows r0-2 .. r1+1):
-//   stage A (row j)   : re-synthesise the warped pixel x and its bilinear partials dx/dsx, dx/dsy; horizontal
-//                       3-tap sums; roll the vertical accumulators -> window statistics of row j-1 complete
-//   stage B (row j-1) : SSIM partials d e/d(E[x], E[x^2], E[xy]) times the upstream gradient routed by `sel`
+//   stage A (row j)   : re-synthesise the warped pixel x and its bilinear partials dx/dsx, dx/dsy from the four RGBX
+//                       taps whose loads were issued one row earlier (software pipeline); issue row j+1's loads
+//   stage B (row j-1) : window sums from the 3-row ring of raw values (vertical taps per lane, horizontal taps via DPP),
+//                       SSIM partials d e/d(Sx, Sxx, Sxy) times the upstream gradient routed by `sel`
 //                       (min-reprojection / automask), box-summed with the ADJOINT reflection weights
 //                       (avg_pool2d + reflection_pad2d backward) -> complete for row j-2
 //   stage C (row j-2) : dL/dx -> dL/d(sx, sy) (zero where the border clamp is active) -> projective chain rule
@@ -15,6 +16,30 @@
 #include "smd_kernels.h"
 
 namespace smd {
+
+// Reflection-weighted horizontal 3-tap through DPP wave shifts, as ONE asm block: keeps shift and FMA adjacent (left
+// alone the compiler batches every shift of a row first and keeps ~50 results live).  s_nop covers the VALU-write ->
+// DPP-read hazard the compiler cannot see inside asm.
+__device__ __forceinline__ float hsum_w(float q, float wl, float wr) {
+#ifdef SMD_NO_DPP
+  return hsum3(q, wl, wr);
+#else
+  float r, t;
+  asm volatile("s_nop 1\n\t"
+               "v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fma_f32 %0, %3, %1, %2\n\t"
+               "v_mov_b32_dpp %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fma_f32 %0, %4, %1, %0"
+               : "=&v"(r), "=&v"(t) : "v"(q), "v"(wl), "v"(wr));
+  return r;
+#endif
+}
+
+struct BwdPending {   // loads in flight for the next row
+  f4 t[4];            // bilinear taps NW, NE, SW, SE (RGBX texels)
+  float y[3];
+  float fx, fy, kx, ky;
+};
 
 __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
   const int lane = threadIdx.x & 63;
@@ -30,22 +55,22 @@ __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
 
   const int u = c0 - 2 + lane;
   const bool col_ok = (u >= 0) && (u < w);
-  const int uc = min(max(u, 0), w - 1);
+  const unsigned uc = (unsigned)min(max(u, 0), w - 1);
   const bool interior = (lane >= 2) && (lane < 2 + kBwdCols) && (u < w);
   float wl, wr, wla, wra;
-  reflect_weights(uc, w, wl, wr);
-  reflect_weights_adj(uc, w, wla, wra);
+  reflect_weights((int)uc, w, wl, wr);
+  reflect_weights_adj((int)uc, w, wla, wra);
   if (!col_ok) { wl = wr = wla = wra = 0.f; }
   const float uf = (float)u;
 
   const bool use_min = a.flags & SMD_USE_MIN;
   const bool l1_only = a.flags & SMD_LOSS_L1;
-  const size_t hw = (size_t)h*w;
+  const unsigned hw = (unsigned)h*(unsigned)w;
   const float w_ssim = l1_only ? 0.f : kWSsim/3.f;
   const float w_l1 = l1_only ? 1.f/3.f : (1.f - kWSsim)/3.f;
   float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
   if (!use_min) gscale /= (float)a.n;
-  const float ninth = 1.f/9.f;
+  constexpr float c1 = 81.f*kC1, c2 = 81.f*kC2;   // window sums stay un-normalised (x9), see smd_recon_fwd.hip
 
   const float* tgt_b = a.tgt + (size_t)bi*3*hw;
   const float* depth_sb = a.depth + ((size_t)s*a.b + bi)*hw;
@@ -55,92 +80,119 @@ __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
   for (int i = 0; i < a.n; ++i) {
     Cam cm;
     make_cam(cm, a.T + ((size_t)i*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16);
-    const float* splane = a.supp + ((size_t)i*a.b + bi)*3*hw;
+    const float* spk = a.supp_pk + ((size_t)i*a.b + bi)*4*hw;
 
-    float ay1[3][2] = {}, ay0[3][2] = {};      // vertical accumulators of {y, y^2}
-    float ax1[3][3] = {}, ax0[3][3] = {};      // ... of {x, x^2, xy}
-    float ac1[3][3] = {}, ac0[3][3] = {};      // ... of the coefficient maps {A, B, C} (adjoint weights)
-    float x1[3] = {}, x2[3] = {};              // warped pixel of rows j-1, j-2
-    float gx1[3] = {}, gx2[3] = {}, gy1[3] = {}, gy2[3] = {};  // dx/dpx, dx/dpy (clamp mask and grid scale folded in)
+    // rings of raw per-pixel values: index 0 = row j, 1 = row j-1, 2 = row j-2
+    float x0[3] = {}, x1[3] = {}, x2[3] = {}, y0[3] = {}, y1[3] = {}, y2[3] = {};
+    float gx0[3] = {}, gx1[3] = {}, gx2[3] = {}, gy0[3] = {}, gy1[3] = {}, gy2[3] = {};  // dx/dpx, dx/dpy (clamp mask, grid scale folded in)
+    float ac1[3][3] = {}, ac0[3][3] = {};      // vertical accumulators of the h-summed coefficient maps {A, B, C}
     float psum[kPoseSums] = {};
+    BwdPending P = {};
+
+    auto issue = [&](int jr, float D) {   // stage 1 of row jr: coordinates + gathers
+      const unsigned ro = (unsigned)jr*(unsigned)w + uc;
+      const float vf = (float)jr;
+      float hx = fmaf(cm.H[0], uf, fmaf(cm.H[1], vf, cm.H[2]));
+      float hyy = fmaf(cm.H[3], uf, fmaf(cm.H[4], vf, cm.H[5]));
+      float hz = fmaf(cm.H[6], uf, fmaf(cm.H[7], vf, cm.H[8]));
+      float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hyy, cm.a1), yz = fmaf(D, hz, cm.tz);
+      float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
+      float sx = fmaf(nx*rz, a.wscale, -0.5f), sy = fmaf(ny*rz, a.hscale, -0.5f);
+      Taps tp = make_taps(sx, sy, h, w);
+      P.fx = tp.fx; P.fy = tp.fy; P.kx = tp.mx*a.wscale; P.ky = tp.my*a.hscale;
+      const unsigned o = (unsigned)tp.off;
+      P.t[0] = ld4(spk, o); P.t[1] = ld4(spk, o + 1u); P.t[2] = ld4(spk, o + (unsigned)w); P.t[3] = ld4(spk, o + (unsigned)w + 1u);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) P.y[c] = ld1(tgt_b, c*hw + ro);
+    };
 
     const int jstart = max(r0 - 2, 0);
+    const int jlast = min(r1 + 1, h - 1);
+    float Dn = ld1(depth_sb, (unsigned)jstart*(unsigned)w + uc);
+    issue(jstart, Dn);
+    if (jstart + 1 <= jlast) Dn = ld1(depth_sb, (unsigned)(jstart + 1)*(unsigned)w + uc);
+
     for (int j = jstart; j <= r1 + 1; ++j) {
-      // ================= stage A: row j =================
-      float hy[3][2] = {}, hxs[3][3] = {};
-      float x0[3] = {}, gx0[3] = {}, gy0[3] = {};
-      if (j < h) {
-        const float D = col_ok ? depth_sb[(size_t)j*w + uc] : 0.f;
-        const float vf = (float)j;
-        float hx = fmaf(cm.H[0], uf, fmaf(cm.H[1], vf, cm.H[2]));
-        float hyy = fmaf(cm.H[3], uf, fmaf(cm.H[4], vf, cm.H[5]));
-        float hz = fmaf(cm.H[6], uf, fmaf(cm.H[7], vf, cm.H[8]));
-        float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hyy, cm.a1), yz = fmaf(D, hz, cm.tz);
-        float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
-        float sx = fmaf(nx*rz, a.wscale, -0.5f), sy = fmaf(ny*rz, a.hscale, -0.5f);
-        Taps tp = make_taps(sx, sy, h, w);
-        const float kx = tp.mx*a.wscale, ky = tp.my*a.hscale;
+      // ================= stage A: row j — consume its loads, issue the next row's =================
+      if (j <= jlast) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float y = col_ok ? tgt_b[(size_t)c*hw + (size_t)j*w + uc] : 0.f;
-          float ddx, ddy;
-          float x = bilerp(splane + (size_t)c*hw, tp, w, ddx, ddy);
-          x = col_ok ? x : 0.f;
-          x0[c] = x; gx0[c] = ddx*kx; gy0[c] = ddy*ky;
-          if (!l1_only) {
-            hy[c][0] = hsum3(y, wl, wr); hy[c][1] = hsum3(y*y, wl, wr);
-            hxs[c][0] = hsum3(x, wl, wr); hxs[c][1] = hsum3(x*x, wl, wr); hxs[c][2] = hsum3(x*y, wl, wr);
-          }
+          const float dn = P.t[1][c] - P.t[0][c], ds = P.t[3][c] - P.t[2][c];
+          const float top = fmaf(P.fx, dn, P.t[0][c]), bot = fmaf(P.fx, ds, P.t[2][c]);
+          const float ddy = bot - top;
+          x0[c] = fmaf(P.fy, ddy, top);
+          gx0[c] = fmaf(P.fy, ds - dn, dn)*P.kx;
+          gy0[c] = ddy*P.ky;
+          y0[c] = P.y[c];
         }
       }
+      if (j + 1 <= jlast) {
+        issue(j + 1, Dn);
+        if (j + 2 <= jlast) Dn = ld1(depth_sb, (unsigned)(j + 2)*(unsigned)w + uc);
+      }
 
-      // ================= stage B: row p = j-1 =================
+      // ================= stage B: row p = j-1 — SSIM partials, h-summed with the adjoint weights =================
       const int p = j - 1;
       float hc[3][3] = {};
       if (!l1_only && p >= max(r0 - 1, 0) && p <= min(r1, h - 1)) {
         float lo_p, hi_p;
-        reflect_weights(p, h, lo_p, hi_p);
-        const uint8_t sl = col_ok ? sel_sb[(size_t)p*w + uc] : (uint8_t)SMD_SEL_MASKED;
+        reflect_weights(p, h, lo_p, hi_p);   // vertical reflection weights of rows p-1 (ring 2) and p+1 (ring 0)
+        if (j >= h) hi_p = 0.f;              // row p+1 does not exist: ring 0 holds stale (finite) values
+        const uint8_t sl = sel_sb[(unsigned)p*(unsigned)w + uc];
         const bool active = use_min ? (sl == (uint8_t)i) : (sl != (uint8_t)SMD_SEL_MASKED);
         const float g = (active && col_ok) ? gscale*w_ssim : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float my = fmaf(hi_p, hy[c][0], ay1[c][0])*ninth, eyy = fmaf(hi_p, hy[c][1], ay1[c][1])*ninth;
-          float cy1 = fmaf(my, my, kC1), cy2 = (eyy - my*my) + kC2;
-          float mx = fmaf(hi_p, hxs[c][0], ax1[c][0])*ninth;
-          float exx = fmaf(hi_p, hxs[c][1], ax1[c][1])*ninth;
-          float exy = fmaf(hi_p, hxs[c][2], ax1[c][2])*ninth;
-          float dmx, dexx, dexy;
-          ssim_err_grad(mx, exx, exy, my, cy1, cy2, dmx, dexx, dexy);
-          hc[c][0] = hsum3(g*dmx, wla, wra);
-          hc[c][1] = hsum3(g*dexx, wla, wra);
-          hc[c][2] = hsum3(g*dexy, wla, wra);
+          const float ya = lo_p*y2[c], yc_ = hi_p*y0[c], xa = lo_p*x2[c], xc_ = hi_p*x0[c];
+          const float sy = hsum_w((ya + y1[c]) + yc_, wl, wr);
+          const float syy = hsum_w(fmaf(yc_, y0[c], fmaf(ya, y2[c], y1[c]*y1[c])), wl, wr);
+          const float sx = hsum_w((xa + x1[c]) + xc_, wl, wr);
+          const float sxx = hsum_w(fmaf(xc_, x0[c], fmaf(xa, x2[c], x1[c]*x1[c])), wl, wr);
+          const float sxy = hsum_w(fmaf(xc_, y0[c], fmaf(xa, y2[c], x1[c]*y1[c])), wl, wr);
+          // e = (1 - N/Dn)/2 with N = a1*a2, Dn = b1*b2 on the x9 sums (both scaled by 81*81)
+          const float t = sx*sy;
+          const float a1 = fmaf(2.f, t, c1), a2 = fmaf(2.f, fmaf(9.f, sxy, -t), c2);
+          const float sx2 = sx*sx;
+          const float b1 = sx2 + fmaf(sy, sy, c1), b2 = fmaf(9.f, sxx, -sx2) + (fmaf(9.f, syy, c2) - sy*sy);
+          const float rden = __builtin_amdgcn_rcpf(b1*b2);
+          const float val = a1*a2*rden;
+          const float e = fmaf(-0.5f, val, 0.5f);
+          const float pass = (e >= 0.f && e <= 1.f) ? -0.5f*g : 0.f;   // d e/d val, gated by the clamp(0,1), times upstream
+          // partials w.r.t. the x9 sums Sx, Sxx, Sxy (a1, a2, b1, b2 as functions of them):
+          //   da1/dSx = 2 Sy, da2/dSx = -2 Sy, db1/dSx = 2 Sx, db2/dSx = -2 Sx, da2/dSxy = 18, db2/dSxx = 9
+          const float prd = pass*rden;
+          const float dSx = prd*(2.f*sy*(a2 - a1) - 2.f*sx*val*(b2 - b1));
+          const float dSxx = prd*(-9.f*val*b1);
+          const float dSxy = prd*(18.f*a1);
+          hc[c][0] = hsum_w(dSx, wla, wra);
+          hc[c][1] = hsum_w(dSxx, wla, wra);
+          hc[c][2] = hsum_w(dSxy, wla, wra);
         }
       }
 
-      // ================= stage C: row q = j-2 =================
+      // ================= stage C: row q = j-2 — dL/dx -> dL/d(px,py) -> depth, pose sums =================
       const int q = j - 2;
       if (q >= r0 && q < r1) {
         float lo_q, hi_q;
         reflect_weights_adj(q, h, lo_q, hi_q);
-        const uint8_t sl = col_ok ? sel_sb[(size_t)q*w + uc] : (uint8_t)SMD_SEL_MASKED;
+        const unsigned rq = (unsigned)q*(unsigned)w + uc;
+        const uint8_t sl = sel_sb[rq];
         const bool active = use_min ? (sl == (uint8_t)i) : (sl != (uint8_t)SMD_SEL_MASKED);
         const float gl = (active && col_ok) ? gscale*w_l1 : 0.f;
         float gpx = 0.f, gpy = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float y = col_ok ? tgt_b[(size_t)c*hw + (size_t)q*w + uc] : 0.f;
-          float d = x2[c] - y;
+          const float d = x2[c] - y2[c];
           float gxc = gl*((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
           if (!l1_only) {
-            float SA = fmaf(hi_q, hc[c][0], ac1[c][0]), SB = fmaf(hi_q, hc[c][1], ac1[c][1]), SC = fmaf(hi_q, hc[c][2], ac1[c][2]);
-            gxc += ninth*(SA + 2.f*x2[c]*SB + y*SC);
+            const float SA = fmaf(hi_q, hc[c][0], ac1[c][0]), SB = fmaf(hi_q, hc[c][1], ac1[c][1]), SC = fmaf(hi_q, hc[c][2], ac1[c][2]);
+            gxc += fmaf(2.f*x2[c], SB, fmaf(y2[c], SC, SA));   // d/dx_q of the x9 sums: 1, 2 x_q, y_q
           }
           gpx = fmaf(gxc, gx2[c], gpx);
           gpy = fmaf(gxc, gy2[c], gpy);
         }
         // projective chain rule at (q, u): recompute the cheap geometry
-        const float D = col_ok ? depth_sb[(size_t)q*w + uc] : 0.f;
+        const float D = ld1(depth_sb, rq);
         const float vf = (float)q;
         float hx = fmaf(cm.H[0], uf, fmaf(cm.H[1], vf, cm.H[2]));
         float hyy = fmaf(cm.H[3], uf, fmaf(cm.H[4], vf, cm.H[5]));
@@ -152,7 +204,7 @@ __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
         if (!interior) { gnx = 0.f; gny = 0.f; gz = 0.f; }
         float gD = fmaf(gnx, hx, fmaf(gny, hyy, gz*hz));
         if (interior) {
-          float* gp = gd_sb + (size_t)q*w + u;
+          float* gp = gd_sb + rq;
           if (i == 0) *gp = gD; else *gp += gD;
         }
         float dnx = gnx*D, dny = gny*D, dz = gz*D;
@@ -163,28 +215,19 @@ __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
       }
 
       // ================= roll =================
-      float lo_n, hi_n, lo_na, hi_na;
-      reflect_weights(min(j + 1, h - 1), h, lo_n, hi_n);
-      if (j + 1 >= h) lo_n = 0.f;
-      reflect_weights_adj(min(max(p + 1, 0), h - 1), h, lo_na, hi_na);  // weight of coefficient row p in out(p+1)
-      if (p + 1 >= h || p < 0) lo_na = 0.f;
       if (!l1_only) {
+        float lo_na, hi_na;
+        reflect_weights_adj(min(max(p + 1, 0), h - 1), h, lo_na, hi_na);  // weight of coefficient row p in out(p+1)
+        if (p + 1 >= h || p < 0) lo_na = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) { ay1[c][k] = ay0[c][k] + hy[c][k]; ay0[c][k] = lo_n*hy[c][k]; }
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            ax1[c][k] = ax0[c][k] + hxs[c][k]; ax0[c][k] = lo_n*hxs[c][k];
-            ac1[c][k] = ac0[c][k] + hc[c][k];  ac0[c][k] = lo_na*hc[c][k];
-          }
-        }
+          for (int k = 0; k < 3; ++k) { ac1[c][k] = ac0[c][k] + hc[c][k]; ac0[c][k] = lo_na*hc[c][k]; }
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        x2[c] = x1[c]; x1[c] = x0[c];
-        gx2[c] = gx1[c]; gx1[c] = gx0[c];
-        gy2[c] = gy1[c]; gy1[c] = gy0[c];
+        x2[c] = x1[c]; x1[c] = x0[c]; y2[c] = y1[c]; y1[c] = y0[c];
+        gx2[c] = gx1[c]; gx1[c] = gx0[c]; gy2[c] = gy1[c]; gy1[c] = gy0[c];
       }
     }
 

@@ -93,10 +93,11 @@ class _ImageRecon(torch.autograd.Function):
         warp0 = torch.empty((n, b, 3, h, w), device=dev, dtype=torch.float32) if want_warp else None
         nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        supp_pk = torch.empty((n, b, h, w, 4), device=dev, dtype=torch.float32)  # RGBX texels, reused by the backward
         call('smd_image_recon_fwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
-             noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
+             noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), supp_pk.data_ptr(), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
              warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, int(flags), _stream())
-        ctx.save_for_backward(depth, tgt, supp, T, K, K_inv, sel)
+        ctx.save_for_backward(depth, tgt, supp_pk, T, K, K_inv, sel)
         ctx.meta = (b, n, S, h, w, int(flags))
         ctx.need_k = bool(ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
         ctx.mark_non_differentiable(err, sel)
@@ -105,7 +106,7 @@ class _ImageRecon(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *_):
-        depth, tgt, supp, T, K, K_inv, sel = ctx.saved_tensors
+        depth, tgt, supp_pk, T, K, K_inv, sel = ctx.saved_tensors
         b, n, S, h, w, flags = ctx.meta
         dev = depth.device
         g_loss = g_loss.to(torch.float32).contiguous()
@@ -116,7 +117,7 @@ class _ImageRecon(torch.autograd.Function):
         if ctx.need_k: flags |= FLAGS['need_k_grad']
         nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        call('smd_image_recon_bwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
+        call('smd_image_recon_bwd', depth.data_ptr(), tgt.data_ptr(), supp_pk.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              sel.data_ptr(), g_loss.data_ptr(), g_depth.data_ptr(), g_T.data_ptr(),
              g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
              ws.data_ptr(), nbytes, b, n, S, h, w, flags, _stream())

@@ -1,0 +1,56 @@
+"""Monodepth(2) decoder — registry key `monodepth` (reference: `src/networks/decoders/monodepth.py:14-89`)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..registry import register
+
+__all__ = ['MonodepthDecoder', 'ACT']
+
+ACT = {'sigmoid': nn.Sigmoid(), 'relu': nn.ReLU(inplace=True), 'none': nn.Identity(), None: nn.Identity()}
+
+
+def conv3x3(cin: int, cout: int) -> nn.Conv2d:
+    """3x3 conv with reflection padding (src/networks/decoders/utils.py:44-46)."""
+    return nn.Conv2d(cin, cout, 3, padding=1, padding_mode='reflect')
+
+
+class ConvELU(nn.Sequential):
+    def __init__(self, cin, cout): super().__init__(conv3x3(cin, cout), nn.ELU(inplace=True))
+
+
+@register('monodepth')
+class MonodepthDecoder(nn.Module):
+    """Five up-convolution stages (256..16 channels) with encoder skips where a matching stride exists, and a
+    3x3 output head per requested scale.
+
+    :param num_ch_enc / enc_sc: channels and strides of the encoder features.
+    :param out_sc: scales (as log2 stride) at which to emit a prediction; out_ch / out_act: its channels / activation.
+    """
+    def __init__(self, num_ch_enc, enc_sc, upsample_mode: str = 'nearest', use_skip: bool = True,
+                 out_sc=(0, 1, 2, 3), out_ch: int = 1, out_act: str = 'sigmoid'):
+        super().__init__()
+        if out_act not in ACT: raise KeyError(f'Invalid activation key. ({out_act} vs. {tuple(ACT.keys())}')
+        self.num_ch_enc, self.enc_sc = list(num_ch_enc), list(enc_sc)
+        self.upsample_mode, self.use_skip, self.out_sc, self.out_ch = upsample_mode, use_skip, list(out_sc), out_ch
+        self.act = ACT[out_act]
+        self.num_ch_dec = [16, 32, 64, 128, 256]
+        self.up0, self.up1, self.out = nn.ModuleDict(), nn.ModuleDict(), nn.ModuleDict()
+        for i in range(4, -1, -1):
+            cin = self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
+            self.up0[str(i)] = ConvELU(cin, self.num_ch_dec[i])
+            cin = self.num_ch_dec[i]
+            if use_skip and 2**i in self.enc_sc: cin += self.num_ch_enc[self.enc_sc.index(2**i)]
+            self.up1[str(i)] = ConvELU(cin, self.num_ch_dec[i])
+        for i in self.out_sc: self.out[str(i)] = conv3x3(self.num_ch_dec[i], out_ch)
+
+    def forward(self, feat):
+        out, x = {}, feat[-1]
+        for i in range(4, -1, -1):
+            x = F.interpolate(self.up0[str(i)](x), scale_factor=2, mode=self.upsample_mode)
+            if self.use_skip and 2**i in self.enc_sc: x = torch.cat((x, feat[self.enc_sc.index(2**i)]), 1)
+            x = self.up1[str(i)](x)
+            if i in self.out_sc: out[i] = self.act(self.out[str(i)](x))
+        return out

@@ -1,0 +1,145 @@
+"""`features_only` image encoders in plain `torch.nn`.
+
+The reference builds its encoders with `timm.create_model(name, features_only=True[, in_chans=6])`
+(src/networks/depth.py:95-98, src/networks/pose.py:39-41).  timm is not available on the MI355X image, so the three
+families the BASELINE configurations name are restated here with the same stage layout, the same multi-scale feature
+list and the same `feature_info.channels()/reduction()` accessors.  Weights are randomly initialised (`pretrained`
+is accepted for cfg compatibility; there is no network access to fetch ImageNet weights).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ['create_encoder', 'FeatureInfo', 'ResNetFeatures', 'ConvNeXtFeatures', 'ENCODERS']
+
+
+class FeatureInfo:
+    def __init__(self, channels, reduction): self._c, self._r = list(channels), list(reduction)
+    def channels(self): return list(self._c)
+    def reduction(self): return list(self._r)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(cout)
+        self.down = None
+        if stride != 1 or cin != cout:
+            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.down is None else self.down(x)
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        return F.relu(self.bn2(self.conv2(x)) + idt, inplace=True)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, mid, stride):
+        super().__init__()
+        cout = mid*4
+        self.conv1 = nn.Conv2d(cin, mid, 1, bias=False); self.bn1 = nn.BatchNorm2d(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False); self.bn2 = nn.BatchNorm2d(mid)
+        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False); self.bn3 = nn.BatchNorm2d(cout)
+        self.down = None
+        if stride != 1 or cin != cout:
+            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.down is None else self.down(x)
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = F.relu(self.bn2(self.conv2(x)), inplace=True)
+        return F.relu(self.bn3(self.conv3(x)) + idt, inplace=True)
+
+
+class ResNetFeatures(nn.Module):
+    """ResNet trunk returning [stem (1/2), layer1 (1/4), layer2 (1/8), layer3 (1/16), layer4 (1/32)]."""
+    def __init__(self, layers=(2, 2, 2, 2), bottleneck=False, in_chans=3):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_chans, 64, 7, 2, 3, bias=False); self.bn1 = nn.BatchNorm2d(64)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        widths, exp = (64, 128, 256, 512), (4 if bottleneck else 1)
+        stages, cin = [], 64
+        for i, (wd, nb) in enumerate(zip(widths, layers)):
+            blocks = []
+            for j in range(nb):
+                stride = 2 if (j == 0 and i > 0) else 1
+                blocks.append(Bottleneck(cin, wd, stride) if bottleneck else BasicBlock(cin, wd, stride))
+                cin = wd*exp
+            stages.append(nn.Sequential(*blocks))
+        self.layers = nn.ModuleList(stages)
+        self.feature_info = FeatureInfo([64] + [wd*exp for wd in widths], [2, 4, 8, 16, 32])
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d): nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        feats = [x]
+        x = self.maxpool(x)
+        for layer in self.layers:
+            x = layer(x); feats.append(x)
+        return feats
+
+
+class LayerNorm2d(nn.LayerNorm):
+    """LayerNorm over the channel dim of an NCHW tensor."""
+    def forward(self, x):
+        return F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+
+
+class ConvNeXtBlock(nn.Module):
+    def __init__(self, dim, ls_init=1e-6):
+        super().__init__()
+        self.dw = nn.Conv2d(dim, dim, 7, padding=3, groups=dim)
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.fc1 = nn.Linear(dim, 4*dim); self.fc2 = nn.Linear(4*dim, dim)
+        self.gamma = nn.Parameter(ls_init*torch.ones(dim))
+
+    def forward(self, x):
+        y = self.dw(x).permute(0, 2, 3, 1)
+        y = self.fc2(F.gelu(self.fc1(self.norm(y))))*self.gamma
+        return x + y.permute(0, 3, 1, 2)
+
+
+class ConvNeXtFeatures(nn.Module):
+    """ConvNeXt trunk returning the four stage outputs at strides [4, 8, 16, 32]."""
+    def __init__(self, depths=(3, 3, 9, 3), dims=(96, 192, 384, 768), in_chans=3):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(in_chans, dims[0], 4, 4), LayerNorm2d(dims[0], eps=1e-6))
+        stages = []
+        for i, (d, c) in enumerate(zip(depths, dims)):
+            mods = []
+            if i > 0: mods += [LayerNorm2d(dims[i - 1], eps=1e-6), nn.Conv2d(dims[i - 1], c, 2, 2)]
+            mods += [ConvNeXtBlock(c) for _ in range(d)]
+            stages.append(nn.Sequential(*mods))
+        self.stages = nn.ModuleList(stages)
+        self.feature_info = FeatureInfo(dims, [4, 8, 16, 32])
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None: nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        x = self.stem(x)
+        feats = []
+        for st in self.stages:
+            x = st(x); feats.append(x)
+        return feats
+
+
+ENCODERS = {
+    'resnet18': lambda c: ResNetFeatures((2, 2, 2, 2), False, c),
+    'resnet34': lambda c: ResNetFeatures((3, 4, 6, 3), False, c),
+    'resnet50': lambda c: ResNetFeatures((3, 4, 6, 3), True, c),
+    'convnext_tiny': lambda c: ConvNeXtFeatures((3, 3, 9, 3), (96, 192, 384, 768), c),
+    'convnext_small': lambda c: ConvNeXtFeatures((3, 3, 27, 3), (96, 192, 384, 768), c),
+    'convnext_base': lambda c: ConvNeXtFeatures((3, 3, 27, 3), (128, 256, 512, 1024), c),
+}
+
+
+def create_encoder(name: str, in_chans: int = 3, pretrained: bool = False) -> nn.Module:
+    """Stand-in for `timm.create_model(name, features_only=True, in_chans=...)`; `pretrained` cannot be honoured offline."""
+    if name not in ENCODERS: raise KeyError(f'Unknown encoder "{name}". Available: {sorted(ENCODERS)}')
+    return ENCODERS[name](in_chans)

@@ -1,0 +1,121 @@
+"""Training entry point: `python -m slowtv_monodepth_amd.train -c cfg.yaml [override.yaml ...] -n NAME [-v 0] [-s 42] [-g N]`.
+
+Mirrors the flags and cfg handling of the reference's `api/train/train.py:16-33` (ordered YAML merge, seed, number of
+GPUs) with an own loop instead of PyTorch-Lightning: one process per GPU (`torchrun`/`torch.distributed.run` sets
+RANK/LOCAL_RANK/WORLD_SIZE), DistributedDataParallel over RCCL with the gradient all-reduce overlapped with backward,
+`no_sync()` on gradient-accumulation micro-steps (`trainer.accumulate_grad_batches`, train.py:110), AdamW +
+StepLR∘LinearLR.  Data are device-resident synthetic triplets (`synthetic.make_batch`); the dataset section of a
+reference cfg is ignored.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+from contextlib import nullcontext
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import io
+from .synthetic import make_batch
+from .trainer import MonoDepthModule
+
+__all__ = ['StepModule', 'wrap_ddp', 'train_steps', 'init_distributed', 'main']
+
+
+class StepModule(nn.Module):
+    """DDP hooks the module whose `forward` it is given; the training step is that forward (as Lightning does)."""
+    def __init__(self, module: MonoDepthModule):
+        super().__init__()
+        self.module = module
+
+    def forward(self, batch):
+        loss, loss_dict, _ = self.module.step(batch)
+        return loss, {k: v.detach() for k, v in loss_dict.items() if k.startswith('loss_')}
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    """(rank, local_rank, world) from the torchrun environment; initialises the process group when world > 1."""
+    world = int(os.environ.get('WORLD_SIZE', 1)); rank = int(os.environ.get('RANK', 0)); local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')  # 'nccl' is RCCL on ROCm
+        if backend == 'nccl': torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def wrap_ddp(step: StepModule, device: torch.device, bucket_cap_mb: int = 25) -> nn.Module:
+    """DDP over RCCL/xGMI: gradients are reduced in `bucket_cap_mb` buckets as backward produces them (overlap), buckets
+    alias the .grad tensors, BatchNorm statistics stay per rank (the reference does not enable SyncBN)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1): return step
+    ids = [device.index] if device.type == 'cuda' else None
+    return nn.parallel.DistributedDataParallel(step, device_ids=ids, broadcast_buffers=False, gradient_as_bucket_view=True,
+                                               bucket_cap_mb=bucket_cap_mb, static_graph=True)
+
+
+def train_steps(model: nn.Module, opt: torch.optim.Optimizer, batch_fn, steps: int, accumulate: int = 1, clip=None):
+    """Run `steps` optimizer micro-steps (each = forward + backward on one batch; the optimizer fires every `accumulate`).
+    LR schedulers step per epoch in the reference (Lightning's default interval), so they are the caller's business.
+    Returns the list of (detached) loss tensors; nothing in here synchronises with the host."""
+    losses = []
+    ddp = isinstance(model, nn.parallel.DistributedDataParallel)
+    for it in range(steps):
+        boundary = (it + 1) % accumulate == 0
+        ctx = model.no_sync() if (ddp and not boundary) else nullcontext()
+        with ctx:
+            loss, _ = model(batch_fn(it))
+            (loss/accumulate).backward()
+        if boundary:
+            if clip: torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        losses.append(loss.detach())
+    return losses
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description='Monocular depth trainer (MI355X hot path).')
+    p.add_argument('--cfg-files', '-c', type=Path, nargs='*', required=True, help='YAML configs (default, override...).')
+    p.add_argument('--ckpt-dir', '-o', default=Path('runs'), type=Path)
+    p.add_argument('--name', '-n', required=True, type=str)
+    p.add_argument('--version', '-v', default=0, type=int)
+    p.add_argument('--seed', '-s', default=42, type=int)
+    p.add_argument('--gpus', '-g', default=1, type=int, help='informational: launch with torch.distributed.run --nproc-per-node N')
+    p.add_argument('--steps', default=100, type=int, help='optimizer micro-steps per epoch on synthetic data')
+    p.add_argument('--shape', default=[192, 640], type=int, nargs=2)
+    args = p.parse_args(argv)
+
+    cfg = io.load_merge_yaml(*args.cfg_files)
+    rank, local, world = init_distributed()
+    device = torch.device('cuda', local) if torch.cuda.is_available() else torch.device('cpu')
+    torch.manual_seed(args.seed)
+    module = MonoDepthModule(cfg).to(device)
+    conf = module.configure_optimizers()
+    opt, sched = conf['optimizer'], conf.get('lr_scheduler')
+    tcfg = cfg.get('trainer', {})
+    acc = tcfg.get('accumulate_grad_batches', 1)
+    if module.auto_scale_lr:
+        for g in opt.param_groups: g['lr'] *= world*acc
+    b = cfg.get('loader', {}).get('batch_size', 12)
+    supp_idxs = next((d.get('supp_idxs') for d in (cfg.get('dataset') or {}).values() if isinstance(d, dict) and d.get('supp_idxs')), [-1, 1])
+    batch = make_batch(b, args.shape[0], args.shape[1], supp_idxs, seed=args.seed + rank, device=device)
+    model = wrap_ddp(StepModule(module), device)
+    save_dir = args.ckpt_dir/args.name/f'{args.version:03}'
+    if rank == 0: save_dir.mkdir(parents=True, exist_ok=True)
+    for epoch in range(tcfg.get('max_epochs', 1)):
+        t0 = time.time()
+        losses = train_steps(model, opt, lambda it: batch, args.steps, accumulate=acc, clip=tcfg.get('gradient_clip_val'))
+        if sched is not None: sched.step()
+        last = losses[-1].item()
+        if rank == 0:
+            dt = time.time() - t0
+            print(f'epoch {epoch}: loss {last:.6f}  {args.steps*b*world/dt:.1f} img/s', flush=True)
+            torch.save({'epoch': epoch, 'nets': module.nets.state_dict(), 'opt': opt.state_dict()}, save_dir/'last.ckpt')
+    if world > 1: dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

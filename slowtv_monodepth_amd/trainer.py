@@ -1,0 +1,170 @@
+"""`MonoDepthModule` — the training step around the hot path (reference: `src/core/trainer.py:17-472`).
+
+Same cfg sections (`net`, `loss`, `optimizer`, `scheduler`, `trainer`), same phase structure
+(`forward` -> `forward_postprocess` -> `forward_loss`), same `fwd` / `loss_dict` keys.  What differs is what runs
+underneath: the post-process + loss phases are three HIP launches forward and three backward instead of ~300 ATen
+kernels, and the reference's per-phase `cuda.synchronize()` timers (src/utils/timers.py:178,195) are replaced by HIP
+events that are only read when someone asks for them.  The Lightning shell is replaced by `fit()` in `train.py`.
+"""
+from __future__ import annotations
+
+import copy
+from contextlib import contextmanager, nullcontext
+
+import torch
+import torch.nn as nn
+
+from . import parsers
+from .geometry import T_from_AAt, ViewSynth, resize_K
+
+__all__ = ['MonoDepthModule', 'HipLossBackend', 'EventTimer']
+
+
+class HipLossBackend:
+    """The product loss path: K0 kernel + fused handlers.  (Tests may inject another object with the same three methods,
+    e.g. the CPU oracle, to exercise the host logic on machines without a GPU; the product never does.)"""
+    def postprocess(self, disps: dict, size, min_depth, max_depth):
+        from . import functional as F
+        from .handlers import ScaleDict
+        keys = list(disps.keys())
+        depth_up, disp_up = F.disp_to_depth([disps[k].float() for k in keys], size, min_depth, max_depth, want_disp_up=True)
+        return ScaleDict.from_stack(keys, disp_up), ScaleDict.from_stack(keys, depth_up)
+
+    def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True):
+        from . import handlers
+        return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), want_warp=want_warp)
+
+    def disp_smooth(self, crit, disps, imgs):
+        from . import handlers
+        return handlers.disp_smooth(crit, {k: d.float() for k, d in disps.items()}, imgs)
+
+
+class EventTimer:
+    """Nested phase timer with the reference's keys ('Total', 'Forward', 'Post-Process', 'Loss', 'Loss-<k>', 'Backward';
+    src/core/trainer.py:100-102,170-175,384) that records HIP events instead of synchronising the device per phase."""
+    def __init__(self, enabled: bool = False):
+        self.enabled, self.events = enabled, {}
+
+    @contextmanager
+    def __call__(self, key: str):
+        if not (self.enabled and torch.cuda.is_available()):
+            yield
+            return
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        try: yield
+        finally:
+            end.record()
+            self.events[key] = (start, end)
+
+    def to_dict(self) -> dict:
+        if not self.events: return {}
+        torch.cuda.synchronize()
+        return {k: s.elapsed_time(e) for k, (s, e) in self.events.items()}
+
+    def reset(self): self.events = {}
+
+
+class MonoDepthModule(nn.Module):
+    """Depth + pose networks, losses and the per-batch step.
+
+    :param cfg: the reference's config dict (see cfg/default.yaml there); sections `net`, `loss`, `trainer` are read here.
+    :param loss_backend: object providing postprocess / image_recon / disp_smooth (default: the HIP path).
+    """
+    def __init__(self, cfg: dict, loss_backend=None):
+        super().__init__()
+        self.cfg = cfg
+        tcfg = cfg.get('trainer', {})
+        self.nets = parsers.get_net(cfg['net'])
+        self.losses, self.weights = parsers.get_loss(copy.deepcopy(cfg['loss']))
+        self.backend = loss_backend or HipLossBackend()
+        self.synth = None
+        self.scales = self.nets['depth'].out_scales
+        self.n_scales = len(self.scales)
+        self.min_depth, self.max_depth = tcfg.get('min_depth', None), tcfg.get('max_depth', None)
+        self.always_fwd_pose = tcfg.get('always_fwd_pose', True)
+        self.auto_scale_lr = tcfg.get('auto_scale_lr', False)
+        if tcfg.get('aspect_ratio_aug_prob', 0.0): pass  # GPU-side aspect-ratio augmentation is a "next" row
+        prec = str(tcfg.get('precision', 32))
+        self.amp_dtype = {'32': None, '32-true': None, 'bf16': torch.bfloat16, 'bf16-mixed': torch.bfloat16}.get(prec, None)
+        self.channels_last = bool(tcfg.get('channels_last', False))
+        self.want_aux = bool(tcfg.get('log_images', False))  # supp_imgs_warp etc. are only for the image logger
+        self.timer = EventTimer(enabled=bool(tcfg.get('profile_phases', False)))
+        if self.channels_last: self.nets.to(memory_format=torch.channels_last)
+
+    # ------------------------------------------------------------------------------------------------
+    def _autocast(self, device_type):
+        return torch.autocast(device_type, dtype=self.amp_dtype) if self.amp_dtype is not None else nullcontext()
+
+    def forward(self, x: dict) -> dict:
+        """Network forward (src/core/trainer.py:192-278): `disp` {s: (b,1,h/2^s,w/2^s)}, `T_{idx}` (b,4,4) per support,
+        and with a `learn_K` pose net `K` (b,4,4), `fs`, `cs`."""
+        fwd = {}
+        imgs = x['imgs']
+        if self.channels_last: imgs = imgs.contiguous(memory_format=torch.channels_last)
+        idxs_all = [int(i) for i in x['supp_idxs']]
+        for key, net in self.nets.items():
+            if key == 'depth':
+                with self._autocast(imgs.device.type): out = net(imgs)
+                fwd.update(out)
+            elif key == 'pose':
+                inv = lambda i: self.always_fwd_pose and i < 0
+                pairs = torch.stack([torch.cat([supp, x['imgs']] if inv(i) else [x['imgs'], supp], dim=1)
+                                     for i, supp in zip(idxs_all, x['supp_imgs']) if i != 0])   # (n,b,6,h,w)
+                sh = pairs.shape[:2]
+                pin = pairs.flatten(0, 1)
+                if self.channels_last: pin = pin.contiguous(memory_format=torch.channels_last)
+                with self._autocast(imgs.device.type): pose = net(pin)
+                pose = {k: v.float() for k, v in pose.items()}
+                Ts = T_from_AAt(aa=pose['R'][:, 0], t=pose['t'][:, 0]).unflatten(0, sh)
+                idxs = [i for i in idxs_all if i != 0]
+                for i, T in zip(idxs, Ts): fwd[f'T_{i}'] = torch.linalg.inv(T) if inv(i) else T
+                if 'fs' in pose and 'fs' not in fwd:
+                    fwd['fs'], fwd['cs'] = pose['fs'].unflatten(0, sh), pose['cs'].unflatten(0, sh)
+                    K = net.build_K(pose['fs'], pose['cs']).unflatten(0, sh)[0]   # first support's prediction only
+                    fwd['K'] = resize_K(K, x['imgs'].shape[-2:])
+            else:
+                raise KeyError(f'Unrecognized key: {key}.')
+        return fwd
+
+    def forward_postprocess(self, fwd: dict, x: dict, y: dict) -> dict:
+        """Upsample + to-depth of every scale in one launch, and stack the poses (src/core/trainer.py:280-348)."""
+        fwd['disp_up'], fwd['depth_up'] = self.backend.postprocess(fwd['disp'], tuple(x['imgs'].shape[-2:]), self.min_depth, self.max_depth)
+        fwd['Ts'] = torch.stack([fwd[f'T_{int(i)}'] for i in x['supp_idxs']])
+        return fwd
+
+    def forward_loss(self, fwd: dict, x: dict, y: dict):
+        """Weighted sum of the configured losses (src/core/trainer.py:350-472); `loss_dict['loss_<k>']` per loss."""
+        loss, loss_dict = 0., {}
+        for k, crit in self.losses.items():
+            with self.timer(f'Loss-{k}'):
+                if k == 'img_recon':
+                    l, ld = self.backend.image_recon(crit, self.synth, fwd['depth_up'], fwd.get('mask_up'), y['imgs'], y['supp_imgs'],
+                                                     fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux)
+                elif k == 'disp_smooth':
+                    l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'])
+                else:
+                    raise ValueError(f'Missing loss key: "{k}"')
+            loss = loss + self.weights[k]*l
+            loss_dict[f'loss_{k}'] = l
+            loss_dict.update(ld)
+        return loss, loss_dict
+
+    def step(self, batch, mode: str = 'train'):
+        """One forward pass + losses (src/core/trainer.py:115-190) -> (loss, loss_dict, fwd)."""
+        x, y, m = batch
+        self.synth = ViewSynth(x['imgs'].shape[-2:])
+        with self.timer('Total'):
+            with self.timer('Forward'): fwd = self.forward(x)
+            with self.timer('Post-Process'): fwd = self.forward_postprocess(fwd, x, y)
+            with self.timer('Loss'): loss, loss_dict = self.forward_loss(fwd, x, y)
+        return loss, loss_dict, fwd
+
+    # ------------------------------------------------------------------------------------------------
+    def configure_optimizers(self):
+        """Optimizer + chained schedulers (src/core/trainer.py:82-92)."""
+        out = {'optimizer': parsers.get_opt(self.nets, self.cfg['optimizer'])}
+        if cfg := self.cfg.get('scheduler'):
+            sch = parsers.get_sched(out['optimizer'], cfg)
+            out['lr_scheduler'] = torch.optim.lr_scheduler.ChainedScheduler(list(sch.values()))
+        return out
