@@ -58,8 +58,10 @@ int smd_abi_version(void);
  * OUTPUT (d depth/d d = -depth^2 on the pass-through branch), not the low-resolution disparity. */
 int smd_disp_to_depth_fwd(const float* const* disp, const int* hs, const int* ws, int S, int b, int h, int w,
                           float min_depth, float max_depth, float* depth_up, float* disp_up, void* stream);
+size_t smd_disp_to_depth_workspace_bytes(const int* hs, const int* ws, int S, int b, int h, int w);
 int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int w, float min_depth, float max_depth,
-                          const float* depth_up, const float* g_depth_up, float* const* g_disp, void* stream);
+                          const float* depth_up, const float* g_depth_up, float* const* g_disp,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused image reconstruction.  Replaces `handlers.image_recon(crit, synth, depths, None, imgs, supp_imgs, Ts, Ks)`

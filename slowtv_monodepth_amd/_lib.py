@@ -29,7 +29,8 @@ PROTOTYPES = {
     'smd_last_error': (C.c_char_p, []),
     'smd_abi_version': (_i, []),
     'smd_disp_to_depth_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
-    'smd_disp_to_depth_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    'smd_disp_to_depth_workspace_bytes': (_sz, [_vp, _vp, _i, _i, _i, _i]),
+    'smd_disp_to_depth_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'smd_image_recon_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'smd_packed_supports_bytes': (_sz, [_i, _i, _i, _i]),
     'smd_image_recon_fwd': (_i, [_vp]*7 + [_u64] + [_vp]*6 + [_sz] + [_i]*6 + [_vp]),

@@ -114,14 +114,24 @@ int smd_disp_to_depth_fwd(const float* const* disp, const int* hs, const int* ws
   return check_launch(smd::launch_disp_to_depth_fwd(sc, b, h, w, min_depth, max_depth, depth_up, disp_up, (hipStream_t)stream), "disp_to_depth_fwd");
 }
 
+size_t smd_disp_to_depth_workspace_bytes(const int* hs, const int* ws, int S, int b, int h, int w) {
+  smd::ScaleSet sc;
+  if (b < 1 || h < 1 || w < 1 || fill_scales(sc, nullptr, nullptr, hs, ws, nullptr, S)) return 0;
+  return align256(smd::disp_to_depth_bwd_tmp_floats(sc, b, h, w, nullptr)*sizeof(float)) + 256;
+}
+
 int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int w, float min_depth, float max_depth,
-                          const float* depth_up, const float* g_depth_up, float* const* g_disp, void* stream) {
-  if (!depth_up || !g_depth_up || !g_disp) return fail(SMD_E_INVALID, "null pointer");
+                          const float* depth_up, const float* g_depth_up, float* const* g_disp,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (!depth_up || !g_depth_up || !g_disp || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");
   smd::ScaleSet sc;
   if (int rc = fill_scales(sc, nullptr, g_disp, hs, ws, nullptr, S)) return rc;
   for (int s = 0; s < S; ++s) if (!g_disp[s]) return fail(SMD_E_INVALID, "null gradient pointer for scale %d", s);
-  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth_up, (hipStream_t)stream), "disp_to_depth_bwd");
+  const size_t need = smd_disp_to_depth_workspace_bytes(hs, ws, S, b, h, w);
+  if (workspace_bytes < need) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth_up, (float*)workspace,
+                                                    (hipStream_t)stream), "disp_to_depth_bwd");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -216,12 +226,12 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
 static int smooth_chunks(const int* hs, const int* ws, int S) {
   int maxpix = 0;
   for (int s = 0; s < S; ++s) maxpix = hs[s]*ws[s] > maxpix ? hs[s]*ws[s] : maxpix;
-  return smd::ceil_div(maxpix, 2048);
+  return smd::ceil_div(maxpix, 1024);
 }
 
 size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int b) {
   if (!hs || !ws || S < 1 || S > SMD_MAX_SCALES || b < 1) return 0;
-  return align256((size_t)S*b*smooth_chunks(hs, ws, S)*sizeof(float));
+  return align256((size_t)S*b*smooth_chunks(hs, ws, S)*2*sizeof(float));
 }
 
 int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,

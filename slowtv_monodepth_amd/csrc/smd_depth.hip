@@ -49,59 +49,121 @@ hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, flo
   return hipGetLastError();
 }
 
-// Adjoint.  depth = 1/d on the pass-through branch, so d depth/d d = -depth^2 (0 where depth is 0 or pinned at 1/eps);
-// the bilinear adjoint is evaluated as a GATHER per low-resolution pixel (deterministic, no atomics): 16 lanes
-// share one low-res pixel and stride over its full-resolution footprint.
-__global__ __launch_bounds__(256) void k_disp_to_depth_bwd(const ScaleSet sc, int b, int h, int w, float a_scale,
-                                                           const float* __restrict__ depth_up, const float* __restrict__ g_depth_up) {
-  const int s = blockIdx.z, bi = blockIdx.y;
+// Adjoint.  depth = 1/d on the pass-through branch, so d depth/d d = -depth^2 (0 where depth is 0 or pinned at 1/eps).
+// A scale whose disparity already has the image size is a pure element-wise product.  For the others the bilinear
+// adjoint A_y^T (G .* f') A_x is evaluated separably and as GATHERS (deterministic, no atomics), both passes coalesced:
+//   pass 1: tmp[v][jx] = sum_u wx(u -> jx) G[v][u] f'(depth[v][u])      thread per (v, jx), walks <= 2f+2 columns
+//   pass 2: out[jy][jx] = a * sum_v wy(v -> jy) tmp[v][jx]               thread per (jy, jx), walks <= 2f+2 rows
+// Blocks are mapped to (scale, chunk) through a prefix table so that no block is launched for work that does not exist.
+struct BwdMap { int first_block[SMD_MAX_SCALES + 1]; size_t tmp_off[SMD_MAX_SCALES]; };
+
+__device__ __forceinline__ int scale_of_block(const BwdMap& map, int S, int blk) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < SMD_MAX_SCALES; ++k) if (k < S && blk >= map.first_block[k]) s = k;
+  return s;
+}
+
+__device__ __forceinline__ void footprint(int j, float f, int n_lo, int n_hi, int& lo, int& hi) {
+  lo = max((int)floorf(((float)j - 0.5f)*f - 0.5f), 0);
+  hi = min((int)ceilf(((float)j + 1.5f)*f - 0.5f), n_hi - 1);
+  if (j == 0) lo = 0;
+  if (j == n_lo - 1) hi = n_hi - 1;
+}
+
+__global__ __launch_bounds__(256) void k_disp_to_depth_bwd_h(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
+                                                             const float* __restrict__ depth_up, const float* __restrict__ g_depth_up,
+                                                             float* __restrict__ tmp) {
+  const int s = scale_of_block(map, sc.S, blockIdx.x);
+  const int blk = blockIdx.x - map.first_block[s], bi = blockIdx.y;
   const int hs = sc.hs[s], ws = sc.ws[s];
-  float* __restrict__ gout = sc.g[s] + (size_t)bi*hs*ws;
   const size_t ibase = ((size_t)s*b + bi)*h*w;
-  const float sy = (float)hs/(float)h, sx = (float)ws/(float)w;
-  const float fy = (float)h/(float)hs, fx = (float)w/(float)ws;
-  const int sub = threadIdx.x & 15;
   const float dmax = 1.f/kEps32;
-  for (int lp = blockIdx.x*16 + (threadIdx.x >> 4); lp < ((hs*ws + 15)/16)*16; lp += gridDim.x*16) {
-    const bool live = lp < hs*ws;
-    const int jy = live ? lp/ws : 0, jx = live ? lp - (lp/ws)*ws : 0;
-    float acc = 0.f;
-    if (live) {
-      int vlo = max((int)floorf(((float)jy - 0.5f)*fy - 0.5f) - 1, 0), vhi = min((int)ceilf(((float)jy + 1.5f)*fy - 0.5f) + 1, h - 1);
-      int ulo = max((int)floorf(((float)jx - 0.5f)*fx - 0.5f) - 1, 0), uhi = min((int)ceilf(((float)jx + 1.5f)*fx - 0.5f) + 1, w - 1);
-      if (jy == 0) vlo = 0;
-      if (jx == 0) ulo = 0;
-      if (jy == hs - 1) vhi = h - 1;
-      if (jx == ws - 1) uhi = w - 1;
-      const int nu = uhi - ulo + 1, cnt = (vhi - vlo + 1)*nu;
-      for (int k = sub; k < cnt; k += 16) {
-        const int v = vlo + k/nu, u = ulo + k - (k/nu)*nu;
-        int y0, y1, x0, x1; float ly, lx;
-        src_index(v, sy, hs, y0, y1, ly);
-        src_index(u, sx, ws, x0, x1, lx);
-        float wy = ((y0 == jy) ? 1.f - ly : 0.f) + ((y1 == jy) ? ly : 0.f);
-        float wx = ((x0 == jx) ? 1.f - lx : 0.f) + ((x1 == jx) ? lx : 0.f);
-        if (wy != 0.f && wx != 0.f) {
-          float dep = depth_up[ibase + (size_t)v*w + u];
-          float dd = (dep < dmax) ? -dep*dep : 0.f;
-          acc = fmaf(wy*wx, g_depth_up[ibase + (size_t)v*w + u]*dd, acc);
-        }
+  if (hs == h && ws == w) {   // identity resampling: element-wise, 4 consecutive pixels per thread
+    float* __restrict__ gout = sc.g[s] + (size_t)bi*hs*ws;
+    const int pix0 = (blk*256 + threadIdx.x)*4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = pix0 + k;
+      if (pix < h*w) {
+        const float dep = depth_up[ibase + pix];
+        gout[pix] = g_depth_up[ibase + pix]*((dep < dmax) ? -dep*dep : 0.f)*a_scale;
       }
     }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (live && sub == 0) gout[lp] = acc*a_scale;
+    return;
   }
+  const int idx = blk*256 + threadIdx.x;    // (v, jx), jx fastest
+  if (idx >= h*ws) return;
+  const int v = idx/ws, jx = idx - v*ws;
+  const float sx = (float)ws/(float)w;
+  int ulo, uhi;
+  footprint(jx, (float)w/(float)ws, ws, w, ulo, uhi);
+  const float* __restrict__ drow = depth_up + ibase + (size_t)v*w;
+  const float* __restrict__ grow = g_depth_up + ibase + (size_t)v*w;
+  float acc = 0.f;
+  for (int u = ulo; u <= uhi; ++u) {
+    int x0, x1; float lx;
+    src_index(u, sx, ws, x0, x1, lx);
+    const float wx = ((x0 == jx) ? 1.f - lx : 0.f) + ((x1 == jx) ? lx : 0.f);
+    const float dep = drow[u];
+    acc = fmaf(wx, grow[u]*((dep < dmax) ? -dep*dep : 0.f), acc);
+  }
+  tmp[map.tmp_off[s] + ((size_t)bi*h + v)*ws + jx] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
+                                                             const float* __restrict__ tmp) {
+  const int s = scale_of_block(map, sc.S, blockIdx.x);
+  const int blk = blockIdx.x - map.first_block[s], bi = blockIdx.y;
+  const int hs = sc.hs[s], ws = sc.ws[s];
+  if (hs == h && ws == w) return;           // handled element-wise in pass 1
+  const int lp = blk*256 + threadIdx.x;
+  if (lp >= hs*ws) return;
+  const int jy = lp/ws, jx = lp - jy*ws;
+  const float sy = (float)hs/(float)h;
+  int vlo, vhi;
+  footprint(jy, (float)h/(float)hs, hs, h, vlo, vhi);
+  const float* __restrict__ col = tmp + map.tmp_off[s] + (size_t)bi*h*ws + jx;
+  float acc = 0.f;
+  for (int v = vlo; v <= vhi; ++v) {
+    int y0, y1; float ly;
+    src_index(v, sy, hs, y0, y1, ly);
+    const float wy = ((y0 == jy) ? 1.f - ly : 0.f) + ((y1 == jy) ? ly : 0.f);
+    acc = fmaf(wy, col[(size_t)v*ws], acc);
+  }
+  sc.g[s][(size_t)bi*hs*ws + lp] = acc*a_scale;
+}
+
+size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, BwdMap* map) {
+  size_t off = 0;
+  for (int s = 0; s < sc.S; ++s) {
+    if (map) map->tmp_off[s] = off;
+    if (!(sc.hs[s] == h && sc.ws[s] == w)) off += (size_t)b*h*sc.ws[s];
+  }
+  return off;
 }
 
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
-                                    const float* depth_up, const float* g_depth_up, hipStream_t st) {
+                                    const float* depth_up, const float* g_depth_up, float* tmp, hipStream_t st) {
   float a_scale = 1.f;
   if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
-  int maxpix = 0;
-  for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
-  dim3 grid(min(ceil_div(maxpix, 16), 2048), b, sc.S);
-  hipLaunchKernelGGL(k_disp_to_depth_bwd, grid, dim3(256), 0, st, sc, b, h, w, a_scale, depth_up, g_depth_up);
+  BwdMap m1, m2;
+  disp_to_depth_bwd_tmp_floats(sc, b, h, w, &m1);
+  m2 = m1;
+  int n1 = 0, n2 = 0;
+  bool resampled = false;
+  for (int s = 0; s < SMD_MAX_SCALES; ++s) {
+    m1.first_block[s] = n1; m2.first_block[s] = n2;
+    if (s < sc.S) {
+      const bool ident = sc.hs[s] == h && sc.ws[s] == w;
+      n1 += ident ? ceil_div(h*w, 1024) : ceil_div(h*sc.ws[s], 256);
+      n2 += ident ? 0 : ceil_div(sc.hs[s]*sc.ws[s], 256);
+      resampled |= !ident;
+    }
+  }
+  m1.first_block[SMD_MAX_SCALES] = n1; m2.first_block[SMD_MAX_SCALES] = n2;
+  hipLaunchKernelGGL(k_disp_to_depth_bwd_h, dim3(n1, b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp);
+  if (resampled) hipLaunchKernelGGL(k_disp_to_depth_bwd_v, dim3(n2, b), dim3(256), 0, st, sc, m2, b, h, w, a_scale, tmp);
   return hipGetLastError();
 }
 

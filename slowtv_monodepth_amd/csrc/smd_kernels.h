@@ -70,8 +70,10 @@ hipError_t launch_pose_finalize(const float* pose_partial, int entries, const fl
 
 hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
                                     float* depth_up, float* disp_up, hipStream_t st);
+struct BwdMap;
+size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, BwdMap* map);
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
-                                    const float* depth_up, const float* g_depth_up, hipStream_t st);
+                                    const float* depth_up, const float* g_depth_up, float* tmp, hipStream_t st);
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, hipStream_t st);
@@ -98,7 +100,8 @@ inline int ceil_div(int a, int b) { return (a + b - 1)/b; }
 // Rows per strip: enough strips to give every SIMD several waves, few enough that the halo rows stay cheap.
 inline int pick_rows_per_strip(int b, int S, int h, int w, int cols, int halo) {
   const int nsx = ceil_div(w, cols);
-  const long target_waves = 1024L*4;  // 256 CUs x 4 SIMDs x 4 waves
+  // 256 CUs x 4 SIMDs x ~4-5 resident waves; measured optimum on cfg 2 (scripts/dev/microbench.py): fwd rh=24, bwd rh=20
+  const long target_waves = (cols == kFwdCols) ? 1024L*4 : 1024L*5;
   int best = 8;
   for (int rh = 64; rh >= 8; rh -= 4) {
     long waves = (long)nsx*ceil_div(h, rh)*b*S;

@@ -256,24 +256,20 @@ __global__ __launch_bounds__(256) void k_pose_finalize(const float* __restrict__
                                                        const float* __restrict__ T, const float* __restrict__ K,
                                                        const float* __restrict__ Kinv, float* g_T, float* g_K, float* g_Kinv,
                                                        int b, int n) {
-  __shared__ double red[256];
   __shared__ double tot[kPoseSums];
-  const int bi = blockIdx.x;
+  const int bi = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double gK[6] = {0, 0, 0, 0, 0, 0}, gKi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < n; ++i) {
     const float* pp = pose_partial + ((size_t)i*b + bi)*(size_t)entries*kPoseSums;
-    for (int k = 0; k < kPoseSums; ++k) {
+    // each of the four waves reduces three of the twelve sums (fp64, fixed order -> deterministic)
+    for (int k = wv*3; k < wv*3 + 3; ++k) {
       double acc = 0.0;
-      for (int e = threadIdx.x; e < entries; e += 256) acc += (double)pp[(size_t)e*kPoseSums + k];
-      red[threadIdx.x] = acc;
-      __syncthreads();
-      for (int sft = 128; sft > 0; sft >>= 1) {
-        if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) tot[k] = red[0];
-      __syncthreads();
+      for (int e = lane; e < entries; e += 64) acc += (double)pp[(size_t)e*kPoseSums + k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) tot[k] = acc;
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
       const float* Tm = T + ((size_t)i*b + bi)*16;
       const float* Km = K + (size_t)bi*16;

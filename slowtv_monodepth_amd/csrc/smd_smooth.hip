@@ -13,7 +13,7 @@
 
 namespace smd {
 
-constexpr int kSmoothChunk = 2048;  // pixels per block in the main pass
+constexpr int kSmoothChunk = 1024;  // pixels per block in the main pass (4 per thread)
 
 __device__ __forceinline__ void src_index_s(int dst, float scale, int n_in, int& i0, int& i1, float& l1) {
   float src = fmaxf(scale*((float)dst + 0.5f) - 0.5f, 0.f);
@@ -48,78 +48,103 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// Phase 1: mean disparity per (scale, sample).  One block per image (all images are small and L2 resident).
-__global__ __launch_bounds__(256) void k_smooth_mean(const ScaleSet sc, int b, float* __restrict__ stats) {
-  __shared__ float red[4];
-  const int s = blockIdx.y, bi = blockIdx.x;
-  const int n = sc.hs[s]*sc.ws[s];
-  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) acc += d[i];
-  float tot = block_sum_256(acc, red);
-  if (threadIdx.x == 0) stats[((size_t)s*b + bi)*2 + 0] = tot/(float)n;
-}
-
-// Phase 2: per-block partial of E for its chunk of pixels; optional aux maps for scale index 0.
+// Pass 1: per block, partial sums of the UN-normalised edge energy E' = sum w |d_p - d_q| and of d itself.  Because
+// dhat = d / m with one m > 0 per image, E = E' / m: the mean is not needed inside the pixel loop, so the reference's
+// mean pass and its stencil pass collapse into one sweep.
 __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
-                                                     const float* __restrict__ stats, float* __restrict__ partial, int max_chunks,
-                                                     float* __restrict__ disp_grad, float* __restrict__ image_grad) {
+                                                     float* __restrict__ partial, int max_chunks) {
   __shared__ float red[4];
   const int s = blockIdx.z, bi = blockIdx.y, chunk = blockIdx.x;
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
   if (chunk*kSmoothChunk >= n) return;
   const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
   const float* __restrict__ im = img + (size_t)bi*3*h*w;
-  const float inv_m = 1.f/fmaxf(stats[((size_t)s*b + bi)*2], kEps32);
   const bool edges = flags & SMD_USE_EDGES;
-  float acc = 0.f;
+  float accE = 0.f, accD = 0.f;
+#pragma unroll
   for (int k = 0; k < kSmoothChunk/256; ++k) {
     const int pix = chunk*kSmoothChunk + k*256 + threadIdx.x;
     if (pix < n) {
       const int v = pix/ws, u = pix - v*ws;
-      const float dc = d[pix]*inv_m;
+      const float dc = d[pix];
+      accD += dc;
       float gx = 0.f, gy = 0.f, ax = 0.f, ay = 0.f;
       float ic[3];
-      img_at(im, h, w, hs, ws, v, u, ic);
+      if (edges) img_at(im, h, w, hs, ws, v, u, ic);
       if (u < ws - 1) {
-        gx = fabsf(dc - d[pix + 1]*inv_m);
-        float ir[3]; img_at(im, h, w, hs, ws, v, u + 1, ir);
-        ax = (fabsf(ic[0] - ir[0]) + fabsf(ic[1] - ir[1]) + fabsf(ic[2] - ir[2]))*(1.f/3.f);
+        gx = fabsf(dc - d[pix + 1]);
+        if (edges) { float ir[3]; img_at(im, h, w, hs, ws, v, u + 1, ir); ax = (fabsf(ic[0] - ir[0]) + fabsf(ic[1] - ir[1]) + fabsf(ic[2] - ir[2]))*(1.f/3.f); }
       }
       if (v < hs - 1) {
-        gy = fabsf(dc - d[pix + ws]*inv_m);
-        float ib[3]; img_at(im, h, w, hs, ws, v + 1, u, ib);
-        ay = (fabsf(ic[0] - ib[0]) + fabsf(ic[1] - ib[1]) + fabsf(ic[2] - ib[2]))*(1.f/3.f);
+        gy = fabsf(dc - d[pix + ws]);
+        if (edges) { float ib[3]; img_at(im, h, w, hs, ws, v + 1, u, ib); ay = (fabsf(ic[0] - ib[0]) + fabsf(ic[1] - ib[1]) + fabsf(ic[2] - ib[2]))*(1.f/3.f); }
       }
-      if (s == 0 && disp_grad) disp_grad[(size_t)bi*n + pix] = sqrtf(fmaxf(gx*gx + gy*gy, kEps32));
-      if (s == 0 && image_grad) image_grad[(size_t)bi*n + pix] = sqrtf(fmaxf(ax*ax + ay*ay, kEps32));
-      acc += edges ? (gx*__expf(-ax) + gy*__expf(-ay)) : (gx + gy);
+      accE += edges ? (gx*__expf(-ax) + gy*__expf(-ay)) : (gx + gy);
     }
   }
-  float tot = block_sum_256(acc, red);
-  if (threadIdx.x == 0) partial[((size_t)s*b + bi)*max_chunks + chunk] = tot;
+  const float totE = block_sum_256(accE, red);
+  const float totD = block_sum_256(accD, red);
+  if (threadIdx.x == 0) {
+    float* pp = partial + (((size_t)s*b + bi)*max_chunks + chunk)*2;
+    pp[0] = totE; pp[1] = totD;
+  }
 }
 
-// Phase 3: E per image -> stats[...,1]; loss = mean_s( 2^-scale_s * sum_b E / (b*hs*ws) ).  `sc.key[s]` is the
-// dictionary key of the scale (handlers.py:279 divides by 2**key).
-__global__ __launch_bounds__(64) void k_smooth_finalize(const ScaleSet sc, int b, const float* __restrict__ partial, int max_chunks,
-                                                        float* __restrict__ stats, float* __restrict__ loss) {
-  double total = 0.0;
-  for (int s = 0; s < sc.S; ++s) {
+// Pass 2: per image mean m and E = E'/max(m, eps) -> stats; loss = mean_s( 2^-key_s * sum_b E / (b*hs*ws) ).
+// One wave per (scale, sample) pair, 16 waves per block, one block.
+__global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int b, const float* __restrict__ partial, int max_chunks,
+                                                          float* __restrict__ stats, float* __restrict__ loss) {
+  __shared__ double contrib[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double mine = 0.0;
+  for (int pair = wv; pair < sc.S*b; pair += 16) {
+    const int s = pair/b;
     const int n = sc.hs[s]*sc.ws[s];
     const int chunks = (n + kSmoothChunk - 1)/kSmoothChunk;
-    double es = 0.0;
-    for (int bi = 0; bi < b; ++bi) {
-      double e = 0.0;
-      for (int c = threadIdx.x; c < chunks; c += 64) e += (double)partial[((size_t)s*b + bi)*max_chunks + c];
+    double e = 0.0, dsum = 0.0;
+    for (int c = lane; c < chunks; c += 64) { e += (double)partial[((size_t)pair*max_chunks + c)*2]; dsum += (double)partial[((size_t)pair*max_chunks + c)*2 + 1]; }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
-      if (threadIdx.x == 0) stats[((size_t)s*b + bi)*2 + 1] = (float)e;
-      es += e;
-    }
-    total += es/((double)b*n)*exp2(-(double)sc.key[s]);
+    for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); dsum += __shfl_xor(dsum, off, 64); }
+    const float mean = (float)(dsum/n);
+    const float E = (float)(e/(double)fmaxf(mean, kEps32));
+    if (lane == 0) { stats[(size_t)pair*2] = mean; stats[(size_t)pair*2 + 1] = E; }
+    mine += (double)E/((double)b*n)*exp2(-(double)sc.key[s]);
   }
-  if (threadIdx.x == 0) loss[0] = (float)(total/sc.S);
+  if (lane == 0) contrib[wv] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double total = 0.0;
+    for (int k = 0; k < 16; ++k) total += contrib[k];
+    loss[0] = (float)(total/sc.S);
+  }
+}
+
+// Optional aux maps of the first scale (`disp_grad`, `image_grad` of smooth.py:86,89) — logging only, not on the timed path.
+__global__ __launch_bounds__(256) void k_smooth_aux(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w,
+                                                    const float* __restrict__ stats, float* __restrict__ disp_grad, float* __restrict__ image_grad) {
+  const int bi = blockIdx.y;
+  const int hs = sc.hs[0], ws = sc.ws[0], n = hs*ws;
+  const float* __restrict__ d = sc.p[0] + (size_t)bi*n;
+  const float* __restrict__ im = img + (size_t)bi*3*h*w;
+  const float inv_m = 1.f/fmaxf(stats[(size_t)bi*2], kEps32);
+  for (int pix = blockIdx.x*256 + threadIdx.x; pix < n; pix += gridDim.x*256) {
+    const int v = pix/ws, u = pix - v*ws;
+    const float dc = d[pix]*inv_m;
+    float gx = 0.f, gy = 0.f, ax = 0.f, ay = 0.f, ic[3];
+    img_at(im, h, w, hs, ws, v, u, ic);
+    if (u < ws - 1) {
+      gx = fabsf(dc - d[pix + 1]*inv_m);
+      float ir[3]; img_at(im, h, w, hs, ws, v, u + 1, ir);
+      ax = (fabsf(ic[0] - ir[0]) + fabsf(ic[1] - ir[1]) + fabsf(ic[2] - ir[2]))*(1.f/3.f);
+    }
+    if (v < hs - 1) {
+      gy = fabsf(dc - d[pix + ws]*inv_m);
+      float ib[3]; img_at(im, h, w, hs, ws, v + 1, u, ib);
+      ay = (fabsf(ic[0] - ib[0]) + fabsf(ic[1] - ib[1]) + fabsf(ic[2] - ib[2]))*(1.f/3.f);
+    }
+    if (disp_grad) disp_grad[(size_t)bi*n + pix] = sqrtf(fmaxf(gx*gx + gy*gy, kEps32));
+    if (image_grad) image_grad[(size_t)bi*n + pix] = sqrtf(fmaxf(ax*ax + ay*ay, kEps32));
+  }
 }
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
@@ -127,10 +152,10 @@ hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h,
   int maxpix = 0;
   for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
   const int max_chunks = ceil_div(maxpix, kSmoothChunk);
-  hipLaunchKernelGGL(k_smooth_mean, dim3(b, sc.S), dim3(256), 0, st, sc, b, stats);
-  hipLaunchKernelGGL(k_smooth_main, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, ws_sums, max_chunks,
-                     disp_grad, image_grad);
-  hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(64), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
+  hipLaunchKernelGGL(k_smooth_main, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks);
+  hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
+  if (disp_grad || image_grad)
+    hipLaunchKernelGGL(k_smooth_aux, dim3(min(ceil_div(sc.hs[0]*sc.ws[0], 256), 480), b), dim3(256), 0, st, sc, b, img, h, w, stats, disp_grad, image_grad);
   return hipGetLastError();
 }
 
@@ -146,7 +171,11 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
   const bool edges = flags & SMD_USE_EDGES;
   const float gs = g_loss[0]*exp2f(-(float)sc.key[s])/((float)sc.S*(float)b*(float)n);
   const float mean_term = (mean >= kEps32) ? E*inv_m/(float)n : 0.f;
-  for (int pix = blockIdx.x*256 + threadIdx.x; pix < n; pix += gridDim.x*256) {
+  if ((int)blockIdx.x*kSmoothChunk >= n) return;
+#pragma unroll
+  for (int kk = 0; kk < kSmoothChunk/256; ++kk) {
+    const int pix = blockIdx.x*kSmoothChunk + kk*256 + threadIdx.x;
+    if (pix >= n) continue;
     const int v = pix/ws, u = pix - v*ws;
     const float dc = d[pix]*inv_m;
     float ic[3];
@@ -184,7 +213,7 @@ hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h,
                              const float* g_loss, hipStream_t st) {
   int maxpix = 0;
   for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
-  hipLaunchKernelGGL(k_smooth_bwd, dim3(min(ceil_div(maxpix, 256), 256), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, g_loss);
+  hipLaunchKernelGGL(k_smooth_bwd, dim3(ceil_div(maxpix, kSmoothChunk), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, g_loss);
   return hipGetLastError();
 }
 

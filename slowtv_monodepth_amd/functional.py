@@ -62,8 +62,11 @@ class _DispToDepth(torch.autograd.Function):
         hs, ws, S, b, h, w, mn, mx = ctx.meta
         g_depth_up = _check('grad(depth_up)', g_depth_up)
         g_disps = [torch.empty((b, 1, hs[s], ws[s]), device=depth_up.device, dtype=torch.float32) for s in range(S)]
-        call('smd_disp_to_depth_bwd', int_array(hs), int_array(ws), S, b, h, w, mn, mx, depth_up.data_ptr(), g_depth_up.data_ptr(),
-             ptr_array([g.data_ptr() for g in g_disps]), _stream())
+        hs_a, ws_a = int_array(hs), int_array(ws)
+        nbytes = _lib.lib.smd_disp_to_depth_workspace_bytes(hs_a, ws_a, S, b, h, w)
+        wsp = torch.empty(nbytes, device=depth_up.device, dtype=torch.uint8)
+        call('smd_disp_to_depth_bwd', hs_a, ws_a, S, b, h, w, mn, mx, depth_up.data_ptr(), g_depth_up.data_ptr(),
+             ptr_array([g.data_ptr() for g in g_disps]), wsp.data_ptr(), nbytes, _stream())
         return (None, None, None, None, *g_disps)
 
 
