@@ -66,7 +66,8 @@ def cpu_baseline(wl: dict, sample_b: int = 4, steps: int = 5) -> dict:
     from slowtv_monodepth_amd.synthetic import make_batch
     from slowtv_monodepth_amd.train import StepModule, train_steps
     from slowtv_monodepth_amd.trainer import MonoDepthModule
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = int(os.environ.get('SMD_CPU_THREADS', min(avail, 16)))   # measured on the 256-thread GPU host: 16 threads is the fastest setting (8: 3.1, 16: 4.7, 32: 3.3, 64: 1.8 img/s)
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     module = MonoDepthModule(make_cfg({**wl, 'precision': 32}), loss_backend=OracleBackend(aten=True))
@@ -90,6 +91,7 @@ def main():
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     ap.add_argument('--channels-last', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default=None, choices=['32', 'bf16'], help='override the network autocast precision of the workload (the loss path is always fp32)')
     args = ap.parse_args()
 
     from slowtv_monodepth_amd import _lib
@@ -104,7 +106,8 @@ def main():
     torch.cuda.set_device(device)
     # NOTE: cudnn.benchmark (MIOpen exhaustive find) is left OFF: on a fresh box every candidate solver would be JIT-compiled
     # (tens of minutes); immediate mode compiles only the chosen kernel per convolution during the warm-up steps.
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.precision: wl['precision'] = 32 if args.precision == '32' else 'bf16'
     torch.manual_seed(42)
     module = MonoDepthModule(make_cfg(wl, args.channels_last)).to(device)
     opt = module.configure_optimizers()['optimizer']

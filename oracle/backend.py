@@ -14,8 +14,9 @@ from . import view_synth_oracle as O
 class OracleBackend:
     def __init__(self, aten: bool = True): self.aten = aten
 
-    def postprocess(self, disps, size, min_depth, max_depth):
-        return O.disp_to_depth_up({k: d.float() for k, d in disps.items()}, size, min_depth, max_depth, aten=self.aten)
+    def postprocess(self, disps, size, min_depth, max_depth, want_disp_up=True):
+        disp_up, depth_up = O.disp_to_depth_up({k: d.float() for k, d in disps.items()}, size, min_depth, max_depth, aten=self.aten)
+        return (disp_up if want_disp_up else None), depth_up
 
     def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True):
         if masks is not None: raise NotImplementedError
@@ -24,5 +25,6 @@ class OracleBackend:
         if not want_warp: ld.pop('supp_imgs_warp', None)
         return loss, ld
 
-    def disp_smooth(self, crit, disps, imgs):
-        return O.disp_smooth({k: d.float() for k, d in disps.items()}, imgs, crit.use_edges, aten=self.aten)
+    def disp_smooth(self, crit, disps, imgs, want_aux=True):
+        loss, ld = O.disp_smooth({k: d.float() for k, d in disps.items()}, imgs, crit.use_edges, aten=self.aten)
+        return loss, (ld if want_aux else {})

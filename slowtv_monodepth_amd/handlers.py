@@ -51,10 +51,11 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
     return loss, ld
 
 
-def disp_smooth(crit, disps: dict, imgs: torch.Tensor):
+def disp_smooth(crit, disps: dict, imgs: torch.Tensor, *, want_aux: bool = True):
     """Smoothness over the raw (not up-sampled) multi-scale disparities: mean_s(loss_s / 2^s) (src/core/handlers.py:262-281).
 
+    :param want_aux: also produce the two logging maps (one extra small launch); the training loop turns this off.
     :return: (loss, {'disp_grad', 'image_grad'} of scale 0)
     """
-    loss, dg, ig = F.disp_smooth_fused(disps, imgs, use_edges=crit.use_edges, want_aux=True)
-    return loss, {'disp_grad': dg, 'image_grad': ig}
+    loss, dg, ig = F.disp_smooth_fused(disps, imgs, use_edges=crit.use_edges, want_aux=want_aux)
+    return loss, ({'disp_grad': dg, 'image_grad': ig} if want_aux and dg is not None else {})

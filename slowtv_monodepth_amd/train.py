@@ -53,7 +53,7 @@ def wrap_ddp(step: StepModule, device: torch.device, bucket_cap_mb: int = 25) ->
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1): return step
     ids = [device.index] if device.type == 'cuda' else None
     return nn.parallel.DistributedDataParallel(step, device_ids=ids, broadcast_buffers=False, gradient_as_bucket_view=True,
-                                               bucket_cap_mb=bucket_cap_mb, static_graph=True)
+                                               bucket_cap_mb=bucket_cap_mb)  # (static_graph would forbid no_sync() on the first micro-step)
 
 
 def train_steps(model: nn.Module, opt: torch.optim.Optimizer, batch_fn, steps: int, accumulate: int = 1, clip=None):

@@ -23,20 +23,20 @@ __all__ = ['MonoDepthModule', 'HipLossBackend', 'EventTimer']
 class HipLossBackend:
     """The product loss path: K0 kernel + fused handlers.  (Tests may inject another object with the same three methods,
     e.g. the CPU oracle, to exercise the host logic on machines without a GPU; the product never does.)"""
-    def postprocess(self, disps: dict, size, min_depth, max_depth):
+    def postprocess(self, disps: dict, size, min_depth, max_depth, want_disp_up=True):
         from . import functional as F
         from .handlers import ScaleDict
         keys = list(disps.keys())
-        depth_up, disp_up = F.disp_to_depth([disps[k].float() for k in keys], size, min_depth, max_depth, want_disp_up=True)
-        return ScaleDict.from_stack(keys, disp_up), ScaleDict.from_stack(keys, depth_up)
+        depth_up, disp_up = F.disp_to_depth([disps[k].float() for k in keys], size, min_depth, max_depth, want_disp_up=want_disp_up)
+        return (ScaleDict.from_stack(keys, disp_up) if want_disp_up else None), ScaleDict.from_stack(keys, depth_up)
 
     def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True):
         from . import handlers
         return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), want_warp=want_warp)
 
-    def disp_smooth(self, crit, disps, imgs):
+    def disp_smooth(self, crit, disps, imgs, want_aux=True):
         from . import handlers
-        return handlers.disp_smooth(crit, {k: d.float() for k, d in disps.items()}, imgs)
+        return handlers.disp_smooth(crit, {k: d.float() for k, d in disps.items()}, imgs, want_aux=want_aux)
 
 
 class EventTimer:
@@ -129,7 +129,9 @@ class MonoDepthModule(nn.Module):
 
     def forward_postprocess(self, fwd: dict, x: dict, y: dict) -> dict:
         """Upsample + to-depth of every scale in one launch, and stack the poses (src/core/trainer.py:280-348)."""
-        fwd['disp_up'], fwd['depth_up'] = self.backend.postprocess(fwd['disp'], tuple(x['imgs'].shape[-2:]), self.min_depth, self.max_depth)
+        disp_up, fwd['depth_up'] = self.backend.postprocess(fwd['disp'], tuple(x['imgs'].shape[-2:]), self.min_depth, self.max_depth,
+                                                            want_disp_up=self.want_aux)
+        if disp_up is not None: fwd['disp_up'] = disp_up   # only the image logger reads the un-scaled up-sampled disparity
         fwd['Ts'] = torch.stack([fwd[f'T_{int(i)}'] for i in x['supp_idxs']])
         return fwd
 
@@ -142,7 +144,7 @@ class MonoDepthModule(nn.Module):
                     l, ld = self.backend.image_recon(crit, self.synth, fwd['depth_up'], fwd.get('mask_up'), y['imgs'], y['supp_imgs'],
                                                      fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux)
                 elif k == 'disp_smooth':
-                    l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'])
+                    l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'], want_aux=self.want_aux)
                 else:
                     raise ValueError(f'Missing loss key: "{k}"')
             loss = loss + self.weights[k]*l

@@ -16,6 +16,10 @@ TRAIN_CASES = ['train_kbr_24x32', 'train_kbr_96x128', 'train_learnK_n4_40x56', '
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The package refuses to import without its HIP library (no fallback path); build it once if the tree is fresh.
+    if not (ROOT/'slowtv_monodepth_amd'/'libsmd_hotpath.so').is_file():
+        import subprocess
+        subprocess.run(['make', '-C', str(ROOT/'slowtv_monodepth_amd'/'csrc'), '-j8'], check=True)
 
 
 def load_golden(name: str) -> dict:

@@ -1,0 +1,221 @@
+"""CPU tests of the host side: registry / cfg surface, pose + intrinsics prologue, networks' output contract, the
+training step driven through the oracle backend, and the C-ABI library's symbol table (no compute calls without a GPU)."""
+import copy
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+from conftest import ROOT, case_inputs
+from oracle import view_synth_oracle as O
+from oracle.backend import OracleBackend
+
+import slowtv_monodepth_amd as pkg  # noqa: F401
+from slowtv_monodepth_amd import _lib, geometry, io, ops, parsers, registry
+from slowtv_monodepth_amd.handlers import ScaleDict
+from slowtv_monodepth_amd.losses import ReconstructionLoss
+from slowtv_monodepth_amd.networks import DepthNet, MonodepthDecoder, PoseNet, create_encoder
+from slowtv_monodepth_amd.regularizers import SmoothReg
+from slowtv_monodepth_amd.synthetic import make_batch
+from slowtv_monodepth_amd.trainer import MonoDepthModule
+
+
+# ------------------------------------------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    header = (ROOT/'include'/'smd_hotpath.h').read_text()
+    declared = set(re.findall(r'\b(smd_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(_lib.lib, name), f'{name} declared in include/smd_hotpath.h but not exported by {_lib.lib_path}'
+        assert name in _lib.PROTOTYPES, f'{name} has no ctypes prototype'
+    assert set(_lib.PROTOTYPES) <= declared
+    assert _lib.lib.smd_abi_version() == 1
+    assert _lib.lib.smd_image_recon_workspace_bytes(12, 2, 4, 192, 640) > 12*192*640*4
+    assert _lib.lib.smd_image_recon_workspace_bytes(0, 2, 4, 192, 640) == 0
+    assert _lib.lib.smd_packed_supports_bytes(12, 2, 192, 640) == 2*12*192*640*16
+
+
+def test_abi_rejects_bad_arguments_without_touching_the_gpu():
+    # argument validation happens before any launch, so these are safe on a machine without a GPU
+    rc = _lib.lib.smd_image_recon_fwd(*([None]*7), 0, *([None]*6), 0, 1, 1, 1, 1, 1, 0, None)
+    assert rc == -1 and b'invalid sizes' in _lib.lib.smd_last_error()
+    rc = _lib.lib.smd_image_recon_fwd(*([None]*7), 0, *([None]*6), 0, 2, 2, 4, 8, 8, 0, None)
+    assert rc == -1 and b'null pointer' in _lib.lib.smd_last_error()
+    with pytest.raises(ValueError): _lib.call('smd_debug_lane_shift', None, None, None)
+
+
+def test_hip_path_refuses_cpu_tensors():
+    from slowtv_monodepth_amd import functional as F
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        F.disp_to_depth([torch.rand(1, 1, 4, 4)], (4, 4), 0.1, 100)
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        SmoothReg(use_edges=True)(torch.rand(1, 1, 4, 4), torch.rand(1, 3, 4, 4))
+
+
+# ------------------------------------------------------------------------------------------------- registry / cfg
+def test_registry_semantics():
+    assert {'img_recon', 'disp_smooth'} <= (registry.trigger_losses() or set(registry.LOSS_REG))
+    registry.trigger_nets(); registry.trigger_decoders()
+    assert {'depth', 'pose'} <= set(registry.NET_REG) and 'monodepth' in registry.DEC_REG
+    assert registry.LOSS_REG['img_recon'] is ReconstructionLoss and registry.LOSS_REG['disp_smooth'] is SmoothReg
+
+    @registry.register(('tmp_a', 'tmp_b'))
+    class TmpLoss(torch.nn.Module): pass
+    assert registry.LOSS_REG['tmp_a'] is TmpLoss and registry.LOSS_REG['tmp_b'] is TmpLoss
+    with pytest.raises(ValueError, match='already in'):
+        @registry.register('tmp_a')
+        class OtherLoss(torch.nn.Module): pass
+
+    @registry.register('tmp_a', overwrite=True)
+    class ThirdLoss(torch.nn.Module): pass
+    assert registry.LOSS_REG['tmp_a'] is ThirdLoss
+    with pytest.raises(ValueError, match='no known patterns'):
+        @registry.register('x')
+        class Nameless(torch.nn.Module): pass
+    with pytest.raises(TypeError):
+        @registry.register('x', type='bogus')
+        class SomeNet(torch.nn.Module): pass
+    for k in ('tmp_a', 'tmp_b'): registry.LOSS_REG.pop(k)
+
+
+def test_yaml_merge_rule(tmp_path):
+    (tmp_path/'a.yaml').write_text('net:\n  depth: {enc_name: resnet18, out_scales: [0, 1, 2, 3]}\n  pose: {enc_name: resnet18}\nloss:\n  img_recon: {weight: 1}\n')
+    (tmp_path/'b.yaml').write_text('net:\n  depth: {out_scales: [0]}\n  pose: ~\nloss:\n  disp_smooth: {weight: 0.001, use_edges: True}\n')
+    cfg = io.load_merge_yaml(tmp_path/'a.yaml', tmp_path/'b.yaml')
+    assert cfg['net']['depth'] == {'enc_name': 'resnet18', 'out_scales': [0]}     # dicts merge, lists replace
+    assert cfg['net']['pose'] is None                                              # None disables an entry
+    assert set(cfg['loss']) == {'img_recon', 'disp_smooth'}
+
+
+def test_parsers_build_losses_nets_optimizer():
+    cfg = {'img_recon': {'weight': 1, 'use_min': True, 'use_automask': True}, 'disp_smooth': {'weight': 0.001, 'use_edges': True}, 'feat_peaky': None}
+    losses, weights = parsers.get_loss(cfg)
+    assert list(losses) == ['img_recon', 'disp_smooth'] and 'weight' not in cfg['img_recon']   # `weight` is popped (reference quirk)
+    assert weights['disp_smooth'].item() == pytest.approx(0.001) and not weights['disp_smooth'].requires_grad
+    assert losses['img_recon'].use_min and losses['img_recon'].use_automask and losses['disp_smooth'].use_edges
+    with pytest.raises(KeyError): parsers.get_loss({'nope': {}})
+    with pytest.raises(ValueError): ReconstructionLoss(mask_name='bogus')
+    with pytest.raises(NotImplementedError): ReconstructionLoss(mask_name='explainability')
+    with pytest.raises(NotImplementedError): SmoothReg(use_laplacian=True)
+    with pytest.raises(ValueError, match="original 'source'"):
+        ReconstructionLoss(use_automask=True)(torch.rand(2, 1, 3, 4, 4), torch.rand(1, 3, 4, 4))
+
+    nets = parsers.get_net({'depth': {'enc_name': 'resnet18', 'pretrained': False}, 'pose': {'enc_name': 'resnet18', 'learn_K': True}, 'autoencoder': None})
+    assert list(nets) == ['depth', 'pose']
+    opt = parsers.get_opt(nets, {'type': 'adamw', 'lr': 1e-4, 'weight_decay': 1e-3})
+    decays = {g['weight_decay'] for g in opt.param_groups}
+    assert decays == {0.0, 1e-3}                                                   # biases / norm parameters are exempt
+    assert sum(len(g['params']) for g in opt.param_groups) == sum(1 for p in nets.parameters() if p.requires_grad)
+    sch = parsers.get_sched(opt, {'steplr': {'step_size': 40, 'gamma': 0.1}, 'linear': {'start_factor': 0.1, 'total_iters': 4}})
+    assert set(sch) == {'steplr', 'linear'}
+    with pytest.raises(KeyError): parsers.get_opt(nets, {'lr': 1e-4})
+
+
+# ------------------------------------------------------------------------------------------------- prologue
+def test_pose_and_intrinsics_prologue_match_reference(golden):
+    g = golden('op_T_from_AAt')
+    aa = g['in_aa'].clone().requires_grad_(True); t = g['in_t'].clone().requires_grad_(True)
+    T = geometry.T_from_AAt(aa, t)
+    torch.testing.assert_close(T, g['out_T'], rtol=1e-5, atol=1e-6)
+    (T*g['in_gT']).sum().backward()
+    torch.testing.assert_close(aa.grad, g['grad_aa'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(t.grad, g['grad_t'], rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError): geometry.T_from_AAt(torch.rand(2, 4), torch.rand(2, 3))
+
+    g = golden('train_learnK_n4_40x56')
+    K = geometry.resize_K(geometry.build_K(g['in_fs'], g['in_cs']), (g['meta_h'], g['meta_w']))
+    torch.testing.assert_close(K, g['out_K'], rtol=1e-6, atol=1e-6)
+
+    g = golden('op_to_depth')
+    sd, dep = geometry.to_scaled(g['in_disp'], 0.1, 100)
+    torch.testing.assert_close(sd, g['out_scaled_disp']); torch.testing.assert_close(dep, g['out_depth'])
+    torch.testing.assert_close(geometry.to_inv(g['in_disp']), g['out_inv'])
+    with pytest.raises(ValueError): geometry.to_scaled(g['in_disp'], 0.0)
+
+    x = torch.rand(2, 3, 4, 5)
+    assert ops.expand_dim(x, 7, dim=1, insert=True).shape == (2, 7, 3, 4, 5)
+    assert ops.expand_dim(torch.rand(1, 1, 1), num=(5, 3), dim=(0, 1), insert=True).shape == (5, 3, 1, 1, 1)
+    torch.testing.assert_close(ops.mean_normalize(x).mean(dim=(2, 3)), torch.ones(2, 3))
+    torch.testing.assert_close(ops.unstandardize(ops.standardize(x)), x, rtol=1e-5, atol=1e-6)
+    assert ops.eps() == pytest.approx(1.1920929e-07)
+
+
+# ------------------------------------------------------------------------------------------------- networks
+@pytest.mark.parametrize('enc,chs,red', [('resnet18', [64, 64, 128, 256, 512], [2, 4, 8, 16, 32]),
+                                        ('convnext_tiny', [96, 192, 384, 768], [4, 8, 16, 32])])
+def test_network_output_contract(enc, chs, red):
+    e = create_encoder(enc, in_chans=6)
+    assert e.feature_info.channels() == chs and e.feature_info.reduction() == red
+    feats = e(torch.rand(1, 6, 64, 96))
+    assert [f.shape[1] for f in feats] == chs and [64//f.shape[2] for f in feats] == red
+    d = DepthNet(enc, pretrained=False, out_scales=[0, 1, 2, 3])
+    out = d(torch.rand(2, 3, 64, 96))
+    assert list(out['disp']) == [0, 1, 2, 3]
+    for s, v in out['disp'].items():
+        assert v.shape == (2, 1, 64 >> s, 96 >> s) and v.min() > 0 and v.max() < 1
+    p = PoseNet(enc, learn_K=True)(torch.rand(3, 6, 64, 96))
+    assert p['R'].shape == (3, 2, 3) and p['t'].shape == (3, 2, 3) and p['fs'].shape == (3, 2) and (p['fs'] > 0).all() and (p['cs'] < 1).all()
+    with pytest.raises(KeyError): DepthNet(dec_name='nope')
+    with pytest.raises(NotImplementedError): DepthNet(use_virtual_stereo=True)
+    with pytest.raises(KeyError): MonodepthDecoder([64], [2], out_act='tanh')
+
+
+# ------------------------------------------------------------------------------------------------- training step (oracle backend)
+def _cfg(learn_K=False):
+    return {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False, 'out_scales': [0, 1, 2, 3]},
+                    'pose': {'enc_name': 'resnet18', 'learn_K': learn_K}},
+            'loss': {'img_recon': {'weight': 1, 'use_min': True, 'use_automask': True}, 'disp_smooth': {'weight': 0.001, 'use_edges': True}},
+            'optimizer': {'type': 'adamw', 'lr': 1e-4, 'weight_decay': 1e-3},
+            'scheduler': {'steplr': {'step_size': 40, 'gamma': 0.1}, 'linear': {'start_factor': 0.1, 'total_iters': 4}},
+            'trainer': {'min_depth': 0.1, 'max_depth': 100, 'log_images': True}}
+
+
+@pytest.mark.parametrize('learn_K', [False, True])
+def test_training_step_on_cpu_with_oracle_backend(learn_K):
+    torch.manual_seed(0)
+    cfg = _cfg(learn_K)
+    m = MonoDepthModule(copy.deepcopy(cfg), loss_backend=OracleBackend())
+    batch = make_batch(2, 64, 96, (-1, 1), seed=1)
+    loss, ld, fwd = m.step(batch)
+    assert torch.isfinite(loss) and {'loss_img_recon', 'loss_disp_smooth', 'automask', 'supp_imgs_warp', 'disp_grad', 'image_grad'} <= set(ld)
+    assert ld['supp_imgs_warp'].shape == (2, 2, 3, 64, 96) and ld['automask'].dtype == torch.bool
+    assert fwd['Ts'].shape == (2, 2, 4, 4) and set(fwd['depth_up']) == {0, 1, 2, 3}
+    assert ('K' in fwd) == learn_K
+    torch.testing.assert_close(loss, ld['loss_img_recon'] + 0.001*ld['loss_disp_smooth'])
+    conf = m.configure_optimizers()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.nets['depth'].parameters())
+    pose_grads = [p.grad for n, p in m.nets['pose'].named_parameters() if ('focal' in n or 'offset' in n)]
+    if learn_K: assert pose_grads and all(g is not None for g in pose_grads)      # intrinsics heads receive gradient through K
+    conf['optimizer'].step(); conf['lr_scheduler'].step()
+    with pytest.raises(ValueError, match='Missing loss key'):
+        bad = MonoDepthModule(copy.deepcopy(cfg), loss_backend=OracleBackend())
+        bad.losses['nope'] = SmoothReg(); bad.weights['nope'] = torch.nn.Parameter(torch.tensor(1.), requires_grad=False)
+        bad.step(batch)
+
+
+def test_loss_phases_reproduce_the_reference_numbers(golden):
+    """forward_postprocess + forward_loss of the module (oracle backend) on the reference's own fixture."""
+    g = golden('train_kbr_24x32')
+    leaves, static = case_inputs(g, requires_grad=False)
+    m = MonoDepthModule(_cfg(), loss_backend=OracleBackend(aten=True))
+    n, b = leaves['aa'].shape[:2]
+    Ts = geometry.T_from_AAt(leaves['aa'].flatten(0, 1), leaves['t'].flatten(0, 1)).unflatten(0, (n, b))
+    fwd = {'disp': {s: leaves[f'disp_{s}'] for s in static['scales']}}
+    for i, T in zip(static['supp_idxs'], Ts): fwd[f'T_{i}'] = torch.linalg.inv(T) if i < 0 else T   # always_fwd_pose
+    x = {'imgs': static['imgs'], 'supp_idxs': torch.tensor(static['supp_idxs'])}
+    y = {'imgs': static['imgs'], 'supp_imgs': static['supp_imgs'], 'K': static['K']}
+    torch.manual_seed(42 + 7)   # the seed under which the fixture drew its tie-break noise
+    fwd = m.forward_postprocess(fwd, x, y)
+    loss, ld = m.forward_loss(fwd, x, y)
+    torch.testing.assert_close(fwd['Ts'], g['out_Ts'], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss, g['out_loss'], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(ld['loss_disp_smooth'], g['out_loss_disp_smooth'], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(ld['supp_imgs_warp'], g['out_supp_imgs_warp'], rtol=0, atol=2e-5)
+
+
+def test_scale_dict_is_a_dict_of_views():
+    st = torch.rand(3, 2, 1, 4, 5)
+    sd = ScaleDict.from_stack([0, 1, 3], st)
+    assert list(sd) == [0, 1, 3] and sd.stacked is st and sd[3].data_ptr() == st[2].data_ptr()
