@@ -111,6 +111,39 @@ int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, 
                         float* const* g_disp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Un-fused operators (class-level drop-ins for callers that hold the intermediate tensors).
+ *
+ * smd_view_synth_*: `ViewSynth.forward(input, depth, T, K, K_inv)` (src/tools/geometry.py:366-391) for any
+ * channel count C.  B is the already-expanded batch.  warp (B,C,h,w); depth_warp (B,1,h,w) or NULL;
+ * mask_valid (B,1,h,w) uint8 or NULL.  Backward takes g_warp (and optional g_depth_warp) and emits
+ * g_input (B,C,h,w) or NULL, g_depth (B,1,h,w), g_T (B,4,4), g_K / g_Kinv (B,4,4) or NULL. */
+size_t smd_view_synth_workspace_bytes(int B, int h, int w);
+int smd_view_synth_fwd(const float* input, const float* depth, const float* T, const float* K, const float* K_inv,
+                       float* warp, float* depth_warp, uint8_t* mask_valid, int B, int C, int h, int w, void* stream);
+int smd_view_synth_bwd(const float* input, const float* depth, const float* T, const float* K, const float* K_inv,
+                       const float* g_warp, const float* g_depth_warp,
+                       float* g_input, float* g_depth, float* g_T, float* g_K, float* g_Kinv,
+                       void* workspace, size_t workspace_bytes, int B, int C, int h, int w, void* stream);
+
+/* smd_photo_error_*: `PhotoError(0.85)(pred, target)` / `DenseL1Error` with SMD_LOSS_L1 (src/losses/photometric.py:11-14,
+ * 54-88).  pred, target (N,3,h,w) -> err (N,1,h,w).  Backward: g_err (N,1,h,w) -> g_pred (N,3,h,w). */
+size_t smd_photo_error_workspace_bytes(int N, int h, int w);
+int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int h, int w, int flags, void* stream);
+int smd_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred,
+                        void* workspace, size_t workspace_bytes, int N, int h, int w, int flags, void* stream);
+
+/* smd_recon_reduce_*: the reduction half of `ReconstructionLoss.forward` on per-support error maps
+ * (reconstruction.py:43-44, 59-77, 125).  err_warp (n,B,h,w); err_static (n,B,h,w) (required with SMD_USE_AUTOMASK);
+ * noise (B,h,w) or NULL (in-kernel tie-break noise keyed by `seed`).
+ * -> err (B,h,w), sel (B,h,w) uint8, loss (1).  Backward -> g_err_warp (n,B,h,w). */
+size_t smd_recon_reduce_workspace_bytes(int B, int h, int w);
+int smd_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed,
+                         float* err, uint8_t* sel, float* loss, void* workspace, size_t workspace_bytes,
+                         int n, int B, int h, int w, int flags, void* stream);
+int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp,
+                         int n, int B, int h, int w, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel timing hooks for bench.py: while enabled, every call of the named entry point records a HIP event pair
  * around its DOMINANT kernel (the fused strip kernel; not the identity-error pass or the scalar reductions) on
  * the caller's stream.  smd_profile_collect() waits for the recorded events and returns their durations in ms.

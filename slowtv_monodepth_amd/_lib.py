@@ -38,6 +38,15 @@ PROTOTYPES = {
     'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_disp_smooth_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'smd_disp_smooth_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'smd_view_synth_workspace_bytes': (_sz, [_i, _i, _i]),
+    'smd_view_synth_fwd': (_i, [_vp]*8 + [_i]*4 + [_vp]),
+    'smd_view_synth_bwd': (_i, [_vp]*13 + [_sz] + [_i]*4 + [_vp]),
+    'smd_photo_error_workspace_bytes': (_sz, [_i, _i, _i]),
+    'smd_photo_error_fwd': (_i, [_vp]*3 + [_i]*4 + [_vp]),
+    'smd_photo_error_bwd': (_i, [_vp]*5 + [_sz] + [_i]*4 + [_vp]),
+    'smd_recon_reduce_workspace_bytes': (_sz, [_i, _i, _i]),
+    'smd_recon_reduce_fwd': (_i, [_vp]*3 + [_u64] + [_vp]*4 + [_sz] + [_i]*5 + [_vp]),
+    'smd_recon_reduce_bwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
     'smd_profile_enable': (_i, [_i, _i]),
     'smd_profile_collect': (_i, [_i, _vp, _i, _vp]),
     'smd_debug_lane_shift': (_i, [_vp, _vp, _vp]),

@@ -259,6 +259,70 @@ int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, 
   return check_launch(smd::launch_smooth_bwd(sc, b, img, h, w, flags, stats, g_loss, (hipStream_t)stream), "disp_smooth_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Un-fused operators
+size_t smd_view_synth_workspace_bytes(int B, int h, int w) {
+  if (B < 1 || h < 2 || w < 2) return 0;
+  return align256((size_t)B*smd::ceil_div(h*w, 256)*smd::kPoseSums*sizeof(float));
+}
+
+int smd_view_synth_fwd(const float* input, const float* depth, const float* T, const float* K, const float* K_inv,
+                       float* warp, float* depth_warp, uint8_t* mask_valid, int B, int C, int h, int w, void* stream) {
+  if (!input || !depth || !T || !K || !K_inv || !warp) return fail(SMD_E_INVALID, "null pointer");
+  if (B < 1 || B > 65535 || C < 1 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
+  return check_launch(smd::launch_view_synth_fwd(input, depth, T, K, K_inv, warp, depth_warp, mask_valid, B, C, h, w, (hipStream_t)stream), "view_synth_fwd");
+}
+
+int smd_view_synth_bwd(const float* input, const float* depth, const float* T, const float* K, const float* K_inv,
+                       const float* g_warp, const float* g_depth_warp, float* g_input, float* g_depth, float* g_T, float* g_K, float* g_Kinv,
+                       void* workspace, size_t workspace_bytes, int B, int C, int h, int w, void* stream) {
+  if (!input || !depth || !T || !K || !K_inv || !g_warp || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (B < 1 || B > 65535 || C < 1 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
+  if (workspace_bytes < smd_view_synth_workspace_bytes(B, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_view_synth_bwd(input, depth, T, K, K_inv, g_warp, g_depth_warp, g_input, g_depth, g_T, g_K, g_Kinv,
+                                                 (float*)workspace, B, C, h, w, (hipStream_t)stream), "view_synth_bwd");
+}
+
+size_t smd_photo_error_workspace_bytes(int N, int h, int w) {
+  if (N < 1 || h < 2 || w < 2) return 0;
+  return align256((size_t)N*9*h*w*sizeof(float));
+}
+
+int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int h, int w, int flags, void* stream) {
+  if (!pred || !target || !err) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || N > 65535 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d h=%d w=%d", N, h, w);
+  return check_launch(smd::launch_photo_error_fwd(pred, target, err, N, h, w, flags, (hipStream_t)stream), "photo_error_fwd");
+}
+
+int smd_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred, void* workspace, size_t workspace_bytes,
+                        int N, int h, int w, int flags, void* stream) {
+  if (!pred || !target || !g_err || !g_pred || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || N > 65535 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d h=%d w=%d", N, h, w);
+  if (workspace_bytes < smd_photo_error_workspace_bytes(N, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_photo_error_bwd(pred, target, g_err, g_pred, (float*)workspace, N, h, w, flags, (hipStream_t)stream), "photo_error_bwd");
+}
+
+size_t smd_recon_reduce_workspace_bytes(int B, int h, int w) {
+  if (B < 1 || h < 1 || w < 1) return 0;
+  return align256((size_t)smd::ceil_div(B*h*w, 256)*sizeof(float));
+}
+
+int smd_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed, float* err, uint8_t* sel,
+                         float* loss, void* workspace, size_t workspace_bytes, int n, int B, int h, int w, int flags, void* stream) {
+  if (!err_warp || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if ((flags & SMD_USE_AUTOMASK) && !err_static) return fail(SMD_E_INVALID, "Must provide the original 'source' images when automasking...");
+  if (n < 1 || n >= SMD_SEL_MASKED || B < 1 || h < 1 || w < 1) return fail(SMD_E_INVALID, "invalid sizes");
+  if (workspace_bytes < smd_recon_reduce_workspace_bytes(B, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_recon_reduce_fwd(err_warp, err_static, noise, seed, err, sel, loss, (float*)workspace, n, B, h, w, flags,
+                                                   (hipStream_t)stream), "recon_reduce_fwd");
+}
+
+int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w, int flags, void* stream) {
+  if (!sel || !g_loss || !g_err_warp) return fail(SMD_E_INVALID, "null pointer");
+  if (n < 1 || B < 1 || h < 1 || w < 1) return fail(SMD_E_INVALID, "invalid sizes");
+  return check_launch(smd::launch_recon_reduce_bwd(sel, g_loss, g_err_warp, n, B, h, w, flags, (hipStream_t)stream), "recon_reduce_bwd");
+}
+
 int smd_profile_enable(int which, int capacity) {
   if (which < 0 || which > 1 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
   ProfSlot& p = g_prof[which];

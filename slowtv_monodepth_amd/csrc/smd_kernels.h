@@ -86,7 +86,7 @@ hipError_t launch_view_synth_bwd(const float* input, const float* depth, const f
                                  const float* g_warp, const float* g_depth_warp, float* g_input, float* g_depth,
                                  float* g_T, float* g_K, float* g_Kinv, float* ws, int B, int C, int h, int w, hipStream_t st);
 hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int h, int w, int flags, hipStream_t st);
-hipError_t launch_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred,
+hipError_t launch_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred, float* ws,
                                   int N, int h, int w, int flags, hipStream_t st);
 hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed,
                                    float* err, uint8_t* sel, float* loss, float* ws, int n, int B, int h, int w, int flags,

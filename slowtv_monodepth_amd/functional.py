@@ -12,7 +12,8 @@ import torch
 from . import _lib
 from ._lib import FLAGS, call, int_array, ptr_array
 
-__all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'lane_shift_selftest', 'recon_flags']
+__all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
+           'lane_shift_selftest', 'recon_flags']
 
 
 def _stream() -> int:
@@ -183,6 +184,118 @@ def disp_smooth_fused(disps: dict, imgs, *, use_edges: bool = False, want_aux: b
     keys = [int(k) for k in disps.keys()]
     flags = FLAGS['use_edges'] if use_edges else 0
     return _DispSmooth.apply(imgs, flags, keys, want_aux, *disps.values())
+
+
+# ---------------------------------------------------------------------------------------------------
+# Un-fused, class-level operators
+# ---------------------------------------------------------------------------------------------------
+class _ViewSynth(torch.autograd.Function):
+    """`ViewSynth.forward` (src/tools/geometry.py:366-391) for any channel count."""
+
+    @staticmethod
+    def forward(ctx, inp, depth, T, K, K_inv):
+        B, Cc, h, w = inp.shape
+        inp = _check('input', inp, (B, Cc, h, w)); depth = _check('depth', depth, (B, 1, h, w))
+        T = _check('T', T, (B, 4, 4)); K = _check('K', K, (B, 4, 4)); K_inv = _check('K_inv', K_inv, (B, 4, 4))
+        warp = torch.empty_like(inp)
+        dwarp = torch.empty((B, 1, h, w), device=inp.device, dtype=torch.float32)
+        valid = torch.empty((B, 1, h, w), device=inp.device, dtype=torch.uint8)
+        call('smd_view_synth_fwd', inp.data_ptr(), depth.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(), warp.data_ptr(),
+             dwarp.data_ptr(), valid.data_ptr(), B, Cc, h, w, _stream())
+        ctx.save_for_backward(inp, depth, T, K, K_inv)
+        ctx.mark_non_differentiable(valid)
+        return warp, dwarp, valid
+
+    @staticmethod
+    def backward(ctx, g_warp, g_dwarp, _g_valid):
+        inp, depth, T, K, K_inv = ctx.saved_tensors
+        B, Cc, h, w = inp.shape
+        dev = inp.device
+        g_warp = _check('grad(warp)', g_warp if g_warp is not None else torch.zeros_like(inp))
+        g_dwarp = _check('grad(depth_warp)', g_dwarp) if g_dwarp is not None else None
+        need_in, need_k = ctx.needs_input_grad[0], (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        g_in = torch.empty_like(inp) if need_in else None
+        g_depth = torch.empty_like(depth)
+        g_T = torch.empty((B, 4, 4), device=dev, dtype=torch.float32)
+        g_K = torch.empty((B, 4, 4), device=dev, dtype=torch.float32) if need_k else None
+        g_Ki = torch.empty((B, 4, 4), device=dev, dtype=torch.float32) if need_k else None
+        nbytes = _lib.lib.smd_view_synth_workspace_bytes(B, h, w)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        call('smd_view_synth_bwd', inp.data_ptr(), depth.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(), g_warp.data_ptr(),
+             g_dwarp.data_ptr() if g_dwarp is not None else None, g_in.data_ptr() if need_in else None, g_depth.data_ptr(), g_T.data_ptr(),
+             g_K.data_ptr() if need_k else None, g_Ki.data_ptr() if need_k else None, ws.data_ptr(), nbytes, B, Cc, h, w, _stream())
+        return g_in, g_depth, g_T, (g_K if ctx.needs_input_grad[3] else None), (g_Ki if ctx.needs_input_grad[4] else None)
+
+
+def view_synth(inp, depth, T, K, K_inv=None):
+    """-> (input_warp (B,C,h,w), depth_warp (B,1,h,w), mask_valid (B,1,h,w) bool)."""
+    if K_inv is None: K_inv = torch.linalg.inv(K)
+    warp, dwarp, valid = _ViewSynth.apply(inp, depth, T, K, K_inv)
+    return warp, dwarp, valid.bool()
+
+
+class _PhotoError(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, flags):
+        N, c, h, w = pred.shape
+        if c != 3: raise ValueError(f'photometric error expects 3-channel images, got {c}')
+        pred = _check('pred', pred, (N, 3, h, w)); target = _check('target', target, (N, 3, h, w))
+        err = torch.empty((N, 1, h, w), device=pred.device, dtype=torch.float32)
+        call('smd_photo_error_fwd', pred.data_ptr(), target.data_ptr(), err.data_ptr(), N, h, w, int(flags), _stream())
+        ctx.save_for_backward(pred, target); ctx.flags = int(flags)
+        return err
+
+    @staticmethod
+    def backward(ctx, g_err):
+        pred, target = ctx.saved_tensors
+        N, _, h, w = pred.shape
+        g_err = _check('grad(err)', g_err)
+        g_pred = torch.empty_like(pred)
+        nbytes = _lib.lib.smd_photo_error_workspace_bytes(N, h, w)
+        ws = torch.empty(nbytes, device=pred.device, dtype=torch.uint8)
+        call('smd_photo_error_bwd', pred.data_ptr(), target.data_ptr(), g_err.data_ptr(), g_pred.data_ptr(), ws.data_ptr(), nbytes, N, h, w,
+             ctx.flags, _stream())
+        return g_pred, None, None
+
+
+def photo_error(pred, target, loss_name: str = 'ssim'):
+    """(N,3,h,w) x2 -> (N,1,h,w): 0.85 SSIM + 0.15 L1 ('ssim') or mean |.| ('l1')."""
+    return _PhotoError.apply(pred, target, recon_flags(loss_name))
+
+
+class _ReconReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, err_warp, err_static, noise, seed, flags):
+        n, B, h, w = err_warp.shape
+        err_warp = _check('err_warp', err_warp, (n, B, h, w))
+        if err_static is not None: err_static = _check('err_static', err_static, (n, B, h, w))
+        if noise is not None: noise = _check('noise', noise.reshape(B, h, w), (B, h, w))
+        dev = err_warp.device
+        err = torch.empty((B, h, w), device=dev, dtype=torch.float32)
+        sel = torch.empty((B, h, w), device=dev, dtype=torch.uint8)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        nbytes = _lib.lib.smd_recon_reduce_workspace_bytes(B, h, w)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        call('smd_recon_reduce_fwd', err_warp.data_ptr(), err_static.data_ptr() if err_static is not None else None,
+             noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
+             ws.data_ptr(), nbytes, n, B, h, w, int(flags), _stream())
+        ctx.save_for_backward(sel); ctx.meta = (n, B, h, w, int(flags))
+        ctx.mark_non_differentiable(err, sel)
+        return loss, err, sel
+
+    @staticmethod
+    def backward(ctx, g_loss, *_):
+        (sel,) = ctx.saved_tensors
+        n, B, h, w, flags = ctx.meta
+        g = torch.empty((n, B, h, w), device=sel.device, dtype=torch.float32)
+        call('smd_recon_reduce_bwd', sel.data_ptr(), g_loss.to(torch.float32).contiguous().data_ptr(), g.data_ptr(), n, B, h, w, flags, _stream())
+        return g, None, None, None, None
+
+
+def recon_reduce(err_warp, err_static=None, *, use_min: bool = False, noise=None, seed: int = 0):
+    """Per-support error maps (n,B,h,w) [+ static ones] -> (loss, err (B,h,w), sel uint8 (B,h,w); 255 = auto-masked)."""
+    flags = (FLAGS['use_min'] if use_min else 0) | (FLAGS['use_automask'] if err_static is not None else 0)
+    return _ReconReduce.apply(err_warp, err_static, noise, seed, flags)
 
 
 # ---------------------------------------------------------------------------------------------------

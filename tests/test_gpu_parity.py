@@ -177,3 +177,71 @@ def test_full_size_properties(F, shape):
         _, err_a, sel_a, _ = F.image_recon_fused(depth.detach()[:, :hb], imgs[:hb], supp[:, :hb], T.detach()[:, :hb], K[:hb], flags=flags,
                                                  noise=noise[:, :hb])
         assert torch.equal(err_a, err[:, :hb]) and torch.equal(sel_a, sel[:, :hb])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Un-fused, class-level operators against the reference's own vectors
+# ---------------------------------------------------------------------------------------------------
+def test_view_synth_operator_matches_reference(F, golden):
+    from slowtv_monodepth_amd.geometry import T_from_AAt, ViewSynth
+    g = golden('op_view_synth')
+    dev = 'cuda'
+    feat = g['in_input'].to(dev).requires_grad_(True); depth = g['in_depth'].to(dev).requires_grad_(True)
+    aa = g['in_aa'].to(dev).requires_grad_(True); t = g['in_t'].to(dev).requires_grad_(True); K = g['in_K'].to(dev).requires_grad_(True)
+    T = T_from_AAt(aa, t)
+    warp, dwarp, valid = ViewSynth(feat.shape[-2:])(feat, depth, T, K)
+    torch.testing.assert_close(warp.cpu(), g['out_warp'], rtol=0, atol=1e-4)
+    torch.testing.assert_close(dwarp.cpu(), g['out_depth_warp'], rtol=1e-5, atol=1e-5)
+    assert valid.dtype == torch.bool and (valid.cpu() != g['out_mask_valid']).float().mean() < 3e-3
+    ((warp*g['in_gw'].to(dev)).sum() + (dwarp*g['in_gd'].to(dev)).sum()).backward()
+    for name, leaf in dict(input=feat, depth=depth, aa=aa, t=t, K=K).items():
+        assert rel_to_max(leaf.grad.cpu(), g[f'grad_{name}']) < 1e-3, name
+    with pytest.raises(ValueError): ViewSynth((3, 3))(feat, depth, T, K)
+
+
+@pytest.mark.parametrize('loss_name', ['ssim', 'l1'])
+def test_photo_error_operator_matches_reference(F, golden, loss_name):
+    g = golden('op_photo_error')
+    pred = g['in_pred'].cuda().requires_grad_(True); tgt = g['in_target'].cuda()
+    err = F.photo_error(pred, tgt, loss_name)
+    pc = g['in_pred'].clone().requires_grad_(True)
+    ref = O.photo_error(pc, g['in_target'], loss_name)
+    if loss_name == 'ssim': torch.testing.assert_close(err.cpu(), g['out_err'], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(err.detach().cpu(), ref.detach(), rtol=1e-5, atol=2e-6)
+    ge = g['in_ge']
+    (err*ge.cuda()).sum().backward(); (ref*ge).sum().backward()
+    torch.testing.assert_close(pred.grad.cpu(), pc.grad, rtol=2e-4, atol=2e-5)
+    if loss_name == 'ssim': torch.testing.assert_close(pred.grad.cpu(), g['grad_pred'], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', ['train_kbr_24x32', 'train_mean_n1_s1_33x47', 'train_min_noauto_25x38'])
+def test_class_level_path_matches_fused_path(F, golden, name):
+    """ViewSynth -> ReconstructionLoss (un-fused HIP operators, reference call structure of handlers.py:45-62) must agree with
+    the fused handler and with the reference's loss value."""
+    from slowtv_monodepth_amd.geometry import ViewSynth
+    from slowtv_monodepth_amd.losses import ReconstructionLoss
+    g = golden(name)
+    leaves, static = case_inputs(g, device='cuda', requires_grad=False)
+    scales = static['scales']; h, w = static['imgs'].shape[-2:]
+    S, b, n = len(scales), g['meta_b'], g['meta_n']
+    depth_up, _ = F.disp_to_depth([leaves[f'disp_{s}'] for s in scales], (h, w), g['meta_min_depth'] or None, g['meta_max_depth'] or None)
+    depth_up = depth_up.detach().requires_grad_(True)
+    Ts = g['out_Ts'].cuda().requires_grad_(True); K = g['in_K'].cuda()
+    crit = ReconstructionLoss(g['meta_loss_name'], bool(g['meta_use_min']), bool(g['meta_use_automask']))
+    # reference-style expansion to (n, S*b, ...)
+    dep = depth_up.flatten(0, 1)[None].expand(n, -1, -1, -1, -1).flatten(0, 1)
+    src = static['supp_imgs'][:, None].expand(n, S, b, 3, h, w).flatten(1, 2)
+    T = Ts[:, None].expand(n, S, b, 4, 4).flatten(0, 2); Kx = K[None, None].expand(n, S, b, 4, 4).flatten(0, 2)
+    warp = ViewSynth((h, w))(src.flatten(0, 1).contiguous(), dep.contiguous(), T.contiguous(), Kx.contiguous())[0].unflatten(0, (n, S*b))
+    tgt = static['imgs'][None].expand(S, b, 3, h, w).flatten(0, 1)
+    l, ld = crit(warp, tgt, source=src, noise=static['noise'])
+    torch.testing.assert_close(l.detach().cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
+    l.backward()
+    g_d_unfused, g_T_unfused = depth_up.grad.clone(), Ts.grad.clone()
+    depth_up.grad = None; Ts.grad = None
+    lf, _, _, _ = F.image_recon_fused(depth_up, static['imgs'], static['supp_imgs'], Ts, K, flags=F.recon_flags(g['meta_loss_name'], bool(g['meta_use_min']), bool(g['meta_use_automask'])), noise=static['noise'])
+    lf.backward()
+    torch.testing.assert_close(lf, l, rtol=1e-5, atol=1e-7)
+    assert rel_to_max(g_d_unfused, depth_up.grad) < 1e-3 and rel_to_max(g_T_unfused[..., :3, :], Ts.grad[..., :3, :]) < 1e-3
+    if g['meta_use_automask']:
+        assert (ld['automask'].unflatten(0, (S, b))[0].cpu() != g['out_automask']).float().mean() < 3e-3
