@@ -144,6 +144,23 @@ int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_w
                          int n, int B, int h, int w, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pose / intrinsics prologue — one launch each instead of ~45 eager ATen launches.
+ *
+ * smd_pose_*: `T_from_AAt(aa, t)` (src/tools/geometry.py:181-209), followed by `T.inverse()` where invert[i] != 0
+ * (src/core/trainer.py:253: supports behind the target when `always_fwd_pose`).  aa, t (N,3) -> T (N,4,4).
+ * Backward: g_T (N,4,4) -> g_aa, g_t (N,3).
+ *
+ * smd_intrinsics_*: with fs != NULL: `resize_K(PoseNet.build_K(fs, cs), (h, w))` (src/networks/pose.py:60-73,
+ * src/tools/geometry.py:249-263) -> K (b,4,4) and its inverse K_inv (the `K.inverse()` of geometry.py:383).
+ * With fs == NULL: K_inv of the caller's K_in (b,4,4) (3x3 block, rest identity).  Backward (learned K only):
+ * g_K, g_Kinv (b,4,4) -> g_fs, g_cs (b,2). */
+int smd_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, void* stream);
+int smd_pose_bwd(const float* aa, const float* t, const uint8_t* invert, int N, const float* g_T, float* g_aa, float* g_t, void* stream);
+int smd_intrinsics_fwd(const float* fs, const float* cs, const float* K_in, int b, int h, int w, float* K, float* K_inv, void* stream);
+int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, const float* g_K, const float* g_Kinv,
+                       float* g_fs, float* g_cs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel timing hooks for bench.py: while enabled, every call of the named entry point records a HIP event pair
  * around its DOMINANT kernel (the fused strip kernel; not the identity-error pass or the scalar reductions) on
  * the caller's stream.  smd_profile_collect() waits for the recorded events and returns their durations in ms.

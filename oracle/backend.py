@@ -18,7 +18,15 @@ class OracleBackend:
         disp_up, depth_up = O.disp_to_depth_up({k: d.float() for k, d in disps.items()}, size, min_depth, max_depth, aten=self.aten)
         return (disp_up if want_disp_up else None), depth_up
 
-    def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True):
+    def pose_matrices(self, aa, t, invert):
+        T = O.T_from_AAt(aa.float(), t.float())
+        if any(invert): T = torch.stack([torch.linalg.inv(Ti) if f else Ti for Ti, f in zip(T, invert)])
+        return T
+
+    def intrinsics(self, fs, cs, size):
+        return O.resize_K(O.build_K(fs.float(), cs.float()), size), None   # K_inv: the oracle inverts K itself, like the reference
+
+    def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True, K_inv=None):
         if masks is not None: raise NotImplementedError
         loss, ld, _ = O.image_recon(depths, imgs, supp_imgs, Ts.float(), Ks.float(), crit.loss_name, crit.use_min, crit.use_automask,
                                     noise=None, aten=self.aten)

@@ -323,6 +323,30 @@ int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_w
   return check_launch(smd::launch_recon_reduce_bwd(sel, g_loss, g_err_warp, n, B, h, w, flags, (hipStream_t)stream), "recon_reduce_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pose / intrinsics prologue
+int smd_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, void* stream) {
+  if (!aa || !t || !T) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1) return fail(SMD_E_INVALID, "invalid size N=%d", N);
+  return check_launch(smd::launch_pose_fwd(aa, t, invert, N, T, (hipStream_t)stream), "pose_fwd");
+}
+int smd_pose_bwd(const float* aa, const float* t, const uint8_t* invert, int N, const float* g_T, float* g_aa, float* g_t, void* stream) {
+  if (!aa || !t || !g_T || !g_aa || !g_t) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1) return fail(SMD_E_INVALID, "invalid size N=%d", N);
+  return check_launch(smd::launch_pose_bwd(aa, t, invert, N, g_T, g_aa, g_t, (hipStream_t)stream), "pose_bwd");
+}
+int smd_intrinsics_fwd(const float* fs, const float* cs, const float* K_in, int b, int h, int w, float* K, float* K_inv, void* stream) {
+  if (!K_inv || (fs && (!cs || !K)) || (!fs && !K_in)) return fail(SMD_E_INVALID, "null pointer");
+  if (b < 1 || h < 1 || w < 1) return fail(SMD_E_INVALID, "invalid sizes");
+  return check_launch(smd::launch_intrinsics_fwd(fs, cs, K_in, b, h, w, K, K_inv, (hipStream_t)stream), "intrinsics_fwd");
+}
+int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, const float* g_K, const float* g_Kinv,
+                       float* g_fs, float* g_cs, void* stream) {
+  if (!fs || !cs || !g_K || !g_Kinv || !g_fs || !g_cs) return fail(SMD_E_INVALID, "null pointer");
+  if (b < 1 || h < 1 || w < 1) return fail(SMD_E_INVALID, "invalid sizes");
+  return check_launch(smd::launch_intrinsics_bwd(fs, cs, b, h, w, g_K, g_Kinv, g_fs, g_cs, (hipStream_t)stream), "intrinsics_bwd");
+}
+
 int smd_profile_enable(int which, int capacity) {
   if (which < 0 || which > 1 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
   ProfSlot& p = g_prof[which];

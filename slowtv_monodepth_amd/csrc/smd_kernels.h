@@ -94,6 +94,11 @@ hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_stati
 hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w,
                                    int flags, hipStream_t st);
 hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
+hipError_t launch_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, hipStream_t st);
+hipError_t launch_pose_bwd(const float* aa, const float* t, const uint8_t* invert, int N, const float* g_T, float* g_aa, float* g_t, hipStream_t st);
+hipError_t launch_intrinsics_fwd(const float* fs, const float* cs, const float* Kin, int b, int h, int w, float* K, float* Kinv, hipStream_t st);
+hipError_t launch_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, const float* g_K, const float* g_Kinv,
+                                 float* g_fs, float* g_cs, hipStream_t st);
 
 inline int ceil_div(int a, int b) { return (a + b - 1)/b; }
 

@@ -35,6 +35,30 @@ __device__ __forceinline__ float hsum_w(float q, float wl, float wr) {
 #endif
 }
 
+// Three independent weighted sums in one block: one hazard nop, interleaved shifts and FMAs.
+__device__ __forceinline__ void hsum_w3(float a, float b, float c, float wl, float wr, float& ra, float& rb, float& rc) {
+#ifdef SMD_NO_DPP
+  ra = hsum3(a, wl, wr); rb = hsum3(b, wl, wr); rc = hsum3(c, wl, wr);
+#else
+  float ta, tb, tc;
+  asm volatile("s_nop 1\n\t"
+               "v_mov_b32_dpp %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_mov_b32_dpp %4, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_mov_b32_dpp %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fma_f32 %0, %9, %3, %6\n\t"
+               "v_fma_f32 %1, %9, %4, %7\n\t"
+               "v_fma_f32 %2, %9, %5, %8\n\t"
+               "v_mov_b32_dpp %3, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_mov_b32_dpp %4, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_mov_b32_dpp %5, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fma_f32 %0, %10, %3, %0\n\t"
+               "v_fma_f32 %1, %10, %4, %1\n\t"
+               "v_fma_f32 %2, %10, %5, %2"
+               : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(ta), "=&v"(tb), "=&v"(tc)
+               : "v"(a), "v"(b), "v"(c), "v"(wl), "v"(wr));
+#endif
+}
+
 struct BwdPending {   // loads in flight for the next row
   f4 t[4];            // bilinear taps NW, NE, SW, SE (RGBX texels)
   float y[3];
@@ -144,11 +168,10 @@ __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float ya = lo_p*y2[c], yc_ = hi_p*y0[c], xa = lo_p*x2[c], xc_ = hi_p*x0[c];
-          const float sy = hsum_w((ya + y1[c]) + yc_, wl, wr);
-          const float syy = hsum_w(fmaf(yc_, y0[c], fmaf(ya, y2[c], y1[c]*y1[c])), wl, wr);
-          const float sx = hsum_w((xa + x1[c]) + xc_, wl, wr);
-          const float sxx = hsum_w(fmaf(xc_, x0[c], fmaf(xa, x2[c], x1[c]*x1[c])), wl, wr);
-          const float sxy = hsum_w(fmaf(xc_, y0[c], fmaf(xa, y2[c], x1[c]*y1[c])), wl, wr);
+          float sy, syy, sx, sxx, sxy, unused;
+          hsum_w3((xa + x1[c]) + xc_, fmaf(xc_, x0[c], fmaf(xa, x2[c], x1[c]*x1[c])), fmaf(xc_, y0[c], fmaf(xa, y2[c], x1[c]*y1[c])),
+                  wl, wr, sx, sxx, sxy);
+          hsum_w3((ya + y1[c]) + yc_, fmaf(yc_, y0[c], fmaf(ya, y2[c], y1[c]*y1[c])), 0.f, wl, wr, sy, syy, unused);
           // e = (1 - N/Dn)/2 with N = a1*a2, Dn = b1*b2 on the x9 sums (both scaled by 81*81)
           const float t = sx*sy;
           const float a1 = fmaf(2.f, t, c1), a2 = fmaf(2.f, fmaf(9.f, sxy, -t), c2);
@@ -164,9 +187,7 @@ __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
           const float dSx = prd*(2.f*sy*(a2 - a1) - 2.f*sx*val*(b2 - b1));
           const float dSxx = prd*(-9.f*val*b1);
           const float dSxy = prd*(18.f*a1);
-          hc[c][0] = hsum_w(dSx, wla, wra);
-          hc[c][1] = hsum_w(dSxx, wla, wra);
-          hc[c][2] = hsum_w(dSxy, wla, wra);
+          hsum_w3(dSx, dSxx, dSxy, wla, wra, hc[c][0], hc[c][1], hc[c][2]);
         }
       }
 

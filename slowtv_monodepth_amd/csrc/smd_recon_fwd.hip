@@ -40,19 +40,36 @@ struct Pending {           // loads in flight for the NEXT row (software pipelin
 // Horizontal 3-tap sum through DPP wave shifts (the compiler folds each shift into a v_add_f32_dpp).  No weights are
 // needed for the reflection padding: the halo lane left of column 0 (right of column w-1) synthesises column 1
 // (w-2) itself, i.e. it holds the reflected value.
-// Written as one asm block so that the two DPP adds stay fused and adjacent: left to itself the compiler batches all
-// 48 shifts of a row first (as v_mov_b32_dpp) and keeps their results live, which costs a wave of occupancy.  The
-// leading s_nop covers the VALU-write -> DPP-read hazard (2 wait states) that the compiler cannot see inside asm.
-__device__ __forceinline__ float hsum(float q) {
+// Written as asm blocks so that each shift stays fused into its add (v_add_f32_dpp) and the pairs stay adjacent: left to
+// itself the compiler emits all 48 shifts of a row first (as v_mov_b32_dpp) and keeps their results live, which costs
+// a wave of occupancy.  Two or three independent sums share one block: one s_nop covers the VALU-write -> DPP-read
+// hazard (2 wait states) that the compiler cannot see inside asm, and the interleaving hides the add latency.
+#define SMD_DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define SMD_DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void hsum2(float a, float b, float& ra, float& rb) {
 #ifdef SMD_NO_DPP
-  return (q + lane_left(q)) + lane_right(q);
+  ra = (a + lane_left(a)) + lane_right(a); rb = (b + lane_left(b)) + lane_right(b);
 #else
-  float r;
   asm volatile("s_nop 1\n\t"
-               "v_add_f32_dpp %0, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_add_f32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-               : "=&v"(r) : "v"(q));
-  return r;
+               "v_add_f32_dpp %0, %2, %2" SMD_DPP_SHR
+               "v_add_f32_dpp %1, %3, %3" SMD_DPP_SHR
+               "v_add_f32_dpp %0, %2, %0" SMD_DPP_SHL
+               "v_add_f32_dpp %1, %3, %1" SMD_DPP_SHL
+               : "=&v"(ra), "=&v"(rb) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void hsum3(float a, float b, float c, float& ra, float& rb, float& rc) {
+#ifdef SMD_NO_DPP
+  ra = (a + lane_left(a)) + lane_right(a); rb = (b + lane_left(b)) + lane_right(b); rc = (c + lane_left(c)) + lane_right(c);
+#else
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %3, %3" SMD_DPP_SHR
+               "v_add_f32_dpp %1, %4, %4" SMD_DPP_SHR
+               "v_add_f32_dpp %2, %5, %5" SMD_DPP_SHR
+               "v_add_f32_dpp %0, %3, %0" SMD_DPP_SHL
+               "v_add_f32_dpp %1, %4, %1" SMD_DPP_SHL
+               "v_add_f32_dpp %2, %5, %2" SMD_DPP_SHL
+               : "=&v"(ra), "=&v"(rb), "=&v"(rc) : "v"(a), "v"(b), "v"(c));
 #endif
 }
 
@@ -134,8 +151,8 @@ struct FwdCtx {
     if (SSIM) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float s1 = hsum(vsum(A.yc[c], B.yc[c], C.yc[c]));
-        float s2 = hsum(vdot(A.yc[c], A.yc[c], B.yc[c], B.yc[c], C.yc[c], C.yc[c]));
+        float s1, s2;
+        hsum2(vsum(A.yc[c], B.yc[c], C.yc[c]), vdot(A.yc[c], A.yc[c], B.yc[c], B.yc[c], C.yc[c], C.yc[c]), s1, s2);
         sy[c] = s1; cy1[c] = fmaf(s1, s1, c1); cy2[c] = fmaf(9.f, s2, c2) - s1*s1;
       }
     }
@@ -148,9 +165,10 @@ struct FwdCtx {
       for (int c = 0; c < 3; ++c) {
         el += fabsf(B.xc[k][c] - B.yc[c]);
         if (SSIM) {
-          float sx = hsum(vsum(A.xc[k][c], B.xc[k][c], C.xc[k][c]));
-          float sxx = hsum(vdot(A.xc[k][c], A.xc[k][c], B.xc[k][c], B.xc[k][c], C.xc[k][c], C.xc[k][c]));
-          float sxy = hsum(vdot(A.xc[k][c], A.yc[c], B.xc[k][c], B.yc[c], C.xc[k][c], C.yc[c]));
+          float sx, sxx, sxy;
+          hsum3(vsum(A.xc[k][c], B.xc[k][c], C.xc[k][c]),
+                vdot(A.xc[k][c], A.xc[k][c], B.xc[k][c], B.xc[k][c], C.xc[k][c], C.xc[k][c]),
+                vdot(A.xc[k][c], A.yc[c], B.xc[k][c], B.yc[c], C.xc[k][c], C.yc[c]), sx, sxx, sxy);
           float t = sx*sy[c];
           float num = fmaf(2.f, t, c1)*fmaf(2.f, fmaf(9.f, sxy, -t), c2);
           float sx2 = sx*sx;
@@ -196,6 +214,7 @@ struct FwdCtx {
   // The row loop.  Ring: A = row j-2, B = row j-1, C = row j.  Software pipeline per step j:
   //   finish(C <- loads of row j, issued during step j-1) | issue(loads of row j+1; needs depth(j+1), loaded during
   //   step j-1) | load depth(j+2) | emit(row j-1)  — so a row's gathers are in flight under the previous row's SSIM math.
+  // (Unrolling by 3 to avoid shifting the ring was measured slower: 114 VGPRs / 4 waves and 3x the code vs 95 / 5.)
   __device__ __forceinline__ void run() {
     RowState<NI> A = {}, B = {}, C = {};
     Pending<NI, WARP> P = {};

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import FLAGS, call, int_array, ptr_array
 
 __all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
-           'lane_shift_selftest', 'recon_flags']
+           'lane_shift_selftest', 'recon_flags', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
 def _stream() -> int:
@@ -132,7 +132,7 @@ def image_recon_fused(depth, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int,
     """depth (S,b,1,h,w)|(S,b,h,w); returns (loss, err (S,b,1,h,w), sel uint8 (S,b,1,h,w), warp0 (n,b,3,h,w)|None).
 
     `K_inv=None` inverts `Ks` with torch (differentiable), as `ViewSynth.forward` does (src/tools/geometry.py:383)."""
-    if K_inv is None: K_inv = torch.linalg.inv(Ks)
+    if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else inv_intrinsics(Ks)
     was5 = depth.ndim == 5
     d4 = depth.squeeze(2) if was5 else depth
     return _ImageRecon.apply(d4, imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp)
@@ -299,6 +299,75 @@ def recon_reduce(err_warp, err_static=None, *, use_min: bool = False, noise=None
 
 
 # ---------------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------
+class _PoseMatrices(torch.autograd.Function):
+    """`T_from_AAt` (+ rigid inverse where flagged) in one launch (src/tools/geometry.py:181-209, src/core/trainer.py:253)."""
+
+    @staticmethod
+    def forward(ctx, aa, t, invert):
+        aa = _check('aa', aa); t = _check('t', t, aa.shape)
+        if aa.ndim != 2 or aa.shape[1] != 3: raise ValueError(f'aa and t must be (N,3), got {tuple(aa.shape)}')
+        N = aa.shape[0]
+        if invert is not None:
+            if invert.dtype != torch.uint8 or tuple(invert.shape) != (N,) or not invert.is_cuda: raise ValueError('invert must be a CUDA uint8 (N,) tensor')
+            invert = invert.contiguous()
+        T = torch.empty((N, 4, 4), device=aa.device, dtype=torch.float32)
+        call('smd_pose_fwd', aa.data_ptr(), t.data_ptr(), invert.data_ptr() if invert is not None else None, N, T.data_ptr(), _stream())
+        ctx.save_for_backward(aa, t, invert)
+        return T
+
+    @staticmethod
+    def backward(ctx, g_T):
+        aa, t, invert = ctx.saved_tensors
+        g_T = g_T.contiguous()
+        g_aa, g_t = torch.empty_like(aa), torch.empty_like(t)
+        call('smd_pose_bwd', aa.data_ptr(), t.data_ptr(), invert.data_ptr() if invert is not None else None, aa.shape[0], g_T.data_ptr(),
+             g_aa.data_ptr(), g_t.data_ptr(), _stream())
+        return g_aa, g_t, None
+
+
+def pose_matrices(aa, t, invert=None):
+    """Axis-angle + translation (N,3) -> (N,4,4) transforms; rows with `invert[i] != 0` hold the inverse transform."""
+    return _PoseMatrices.apply(aa, t, invert)
+
+
+class _Intrinsics(torch.autograd.Function):
+    """`resize_K(build_K(fs, cs), (h, w))` and its inverse in one launch (src/networks/pose.py:60-73, geometry.py:249-263, 383)."""
+
+    @staticmethod
+    def forward(ctx, fs, cs, h, w):
+        fs = _check('fs', fs); cs = _check('cs', cs, fs.shape)
+        if fs.ndim != 2 or fs.shape[1] != 2: raise ValueError(f'fs and cs must be (b,2), got {tuple(fs.shape)}')
+        b = fs.shape[0]
+        K = torch.empty((b, 4, 4), device=fs.device, dtype=torch.float32); K_inv = torch.empty_like(K)
+        call('smd_intrinsics_fwd', fs.data_ptr(), cs.data_ptr(), None, b, h, w, K.data_ptr(), K_inv.data_ptr(), _stream())
+        ctx.save_for_backward(fs, cs); ctx.size = (h, w)
+        return K, K_inv
+
+    @staticmethod
+    def backward(ctx, g_K, g_Kinv):
+        fs, cs = ctx.saved_tensors
+        h, w = ctx.size
+        g_fs, g_cs = torch.empty_like(fs), torch.empty_like(cs)
+        call('smd_intrinsics_bwd', fs.data_ptr(), cs.data_ptr(), fs.shape[0], h, w, g_K.contiguous().data_ptr(), g_Kinv.contiguous().data_ptr(),
+             g_fs.data_ptr(), g_cs.data_ptr(), _stream())
+        return g_fs, g_cs, None, None
+
+
+def intrinsics(fs, cs, size):
+    """Normalised focal lengths / principal point (b,2) -> (K, K_inv) (b,4,4) at image size `size=(h, w)`."""
+    return _Intrinsics.apply(fs, cs, int(size[0]), int(size[1]))
+
+
+def inv_intrinsics(K):
+    """Inverse of caller-supplied intrinsics (b,4,4) (3x3 block; not differentiable — dataset intrinsics are constants)."""
+    K = _check('K', K.detach())
+    if K.ndim != 3 or tuple(K.shape[1:]) != (4, 4): raise ValueError(f'K must be (b,4,4), got {tuple(K.shape)}')
+    K_inv = torch.empty_like(K)
+    call('smd_intrinsics_fwd', None, None, K.data_ptr(), K.shape[0], 1, 1, None, K_inv.data_ptr(), _stream())
+    return K_inv
+
+
 def lane_shift_selftest(device='cuda'):
     """Returns (left, right): left[l] = l-1 (0 at lane 0), right[l] = l+1 (0 at lane 63) if the DPP wave shifts that the
     stencil kernels rely on behave as documented."""

@@ -26,7 +26,7 @@ class ScaleDict(dict):
 
 
 def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs: torch.Tensor, Ts: torch.Tensor, Ks: torch.Tensor,
-                *, noise: torch.Tensor | None = None, want_warp: bool = True):
+                *, K_inv: torch.Tensor | None = None, noise: torch.Tensor | None = None, want_warp: bool = True):
     """Reconstruction loss over all scales and supports (src/core/handlers.py:14-67).
 
     :param crit: `ReconstructionLoss` (its loss_name / use_min / use_automask select the kernel flags).
@@ -34,6 +34,7 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
     :param depths: {s: (b,1,h,w)} up-sampled depth per scale (a `ScaleDict` avoids one copy).
     :param masks: must be None (predictive masks are outside the accelerated path).
     :param imgs: (b,3,h,w) target; supp_imgs: (n,b,3,h,w); Ts: (n,b,4,4); Ks: (b,4,4).
+    :param K_inv: optional (b,4,4) inverse intrinsics when the caller already has them (`functional.intrinsics`).
     :param noise: optional (S*b,1,h,w) replacement for the reference's `randn_like` tie-break draw (reconstruction.py:72).
     :return: (loss, {'supp_imgs_warp': (n,b,3,h,w) of scale 0 [, 'automask': (b,1,h,w) bool of scale 0]})
     """
@@ -43,7 +44,7 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
     stacked = getattr(depths, 'stacked', None)
     if stacked is None: stacked = torch.stack(list(depths.values()))
     flags = F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask)
-    loss, err, sel, warp0 = F.image_recon_fused(stacked, imgs, supp_imgs, Ts, Ks, flags=flags, noise=noise, seed=crit.next_seed(),
+    loss, err, sel, warp0 = F.image_recon_fused(stacked, imgs, supp_imgs, Ts, Ks, K_inv, flags=flags, noise=noise, seed=crit.next_seed(),
                                                 want_warp=want_warp)
     ld = {}
     if crit.use_automask: ld['automask'] = sel[0] != 255

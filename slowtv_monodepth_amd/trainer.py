@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import parsers
-from .geometry import T_from_AAt, ViewSynth, resize_K
+from .geometry import ViewSynth
 
 __all__ = ['MonoDepthModule', 'HipLossBackend', 'EventTimer']
 
@@ -30,9 +30,19 @@ class HipLossBackend:
         depth_up, disp_up = F.disp_to_depth([disps[k].float() for k in keys], size, min_depth, max_depth, want_disp_up=want_disp_up)
         return (ScaleDict.from_stack(keys, disp_up) if want_disp_up else None), ScaleDict.from_stack(keys, depth_up)
 
-    def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True):
+    def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True, K_inv=None):
         from . import handlers
-        return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), want_warp=want_warp)
+        return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), K_inv=K_inv, want_warp=want_warp)
+
+    def pose_matrices(self, aa, t, invert):
+        """(N,3),(N,3) + python bool list -> (N,4,4); one launch for Rodrigues + the backward-in-time inverses."""
+        from . import functional as F
+        inv = torch.tensor(invert, dtype=torch.uint8).to(aa.device, non_blocking=True) if any(invert) else None
+        return F.pose_matrices(aa.float(), t.float(), inv)
+
+    def intrinsics(self, fs, cs, size):
+        from . import functional as F
+        return F.intrinsics(fs.float(), cs.float(), size)
 
     def disp_smooth(self, crit, disps, imgs, want_aux=True):
         from . import handlers
@@ -116,13 +126,13 @@ class MonoDepthModule(nn.Module):
                 if self.channels_last: pin = pin.contiguous(memory_format=torch.channels_last)
                 with self._autocast(imgs.device.type): pose = net(pin)
                 pose = {k: v.float() for k, v in pose.items()}
-                Ts = T_from_AAt(aa=pose['R'][:, 0], t=pose['t'][:, 0]).unflatten(0, sh)
                 idxs = [i for i in idxs_all if i != 0]
-                for i, T in zip(idxs, Ts): fwd[f'T_{i}'] = torch.linalg.inv(T) if inv(i) else T
+                flags = [bool(inv(i)) for i in idxs for _ in range(sh[1])]
+                Ts = self.backend.pose_matrices(pose['R'][:, 0], pose['t'][:, 0], flags).unflatten(0, sh)
+                for i, T in zip(idxs, Ts): fwd[f'T_{i}'] = T
                 if 'fs' in pose and 'fs' not in fwd:
                     fwd['fs'], fwd['cs'] = pose['fs'].unflatten(0, sh), pose['cs'].unflatten(0, sh)
-                    K = net.build_K(pose['fs'], pose['cs']).unflatten(0, sh)[0]   # first support's prediction only
-                    fwd['K'] = resize_K(K, x['imgs'].shape[-2:])
+                    fwd['K'], fwd['K_inv'] = self.backend.intrinsics(fwd['fs'][0], fwd['cs'][0], x['imgs'].shape[-2:])  # first support's prediction only
             else:
                 raise KeyError(f'Unrecognized key: {key}.')
         return fwd
@@ -142,7 +152,7 @@ class MonoDepthModule(nn.Module):
             with self.timer(f'Loss-{k}'):
                 if k == 'img_recon':
                     l, ld = self.backend.image_recon(crit, self.synth, fwd['depth_up'], fwd.get('mask_up'), y['imgs'], y['supp_imgs'],
-                                                     fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux)
+                                                     fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux, K_inv=fwd.get('K_inv'))
                 elif k == 'disp_smooth':
                     l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'], want_aux=self.want_aux)
                 else:

@@ -245,3 +245,88 @@ def test_class_level_path_matches_fused_path(F, golden, name):
     assert rel_to_max(g_d_unfused, depth_up.grad) < 1e-3 and rel_to_max(g_T_unfused[..., :3, :], Ts.grad[..., :3, :]) < 1e-3
     if g['meta_use_automask']:
         assert (ld['automask'].unflatten(0, (S, b))[0].cpu() != g['out_automask']).float().mean() < 3e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# Pose / intrinsics prologue (smd_pose_*, smd_intrinsics_*)
+def test_pose_matrices_match_reference(F, golden):
+    g = golden('op_T_from_AAt')
+    aa = g['in_aa'].cuda().requires_grad_(True); t = g['in_t'].cuda().requires_grad_(True)
+    T = F.pose_matrices(aa, t)
+    torch.testing.assert_close(T.cpu(), g['out_T'], rtol=1e-6, atol=1e-6)
+    T.backward(g['in_gT'].cuda())
+    torch.testing.assert_close(aa.grad.cpu(), g['grad_aa'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(t.grad.cpu(), g['grad_t'], rtol=1e-5, atol=1e-6)
+
+
+def test_inverted_pose_matches_general_inverse(F):
+    """Rows flagged `invert` hold T^-1 (src/core/trainer.py:253); gradients equal those of the general 4x4 inverse."""
+    from oracle import view_synth_oracle as O
+    gen = torch.Generator().manual_seed(5)
+    N = 9
+    aa = torch.randn(N, 3, generator=gen)*0.3; t = torch.randn(N, 3, generator=gen)
+    aa[0] = 0.0                       # |aa| = 0: clip branch, zero sub-gradient of the norm
+    aa[1] = aa[1]*1e-4/aa[1].norm()   # |aa| < eps branch
+    inv = torch.tensor([0, 1, 1, 0, 1, 0, 1, 1, 0], dtype=torch.uint8)
+    gT = torch.randn(N, 4, 4, generator=gen)
+    aa_c, t_c = aa.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    T_c = O.T_from_AAt(aa_c, t_c)
+    T_c = torch.stack([torch.linalg.inv(Ti) if f else Ti for Ti, f in zip(T_c, inv)])
+    T_c.backward(gT)
+    aa_g, t_g = aa.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    T_g = F.pose_matrices(aa_g, t_g, inv.cuda())
+    T_g.backward(gT.cuda())
+    torch.testing.assert_close(T_g.detach().cpu(), T_c.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(aa_g.grad.cpu(), aa_c.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(t_g.grad.cpu(), t_c.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_intrinsics_match_oracle(F):
+    from oracle import view_synth_oracle as O
+    gen = torch.Generator().manual_seed(6)
+    b, size = 5, (96, 320)
+    fs = torch.rand(b, 2, generator=gen) + 0.5; cs = torch.rand(b, 2, generator=gen)*0.2 + 0.4
+    gK, gKi = torch.randn(b, 4, 4, generator=gen), torch.randn(b, 4, 4, generator=gen)
+    fs_c, cs_c = fs.clone().requires_grad_(True), cs.clone().requires_grad_(True)
+    K_c = O.resize_K(O.build_K(fs_c, cs_c), size); Ki_c = torch.linalg.inv(K_c)
+    ((K_c*gK).sum() + (Ki_c*gKi).sum()).backward()
+    fs_g, cs_g = fs.cuda().requires_grad_(True), cs.cuda().requires_grad_(True)
+    K_g, Ki_g = F.intrinsics(fs_g, cs_g, size)
+    ((K_g*gK.cuda()).sum() + (Ki_g*gKi.cuda()).sum()).backward()
+    torch.testing.assert_close(K_g.detach().cpu(), K_c.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(Ki_g.detach().cpu(), Ki_c.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(fs_g.grad.cpu(), fs_c.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(cs_g.grad.cpu(), cs_c.grad, rtol=1e-4, atol=1e-5)
+    # caller-supplied K (with skew): adjugate inverse of the 3x3 block
+    K = K_c.detach().clone(); K[:, 0, 1] = 0.7
+    torch.testing.assert_close(F.inv_intrinsics(K.cuda()).cpu(), torch.linalg.inv(K), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['train_learnK_n4_40x56', 'train_kbr_24x32'])
+def test_whole_chain_from_network_outputs_matches_reference_gradients(F, golden, name):
+    """aa, t, (fs, cs), disp -> pose/intrinsics kernels -> K0 -> fused loss; gradients w.r.t. every network output against the
+    reference's own autograd (the fixtures were recorded through src/core/trainer.py's forward_postprocess + forward_loss)."""
+    g = golden(name)
+    leaves, static = case_inputs(g, device='cuda')
+    scales, idxs = static['scales'], static['supp_idxs']
+    n, b = leaves['aa'].shape[:2]
+    h, w = static['imgs'].shape[-2:]
+    inv = torch.tensor([bool(g['meta_always_fwd_pose']) and i < 0 for i in idxs for _ in range(b)], dtype=torch.uint8).cuda()
+    Ts = F.pose_matrices(leaves['aa'].flatten(0, 1), leaves['t'].flatten(0, 1), inv).unflatten(0, (n, b))
+    torch.testing.assert_close(Ts.detach().cpu(), g['out_Ts'], rtol=1e-5, atol=1e-6)
+    if g['meta_learn_K']:
+        K, K_inv = F.intrinsics(leaves['fs'], leaves['cs'], (h, w))
+        torch.testing.assert_close(K.detach().cpu(), g['out_K'], rtol=1e-6, atol=1e-5)
+    else:
+        K, K_inv = static['K'], None
+    depth_up, _ = F.disp_to_depth([leaves[f'disp_{s}'] for s in scales], (h, w), g['meta_min_depth'] or None, g['meta_max_depth'] or None)
+    flags = F.recon_flags(g['meta_loss_name'], bool(g['meta_use_min']), bool(g['meta_use_automask']))
+    loss, *_ = F.image_recon_fused(depth_up, static['imgs'], static['supp_imgs'], Ts, K, K_inv, flags=flags, noise=static['noise'])
+    if g['meta_w_smooth'] >= 0:
+        l_sm, _, _ = F.disp_smooth_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'], use_edges=bool(g['meta_use_edges']), want_aux=False)
+        loss = loss + g['meta_w_smooth']*l_sm
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+    for k in ['aa', 't'] + (['fs', 'cs'] if g['meta_learn_K'] else []) + [f'disp_{s}' for s in scales]:
+        e = rel_to_max(leaves[k].grad.cpu(), g[f'grad_{k}'])
+        assert e < 1e-3, f'{name}: d loss / d {k} off by {e:.3e} (rel. to max) vs the reference autograd'
