@@ -1,7 +1,24 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 kernel_trace.csv: per-kernel count / avg / min / max duration (us), VGPRs, LDS, grid."""
+"""Summarise a rocprofv3 kernel_trace.csv: per-kernel count / avg / min / max duration (us), VGPRs, LDS, grid.
+
+usage: summarize_trace.py kernel_trace.csv [--steady MARKER N]
+  --steady MARKER N   keep only the dispatches of the last N training steps, delimited by the launches of the kernel whose
+                      name contains MARKER (one launch per step), so that MIOpen's first-use solver search during warm-up
+                      does not drown the steady state.  Totals are then also printed per step.
+"""
 import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
+args = sys.argv[1:]
+rows = list(csv.DictReader(open(args[0])))
+steps = None
+if len(args) >= 4 and args[1] == '--steady':
+    marker, n = args[2], int(args[3])
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    marks = [int(r['Start_Timestamp']) for r in rows if marker in r['Kernel_Name']]
+    if len(marks) > n:
+        lo, hi = marks[-n - 1], marks[-1]
+        rows = [r for r in rows if lo <= int(r['Start_Timestamp']) < hi]
+        steps = n
+        print(f'steady-state window: last {n} steps delimited by "{marker}", wall {(hi - lo)/1e6/n:.3f} ms/step')
 agg = collections.OrderedDict()
 for r in rows:
     k = r['Kernel_Name']
@@ -11,7 +28,9 @@ for r in rows:
                            'grid': (r.get('Grid_Size_X', ''), r.get('Grid_Size_Y', ''), r.get('Grid_Size_Z', '')), 'wg': r.get('Workgroup_Size_X', '')})
     a['n'] += 1; a['t'] += d; a['min'] = min(a['min'], d); a['max'] = max(a['max'], d)
 tot = sum(a['t'] for a in agg.values())
-print(f'total kernel time {tot/1e3:.3f} ms over {len(rows)} dispatches')
+print(f'total kernel time {tot/1e3:.3f} ms over {len(rows)} dispatches' + (f'  ({tot/1e3/steps:.3f} ms, {len(rows)//steps} dispatches per step)' if steps else ''))
+smd = sum(a['t'] for k, a in agg.items() if 'smd::' in k)
+print(f'smd:: kernels (this library): {smd/1e3:.3f} ms = {100*smd/max(tot, 1e-9):.2f} % of kernel time' + (f'  ({smd/steps:.1f} us per step)' if steps else ''))
 print(f'{"kernel":90s} {"n":>6s} {"total_us":>11s} {"%":>6s} {"avg_us":>9s} {"min_us":>9s} {"max_us":>9s} vgpr sgpr lds grid wg')
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1]['t']):
     print(f'{k[:90]:90s} {a["n"]:6d} {a["t"]:11.1f} {100*a["t"]/tot:6.2f} {a["t"]/a["n"]:9.2f} {a["min"]:9.2f} {a["max"]:9.2f} '
