@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 1
+#define SMD_ABI_VERSION 2
 
 #define SMD_OK 0
 #define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
@@ -38,6 +38,12 @@ extern "C" {
 #define SMD_LOSS_L1 0x4        /* loss_name='l1' (DenseL1Error) instead of 'ssim' (PhotoError 0.85/0.15) */
 #define SMD_NEED_K_GRAD 0x8    /* backward also emits dL/dK and dL/dK_inv (learned intrinsics) */
 #define SMD_USE_EDGES 0x10     /* SmoothReg(use_edges=True) (smooth.py:91-94) */
+#define SMD_LOSS_L2 0x20       /* DenseL2Error (photometric.py:17-20; loss_name='l2', un-fused operators only) */
+/* RegressionLoss (src/losses/regression.py:40-75) */
+#define SMD_REGR_L1 0x0
+#define SMD_REGR_LOG_L1 0x1
+#define SMD_REGR_BERHU 0x2
+#define SMD_REGR_INVERT 0x4    /* RegressionLoss(invert=True): both inputs through to_inv first (:70) */
 
 #define SMD_MAX_SCALES 8
 #define SMD_MAX_SUPPORTS 8
@@ -125,12 +131,23 @@ int smd_view_synth_bwd(const float* input, const float* depth, const float* T, c
                        float* g_input, float* g_depth, float* g_T, float* g_K, float* g_Kinv,
                        void* workspace, size_t workspace_bytes, int B, int C, int h, int w, void* stream);
 
-/* smd_photo_error_*: `PhotoError(0.85)(pred, target)` / `DenseL1Error` with SMD_LOSS_L1 (src/losses/photometric.py:11-14,
- * 54-88).  pred, target (N,3,h,w) -> err (N,1,h,w).  Backward: g_err (N,1,h,w) -> g_pred (N,3,h,w). */
-size_t smd_photo_error_workspace_bytes(int N, int h, int w);
-int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int h, int w, int flags, void* stream);
+/* smd_photo_error_*: `PhotoError(0.85)(pred, target)`, `DenseL1Error` with SMD_LOSS_L1, `DenseL2Error` with SMD_LOSS_L2
+ * (src/losses/photometric.py:11-20, 54-88) for any channel count C (images: 3; `feat_recon` features: 64..256).
+ * pred, target (N,C,h,w) -> err (N,1,h,w).  Backward: g_err (N,1,h,w) -> g_pred (N,C,h,w). */
+size_t smd_photo_error_workspace_bytes(int N, int C, int h, int w);
+int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, void* stream);
 int smd_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred,
-                        void* workspace, size_t workspace_bytes, int N, int h, int w, int flags, void* stream);
+                        void* workspace, size_t workspace_bytes, int N, int C, int h, int w, int flags, void* stream);
+
+/* smd_regression_*: `RegressionLoss.forward(pred, target, mask)` (src/losses/regression.py:69-75) used by the
+ * `stereo_const` and `depth_regr` handlers (src/core/handlers.py:152-259).  pred, target: N floats; mask: N uint8 or
+ * NULL (all ones); flags: SMD_REGR_{L1,LOG_L1,BERHU} | SMD_REGR_INVERT.  -> loss (1), err (N, `err_regr`) or NULL,
+ * stats (8 floats, handed back to the backward).  Backward: g_loss (1) -> g_pred and/or g_target (N). */
+size_t smd_regression_workspace_bytes(size_t N);
+int smd_regression_fwd(const float* pred, const float* target, const uint8_t* mask, size_t N, int flags, float* loss, float* err,
+                       float* stats, void* workspace, size_t workspace_bytes, void* stream);
+int smd_regression_bwd(const float* pred, const float* target, const uint8_t* mask, size_t N, int flags, float* stats,
+                       const float* g_loss, float* g_pred, float* g_target, void* workspace, size_t workspace_bytes, void* stream);
 
 /* smd_recon_reduce_*: the reduction half of `ReconstructionLoss.forward` on per-support error maps
  * (reconstruction.py:43-44, 59-77, 125).  err_warp (n,B,h,w); err_static (n,B,h,w) (required with SMD_USE_AUTOMASK);

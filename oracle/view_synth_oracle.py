@@ -314,3 +314,96 @@ def loss_path(disps: dict, imgs, supp_imgs, Ts, Ks, *, min_depth=0.1, max_depth=
         loss = loss + w_smooth*l_sm
         out.update(loss_disp_smooth=l_sm, **ld_sm)
     return loss, out
+
+
+# ---------------------------------------------------------------------------------------------------
+# §8f rank 3: the other ViewSynth users — regression loss, feature / autoencoder reconstruction,
+# virtual-stereo consistency, proxy-depth regression with the Depth-Hints automask
+# ---------------------------------------------------------------------------------------------------
+def regression_error(pred, target, loss_name='berhu'):
+    """Dense regression errors (src/losses/regression.py:11-37).  'berhu' uses the dynamic threshold
+    delta = 0.2*max|pred - target| over the WHOLE tensor (:32-33), and autograd differentiates through that max."""
+    diff = (pred - target).abs()
+    if loss_name == 'l1': return diff
+    if loss_name == 'log_l1': return (1 + diff).log()
+    if loss_name == 'berhu':
+        delta = 0.2*diff.max()
+        return torch.where(diff <= delta, diff, (diff.pow(2) + delta.pow(2))/(2*delta + EPS32))
+    raise KeyError(loss_name)
+
+
+def regression_loss(pred, target, mask=None, loss_name='berhu', invert=False):
+    """`RegressionLoss.forward` (src/losses/regression.py:69-75): masked mean of the dense error; `invert` maps both
+    inputs through `to_inv` first.  Returns loss, dict(err_regr, mask_regr)."""
+    if invert: pred, target = to_inv(pred), to_inv(target)
+    if mask is None: mask = torch.ones_like(target)
+    err = mask*regression_error(pred, target, loss_name)
+    return err.sum()/mask.sum(), {'err_regr': err, 'mask_regr': mask}
+
+
+def feat_recon(depths: dict, feats, supp_feats, Ts, Ks, loss_name='l2', use_min=True, use_automask=True, noise=None, aten=False):
+    """`handlers.feat_recon` (src/core/handlers.py:70-119) for tensor inputs: features are detached, bilinearly resized
+    to the depth map, and scale 0 alone goes through `image_recon`.  feats (b,c,hf,wf), supp_feats (n,b,c,hf,wf)."""
+    size = depths[0].shape[-2:]
+    feats, supp_feats = feats.detach(), supp_feats.detach()
+    n = supp_feats.shape[0]
+    feats = resize_bilinear(feats, size, aten=aten)
+    supp_feats = resize_bilinear(supp_feats.flatten(0, 1), size, aten=aten).unflatten(0, (n, -1))
+    loss, ld, full = image_recon({0: depths[0]}, feats, supp_feats, Ts, Ks, loss_name, use_min, use_automask, noise, aten)
+    return loss, {'supp_feats_warp': ld['supp_imgs_warp']}, full
+
+
+def autoenc_recon(preds: dict, targets, supp_preds: dict, supp_targets, loss_name='ssim', use_min=False, aten=False):
+    """`handlers.autoenc_recon` (src/core/handlers.py:122-149): every scale's autoencoder output against the input image,
+    target and support frames in one batch.  preds {s: (b,3,h,w)}, supp_preds {s: (n,b,3,h,w)}, supp_targets (n,b,3,h,w)."""
+    S = len(preds)
+    p = torch.stack(list(preds.values())).flatten(0, 1)
+    sp = torch.stack(list(supp_preds.values())).flatten(0, 2)
+    t = targets[None].expand(S, *targets.shape).flatten(0, 1)
+    st = supp_targets[None].expand(S, *supp_targets.shape).flatten(0, 2)
+    loss, _ = recon_loss(torch.cat((p, sp)), torch.cat((t, st)), loss_name=loss_name, use_min=use_min, aten=aten)
+    return loss
+
+
+def stereo_const(disps: dict, depths: dict, disps_stereo: dict, depths_stereo: dict, T_stereo, K, loss_name='l1',
+                 invert=False, aten=False):
+    """`handlers.stereo_const` (src/core/handlers.py:152-198): warp the virtual-stereo disparity into the target view with
+    the target depth (and vice versa with the inverse transform) and regress it on the un-warped disparity."""
+    S = len(disps)
+    d = torch.stack(list(disps.values())).flatten(0, 1); dep = torch.stack(list(depths.values())).flatten(0, 1)
+    ds = torch.stack(list(disps_stereo.values())).flatten(0, 1); deps = torch.stack(list(depths_stereo.values())).flatten(0, 1)
+    T = T_stereo[None].expand(S, *T_stereo.shape).flatten(0, 1)
+    Kx = K[None, None].expand(2, S, *K.shape).flatten(0, 2)
+    all_disps = torch.cat((ds, d))
+    warp = view_synth(all_disps, torch.cat((dep, deps)), torch.cat((T, torch.linalg.inv(T))), Kx, aten=aten)[0]
+    loss, _ = regression_loss(all_disps, warp, None, loss_name, invert)
+    sw, dw = warp.chunk(2)
+    return loss, {'disps_warp': dw.unflatten(0, (S, -1))[0], 'stereo_disps_warp': sw.unflatten(0, (S, -1))[0]}
+
+
+def depth_regr(depths: dict, targets, imgs, supp_imgs, Ts, Ks, loss_name='berhu', invert=False, use_automask=False,
+               photo_loss_name='ssim', photo_use_min=True, aten=False):
+    """`handlers.depth_regr` (src/core/handlers.py:201-259): regress every scale's depth on the proxy depth where it is
+    valid; with `use_automask` only where the proxy depth reconstructs the target better than the prediction does
+    (`photo` is `ReconstructionLoss.compute_photo` of the img_recon criterion, src/core/trainer.py:430)."""
+    S, n = len(depths), supp_imgs.shape[0]
+    b = imgs.shape[0]
+    im = imgs[None].expand(S, *imgs.shape).flatten(0, 1)
+    dep = torch.stack(list(depths.values())).flatten(0, 1)
+    tg = targets[None].expand(S, *targets.shape).flatten(0, 1)
+    masks = tg > 0
+    ld = {}
+    if use_automask:
+        src = supp_imgs[:, None].expand(n, S, *supp_imgs.shape[1:]).flatten(1, 2)                 # (n,S*b,3,h,w)
+        T = Ts[:, None].expand(n, S, b, 4, 4).flatten(0, 2); K = Ks[None, None].expand(n, S, b, 4, 4).flatten(0, 2)
+        ex = lambda z: z[None].expand(n, *z.shape).flatten(0, 1)
+        hints_warp = view_synth(src.flatten(0, 1), ex(tg), T, K, aten=aten)[0].unflatten(0, (n, -1))
+        pred_warp = view_synth(src.flatten(0, 1), ex(dep), T, K, aten=aten)[0].unflatten(0, (n, -1))
+        e_pred = compute_photo(pred_warp, im, photo_loss_name, photo_use_min, aten)[0]
+        e_hint = compute_photo(hints_warp, im, photo_loss_name, photo_use_min, aten)[0]
+        automask = e_pred > e_hint
+        ld['automask_hints'] = automask.unflatten(0, (S, -1))[0]
+        masks = masks & automask
+    loss, out = regression_loss(dep, tg, masks, loss_name, invert)
+    ld['mask_regr'] = out['mask_regr'].unflatten(0, (S, -1))[0]
+    return loss, ld

@@ -12,12 +12,13 @@ from pathlib import Path
 
 import torch  # noqa: F401  MUST precede the CDLL below: the library binds to the HIP runtime torch has already loaded
 
-__all__ = ['lib', 'call', 'lib_path', 'FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError']
+__all__ = ['lib', 'call', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError']
 
 _HERE = Path(__file__).resolve().parent
 lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
 
-FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10}
+FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10, 'loss_l2': 0x20}
+REGR_FLAGS = {'l1': 0x0, 'log_l1': 0x1, 'berhu': 0x2, 'invert': 0x4}
 SEL_MASKED = 255
 MAX_SCALES = 8
 MAX_SUPPORTS = 8
@@ -41,9 +42,12 @@ PROTOTYPES = {
     'smd_view_synth_workspace_bytes': (_sz, [_i, _i, _i]),
     'smd_view_synth_fwd': (_i, [_vp]*8 + [_i]*4 + [_vp]),
     'smd_view_synth_bwd': (_i, [_vp]*13 + [_sz] + [_i]*4 + [_vp]),
-    'smd_photo_error_workspace_bytes': (_sz, [_i, _i, _i]),
-    'smd_photo_error_fwd': (_i, [_vp]*3 + [_i]*4 + [_vp]),
-    'smd_photo_error_bwd': (_i, [_vp]*5 + [_sz] + [_i]*4 + [_vp]),
+    'smd_photo_error_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'smd_photo_error_fwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
+    'smd_photo_error_bwd': (_i, [_vp]*5 + [_sz] + [_i]*5 + [_vp]),
+    'smd_regression_workspace_bytes': (_sz, [_sz]),
+    'smd_regression_fwd': (_i, [_vp]*3 + [_sz, _i] + [_vp]*4 + [_sz, _vp]),
+    'smd_regression_bwd': (_i, [_vp]*3 + [_sz, _i] + [_vp]*5 + [_sz, _vp]),
     'smd_recon_reduce_workspace_bytes': (_sz, [_i, _i, _i]),
     'smd_recon_reduce_fwd': (_i, [_vp]*3 + [_u64] + [_vp]*4 + [_sz] + [_i]*5 + [_vp]),
     'smd_recon_reduce_bwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
@@ -70,7 +74,7 @@ def _load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if handle.smd_abi_version() != 1: raise ImportError(f'ABI version mismatch in {lib_path}')
+    if handle.smd_abi_version() != 2: raise ImportError(f'ABI version mismatch in {lib_path}')
     return handle
 
 

@@ -283,23 +283,47 @@ int smd_view_synth_bwd(const float* input, const float* depth, const float* T, c
                                                  (float*)workspace, B, C, h, w, (hipStream_t)stream), "view_synth_bwd");
 }
 
-size_t smd_photo_error_workspace_bytes(int N, int h, int w) {
-  if (N < 1 || h < 2 || w < 2) return 0;
-  return align256((size_t)N*9*h*w*sizeof(float));
+size_t smd_photo_error_workspace_bytes(int N, int C, int h, int w) {
+  if (N < 1 || C < 1 || h < 2 || w < 2) return 0;
+  return align256((size_t)N*3*C*h*w*sizeof(float));
 }
 
-int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int h, int w, int flags, void* stream) {
+int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, void* stream) {
   if (!pred || !target || !err) return fail(SMD_E_INVALID, "null pointer");
-  if (N < 1 || N > 65535 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d h=%d w=%d", N, h, w);
-  return check_launch(smd::launch_photo_error_fwd(pred, target, err, N, h, w, flags, (hipStream_t)stream), "photo_error_fwd");
+  if (N < 1 || N > 65535 || C < 1 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d h=%d w=%d", N, C, h, w);
+  return check_launch(smd::launch_photo_error_fwd(pred, target, err, N, C, h, w, flags, (hipStream_t)stream), "photo_error_fwd");
 }
 
 int smd_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred, void* workspace, size_t workspace_bytes,
-                        int N, int h, int w, int flags, void* stream) {
+                        int N, int C, int h, int w, int flags, void* stream) {
   if (!pred || !target || !g_err || !g_pred || !workspace) return fail(SMD_E_INVALID, "null pointer");
-  if (N < 1 || N > 65535 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d h=%d w=%d", N, h, w);
-  if (workspace_bytes < smd_photo_error_workspace_bytes(N, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
-  return check_launch(smd::launch_photo_error_bwd(pred, target, g_err, g_pred, (float*)workspace, N, h, w, flags, (hipStream_t)stream), "photo_error_bwd");
+  if (N < 1 || N > 65535 || C < 1 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d h=%d w=%d", N, C, h, w);
+  if (workspace_bytes < smd_photo_error_workspace_bytes(N, C, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_photo_error_bwd(pred, target, g_err, g_pred, (float*)workspace, N, C, h, w, flags, (hipStream_t)stream), "photo_error_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// RegressionLoss
+size_t smd_regression_workspace_bytes(size_t N) {
+  if (N < 1) return 0;
+  return align256((size_t)smd::regr_blocks(N)*3*sizeof(float));
+}
+
+int smd_regression_fwd(const float* pred, const float* target, const uint8_t* mask, size_t N, int flags, float* loss, float* err, float* stats,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pred || !target || !loss || !stats || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || N > ((size_t)1 << 40)) return fail(SMD_E_INVALID, "invalid size N=%zu", N);
+  if (workspace_bytes < smd_regression_workspace_bytes(N)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_regression_fwd(pred, target, mask, N, flags, loss, err, stats, (float*)workspace, (hipStream_t)stream), "regression_fwd");
+}
+
+int smd_regression_bwd(const float* pred, const float* target, const uint8_t* mask, size_t N, int flags, float* stats, const float* g_loss,
+                       float* g_pred, float* g_target, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pred || !target || !stats || !g_loss || !workspace || (!g_pred && !g_target)) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || N > ((size_t)1 << 40)) return fail(SMD_E_INVALID, "invalid size N=%zu", N);
+  if (workspace_bytes < smd_regression_workspace_bytes(N)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_regression_bwd(pred, target, mask, N, flags, stats, g_loss, g_pred, g_target, (float*)workspace, (hipStream_t)stream),
+                      "regression_bwd");
 }
 
 size_t smd_recon_reduce_workspace_bytes(int B, int h, int w) {

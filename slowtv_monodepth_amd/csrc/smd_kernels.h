@@ -85,15 +85,20 @@ hipError_t launch_view_synth_fwd(const float* input, const float* depth, const f
 hipError_t launch_view_synth_bwd(const float* input, const float* depth, const float* T, const float* K, const float* Kinv,
                                  const float* g_warp, const float* g_depth_warp, float* g_input, float* g_depth,
                                  float* g_T, float* g_K, float* g_Kinv, float* ws, int B, int C, int h, int w, hipStream_t st);
-hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int h, int w, int flags, hipStream_t st);
+hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, hipStream_t st);
 hipError_t launch_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred, float* ws,
-                                  int N, int h, int w, int flags, hipStream_t st);
+                                  int N, int C, int h, int w, int flags, hipStream_t st);
 hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed,
                                    float* err, uint8_t* sel, float* loss, float* ws, int n, int B, int h, int w, int flags,
                                    hipStream_t st);
 hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w,
                                    int flags, hipStream_t st);
 hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
+int regr_blocks(size_t N);
+hipError_t launch_regression_fwd(const float* pred, const float* target, const uint8_t* mask, size_t N, int flags, float* loss, float* err,
+                                 float* stats, float* ws, hipStream_t st);
+hipError_t launch_regression_bwd(const float* pred, const float* target, const uint8_t* mask, size_t N, int flags, float* stats,
+                                 const float* g_loss, float* g_pred, float* g_target, float* ws, hipStream_t st);
 hipError_t launch_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, hipStream_t st);
 hipError_t launch_pose_bwd(const float* aa, const float* t, const uint8_t* invert, int N, const float* g_T, float* g_aa, float* g_t, hipStream_t st);
 hipError_t launch_intrinsics_fwd(const float* fs, const float* cs, const float* Kin, int b, int h, int w, float* K, float* Kinv, hipStream_t st);

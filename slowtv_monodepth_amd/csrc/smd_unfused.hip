@@ -130,8 +130,10 @@ hipError_t launch_view_synth_bwd(const float* input, const float* depth, const f
 }
 
 // ---------------------------------------------------------------------------------------------
-// PhotoError(0.85) / DenseL1Error (src/losses/photometric.py:11-14, 54-88)
+// PhotoError(0.85) / DenseL1Error / DenseL2Error for any channel count (src/losses/photometric.py:11-20, 54-88)
 // ---------------------------------------------------------------------------------------------
+enum { kPhotoSsim = 0, kPhotoL1 = 1, kPhotoL2 = 2 };
+
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2*(n - 1) - i : i); }
 
 // Nine-tap (reflection padded) un-normalised window sums of one channel at (v, u).
@@ -151,18 +153,19 @@ __device__ __forceinline__ void window_sums(const float* __restrict__ x, const f
 }
 
 __global__ __launch_bounds__(kUfBlock) void k_photo_error_fwd(const float* __restrict__ pred, const float* __restrict__ target,
-                                                              float* __restrict__ err, int h, int w, int l1_only) {
+                                                              float* __restrict__ err, int C, int h, int w, int mode) {
   const int ni = blockIdx.y;
   const int pix = blockIdx.x*kUfBlock + threadIdx.x;
   if (pix >= h*w) return;
   const int v = pix/w, u = pix - v*w;
   const size_t hw = (size_t)h*w;
   constexpr float c1 = 81.f*kC1, c2 = 81.f*kC2;
-  float es = 0.f, el = 0.f;
-  for (int c = 0; c < 3; ++c) {
-    const float* x = pred + ((size_t)ni*3 + c)*hw; const float* y = target + ((size_t)ni*3 + c)*hw;
-    el += fabsf(x[pix] - y[pix]);
-    if (!l1_only) {
+  float es = 0.f, el = 0.f, e2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* x = pred + ((size_t)ni*C + c)*hw; const float* y = target + ((size_t)ni*C + c)*hw;
+    const float d = x[pix] - y[pix];
+    el += fabsf(d); e2 = fmaf(d, d, e2);
+    if (mode == kPhotoSsim) {
       float sx, sxx, sxy, sy, syy;
       window_sums(x, y, h, w, v, u, sx, sxx, sxy, sy, syy);
       const float t = sx*sy, sx2 = sx*sx;
@@ -171,26 +174,29 @@ __global__ __launch_bounds__(kUfBlock) void k_photo_error_fwd(const float* __res
       es += fminf(fmaxf(fmaf(-0.5f, num/den, 0.5f), 0.f), 1.f);
     }
   }
-  err[(size_t)ni*hw + pix] = l1_only ? el*(1.f/3.f) : fmaf(kWSsim/3.f, es, ((1.f - kWSsim)/3.f)*el);
+  const float rc = 1.f/(float)C;
+  err[(size_t)ni*hw + pix] = mode == kPhotoL2 ? sqrtf(fmaxf(e2, kEps32)) : (mode == kPhotoL1 ? el*rc : fmaf(kWSsim*rc, es, ((1.f - kWSsim)*rc)*el));
 }
 
-hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int h, int w, int flags, hipStream_t st) {
-  hipLaunchKernelGGL(k_photo_error_fwd, dim3(ceil_div(h*w, kUfBlock), N), dim3(kUfBlock), 0, st, pred, target, err, h, w, (flags & SMD_LOSS_L1) ? 1 : 0);
+static inline int photo_mode(int flags) { return (flags & SMD_LOSS_L2) ? kPhotoL2 : ((flags & SMD_LOSS_L1) ? kPhotoL1 : kPhotoSsim); }
+
+hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_photo_error_fwd, dim3(ceil_div(h*w, kUfBlock), N), dim3(kUfBlock), 0, st, pred, target, err, C, h, w, photo_mode(flags));
   return hipGetLastError();
 }
 
 // Backward, pass 1: per pixel p the three SSIM partials (w.r.t. the x9 sums) times the upstream gradient -> coef (N,9,h,w).
 __global__ __launch_bounds__(kUfBlock) void k_photo_coef(const float* __restrict__ pred, const float* __restrict__ target,
-                                                         const float* __restrict__ g_err, float* __restrict__ coef, int h, int w) {
+                                                         const float* __restrict__ g_err, float* __restrict__ coef, int C, int h, int w) {
   const int ni = blockIdx.y;
   const int pix = blockIdx.x*kUfBlock + threadIdx.x;
   if (pix >= h*w) return;
   const int v = pix/w, u = pix - v*w;
   const size_t hw = (size_t)h*w;
   constexpr float c1 = 81.f*kC1, c2 = 81.f*kC2;
-  const float g = g_err[(size_t)ni*hw + pix]*(kWSsim/3.f);
-  for (int c = 0; c < 3; ++c) {
-    const float* x = pred + ((size_t)ni*3 + c)*hw; const float* y = target + ((size_t)ni*3 + c)*hw;
+  const float g = g_err[(size_t)ni*hw + pix]*(kWSsim/(float)C);
+  for (int c = 0; c < C; ++c) {
+    const float* x = pred + ((size_t)ni*C + c)*hw; const float* y = target + ((size_t)ni*C + c)*hw;
     float sx, sxx, sxy, sy, syy;
     window_sums(x, y, h, w, v, u, sx, sxx, sxy, sy, syy);
     const float t = sx*sy, sx2 = sx*sx;
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(kUfBlock) void k_photo_coef(const float* __restrict
     const float b1 = sx2 + fmaf(sy, sy, c1), b2 = fmaf(9.f, sxx, -sx2) + (fmaf(9.f, syy, c2) - sy*sy);
     const float rden = 1.f/(b1*b2), val = a1*a2*rden, e = fmaf(-0.5f, val, 0.5f);
     const float prd = ((e >= 0.f && e <= 1.f) ? -0.5f*g : 0.f)*rden;
-    float* cp = coef + ((size_t)ni*9 + c*3)*hw + pix;
+    float* cp = coef + ((size_t)ni*3*C + c*3)*hw + pix;
     cp[0] = prd*(2.f*sy*(a2 - a1) - 2.f*sx*val*(b2 - b1));
     cp[hw] = prd*(-9.f*val*b1);
     cp[2*hw] = prd*(18.f*a1);
@@ -208,22 +214,30 @@ __global__ __launch_bounds__(kUfBlock) void k_photo_coef(const float* __restrict
 // Backward, pass 2: adjoint of (reflection pad + 3x3 sum) applied to the coefficient maps, plus the L1 term.
 __global__ __launch_bounds__(kUfBlock) void k_photo_error_bwd(const float* __restrict__ pred, const float* __restrict__ target,
                                                               const float* __restrict__ g_err, const float* __restrict__ coef,
-                                                              float* __restrict__ g_pred, int h, int w, int l1_only) {
+                                                              float* __restrict__ g_pred, int C, int h, int w, int mode) {
   const int ni = blockIdx.y;
   const int pix = blockIdx.x*kUfBlock + threadIdx.x;
   if (pix >= h*w) return;
   const int v = pix/w, u = pix - v*w;
   const size_t hw = (size_t)h*w;
-  const float gl = g_err[(size_t)ni*hw + pix]*(l1_only ? 1.f/3.f : (1.f - kWSsim)/3.f);
+  const float ge = g_err[(size_t)ni*hw + pix];
+  if (mode == kPhotoL2) {   // sqrt(clamp(sum d^2, eps)): zero gradient where the clamp is active
+    float e2 = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = pred[((size_t)ni*C + c)*hw + pix] - target[((size_t)ni*C + c)*hw + pix]; e2 = fmaf(d, d, e2); }
+    const float k = (e2 >= kEps32) ? ge/sqrtf(e2) : 0.f;
+    for (int c = 0; c < C; ++c) g_pred[((size_t)ni*C + c)*hw + pix] = k*(pred[((size_t)ni*C + c)*hw + pix] - target[((size_t)ni*C + c)*hw + pix]);
+    return;
+  }
+  const float gl = ge*(mode == kPhotoL1 ? 1.f : (1.f - kWSsim))/(float)C;
   float wv[3], wu[3];
   reflect_weights_adj(v, h, wv[0], wv[2]); wv[1] = 1.f;
   reflect_weights_adj(u, w, wu[0], wu[2]); wu[1] = 1.f;
-  for (int c = 0; c < 3; ++c) {
-    const float x = pred[((size_t)ni*3 + c)*hw + pix], y = target[((size_t)ni*3 + c)*hw + pix];
+  for (int c = 0; c < C; ++c) {
+    const float x = pred[((size_t)ni*C + c)*hw + pix], y = target[((size_t)ni*C + c)*hw + pix];
     const float d = x - y;
     float gx = gl*((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
-    if (!l1_only) {
-      const float* cp = coef + ((size_t)ni*9 + c*3)*hw;
+    if (mode == kPhotoSsim) {
+      const float* cp = coef + ((size_t)ni*3*C + c*3)*hw;
       float SA = 0.f, SB = 0.f, SC = 0.f;
 #pragma unroll
       for (int dv = -1; dv <= 1; ++dv) {
@@ -240,16 +254,16 @@ __global__ __launch_bounds__(kUfBlock) void k_photo_error_bwd(const float* __res
       }
       gx += fmaf(2.f*x, SB, fmaf(y, SC, SA));
     }
-    g_pred[((size_t)ni*3 + c)*hw + pix] = gx;
+    g_pred[((size_t)ni*C + c)*hw + pix] = gx;
   }
 }
 
 hipError_t launch_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred, float* ws,
-                                  int N, int h, int w, int flags, hipStream_t st) {
-  const int l1 = (flags & SMD_LOSS_L1) ? 1 : 0;
+                                  int N, int C, int h, int w, int flags, hipStream_t st) {
+  const int mode = photo_mode(flags);
   dim3 grid(ceil_div(h*w, kUfBlock), N);
-  if (!l1) hipLaunchKernelGGL(k_photo_coef, grid, dim3(kUfBlock), 0, st, pred, target, g_err, ws, h, w);
-  hipLaunchKernelGGL(k_photo_error_bwd, grid, dim3(kUfBlock), 0, st, pred, target, g_err, ws, g_pred, h, w, l1);
+  if (mode == kPhotoSsim) hipLaunchKernelGGL(k_photo_coef, grid, dim3(kUfBlock), 0, st, pred, target, g_err, ws, C, h, w);
+  hipLaunchKernelGGL(k_photo_error_bwd, grid, dim3(kUfBlock), 0, st, pred, target, g_err, ws, g_pred, C, h, w, mode);
   return hipGetLastError();
 }
 

@@ -10,10 +10,10 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import FLAGS, call, int_array, ptr_array
+from ._lib import FLAGS, REGR_FLAGS, call, int_array, ptr_array
 
 __all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
-           'lane_shift_selftest', 'recon_flags', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
+           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
 def _stream() -> int:
@@ -237,30 +237,72 @@ def view_synth(inp, depth, T, K, K_inv=None):
 class _PhotoError(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, flags):
+        if pred.ndim != 4: raise ValueError(f'photometric error expects (N,C,h,w) tensors, got {tuple(pred.shape)}')
         N, c, h, w = pred.shape
-        if c != 3: raise ValueError(f'photometric error expects 3-channel images, got {c}')
-        pred = _check('pred', pred, (N, 3, h, w)); target = _check('target', target, (N, 3, h, w))
+        pred = _check('pred', pred, (N, c, h, w)); target = _check('target', target, (N, c, h, w))
         err = torch.empty((N, 1, h, w), device=pred.device, dtype=torch.float32)
-        call('smd_photo_error_fwd', pred.data_ptr(), target.data_ptr(), err.data_ptr(), N, h, w, int(flags), _stream())
+        call('smd_photo_error_fwd', pred.data_ptr(), target.data_ptr(), err.data_ptr(), N, c, h, w, int(flags), _stream())
         ctx.save_for_backward(pred, target); ctx.flags = int(flags)
         return err
 
     @staticmethod
     def backward(ctx, g_err):
         pred, target = ctx.saved_tensors
-        N, _, h, w = pred.shape
+        N, c, h, w = pred.shape
         g_err = _check('grad(err)', g_err)
         g_pred = torch.empty_like(pred)
-        nbytes = _lib.lib.smd_photo_error_workspace_bytes(N, h, w)
+        nbytes = _lib.lib.smd_photo_error_workspace_bytes(N, c, h, w)
         ws = torch.empty(nbytes, device=pred.device, dtype=torch.uint8)
-        call('smd_photo_error_bwd', pred.data_ptr(), target.data_ptr(), g_err.data_ptr(), g_pred.data_ptr(), ws.data_ptr(), nbytes, N, h, w,
+        call('smd_photo_error_bwd', pred.data_ptr(), target.data_ptr(), g_err.data_ptr(), g_pred.data_ptr(), ws.data_ptr(), nbytes, N, c, h, w,
              ctx.flags, _stream())
         return g_pred, None, None
 
 
 def photo_error(pred, target, loss_name: str = 'ssim'):
-    """(N,3,h,w) x2 -> (N,1,h,w): 0.85 SSIM + 0.15 L1 ('ssim') or mean |.| ('l1')."""
-    return _PhotoError.apply(pred, target, recon_flags(loss_name))
+    """(N,C,h,w) x2 -> (N,1,h,w): 0.85 SSIM + 0.15 L1 ('ssim'), channel-mean |.| ('l1') or Euclidean distance ('l2')."""
+    if loss_name not in ('ssim', 'l1', 'l2'): raise KeyError(loss_name)
+    return _PhotoError.apply(pred, target, {'ssim': 0, 'l1': FLAGS['loss_l1'], 'l2': FLAGS['loss_l2']}[loss_name])
+
+
+class _Regression(torch.autograd.Function):
+    """`RegressionLoss.forward` (src/losses/regression.py:69-75); gradients to both `pred` and `target`."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, flags):
+        pred = _check('pred', pred); target = _check('target', target, pred.shape)
+        if mask is not None:
+            if tuple(mask.shape) != tuple(pred.shape): raise ValueError(f'mask: expected shape {tuple(pred.shape)}, got {tuple(mask.shape)}')
+            mask = (mask if mask.dtype == torch.bool else mask != 0).contiguous().view(torch.uint8)
+        N, dev = pred.numel(), pred.device
+        loss = torch.empty((), device=dev, dtype=torch.float32); err = torch.empty_like(pred)
+        stats = torch.zeros(8, device=dev, dtype=torch.float32)
+        nbytes = _lib.lib.smd_regression_workspace_bytes(N)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        call('smd_regression_fwd', pred.data_ptr(), target.data_ptr(), mask.data_ptr() if mask is not None else None, N, int(flags),
+             loss.data_ptr(), err.data_ptr(), stats.data_ptr(), ws.data_ptr(), nbytes, _stream())
+        ctx.save_for_backward(pred, target, mask, stats); ctx.flags = int(flags)
+        ctx.mark_non_differentiable(err)
+        return loss, err
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_err):
+        pred, target, mask, stats = ctx.saved_tensors
+        N = pred.numel()
+        g_pred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        g_target = torch.empty_like(target) if ctx.needs_input_grad[1] else None
+        if g_pred is None and g_target is None: return None, None, None, None
+        nbytes = _lib.lib.smd_regression_workspace_bytes(N)
+        ws = torch.empty(nbytes, device=pred.device, dtype=torch.uint8)
+        call('smd_regression_bwd', pred.data_ptr(), target.data_ptr(), mask.data_ptr() if mask is not None else None, N, ctx.flags,
+             stats.data_ptr(), g_loss.to(torch.float32).contiguous().data_ptr(), g_pred.data_ptr() if g_pred is not None else None,
+             g_target.data_ptr() if g_target is not None else None, ws.data_ptr(), nbytes, _stream())
+        return g_pred, g_target, None, None
+
+
+def regression_loss(pred, target, mask=None, *, loss_name: str = 'berhu', invert: bool = False):
+    """Masked mean of a dense regression error -> (loss, err).  loss_name in {'l1', 'log_l1', 'berhu'}."""
+    if loss_name not in ('l1', 'log_l1', 'berhu'): raise KeyError(loss_name)
+    return _Regression.apply(pred, target, mask, REGR_FLAGS[loss_name] | (REGR_FLAGS['invert'] if invert else 0))
 
 
 class _ReconReduce(torch.autograd.Function):

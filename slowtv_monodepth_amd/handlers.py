@@ -3,6 +3,10 @@
 `image_recon` and `disp_smooth` keep the reference's signatures and return values, but instead of expanding every
 tensor to (n, S*b, ...) and chaining ViewSynth -> ReconstructionLoss (handlers.py:45-62), they hand the un-expanded
 tensors to one fused HIP forward (and, through autograd, one fused backward).
+
+The other ViewSynth users (`feat_recon`, `autoenc_recon`, `stereo_const`, `depth_regr`) keep the
+reference's structure and run on the un-fused HIP operators (`view_synth`, `photo_error`, `recon_reduce`,
+`regression_loss`), which take any channel count.
 """
 from __future__ import annotations
 
@@ -10,7 +14,7 @@ import torch
 
 from . import functional as F
 
-__all__ = ['image_recon', 'disp_smooth', 'ScaleDict']
+__all__ = ['image_recon', 'disp_smooth', 'feat_recon', 'autoenc_recon', 'stereo_const', 'depth_regr', 'ScaleDict']
 
 
 class ScaleDict(dict):
@@ -41,6 +45,8 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
     if masks is not None: raise NotImplementedError('predictive masks are outside the accelerated path')
     if synth is not None and tuple(synth.shape) != tuple(imgs.shape[-2:]):
         raise ValueError(f'ViewSynth built for {synth.shape}, images are {tuple(imgs.shape[-2:])}')
+    if imgs.shape[1] != 3 or crit.loss_name == 'l2':   # features / Euclidean error: un-fused operators
+        return _image_recon_generic(crit, depths, imgs, supp_imgs, Ts, Ks, K_inv, noise, want_warp)
     stacked = getattr(depths, 'stacked', None)
     if stacked is None: stacked = torch.stack(list(depths.values()))
     flags = F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask)
@@ -50,6 +56,102 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
     if crit.use_automask: ld['automask'] = sel[0] != 255
     if want_warp: ld['supp_imgs_warp'] = warp0
     return loss, ld
+
+
+def _expand_views(depths: dict, imgs, supp_imgs, Ts, Ks, K_inv):
+    """The (n, S*b, ...) expansion of handlers.py:45-56 (views only; the operators read them through `.contiguous()`)."""
+    n, S, b = supp_imgs.shape[0], len(depths), imgs.shape[0]
+    dep = torch.stack(list(depths.values())).flatten(0, 1)                                   # (S*b,1,h,w)
+    tgt = imgs[None].expand(S, *imgs.shape).flatten(0, 1)                                    # (S*b,c,h,w)
+    src = supp_imgs[:, None].expand(n, S, *supp_imgs.shape[1:]).flatten(1, 2)                # (n,S*b,c,h,w)
+    T = Ts[:, None].expand(n, S, b, 4, 4).flatten(0, 2)
+    K = Ks[None, None].expand(n, S, b, 4, 4).flatten(0, 2)
+    Ki = K_inv[None, None].expand(n, S, b, 4, 4).flatten(0, 2)
+    return n, S, b, dep, tgt, src, T, K, Ki
+
+
+def _image_recon_generic(crit, depths, imgs, supp_imgs, Ts, Ks, K_inv, noise, want_warp):
+    if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else F.inv_intrinsics(Ks)
+    n, S, b, dep, tgt, src, T, K, Ki = _expand_views(depths, imgs, supp_imgs, Ts, Ks, K_inv)
+    warp = F.view_synth(src.flatten(0, 1), dep[None].expand(n, *dep.shape).flatten(0, 1), T, K, Ki)[0].unflatten(0, (n, S*b))
+    loss, ld = crit(warp, tgt, source=src, noise=noise)
+    out = {}
+    if crit.use_automask: out['automask'] = ld['automask'].unflatten(0, (S, b))[0]
+    if want_warp: out['supp_imgs_warp'] = warp.unflatten(1, (S, b))[:, 0]
+    return loss, out
+
+
+def feat_recon(crit, synth, depths: dict, masks, feats, supp_feats, Ts: torch.Tensor, Ks: torch.Tensor, *, noise=None):
+    """Feature-metric reconstruction loss on the finest depth map only (src/core/handlers.py:70-119).
+
+    :param feats: (b,c,hf,wf) target encoder features, or the encoder's list of multi-scale features (the 1/4-scale
+        entry `[-4]` is used, as in the reference); supp_feats: (n,b,c,hf,wf) or the matching list.
+    :return: (loss, {'supp_feats_warp': (n,b,c,h,w)})
+    """
+    if masks is not None: raise NotImplementedError('predictive masks are outside the accelerated path')
+    if isinstance(feats, (list, tuple)): feats, supp_feats = feats[-4], supp_feats[-4]
+    size = tuple(depths[0].shape[-2:])
+    with torch.no_grad():   # features are detached and resized to the depth map (handlers.py:102-110)
+        n = supp_feats.shape[0]
+        feats = torch.nn.functional.interpolate(feats.detach().float(), size=size, mode='bilinear', align_corners=False)
+        supp_feats = torch.nn.functional.interpolate(supp_feats.detach().float().flatten(0, 1), size=size, mode='bilinear',
+                                                     align_corners=False).unflatten(0, (n, -1))
+    loss, ld = image_recon(crit, synth, {0: depths[0]}, None, feats, supp_feats, Ts, Ks, noise=noise, want_warp=True)
+    return loss, {'supp_feats_warp': ld['supp_imgs_warp']}
+
+
+def autoenc_recon(crit, preds: dict, targets: torch.Tensor, supp_preds: dict, supp_targets: torch.Tensor):
+    """Autoencoder reconstruction of the target and support frames at every scale (src/core/handlers.py:122-149).
+    preds {s: (b,3,h,w)}, supp_preds {s: (n,b,3,h,w)}, supp_targets (n,b,3,h,w) -> (loss, {})."""
+    S = len(preds)
+    p = torch.stack(list(preds.values())).flatten(0, 1)
+    sp = torch.stack(list(supp_preds.values())).flatten(0, 2)
+    t = targets[None].expand(S, *targets.shape).flatten(0, 1)
+    st = supp_targets[None].expand(S, *supp_targets.shape).flatten(0, 2)
+    loss, _ = crit(torch.cat((p, sp)), torch.cat((t, st)))
+    return loss, {}
+
+
+def stereo_const(crit, synth, disps: dict, depths: dict, disps_stereo: dict, depths_stereo: dict, T_stereo: torch.Tensor, K: torch.Tensor):
+    """Virtual-stereo consistency (src/core/handlers.py:152-198): each view's disparity warped into the other one.
+    :return: (loss, {'disps_warp', 'stereo_disps_warp': (b,1,h,w) of scale 0})"""
+    S = len(disps)
+    d = torch.stack(list(disps.values())).flatten(0, 1); dep = torch.stack(list(depths.values())).flatten(0, 1)
+    ds = torch.stack(list(disps_stereo.values())).flatten(0, 1); deps = torch.stack(list(depths_stereo.values())).flatten(0, 1)
+    N = T_stereo.shape[0]
+    T = T_stereo.float()[None].expand(S, N, 4, 4).flatten(0, 1)
+    T_all = torch.cat((T, torch.linalg.inv(T)))
+    K_all = K.float()[None, None].expand(2, S, *K.shape).flatten(0, 2)
+    Ki_all = (torch.linalg.inv(K) if K.requires_grad else F.inv_intrinsics(K.float()))[None, None].expand(2, S, *K.shape).flatten(0, 2)
+    all_disps = torch.cat((ds, d))
+    warp = F.view_synth(all_disps, torch.cat((dep, deps)), T_all, K_all, Ki_all)[0]
+    loss, _ = crit(all_disps, warp)
+    sw, dw = warp.chunk(2)
+    return loss, {'disps_warp': dw.unflatten(0, (S, -1))[0], 'stereo_disps_warp': sw.unflatten(0, (S, -1))[0]}
+
+
+def depth_regr(crit, synth, photo, depths: dict, targets: torch.Tensor, imgs: torch.Tensor, supp_imgs: torch.Tensor,
+               Ts: torch.Tensor, Ks: torch.Tensor):
+    """Proxy-depth regression with the Depth-Hints automask (src/core/handlers.py:201-259).
+
+    :param photo: `ReconstructionLoss.compute_photo` of the img_recon criterion (src/core/trainer.py:430).
+    :param targets: (b,1,h,w) proxy depth, 0 where missing.
+    :return: (loss, {'mask_regr': (b,1,h,w) bool of scale 0 [, 'automask_hints' is folded into it]})
+    """
+    S, n, b = len(depths), supp_imgs.shape[0], imgs.shape[0]
+    dep = torch.stack(list(depths.values())).flatten(0, 1)
+    tg = targets[None].expand(S, *targets.shape).flatten(0, 1).contiguous()
+    masks = tg > 0
+    if crit.use_automask:
+        with torch.no_grad():   # the mask is a comparison: nothing differentiable flows through either warp
+            K_inv = F.inv_intrinsics(Ks.detach().float())
+            _, _, _, _, im, src, T, K, Ki = _expand_views(depths, imgs, supp_imgs, Ts.detach(), Ks.detach(), K_inv)
+            ex = lambda z: z[None].expand(n, *z.shape).flatten(0, 1)
+            hints_warp = F.view_synth(src.flatten(0, 1), ex(tg), T, K, Ki)[0].unflatten(0, (n, S*b))
+            pred_warp = F.view_synth(src.flatten(0, 1), ex(dep.detach()), T, K, Ki)[0].unflatten(0, (n, S*b))
+            masks = masks & (photo(pred_warp, im) > photo(hints_warp, im))
+    loss, ld = crit(dep, tg, masks)
+    return loss, {'mask_regr': ld['mask_regr'].unflatten(0, (S, -1))[0]}
 
 
 def disp_smooth(crit, disps: dict, imgs: torch.Tensor, *, want_aux: bool = True):

@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-__all__ = ['DenseL1Error', 'PhotoError']
+__all__ = ['DenseL1Error', 'DenseL2Error', 'PhotoError']
 
 
 class DenseL1Error(nn.Module):
@@ -12,6 +12,13 @@ class DenseL1Error(nn.Module):
     def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         from .. import functional as F
         return F.photo_error(pred, target, loss_name='l1')
+
+
+class DenseL2Error(nn.Module):
+    """Euclidean distance over channels, sqrt(clamp(sum (pred - target)^2, eps)) (src/losses/photometric.py:17-20)."""
+    def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        from .. import functional as F
+        return F.photo_error(pred, target, loss_name='l2')
 
 
 class PhotoError(nn.Module):

@@ -1,4 +1,4 @@
-"""`ReconstructionLoss` — registry key `img_recon` (reference: `src/losses/reconstruction.py:12-126`)."""
+"""`ReconstructionLoss` — registry keys `img_recon`, `feat_recon`, `autoenc_recon` (reference: `src/losses/reconstruction.py:12-126`)."""
 from __future__ import annotations
 
 import torch
@@ -9,24 +9,24 @@ from ..registry import register
 __all__ = ['ReconstructionLoss']
 
 
-@register('img_recon')
+@register(('img_recon', 'feat_recon', 'autoenc_recon'))
 class ReconstructionLoss(nn.Module):
     """Photometric reconstruction loss between synthesised support views and the target.
 
-    :param loss_name: 'ssim' (0.85 SSIM + 0.15 L1) or 'l1'. ('l2' belongs to the feature-reconstruction loss, out of scope.)
+    :param loss_name: 'ssim' (0.85 SSIM + 0.15 L1), 'l1', or 'l2' (Euclidean feature distance, used by `feat_recon`).
     :param use_min: minimum over the support views per pixel (Monodepth2) instead of their mean.
     :param use_automask: drop pixels whose un-warped support frame already matches the target better (Monodepth2).
     :param mask_name: must be None — predictive masks (explainability/uncertainty) are not part of the accelerated path.
 
-    When called through `handlers.image_recon` the whole warp + error + reduction runs as ONE fused kernel; calling the
-    module directly on already-warped images (`crit(pred, target, source)`) runs the un-fused HIP operators.
+    When called through `handlers.image_recon` on 3-channel images with 'ssim'/'l1' the whole warp + error + reduction runs
+    as ONE fused kernel; any other channel count, 'l2', or calling the module directly on already-warped tensors
+    (`crit(pred, target, source)`) runs the un-fused HIP operators.
     """
     def __init__(self, loss_name: str = 'ssim', use_min: bool = False, use_automask: bool = False, mask_name: str | None = None):
         super().__init__()
         if mask_name not in {'explainability', 'uncertainty', None}: raise ValueError(f'Invalid mask type: {mask_name}')
         if mask_name is not None: raise NotImplementedError(f"mask_name='{mask_name}' is outside the accelerated path (SURVEY.md §8a)")
         if loss_name not in {'ssim', 'l1', 'l2'}: raise KeyError(loss_name)
-        if loss_name == 'l2': raise NotImplementedError("loss_name='l2' (feature reconstruction) is outside the accelerated path")
         self.loss_name, self.use_min, self.use_automask, self.mask_name = loss_name, use_min, use_automask, mask_name
         self.noise_seed = 0  # advanced on every call so the in-kernel tie-break noise differs between steps
 
@@ -35,7 +35,7 @@ class ReconstructionLoss(nn.Module):
         return self.noise_seed
 
     def compute_photo(self, pred: torch.Tensor, target: torch.Tensor, mask=None) -> torch.Tensor:
-        """(*n,b,3,h,w) predictions vs (b,3,h,w) target -> reduced error (b,1,h,w) (reconstruction.py:79-96)."""
+        """(*n,b,c,h,w) predictions vs (b,c,h,w) target -> reduced error (b,1,h,w) (reconstruction.py:79-96)."""
         from .. import functional as F
         if mask is not None: raise NotImplementedError('weighting masks are outside the accelerated path')
         if pred.ndim == 4: pred = pred[None]

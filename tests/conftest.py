@@ -34,6 +34,11 @@ def load_golden(name: str) -> dict:
     return out
 
 
+def rel_to_max(a, b):
+    """max |a - b| relative to max |b| (gradient comparisons: element-wise rtol is meaningless near zero crossings)."""
+    return ((a - b).abs().max()/b.abs().max().clamp(min=1e-20)).item()
+
+
 def case_inputs(g: dict, device='cpu', dtype=torch.float32, requires_grad=True):
     """Rebuild the leaves of a `train_*` fixture.  Returns (leaves, static) dicts of tensors on `device`."""
     scales = [int(s) for s in g['meta_scales']]

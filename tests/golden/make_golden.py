@@ -14,6 +14,7 @@ Reference entry points driven here (all paths relative to /root/reference):
   * src/losses/photometric.py:54-88 PhotoError, src/losses/reconstruction.py:79-96 compute_photo
   * src/regularizers/smooth.py:51-97 SmoothReg
   * src/networks/pose.py:60-73 PoseNet.build_K (+ geometry.py:249-263 resize_K)
+  * src/core/handlers.py:70-259 feat_recon / autoenc_recon / stereo_const / depth_regr, src/losses/regression.py:40-75
 
 The fixture files hold data only (inputs + expected outputs); no reference source text is stored.
 """
@@ -68,6 +69,8 @@ def import_reference():
     from src.core import handlers
     from src.core.trainer import MonoDepthModule
     from src.losses import PhotoError, ReconstructionLoss
+    from src.losses.photometric import DenseL1Error, DenseL2Error
+    from src.losses.regression import RegressionLoss
     from src.networks.pose import PoseNet
     from src.regularizers import SmoothReg
     from src.tools import ViewSynth, T_from_AAt, resize_K, to_inv, to_scaled
@@ -258,6 +261,101 @@ def run_op_cases(R):
                              out_inv=R.to_inv(d)))
 
 
+def run_handler_cases(R):
+    """The other ViewSynth users: generic-channel photometric errors, RegressionLoss, and the
+    feat_recon / autoenc_recon / stereo_const / depth_regr handlers, with the reference's own autograd gradients."""
+    g = torch.Generator().manual_seed(4321)
+    # --- dense errors on C != 3
+    for name, mod, c in (('op_photo_l2_c7', R.DenseL2Error(), 7), ('op_photo_l1_c4', R.DenseL1Error(), 4), ('op_photo_ssim_c5', R.PhotoError(), 5)):
+        pred = torch.rand(3, c, 13, 19, generator=g).requires_grad_(True)
+        tgt = (pred.detach() + 0.2*torch.randn(3, c, 13, 19, generator=g)).clamp(0, 1)
+        tgt[0, :, :4] = pred.detach()[0, :, :4]   # identical block: |d| = 0 (sign / sqrt-clamp branches)
+        err = mod(pred, tgt)
+        ge = torch.randn(err.shape, generator=g)
+        (err*ge).sum().backward()
+        save(name, dict(in_pred=pred, in_target=tgt, in_ge=ge, out_err=err, grad_pred=pred.grad))
+
+    # --- RegressionLoss
+    for loss_name in ('l1', 'log_l1', 'berhu'):
+        for invert in (False, True):
+            pred = (0.5 + 10*torch.rand(2, 1, 11, 14, generator=g)).requires_grad_(True)
+            tgt = 0.5 + 10*torch.rand(2, 1, 11, 14, generator=g)
+            tgt[0, 0, :3] = 0.0                                             # invalid proxy depth
+            mask = tgt > 0
+            for tag, m in (('', None), ('_mask', mask)):
+                pred.grad = None
+                l, ld = R.RegressionLoss(loss_name=loss_name, invert=invert)(pred, tgt, m)
+                l.backward()
+                save(f'op_regr_{loss_name}{"_inv" if invert else ""}{tag}',
+                     dict(in_pred=pred, in_target=tgt, in_mask=(mask if m is not None else torch.ones_like(mask)), meta_has_mask=int(m is not None),
+                          out_loss=l, out_err=ld['err_regr'], grad_pred=pred.grad.clone()))
+
+    def poses(n, b, scale=0.02):
+        aa = (scale*torch.randn(n, b, 3, generator=g)).requires_grad_(True)
+        t = (4*scale*torch.randn(n, b, 3, generator=g)).requires_grad_(True)
+        return aa, t, R.T_from_AAt(aa.flatten(0, 1), t.flatten(0, 1)).unflatten(0, (n, b))
+
+    def intr(b, h, w):
+        return torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(b, 1, 1)
+
+    # --- feat_recon: c=6 features at 1/4 resolution, l2 error, min + automask
+    b, h, w, n, c = 2, 24, 40, 2, 6
+    depth = (1 + 20*torch.rand(b, 1, h, w, generator=g)).requires_grad_(True)
+    feats = torch.randn(b, c, h//4, w//4, generator=g); supp_feats = feats[None] + 0.3*torch.randn(n, b, c, h//4, w//4, generator=g)
+    aa, t, Ts = poses(n, b); K = intr(b, h, w)
+    crit = R.ReconstructionLoss(loss_name='l2', use_min=True, use_automask=True)
+    noise = torch.randn(b, 1, h, w, generator=g)
+    real_randn = torch.randn_like
+    torch.randn_like = lambda x, **k: noise.to(x)            # pin the tie-break draw (reconstruction.py:72)
+    try: l, ld = R.handlers.feat_recon(crit, R.ViewSynth((h, w)), {0: depth}, None, feats, supp_feats, Ts, K)
+    finally: torch.randn_like = real_randn
+    l.backward()
+    save('hd_feat_recon', dict(in_depth=depth, in_feats=feats, in_supp_feats=supp_feats, in_aa=aa, in_t=t, in_K=K, in_noise=noise,
+                               out_Ts=Ts, out_loss=l, out_supp_feats_warp=ld['supp_feats_warp'], grad_depth=depth.grad, grad_aa=aa.grad, grad_t=t.grad))
+
+    # --- autoenc_recon: 2 scales, ssim, mean
+    b, h, w, n = 2, 16, 24, 2
+    tgt = texture(g, b, h, w); stg = torch.stack([texture(g, b, h, w, shift=(1.5*i, 0.5)) for i in range(n)])
+    preds = {s: (tgt + 0.1*torch.randn(b, 3, h, w, generator=g)).clamp(0, 1).requires_grad_(True) for s in (0, 1)}
+    spreds = {s: (stg + 0.1*torch.randn(n, b, 3, h, w, generator=g)).clamp(0, 1).requires_grad_(True) for s in (0, 1)}
+    l, _ = R.handlers.autoenc_recon(R.ReconstructionLoss(loss_name='ssim', use_min=False), preds, tgt, spreds, stg)
+    l.backward()
+    save('hd_autoenc_recon', dict(in_targets=tgt, in_supp_targets=stg, out_loss=l,
+                                  **{f'in_pred_{s}': v for s, v in preds.items()}, **{f'in_supp_pred_{s}': v for s, v in spreds.items()},
+                                  **{f'grad_pred_{s}': v.grad for s, v in preds.items()}, **{f'grad_supp_pred_{s}': v.grad for s, v in spreds.items()}))
+
+    # --- stereo_const: 2 scales, horizontal baseline
+    b, h, w = 2, 20, 36
+    mk = lambda: {s: (0.05 + 0.9*torch.rand(b, 1, h, w, generator=g)).requires_grad_(True) for s in (0, 1)}
+    disps, disps_st = mk(), mk()
+    depths = {s: R.to_scaled(d, 0.1, 100)[1] for s, d in disps.items()}
+    depths_st = {s: R.to_scaled(d, 0.1, 100)[1] for s, d in disps_st.items()}
+    T_st = torch.eye(4)[None].repeat(b, 1, 1); T_st[:, 0, 3] = torch.tensor([0.54, -0.54])
+    K = intr(b, h, w)
+    l, ld = R.handlers.stereo_const(R.RegressionLoss(loss_name='l1'), R.ViewSynth((h, w)), disps, depths, disps_st, depths_st, T_st, K)
+    l.backward()
+    save('hd_stereo_const', dict(in_T_stereo=T_st, in_K=K, out_loss=l, out_disps_warp=ld['disps_warp'], out_stereo_disps_warp=ld['stereo_disps_warp'],
+                                 **{f'in_disp_{s}': v for s, v in disps.items()}, **{f'in_disp_stereo_{s}': v for s, v in disps_st.items()},
+                                 **{f'grad_disp_{s}': v.grad for s, v in disps.items()}, **{f'grad_disp_stereo_{s}': v.grad for s, v in disps_st.items()}))
+
+    # --- depth_regr: proxy depth with holes, Depth-Hints automask through the img_recon criterion's compute_photo
+    b, h, w, n = 2, 20, 32, 2
+    for tag, kw in (('berhu', dict(loss_name='berhu', invert=False, use_automask=True)),
+                    ('log_l1_inv', dict(loss_name='log_l1', invert=True, use_automask=True)),
+                    ('l1_noauto', dict(loss_name='l1', invert=False, use_automask=False))):
+        imgs = texture(g, b, h, w); supp = torch.stack([texture(g, b, h, w, shift=(2.0*(i - 0.5), 0.3)) for i in range(n)])
+        disps = {s: (0.05 + 0.9*torch.rand(b, 1, h, w, generator=g)).requires_grad_(True) for s in (0, 1)}
+        depths = {s: R.to_scaled(d, 0.1, 100)[1] for s, d in disps.items()}
+        hints = 0.5 + 30*torch.rand(b, 1, h, w, generator=g); hints[:, :, :4] = 0.0
+        aa, t, Ts = poses(n, b); K = intr(b, h, w)
+        photo = R.ReconstructionLoss(loss_name='ssim', use_min=True, use_automask=True).compute_photo
+        l, ld = R.handlers.depth_regr(R.RegressionLoss(**kw), R.ViewSynth((h, w)), photo, depths, hints, imgs, supp, Ts.detach(), K)
+        l.backward()
+        save(f'hd_depth_regr_{tag}', dict(in_imgs=imgs, in_supp_imgs=supp, in_hints=hints, in_Ts=Ts, in_K=K, out_loss=l, out_mask_regr=ld['mask_regr'],
+                                          meta_loss_name=kw['loss_name'], meta_invert=int(kw['invert']), meta_use_automask=int(kw['use_automask']),
+                                          **{f'in_disp_{s}': v for s, v in disps.items()}, **{f'grad_disp_{s}': v.grad for s, v in disps.items()}))
+
+
 def save(name, rec):
     arrs = {}
     for k, v in rec.items():
@@ -269,6 +367,9 @@ def save(name, rec):
 def main():
     torch.set_num_threads(8)
     R = import_reference()
+    if '--handlers-only' in sys.argv:   # regenerate just the §8f rank-3 fixtures
+        run_handler_cases(R)
+        return
     kbr = dict(loss_kw=dict(loss_name='ssim', use_min=True, use_automask=True), smooth_kw=dict(use_edges=True),
                min_depth=0.1, max_depth=100)
     # cfg-1-shaped miniature of the headline configuration
@@ -293,6 +394,7 @@ def main():
     run_trainer_case(R, 'train_bigmotion_24x32', seed=21, b=2, h=24, w=32, n=2, scales=[0, 1], supp_idxs=[-1, 1],
                      pose_scale=0.15, **kbr)
     run_op_cases(R)
+    run_handler_cases(R)
 
 
 if __name__ == '__main__':

@@ -21,10 +21,6 @@ def F():
     return functional
 
 
-def rel_to_max(a, b):
-    return ((a - b).abs().max()/b.abs().max().clamp(min=1e-20)).item()
-
-
 def test_lane_shift_primitive(F):
     left, right = F.lane_shift_selftest()
     lanes = torch.arange(64, dtype=torch.float32)
@@ -330,3 +326,120 @@ def test_whole_chain_from_network_outputs_matches_reference_gradients(F, golden,
     for k in ['aa', 't'] + (['fs', 'cs'] if g['meta_learn_K'] else []) + [f'disp_{s}' for s in scales]:
         e = rel_to_max(leaves[k].grad.cpu(), g[f'grad_{k}'])
         assert e < 1e-3, f'{name}: d loss / d {k} off by {e:.3e} (rel. to max) vs the reference autograd'
+
+
+# ---------------------------------------------------------------------------------------------------
+# §8f rank 3: generic-channel errors, RegressionLoss and the other ViewSynth users, against the reference's vectors
+@pytest.mark.parametrize('name,loss_name', [('op_photo_l2_c7', 'l2'), ('op_photo_l1_c4', 'l1'), ('op_photo_ssim_c5', 'ssim')])
+def test_generic_channel_photo_errors(F, golden, name, loss_name):
+    g = golden(name)
+    pred = g['in_pred'].cuda().requires_grad_(True)
+    err = F.photo_error(pred, g['in_target'].cuda(), loss_name)
+    torch.testing.assert_close(err.cpu(), g['out_err'], rtol=1e-5, atol=2e-6)
+    (err*g['in_ge'].cuda()).sum().backward()
+    assert rel_to_max(pred.grad.cpu(), g['grad_pred']) < 2e-4
+
+
+@pytest.mark.parametrize('name', [f'op_regr_{l}{i}{m}' for l in ('l1', 'log_l1', 'berhu') for i in ('', '_inv') for m in ('', '_mask')])
+def test_regression_loss_matches_reference(F, golden, name):
+    import slowtv_monodepth_amd as amd
+    g = golden(name)
+    loss_name = name[len('op_regr_'):].replace('_mask', '').replace('_inv', '')
+    pred = g['in_pred'].cuda().requires_grad_(True)
+    crit = amd.losses.RegressionLoss(loss_name=loss_name, invert='_inv' in name)
+    l, ld = crit(pred, g['in_target'].cuda(), g['in_mask'].cuda() if g['meta_has_mask'] else None)
+    torch.testing.assert_close(l.cpu(), g['out_loss'], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(ld['err_regr'].cpu(), g['out_err'], rtol=2e-6, atol=1e-7)
+    l.backward()
+    torch.testing.assert_close(pred.grad.cpu(), g['grad_pred'], rtol=2e-5, atol=1e-8)
+
+
+def _gpu_poses(F, g):
+    aa, t = g['in_aa'].cuda().requires_grad_(True), g['in_t'].cuda().requires_grad_(True)
+    n, b = aa.shape[:2]
+    return aa, t, F.pose_matrices(aa.flatten(0, 1), t.flatten(0, 1)).unflatten(0, (n, b))
+
+
+def test_feat_recon_handler_matches_reference(F, golden):
+    import slowtv_monodepth_amd as amd
+    g = golden('hd_feat_recon')
+    depth = g['in_depth'].cuda().requires_grad_(True)
+    aa, t, Ts = _gpu_poses(F, g)
+    crit = amd.losses.ReconstructionLoss(loss_name='l2', use_min=True, use_automask=True)
+    l, ld = amd.handlers.feat_recon(crit, None, {0: depth}, None, g['in_feats'].cuda(), g['in_supp_feats'].cuda(), Ts, g['in_K'].cuda(),
+                                    noise=g['in_noise'].cuda())
+    torch.testing.assert_close(l.cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(ld['supp_feats_warp'].cpu(), g['out_supp_feats_warp'], rtol=1e-4, atol=1e-4)
+    l.backward()
+    for k, v in (('depth', depth), ('aa', aa), ('t', t)): assert rel_to_max(v.grad.cpu(), g[f'grad_{k}']) < 1e-3, k
+
+
+def test_autoenc_recon_handler_matches_reference(F, golden):
+    import slowtv_monodepth_amd as amd
+    g = golden('hd_autoenc_recon')
+    preds = {s: g[f'in_pred_{s}'].cuda().requires_grad_(True) for s in (0, 1)}
+    spreds = {s: g[f'in_supp_pred_{s}'].cuda().requires_grad_(True) for s in (0, 1)}
+    l, _ = amd.handlers.autoenc_recon(amd.losses.ReconstructionLoss(loss_name='ssim', use_min=False), preds, g['in_targets'].cuda(), spreds,
+                                      g['in_supp_targets'].cuda())
+    torch.testing.assert_close(l.cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+    l.backward()
+    for s in (0, 1):
+        assert rel_to_max(preds[s].grad.cpu(), g[f'grad_pred_{s}']) < 2e-4
+        assert rel_to_max(spreds[s].grad.cpu(), g[f'grad_supp_pred_{s}']) < 2e-4
+
+
+def test_stereo_const_handler_matches_reference(F, golden):
+    import slowtv_monodepth_amd as amd
+    g = golden('hd_stereo_const')
+    mk = lambda key: {s: g[f'in_{key}_{s}'].cuda().requires_grad_(True) for s in (0, 1)}
+    disps, disps_st = mk('disp'), mk('disp_stereo')
+    to_depth = lambda d: F.disp_to_depth([d], tuple(d.shape[-2:]), 0.1, 100)[0][0]
+    depths = {s: to_depth(d) for s, d in disps.items()}; depths_st = {s: to_depth(d) for s, d in disps_st.items()}
+    l, ld = amd.handlers.stereo_const(amd.losses.RegressionLoss(loss_name='l1'), None, disps, depths, disps_st, depths_st,
+                                      g['in_T_stereo'].cuda(), g['in_K'].cuda())
+    torch.testing.assert_close(l.cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(ld['disps_warp'].cpu(), g['out_disps_warp'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ld['stereo_disps_warp'].cpu(), g['out_stereo_disps_warp'], rtol=1e-4, atol=1e-5)
+    l.backward()
+    for s in (0, 1):
+        assert rel_to_max(disps[s].grad.cpu(), g[f'grad_disp_{s}']) < 1e-3
+        assert rel_to_max(disps_st[s].grad.cpu(), g[f'grad_disp_stereo_{s}']) < 1e-3
+
+
+@pytest.mark.parametrize('tag', ['berhu', 'log_l1_inv', 'l1_noauto'])
+def test_depth_regr_handler_matches_reference(F, golden, tag):
+    import slowtv_monodepth_amd as amd
+    g = golden(f'hd_depth_regr_{tag}')
+    disps = {s: g[f'in_disp_{s}'].cuda().requires_grad_(True) for s in (0, 1)}
+    to_depth = lambda d: F.disp_to_depth([d], tuple(d.shape[-2:]), 0.1, 100)[0][0]
+    depths = {s: to_depth(d) for s, d in disps.items()}
+    photo = amd.losses.ReconstructionLoss(loss_name='ssim', use_min=True, use_automask=True).compute_photo
+    crit = amd.losses.RegressionLoss(loss_name=g['meta_loss_name'], invert=bool(g['meta_invert']), use_automask=bool(g['meta_use_automask']))
+    l, ld = amd.handlers.depth_regr(crit, None, photo, depths, g['in_hints'].cuda(), g['in_imgs'].cuda(), g['in_supp_imgs'].cuda(),
+                                    g['in_Ts'].cuda(), g['in_K'].cuda())
+    flips = (ld['mask_regr'].cpu() != g['out_mask_regr']).float().mean().item()
+    assert flips <= 2e-3, f'regression mask differs on {flips:.2%} of pixels'
+    torch.testing.assert_close(l.cpu(), g['out_loss'], rtol=2e-3 if flips else 2e-5, atol=1e-7)
+    l.backward()
+    for s in (0, 1): assert rel_to_max(disps[s].grad.cpu(), g[f'grad_disp_{s}']) < (2e-2 if flips else 2e-4), s
+
+
+def test_depth_hint_fusion_like_the_offline_tool(F):
+    """api/data/preprocess/compute_kitti_hints.py:88-97: warp the stereo frame with H depth hypotheses, take the per-pixel
+    argmin of the photometric error.  Class-level operators against the oracle."""
+    from oracle import view_synth_oracle as O
+    import slowtv_monodepth_amd as amd
+    gen = torch.Generator().manual_seed(9)
+    H, h, w = 12, 40, 96
+    img = torch.rand(1, 3, h, w, generator=gen); supp = torch.rand(1, 3, h, w, generator=gen)
+    depths = 1 + 40*torch.rand(H, 1, h, w, generator=gen)
+    T = torch.eye(4)[None].repeat(H, 1, 1); T[:, 0, 3] = -0.54
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(H, 1, 1)
+    warp_o = O.view_synth(supp.expand(H, -1, -1, -1), depths, T, K)[0]
+    err_o = O.photo_error(warp_o, img.expand(H, -1, -1, -1))
+    warp, _, _ = amd.geometry.ViewSynth((h, w))(supp.expand(H, -1, -1, -1).cuda(), depths.cuda(), T.cuda(), K.cuda())
+    err = amd.losses.PhotoError()(warp, img.expand(H, -1, -1, -1).cuda())
+    torch.testing.assert_close(err.cpu(), err_o, rtol=1e-4, atol=2e-5)
+    srt = err_o.sort(dim=0)[0]
+    decided = (srt[1] - srt[0]) > 1e-4      # ignore pixels whose two best hypotheses are tied to rounding
+    assert (err.argmin(dim=0).cpu() == err_o.argmin(dim=0))[decided].all()

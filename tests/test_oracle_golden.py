@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from conftest import TRAIN_CASES, case_inputs
+from conftest import TRAIN_CASES, case_inputs, rel_to_max
 from oracle import view_synth_oracle as O
 
 
@@ -120,3 +120,89 @@ def test_pose_and_depth_conversions(golden):
     torch.testing.assert_close(O.to_inv(g['in_disp']), g['out_inv'])
     with pytest.raises(ValueError): O.to_scaled(g['in_disp'], 0.0, 100)
     with pytest.raises(ValueError): O.to_scaled(g['in_disp'], 1.0, 0.5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# §8f rank 3: generic-channel errors, RegressionLoss, feat_recon / autoenc_recon / stereo_const / depth_regr
+@pytest.mark.parametrize('name,loss_name', [('op_photo_l2_c7', 'l2'), ('op_photo_l1_c4', 'l1'), ('op_photo_ssim_c5', 'ssim')])
+def test_generic_channel_photo_errors(golden, name, loss_name):
+    g = golden(name)
+    pred = g['in_pred'].clone().requires_grad_(True)
+    err = O.photo_error(pred, g['in_target'], loss_name)
+    torch.testing.assert_close(err, g['out_err'], rtol=1e-5, atol=2e-6)
+    (err*g['in_ge']).sum().backward()
+    torch.testing.assert_close(pred.grad, g['grad_pred'], rtol=1e-4, atol=2e-5)
+
+
+REGR_CASES = [f'op_regr_{l}{i}{m}' for l in ('l1', 'log_l1', 'berhu') for i in ('', '_inv') for m in ('', '_mask')]
+
+
+@pytest.mark.parametrize('name', REGR_CASES)
+def test_regression_loss(golden, name):
+    g = golden(name)
+    loss_name = name[len('op_regr_'):].replace('_mask', '').replace('_inv', '')
+    pred = g['in_pred'].clone().requires_grad_(True)
+    l, ld = O.regression_loss(pred, g['in_target'], g['in_mask'] if g['meta_has_mask'] else None, loss_name, '_inv' in name)
+    torch.testing.assert_close(l, g['out_loss'], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ld['err_regr'], g['out_err'], rtol=1e-6, atol=1e-7)
+    l.backward()
+    torch.testing.assert_close(pred.grad, g['grad_pred'], rtol=1e-5, atol=1e-8)
+
+
+def _poses(g):
+    aa, t = g['in_aa'].clone().requires_grad_(True), g['in_t'].clone().requires_grad_(True)
+    n, b = aa.shape[:2]
+    return aa, t, O.T_from_AAt(aa.flatten(0, 1), t.flatten(0, 1)).unflatten(0, (n, b))
+
+
+def test_feat_recon_handler(golden):
+    g = golden('hd_feat_recon')
+    depth = g['in_depth'].clone().requires_grad_(True)
+    aa, t, Ts = _poses(g)
+    l, ld, _ = O.feat_recon({0: depth}, g['in_feats'], g['in_supp_feats'], Ts, g['in_K'], noise=g['in_noise'], aten=True)
+    torch.testing.assert_close(l, g['out_loss'], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(ld['supp_feats_warp'], g['out_supp_feats_warp'], rtol=1e-4, atol=1e-5)
+    l.backward()
+    for k, v in (('depth', depth), ('aa', aa), ('t', t)): assert rel_to_max(v.grad, g[f'grad_{k}']) < 1e-3, k
+
+
+def test_autoenc_recon_handler(golden):
+    g = golden('hd_autoenc_recon')
+    preds = {s: g[f'in_pred_{s}'].clone().requires_grad_(True) for s in (0, 1)}
+    spreds = {s: g[f'in_supp_pred_{s}'].clone().requires_grad_(True) for s in (0, 1)}
+    l = O.autoenc_recon(preds, g['in_targets'], spreds, g['in_supp_targets'])
+    torch.testing.assert_close(l, g['out_loss'], rtol=1e-5, atol=1e-7)
+    l.backward()
+    for s in (0, 1):
+        assert rel_to_max(preds[s].grad, g[f'grad_pred_{s}']) < 1e-4
+        assert rel_to_max(spreds[s].grad, g[f'grad_supp_pred_{s}']) < 1e-4
+
+
+def test_stereo_const_handler(golden):
+    g = golden('hd_stereo_const')
+    disps = {s: g[f'in_disp_{s}'].clone().requires_grad_(True) for s in (0, 1)}
+    disps_st = {s: g[f'in_disp_stereo_{s}'].clone().requires_grad_(True) for s in (0, 1)}
+    depths = {s: O.to_scaled(d, 0.1, 100)[1] for s, d in disps.items()}
+    depths_st = {s: O.to_scaled(d, 0.1, 100)[1] for s, d in disps_st.items()}
+    l, ld = O.stereo_const(disps, depths, disps_st, depths_st, g['in_T_stereo'], g['in_K'], 'l1')
+    torch.testing.assert_close(l, g['out_loss'], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(ld['disps_warp'], g['out_disps_warp'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ld['stereo_disps_warp'], g['out_stereo_disps_warp'], rtol=1e-4, atol=1e-5)
+    l.backward()
+    for s in (0, 1):
+        assert rel_to_max(disps[s].grad, g[f'grad_disp_{s}']) < 1e-3
+        assert rel_to_max(disps_st[s].grad, g[f'grad_disp_stereo_{s}']) < 1e-3
+
+
+@pytest.mark.parametrize('tag', ['berhu', 'log_l1_inv', 'l1_noauto'])
+def test_depth_regr_handler(golden, tag):
+    g = golden(f'hd_depth_regr_{tag}')
+    disps = {s: g[f'in_disp_{s}'].clone().requires_grad_(True) for s in (0, 1)}
+    depths = {s: O.to_scaled(d, 0.1, 100)[1] for s, d in disps.items()}
+    l, ld = O.depth_regr(depths, g['in_hints'], g['in_imgs'], g['in_supp_imgs'], g['in_Ts'], g['in_K'], g['meta_loss_name'],
+                         bool(g['meta_invert']), bool(g['meta_use_automask']))
+    flips = (ld['mask_regr'] != g['out_mask_regr']).float().mean().item()
+    assert flips <= 2e-3, f'regression mask differs on {flips:.2%} of pixels'
+    torch.testing.assert_close(l, g['out_loss'], rtol=2e-3 if flips else 1e-5, atol=1e-7)
+    l.backward()
+    for s in (0, 1): assert rel_to_max(disps[s].grad, g[f'grad_disp_{s}']) < (2e-2 if flips else 1e-4), s
