@@ -155,6 +155,11 @@ class MonoDepthModule(nn.Module):
                                                      fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux, K_inv=fwd.get('K_inv'))
                 elif k == 'disp_smooth':
                     l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'], want_aux=self.want_aux)
+                elif k == 'depth_regr':   # proxy-depth (Depth Hints) regression, src/core/trainer.py:425-433
+                    if 'depth_hints' not in y: raise KeyError('Missing proxy depth prediction "depth_hints".')
+                    from . import handlers
+                    l, ld = handlers.depth_regr(crit, self.synth, self.losses['img_recon'].compute_photo, fwd['depth_up'], y['depth_hints'],
+                                                y['imgs'], y['supp_imgs'], fwd['Ts'], fwd.get('K', y['K']))
                 else:
                     raise ValueError(f'Missing loss key: "{k}"')
             loss = loss + self.weights[k]*l

@@ -8,7 +8,7 @@ Tolerances (fp32 path, stated per BASELINE.json: loss within 1e-4 relative of th
 import pytest
 import torch
 
-from conftest import TRAIN_CASES, case_inputs
+from conftest import TRAIN_CASES, case_inputs, rel_to_max
 from oracle import view_synth_oracle as O
 
 pytestmark = pytest.mark.gpu
