@@ -51,6 +51,10 @@ PROTOTYPES = {
     'smd_recon_reduce_workspace_bytes': (_sz, [_i, _i, _i]),
     'smd_recon_reduce_fwd': (_i, [_vp]*3 + [_u64] + [_vp]*4 + [_sz] + [_i]*5 + [_vp]),
     'smd_recon_reduce_bwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
+    'smd_elu_pad_fwd': (_i, [_vp, _vp] + [_i]*5 + [_vp]),
+    'smd_elu_pad_bwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
+    'smd_elu_up_cat_pad_fwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
+    'smd_elu_up_cat_pad_bwd': (_i, [_vp]*4 + [_i]*5 + [_vp]),
     'smd_pose_fwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     'smd_pose_bwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'smd_intrinsics_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

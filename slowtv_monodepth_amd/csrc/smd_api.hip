@@ -348,6 +348,34 @@ int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_w
 }
 
 // ------------------------------------------------------------------------------------------------
+// Monodepth decoder glue
+static bool dec_sizes_ok(long long planes, int h, int w) {
+  return planes >= 1 && h >= 2 && w >= 2 && (long long)(h + 2)*(w + 2) < (1ll << 30) && planes*(((long long)(h + 2)*(w + 2) + 255)/256) < (1ll << 31);
+}
+int smd_elu_pad_fwd(const float* x, float* out, int B, int C, int h, int w, int apply_elu, void* stream) {
+  if (!x || !out) return fail(SMD_E_INVALID, "null pointer");
+  if (B < 1 || C < 1 || !dec_sizes_ok((long long)B*C, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
+  return check_launch(smd::launch_elu_pad_fwd(x, out, (size_t)B*C, h, w, apply_elu, (hipStream_t)stream), "elu_pad_fwd");
+}
+int smd_elu_pad_bwd(const float* x, const float* g_out, float* g_x, int B, int C, int h, int w, int apply_elu, void* stream) {
+  if (!x || !g_out || !g_x) return fail(SMD_E_INVALID, "null pointer");
+  if (B < 1 || C < 1 || !dec_sizes_ok((long long)B*C, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
+  return check_launch(smd::launch_elu_pad_bwd(x, g_out, g_x, (size_t)B*C, h, w, apply_elu, (hipStream_t)stream), "elu_pad_bwd");
+}
+int smd_elu_up_cat_pad_fwd(const float* a, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, void* stream) {
+  if (!a || !out || (Cs > 0 && !skip)) return fail(SMD_E_INVALID, "null pointer");
+  if (B < 1 || Ca < 1 || Cs < 0 || h < 1 || w < 1 || !dec_sizes_ok((long long)B*(Ca + Cs), 2*h, 2*w))
+    return fail(SMD_E_INVALID, "invalid sizes B=%d Ca=%d Cs=%d h=%d w=%d", B, Ca, Cs, h, w);
+  return check_launch(smd::launch_elu_up_cat_pad_fwd(a, skip, out, B, Ca, Cs, h, w, (hipStream_t)stream), "elu_up_cat_pad_fwd");
+}
+int smd_elu_up_cat_pad_bwd(const float* a, const float* g_out, float* g_a, float* g_skip, int B, int Ca, int Cs, int h, int w, void* stream) {
+  if (!a || !g_out || (!g_a && !g_skip)) return fail(SMD_E_INVALID, "null pointer");
+  if (B < 1 || Ca < 1 || Cs < 0 || h < 1 || w < 1 || !dec_sizes_ok((long long)B*(Ca + Cs), 2*h, 2*w))
+    return fail(SMD_E_INVALID, "invalid sizes B=%d Ca=%d Cs=%d h=%d w=%d", B, Ca, Cs, h, w);
+  return check_launch(smd::launch_elu_up_cat_pad_bwd(a, g_out, g_a, g_skip, B, Ca, Cs, h, w, (hipStream_t)stream), "elu_up_cat_pad_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pose / intrinsics prologue
 int smd_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, void* stream) {
   if (!aa || !t || !T) return fail(SMD_E_INVALID, "null pointer");

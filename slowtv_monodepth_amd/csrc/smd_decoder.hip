@@ -1,0 +1,153 @@
+// smd_decoder.hip — glue between the 3x3 convolutions of the Monodepth decoder.
+//
+// The reference decoder (src/networks/decoders/monodepth.py:71-89, decoders/utils.py:44-54) runs, per stage,
+//   reflect-pad -> conv3x3 -> ELU -> nearest x2 -> cat(skip) -> reflect-pad -> conv3x3 -> ELU -> [reflect-pad -> conv3x3 -> sigmoid]
+// as separate ATen kernels, each a full read + write of the activation.  The convolutions stay with MIOpen; everything
+// between them collapses into two gather kernels that write the NEXT convolution's already-padded input:
+//   k_elu_pad         out = reflect_pad1(elu(x))                              (B,C,h,w)           -> (B,C,h+2,w+2)
+//   k_elu_up_cat_pad  out = reflect_pad1(cat(nearest_x2(elu(a)), skip))       (B,Ca,h,w),(B,Cs,2h,2w) -> (B,Ca+Cs,2h+2,2w+2)
+// and two adjoint gathers (deterministic, no atomics).  ELU is recomputed from the saved pre-activation in the backward
+// (elu'(x) = x > 0 ? 1 : exp(x)), so no activated tensor is kept.
+#include "smd_common.h"
+#include "smd_kernels.h"
+
+namespace smd {
+
+constexpr int kDecBlock = 256;
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : expf(x); }
+__device__ __forceinline__ int unpad_reflect(int p, int n) { const int r = p - 1; return r < 0 ? -r : (r >= n ? 2*(n - 1) - r : r); }
+
+// Sum of g over the padded positions that read un-padded index r along one axis of length n: p = r+1, plus the mirrored
+// border cell when r is the second / second-to-last element.
+#define SMD_PAD_ADJ_POS(r, n, p0, p1, p2) const int p0 = (r) + 1, p1 = ((r) == 1) ? 0 : -1, p2 = ((r) == (n) - 2) ? (n) + 1 : -1
+
+__global__ __launch_bounds__(kDecBlock) void k_elu_pad_fwd(const float* __restrict__ x, float* __restrict__ out, int h, int w, int apply_elu, unsigned chunks) {
+  const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
+  const int H = h + 2, W = w + 2;
+  const int idx = chunk*kDecBlock + threadIdx.x;
+  if (idx >= H*W) return;
+  const int py = idx/W, px = idx - py*W;
+  const float v = x[(size_t)plane*h*w + unpad_reflect(py, h)*w + unpad_reflect(px, w)];
+  out[(size_t)plane*H*W + idx] = apply_elu ? elu1(v) : v;
+}
+
+__global__ __launch_bounds__(kDecBlock) void k_elu_pad_bwd(const float* __restrict__ x, const float* __restrict__ g_out, float* __restrict__ g_x,
+                                                           int h, int w, int apply_elu, unsigned chunks) {
+  const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
+  const int W = w + 2;
+  const int idx = chunk*kDecBlock + threadIdx.x;
+  if (idx >= h*w) return;
+  const int i = idx/w, j = idx - i*w;
+  const float* g = g_out + (size_t)plane*(h + 2)*W;
+  SMD_PAD_ADJ_POS(i, h, y0, y1, y2); SMD_PAD_ADJ_POS(j, w, x0, x1, x2);
+  const int ys[3] = {y0, y1, y2}, xs[3] = {x0, x1, x2};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (ys[a] < 0) continue;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) if (xs[b] >= 0) acc += g[ys[a]*W + xs[b]];
+  }
+  g_x[(size_t)plane*h*w + idx] = apply_elu ? acc*elu1_grad(x[(size_t)plane*h*w + idx]) : acc;
+}
+
+__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_fwd(const float* __restrict__ a, const float* __restrict__ skip, float* __restrict__ out,
+                                                                  int Ca, int Cs, int h, int w, unsigned chunks) {
+  const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*(Ca+Cs) + c
+  const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, H = H2 + 2, W = W2 + 2;
+  const int idx = chunk*kDecBlock + threadIdx.x;
+  if (idx >= H*W) return;
+  const int py = idx/W, px = idx - py*W;
+  const int r = unpad_reflect(py, H2), q = unpad_reflect(px, W2);
+  const unsigned b = plane/C, c = plane - b*C;
+  float v;
+  if ((int)c < Ca) v = elu1(a[((size_t)b*Ca + c)*h*w + (r >> 1)*w + (q >> 1)]);
+  else v = skip[((size_t)b*Cs + (c - Ca))*H2*W2 + r*W2 + q];
+  out[(size_t)plane*H*W + idx] = v;
+}
+
+// Adjoint w.r.t. `a` (low resolution): each source pixel feeds a 2x2 block of the up-sampled map, each cell of which
+// feeds its padded position plus (on the second / second-to-last row or column) the mirrored border cell.
+__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float* __restrict__ a, const float* __restrict__ g_out, float* __restrict__ g_a,
+                                                                    int Ca, int Cs, int h, int w, unsigned chunks) {
+  const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*Ca + c
+  const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, W = W2 + 2;
+  const int idx = chunk*kDecBlock + threadIdx.x;
+  if (idx >= h*w) return;
+  const int i = idx/w, j = idx - i*w;
+  const unsigned b = plane/Ca, c = plane - b*Ca;
+  const float* g = g_out + ((size_t)b*C + c)*(H2 + 2)*W;
+  float acc = 0.f;
+#pragma unroll
+  for (int dr = 0; dr < 2; ++dr) {
+    const int r = 2*i + dr;
+    SMD_PAD_ADJ_POS(r, H2, y0, y1, y2);
+    const int ys[3] = {y0, y1, y2};
+#pragma unroll
+    for (int dq = 0; dq < 2; ++dq) {
+      const int q = 2*j + dq;
+      SMD_PAD_ADJ_POS(q, W2, x0, x1, x2);
+      const int xs[3] = {x0, x1, x2};
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        if (ys[m] < 0) continue;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) if (xs[n] >= 0) acc += g[ys[m]*W + xs[n]];
+      }
+    }
+  }
+  g_a[(size_t)plane*h*w + idx] = acc*elu1_grad(a[(size_t)plane*h*w + idx]);
+}
+
+// Adjoint w.r.t. the skip tensor (full resolution): plain reflection-pad adjoint of its channel slice.
+__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_skip(const float* __restrict__ g_out, float* __restrict__ g_skip,
+                                                                       int Ca, int Cs, int h, int w, unsigned chunks) {
+  const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*Cs + c
+  const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, W = W2 + 2;
+  const int idx = chunk*kDecBlock + threadIdx.x;
+  if (idx >= H2*W2) return;
+  const int r = idx/W2, q = idx - r*W2;
+  const unsigned b = plane/Cs, c = plane - b*Cs;
+  const float* g = g_out + ((size_t)b*C + Ca + c)*(H2 + 2)*W;
+  SMD_PAD_ADJ_POS(r, H2, y0, y1, y2); SMD_PAD_ADJ_POS(q, W2, x0, x1, x2);
+  const int ys[3] = {y0, y1, y2}, xs[3] = {x0, x1, x2};
+  float acc = 0.f;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    if (ys[m] < 0) continue;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) if (xs[n] >= 0) acc += g[ys[m]*W + xs[n]];
+  }
+  g_skip[(size_t)plane*H2*W2 + idx] = acc;
+}
+
+hipError_t launch_elu_pad_fwd(const float* x, float* out, size_t planes, int h, int w, int apply_elu, hipStream_t st) {
+  const unsigned chunks = ceil_div((h + 2)*(w + 2), kDecBlock);
+  hipLaunchKernelGGL(k_elu_pad_fwd, dim3((unsigned)(planes*chunks)), dim3(kDecBlock), 0, st, x, out, h, w, apply_elu, chunks);
+  return hipGetLastError();
+}
+hipError_t launch_elu_pad_bwd(const float* x, const float* g_out, float* g_x, size_t planes, int h, int w, int apply_elu, hipStream_t st) {
+  const unsigned chunks = ceil_div(h*w, kDecBlock);
+  hipLaunchKernelGGL(k_elu_pad_bwd, dim3((unsigned)(planes*chunks)), dim3(kDecBlock), 0, st, x, g_out, g_x, h, w, apply_elu, chunks);
+  return hipGetLastError();
+}
+hipError_t launch_elu_up_cat_pad_fwd(const float* a, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, hipStream_t st) {
+  const unsigned chunks = ceil_div((2*h + 2)*(2*w + 2), kDecBlock);
+  hipLaunchKernelGGL(k_elu_up_cat_pad_fwd, dim3((unsigned)((size_t)B*(Ca + Cs)*chunks)), dim3(kDecBlock), 0, st, a, skip, out, Ca, Cs, h, w, chunks);
+  return hipGetLastError();
+}
+hipError_t launch_elu_up_cat_pad_bwd(const float* a, const float* g_out, float* g_a, float* g_skip, int B, int Ca, int Cs, int h, int w, hipStream_t st) {
+  if (g_a) {
+    const unsigned chunks = ceil_div(h*w, kDecBlock);
+    hipLaunchKernelGGL(k_elu_up_cat_pad_bwd_a, dim3((unsigned)((size_t)B*Ca*chunks)), dim3(kDecBlock), 0, st, a, g_out, g_a, Ca, Cs, h, w, chunks);
+  }
+  if (g_skip && Cs > 0) {
+    const unsigned chunks = ceil_div(4*h*w, kDecBlock);
+    hipLaunchKernelGGL(k_elu_up_cat_pad_bwd_skip, dim3((unsigned)((size_t)B*Cs*chunks)), dim3(kDecBlock), 0, st, g_out, g_skip, Ca, Cs, h, w, chunks);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace smd

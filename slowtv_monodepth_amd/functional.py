@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, call, int_array, ptr_array
 
 __all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
-           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
+           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
 def _stream() -> int:
@@ -341,6 +341,65 @@ def recon_reduce(err_warp, err_static=None, *, use_min: bool = False, noise=None
 
 
 # ---------------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------
+class _EluPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, apply_elu):
+        x = _check('x', x)
+        if x.ndim != 4: raise ValueError(f'expected (B,C,h,w), got {tuple(x.shape)}')
+        B, C, h, w = x.shape
+        out = torch.empty((B, C, h + 2, w + 2), device=x.device, dtype=torch.float32)
+        call('smd_elu_pad_fwd', x.data_ptr(), out.data_ptr(), B, C, h, w, int(apply_elu), _stream())
+        ctx.save_for_backward(x); ctx.apply_elu = int(apply_elu)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (x,) = ctx.saved_tensors
+        B, C, h, w = x.shape
+        g_x = torch.empty_like(x)
+        call('smd_elu_pad_bwd', x.data_ptr(), g_out.contiguous().data_ptr(), g_x.data_ptr(), B, C, h, w, ctx.apply_elu, _stream())
+        return g_x, None
+
+
+def elu_pad(x, apply_elu: bool = True):
+    """reflect_pad1(elu(x)) (or just the padding): the input of the next 3x3 convolution of the decoder."""
+    return _EluPad.apply(x, apply_elu)
+
+
+class _EluUpCatPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, skip):
+        a = _check('a', a)
+        if a.ndim != 4: raise ValueError(f'expected (B,C,h,w), got {tuple(a.shape)}')
+        B, Ca, h, w = a.shape
+        Cs = 0
+        if skip is not None:
+            Cs = skip.shape[1]
+            skip = _check('skip', skip, (B, Cs, 2*h, 2*w))
+        out = torch.empty((B, Ca + Cs, 2*h + 2, 2*w + 2), device=a.device, dtype=torch.float32)
+        call('smd_elu_up_cat_pad_fwd', a.data_ptr(), skip.data_ptr() if skip is not None else None, out.data_ptr(), B, Ca, Cs, h, w, _stream())
+        ctx.save_for_backward(a); ctx.Cs = Cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (a,) = ctx.saved_tensors
+        B, Ca, h, w = a.shape
+        Cs = ctx.Cs
+        g_a = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        g_skip = torch.empty((B, Cs, 2*h, 2*w), device=a.device, dtype=torch.float32) if (Cs and ctx.needs_input_grad[1]) else None
+        if g_a is None and g_skip is None: return None, None
+        call('smd_elu_up_cat_pad_bwd', a.data_ptr(), g_out.contiguous().data_ptr(), g_a.data_ptr() if g_a is not None else None,
+             g_skip.data_ptr() if g_skip is not None else None, B, Ca, Cs, h, w, _stream())
+        return g_a, g_skip
+
+
+def elu_up_cat_pad(a, skip=None):
+    """reflect_pad1(cat(nearest_x2(elu(a)), skip)): (B,Ca,h,w) [+ (B,Cs,2h,2w)] -> (B,Ca+Cs,2h+2,2w+2)."""
+    return _EluUpCatPad.apply(a, skip)
+
+
 # ---------------------------------------------------------------------------------------------------
 class _PoseMatrices(torch.autograd.Function):
     """`T_from_AAt` (+ rigid inverse where flagged) in one launch (src/tools/geometry.py:181-209, src/core/trainer.py:253)."""

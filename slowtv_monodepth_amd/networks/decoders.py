@@ -47,10 +47,29 @@ class MonodepthDecoder(nn.Module):
         for i in self.out_sc: self.out[str(i)] = conv3x3(self.num_ch_dec[i], out_ch)
 
     def forward(self, feat):
-        out, x = {}, feat[-1]
+        x = feat[-1]
+        if x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.upsample_mode == 'nearest':
+            return self._forward_glued(feat)
+        out = {}
         for i in range(4, -1, -1):
             x = F.interpolate(self.up0[str(i)](x), scale_factor=2, mode=self.upsample_mode)
             if self.use_skip and 2**i in self.enc_sc: x = torch.cat((x, feat[self.enc_sc.index(2**i)]), 1)
             x = self.up1[str(i)](x)
             if i in self.out_sc: out[i] = self.act(self.out[str(i)](x))
+        return out
+
+    def _forward_glued(self, feat):
+        """Same network, same parameters; the ops BETWEEN the convolutions (ELU, nearest x2, cat, reflection pad) run as
+        the two gather kernels of `csrc/smd_decoder.hip`, each writing the next convolution's padded input, and the
+        padded ELU output of a stage is shared by its output head and the next stage (the reference pads it twice)."""
+        from .. import functional as HF
+        conv = lambda m, xp: F.conv2d(xp, m.weight, m.bias)     # input is already reflection-padded
+        out = {}
+        xp = HF.elu_pad(feat[-1], apply_elu=False)
+        for i in range(4, -1, -1):
+            a = conv(self.up0[str(i)][0], xp)
+            skip = feat[self.enc_sc.index(2**i)] if (self.use_skip and 2**i in self.enc_sc) else None
+            c = conv(self.up1[str(i)][0], HF.elu_up_cat_pad(a, skip))
+            if i in self.out_sc or i > 0: xp = HF.elu_pad(c, apply_elu=True)
+            if i in self.out_sc: out[i] = self.act(conv(self.out[str(i)], xp))
         return out
