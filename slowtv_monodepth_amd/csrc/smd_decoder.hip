@@ -14,9 +14,11 @@
 namespace smd {
 
 constexpr int kDecBlock = 256;
+constexpr int kDecPerThread = 4;   // block-strided elements per thread: 4 independent load->store chains, 4x fewer blocks
+constexpr int kDecChunk = kDecBlock*kDecPerThread;
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
-__device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : expf(x); }
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+__device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : __expf(x); }
 __device__ __forceinline__ int unpad_reflect(int p, int n) { const int r = p - 1; return r < 0 ? -r : (r >= n ? 2*(n - 1) - r : r); }
 
 // Sum of g over the padded positions that read un-padded index r along one axis of length n: p = r+1, plus the mirrored
@@ -26,46 +28,57 @@ __device__ __forceinline__ int unpad_reflect(int p, int n) { const int r = p - 1
 __global__ __launch_bounds__(kDecBlock) void k_elu_pad_fwd(const float* __restrict__ x, float* __restrict__ out, int h, int w, int apply_elu, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
   const int H = h + 2, W = w + 2;
-  const int idx = chunk*kDecBlock + threadIdx.x;
-  if (idx >= H*W) return;
-  const int py = idx/W, px = idx - py*W;
-  const float v = x[(size_t)plane*h*w + unpad_reflect(py, h)*w + unpad_reflect(px, w)];
-  out[(size_t)plane*H*W + idx] = apply_elu ? elu1(v) : v;
+#pragma unroll
+  for (int k = 0; k < kDecPerThread; ++k) {
+    const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
+    if (idx >= H*W) break;
+    const int py = idx/W, px = idx - py*W;
+    const float v = x[(size_t)plane*h*w + unpad_reflect(py, h)*w + unpad_reflect(px, w)];
+    out[(size_t)plane*H*W + idx] = apply_elu ? elu1(v) : v;
+  }
 }
 
 __global__ __launch_bounds__(kDecBlock) void k_elu_pad_bwd(const float* __restrict__ x, const float* __restrict__ g_out, float* __restrict__ g_x,
                                                            int h, int w, int apply_elu, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
   const int W = w + 2;
-  const int idx = chunk*kDecBlock + threadIdx.x;
-  if (idx >= h*w) return;
-  const int i = idx/w, j = idx - i*w;
   const float* g = g_out + (size_t)plane*(h + 2)*W;
-  SMD_PAD_ADJ_POS(i, h, y0, y1, y2); SMD_PAD_ADJ_POS(j, w, x0, x1, x2);
-  const int ys[3] = {y0, y1, y2}, xs[3] = {x0, x1, x2};
-  float acc = 0.f;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    if (ys[a] < 0) continue;
+  for (int k = 0; k < kDecPerThread; ++k) {
+    const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
+    if (idx >= h*w) break;
+    const int i = idx/w, j = idx - i*w;
+    float acc = g[(i + 1)*W + j + 1];
+    if (i == 1 || i == h - 2 || j == 1 || j == w - 2) {   // rare: mirrored border cells
+      SMD_PAD_ADJ_POS(i, h, y0, y1, y2); SMD_PAD_ADJ_POS(j, w, x0, x1, x2);
+      const int ys[3] = {y0, y1, y2}, xs[3] = {x0, x1, x2};
+      acc = 0.f;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) if (xs[b] >= 0) acc += g[ys[a]*W + xs[b]];
+      for (int a = 0; a < 3; ++a) {
+        if (ys[a] < 0) continue;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) if (xs[b] >= 0) acc += g[ys[a]*W + xs[b]];
+      }
+    }
+    g_x[(size_t)plane*h*w + idx] = apply_elu ? acc*elu1_grad(x[(size_t)plane*h*w + idx]) : acc;
   }
-  g_x[(size_t)plane*h*w + idx] = apply_elu ? acc*elu1_grad(x[(size_t)plane*h*w + idx]) : acc;
 }
 
 __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_fwd(const float* __restrict__ a, const float* __restrict__ skip, float* __restrict__ out,
                                                                   int Ca, int Cs, int h, int w, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*(Ca+Cs) + c
   const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, H = H2 + 2, W = W2 + 2;
-  const int idx = chunk*kDecBlock + threadIdx.x;
-  if (idx >= H*W) return;
-  const int py = idx/W, px = idx - py*W;
-  const int r = unpad_reflect(py, H2), q = unpad_reflect(px, W2);
   const unsigned b = plane/C, c = plane - b*C;
-  float v;
-  if ((int)c < Ca) v = elu1(a[((size_t)b*Ca + c)*h*w + (r >> 1)*w + (q >> 1)]);
-  else v = skip[((size_t)b*Cs + (c - Ca))*H2*W2 + r*W2 + q];
-  out[(size_t)plane*H*W + idx] = v;
+  const bool from_a = (int)c < Ca;
+  const float* src = from_a ? a + ((size_t)b*Ca + c)*h*w : skip + ((size_t)b*Cs + (c - Ca))*H2*W2;
+#pragma unroll
+  for (int k = 0; k < kDecPerThread; ++k) {
+    const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
+    if (idx >= H*W) break;
+    const int py = idx/W, px = idx - py*W;
+    const int r = unpad_reflect(py, H2), q = unpad_reflect(px, W2);
+    out[(size_t)plane*H*W + idx] = from_a ? elu1(src[(r >> 1)*w + (q >> 1)]) : src[r*W2 + q];
+  }
 }
 
 // Adjoint w.r.t. `a` (low resolution): each source pixel feeds a 2x2 block of the up-sampled map, each cell of which
@@ -74,12 +87,17 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float*
                                                                     int Ca, int Cs, int h, int w, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*Ca + c
   const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, W = W2 + 2;
-  const int idx = chunk*kDecBlock + threadIdx.x;
-  if (idx >= h*w) return;
-  const int i = idx/w, j = idx - i*w;
   const unsigned b = plane/Ca, c = plane - b*Ca;
   const float* g = g_out + ((size_t)b*C + c)*(H2 + 2)*W;
+  for (int k = 0; k < kDecPerThread; ++k) {
+  const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
+  if (idx >= h*w) break;
+  const int i = idx/w, j = idx - i*w;
   float acc = 0.f;
+  if (i > 0 && i < h - 1 && j > 0 && j < w - 1) {   // interior: the plain 2x2 block
+    const float* gp = g + (2*i + 1)*W + 2*j + 1;
+    acc = (gp[0] + gp[1]) + (gp[W] + gp[W + 1]);
+  } else
 #pragma unroll
   for (int dr = 0; dr < 2; ++dr) {
     const int r = 2*i + dr;
@@ -99,6 +117,7 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float*
     }
   }
   g_a[(size_t)plane*h*w + idx] = acc*elu1_grad(a[(size_t)plane*h*w + idx]);
+  }
 }
 
 // Adjoint w.r.t. the skip tensor (full resolution): plain reflection-pad adjoint of its channel slice.
@@ -106,45 +125,51 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_skip(const flo
                                                                        int Ca, int Cs, int h, int w, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*Cs + c
   const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, W = W2 + 2;
-  const int idx = chunk*kDecBlock + threadIdx.x;
-  if (idx >= H2*W2) return;
-  const int r = idx/W2, q = idx - r*W2;
   const unsigned b = plane/Cs, c = plane - b*Cs;
   const float* g = g_out + ((size_t)b*C + Ca + c)*(H2 + 2)*W;
-  SMD_PAD_ADJ_POS(r, H2, y0, y1, y2); SMD_PAD_ADJ_POS(q, W2, x0, x1, x2);
-  const int ys[3] = {y0, y1, y2}, xs[3] = {x0, x1, x2};
-  float acc = 0.f;
 #pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    if (ys[m] < 0) continue;
+  for (int k = 0; k < kDecPerThread; ++k) {
+    const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
+    if (idx >= H2*W2) break;
+    const int r = idx/W2, q = idx - r*W2;
+    float acc = g[(r + 1)*W + q + 1];
+    if (r == 1 || r == H2 - 2 || q == 1 || q == W2 - 2) {
+      SMD_PAD_ADJ_POS(r, H2, y0, y1, y2); SMD_PAD_ADJ_POS(q, W2, x0, x1, x2);
+      const int ys[3] = {y0, y1, y2}, xs[3] = {x0, x1, x2};
+      acc = 0.f;
 #pragma unroll
-    for (int n = 0; n < 3; ++n) if (xs[n] >= 0) acc += g[ys[m]*W + xs[n]];
+      for (int m = 0; m < 3; ++m) {
+        if (ys[m] < 0) continue;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) if (xs[n] >= 0) acc += g[ys[m]*W + xs[n]];
+      }
+    }
+    g_skip[(size_t)plane*H2*W2 + idx] = acc;
   }
-  g_skip[(size_t)plane*H2*W2 + idx] = acc;
 }
 
 hipError_t launch_elu_pad_fwd(const float* x, float* out, size_t planes, int h, int w, int apply_elu, hipStream_t st) {
-  const unsigned chunks = ceil_div((h + 2)*(w + 2), kDecBlock);
+  const unsigned chunks = ceil_div((h + 2)*(w + 2), kDecChunk);
   hipLaunchKernelGGL(k_elu_pad_fwd, dim3((unsigned)(planes*chunks)), dim3(kDecBlock), 0, st, x, out, h, w, apply_elu, chunks);
   return hipGetLastError();
 }
 hipError_t launch_elu_pad_bwd(const float* x, const float* g_out, float* g_x, size_t planes, int h, int w, int apply_elu, hipStream_t st) {
-  const unsigned chunks = ceil_div(h*w, kDecBlock);
+  const unsigned chunks = ceil_div(h*w, kDecChunk);
   hipLaunchKernelGGL(k_elu_pad_bwd, dim3((unsigned)(planes*chunks)), dim3(kDecBlock), 0, st, x, g_out, g_x, h, w, apply_elu, chunks);
   return hipGetLastError();
 }
 hipError_t launch_elu_up_cat_pad_fwd(const float* a, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, hipStream_t st) {
-  const unsigned chunks = ceil_div((2*h + 2)*(2*w + 2), kDecBlock);
+  const unsigned chunks = ceil_div((2*h + 2)*(2*w + 2), kDecChunk);
   hipLaunchKernelGGL(k_elu_up_cat_pad_fwd, dim3((unsigned)((size_t)B*(Ca + Cs)*chunks)), dim3(kDecBlock), 0, st, a, skip, out, Ca, Cs, h, w, chunks);
   return hipGetLastError();
 }
 hipError_t launch_elu_up_cat_pad_bwd(const float* a, const float* g_out, float* g_a, float* g_skip, int B, int Ca, int Cs, int h, int w, hipStream_t st) {
   if (g_a) {
-    const unsigned chunks = ceil_div(h*w, kDecBlock);
+    const unsigned chunks = ceil_div(h*w, kDecChunk);
     hipLaunchKernelGGL(k_elu_up_cat_pad_bwd_a, dim3((unsigned)((size_t)B*Ca*chunks)), dim3(kDecBlock), 0, st, a, g_out, g_a, Ca, Cs, h, w, chunks);
   }
   if (g_skip && Cs > 0) {
-    const unsigned chunks = ceil_div(4*h*w, kDecBlock);
+    const unsigned chunks = ceil_div(4*h*w, kDecChunk);
     hipLaunchKernelGGL(k_elu_up_cat_pad_bwd_skip, dim3((unsigned)((size_t)B*Cs*chunks)), dim3(kDecBlock), 0, st, g_out, g_skip, Ca, Cs, h, w, chunks);
   }
   return hipGetLastError();
