@@ -116,7 +116,7 @@ def main():
     batch_fn = lambda it: batch
 
     def fence():
-        if world > 1: dist.barrier()
+        if dist.is_initialized(): dist.barrier()
         torch.cuda.synchronize()
 
     def note(msg):
@@ -133,7 +133,7 @@ def main():
     losses = train_steps(model, opt, batch_fn, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -176,7 +176,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(wl)
             note('cpu baseline done')
         print(json.dumps(out), flush=True)
-    if world > 1: dist.destroy_process_group()
+    if dist.is_initialized(): dist.destroy_process_group()
 
 
 if __name__ == '__main__':

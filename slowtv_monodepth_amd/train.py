@@ -40,7 +40,8 @@ class StepModule(nn.Module):
 def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     """(rank, local_rank, world) from the torchrun environment; initialises the process group when world > 1."""
     world = int(os.environ.get('WORLD_SIZE', 1)); rank = int(os.environ.get('RANK', 0)); local = int(os.environ.get('LOCAL_RANK', 0))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('SMD_FORCE_DDP') == '1' and 'MASTER_ADDR' in os.environ   # exercise RCCL + DDP on a single GPU
+    if (world > 1 or force) and not dist.is_initialized():
         backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')  # 'nccl' is RCCL on ROCm
         if backend == 'nccl': torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -50,7 +51,8 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
 def wrap_ddp(step: StepModule, device: torch.device, bucket_cap_mb: int = 25) -> nn.Module:
     """DDP over RCCL/xGMI: gradients are reduced in `bucket_cap_mb` buckets as backward produces them (overlap), buckets
     alias the .grad tensors, BatchNorm statistics stay per rank (the reference does not enable SyncBN)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1): return step
+    force = os.environ.get('SMD_FORCE_DDP') == '1'
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)): return step
     ids = [device.index] if device.type == 'cuda' else None
     return nn.parallel.DistributedDataParallel(step, device_ids=ids, broadcast_buffers=False, gradient_as_bucket_view=True,
                                                bucket_cap_mb=bucket_cap_mb)  # (static_graph would forbid no_sync() on the first micro-step)
