@@ -175,6 +175,22 @@ int smd_elu_up_cat_pad_fwd(const float* a, const float* skip, float* out, int B,
 int smd_elu_up_cat_pad_bwd(const float* a, const float* g_out, float* g_a, float* g_skip, int B, int Ca, int Cs, int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Producer side of the path: training-mode BatchNorm2d of the ResNet encoders fused with the residual add and ReLU
+ * that follow it (timm resnet blocks built at src/networks/depth.py:95-98, src/networks/pose.py:39-41;
+ * `F.batch_norm(training=True, momentum, eps)` semantics: biased variance for normalisation, unbiased for the running
+ * estimate).  x, y, residual (N,C,H,W) with HW = H*W; gamma, beta, running_*, save_* (C).
+ *   y = [relu]( (x - mean)/sqrt(var + eps) * gamma + beta [+ residual] )
+ * Backward: g_y -> g_x, g_gamma, g_beta and, when g_residual != NULL, the gradient of the residual branch
+ * (g_y masked by y > 0 when relu). */
+size_t smd_bn_workspace_bytes(int N, int C, int HW);
+int smd_bn_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd,
+               void* workspace, size_t workspace_bytes, int N, int C, int HW, void* stream);
+int smd_bn_bwd(const float* x, const float* y, const float* g_y, const float* gamma, const float* save_mean, const float* save_invstd,
+               int relu, float* g_x, float* g_residual, float* g_gamma, float* g_beta,
+               void* workspace, size_t workspace_bytes, int N, int C, int HW, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Pose / intrinsics prologue — one launch each instead of ~45 eager ATen launches.
  *
  * smd_pose_*: `T_from_AAt(aa, t)` (src/tools/geometry.py:181-209), followed by `T.inverse()` where invert[i] != 0
@@ -200,6 +216,10 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
 #define SMD_PROF_RECON_BWD 1
 int smd_profile_enable(int which, int capacity);
 int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out);
+
+/* Measurement aid: STREAM-style device copy of nbytes (multiple of 16) src -> dst; bench.py times it to quote the measured
+ * HBM copy ceiling of the box beside the datasheet peak. */
+int smd_debug_stream_copy(const void* src, void* dst, size_t nbytes, void* stream);
 
 /* Debug/self-test: out[l] = {value held by lane l-1, value held by lane l+1} for in[l] = l (64 lanes).
  * Used by the GPU tests to pin the cross-lane primitive the stencil kernels rely on. */

@@ -55,12 +55,16 @@ PROTOTYPES = {
     'smd_elu_pad_bwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
     'smd_elu_up_cat_pad_fwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
     'smd_elu_up_cat_pad_bwd': (_i, [_vp]*4 + [_i]*5 + [_vp]),
+    'smd_bn_workspace_bytes': (_sz, [_i, _i, _i]),
+    'smd_bn_fwd': (_i, [_vp]*6 + [_f, _f, _i] + [_vp]*4 + [_sz] + [_i]*3 + [_vp]),
+    'smd_bn_bwd': (_i, [_vp]*6 + [_i] + [_vp]*5 + [_sz] + [_i]*3 + [_vp]),
     'smd_pose_fwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     'smd_pose_bwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'smd_intrinsics_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'smd_intrinsics_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'smd_profile_enable': (_i, [_i, _i]),
     'smd_profile_collect': (_i, [_i, _vp, _i, _vp]),
+    'smd_debug_stream_copy': (_i, [_vp, _vp, _sz, _vp]),
     'smd_debug_lane_shift': (_i, [_vp, _vp, _vp]),
 }
 

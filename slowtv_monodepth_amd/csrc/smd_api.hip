@@ -376,6 +376,32 @@ int smd_elu_up_cat_pad_bwd(const float* a, const float* g_out, float* g_a, float
 }
 
 // ------------------------------------------------------------------------------------------------
+// BatchNorm (+ residual, + ReLU)
+size_t smd_bn_workspace_bytes(int N, int C, int HW) {
+  if (N < 1 || C < 1 || HW < 1) return 0;
+  return align256(((size_t)C*smd::bn_chunks(N, HW)*2 + (size_t)C*3)*sizeof(float));
+}
+int smd_bn_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
+               int N, int C, int HW, void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || C < 1 || C > 65535 || HW < 1 || (long long)N*HW < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d HW=%d", N, C, HW);
+  if (workspace_bytes < smd_bn_workspace_bytes(N, C, HW)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_bn_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean, save_invstd,
+                                         (float*)workspace, N, C, HW, (hipStream_t)stream), "bn_fwd");
+}
+int smd_bn_bwd(const float* x, const float* y, const float* g_y, const float* gamma, const float* save_mean, const float* save_invstd, int relu,
+               float* g_x, float* g_residual, float* g_gamma, float* g_beta, void* workspace, size_t workspace_bytes, int N, int C, int HW,
+               void* stream) {
+  if (!x || !g_y || !gamma || !save_mean || !save_invstd || !g_x || !g_gamma || !g_beta || !workspace || (relu && !y))
+    return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || C < 1 || C > 65535 || HW < 1) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d HW=%d", N, C, HW);
+  if (workspace_bytes < smd_bn_workspace_bytes(N, C, HW)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_bn_bwd(x, y, g_y, gamma, save_mean, save_invstd, relu, g_x, g_residual, g_gamma, g_beta, (float*)workspace,
+                                         N, C, HW, (hipStream_t)stream), "bn_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pose / intrinsics prologue
 int smd_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, void* stream) {
   if (!aa || !t || !T) return fail(SMD_E_INVALID, "null pointer");
@@ -426,6 +452,12 @@ int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out) {
   p.used = 0;
   *n_out = n;
   return SMD_OK;
+}
+
+int smd_debug_stream_copy(const void* src, void* dst, size_t nbytes, void* stream) {
+  if (!src || !dst) return fail(SMD_E_INVALID, "null pointer");
+  if (nbytes < 16 || (nbytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(SMD_E_INVALID, "size and pointers must be multiples of 16");
+  return check_launch(smd::launch_stream_copy(src, dst, nbytes, (hipStream_t)stream), "stream_copy");
 }
 
 int smd_debug_lane_shift(float* out_left, float* out_right, void* stream) {

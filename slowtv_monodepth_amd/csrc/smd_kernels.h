@@ -94,10 +94,17 @@ hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_stati
 hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w,
                                    int flags, hipStream_t st);
 hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
+hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, hipStream_t st);
 hipError_t launch_elu_pad_fwd(const float* x, float* out, size_t planes, int h, int w, int apply_elu, hipStream_t st);
 hipError_t launch_elu_pad_bwd(const float* x, const float* g_out, float* g_x, size_t planes, int h, int w, int apply_elu, hipStream_t st);
 hipError_t launch_elu_up_cat_pad_fwd(const float* a, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, hipStream_t st);
 hipError_t launch_elu_up_cat_pad_bwd(const float* a, const float* g_out, float* g_a, float* g_skip, int B, int Ca, int Cs, int h, int w, hipStream_t st);
+int bn_chunks(int N, int HW);
+hipError_t launch_bn_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd, float* ws, int N, int C, int HW,
+                         hipStream_t st);
+hipError_t launch_bn_bwd(const float* x, const float* y, const float* g_y, const float* gamma, const float* save_mean, const float* save_invstd,
+                         int relu, float* g_x, float* g_res, float* g_gamma, float* g_beta, float* ws, int N, int C, int HW, hipStream_t st);
 int regr_blocks(size_t N);
 hipError_t launch_regression_fwd(const float* pred, const float* target, const uint8_t* mask, size_t N, int flags, float* loss, float* err,
                                  float* stats, float* ws, hipStream_t st);

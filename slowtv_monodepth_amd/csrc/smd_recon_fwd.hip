@@ -349,6 +349,15 @@ hipError_t launch_sum_partials(const float* partial, int count, double scale, fl
   return hipGetLastError();
 }
 
+// STREAM-style device copy (16 B per lane, grid-stride): the measured HBM ceiling quoted beside the datasheet peak.
+__global__ __launch_bounds__(256) void k_stream_copy(const f4* __restrict__ src, f4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x*256 + threadIdx.x; i < n16; i += (size_t)gridDim.x*256) dst[i] = __builtin_nontemporal_load(src + i);
+}
+hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, hipStream_t st) {
+  hipLaunchKernelGGL(k_stream_copy, dim3(256*16), dim3(256), 0, st, (const f4*)src, (f4*)dst, nbytes/16);
+  return hipGetLastError();
+}
+
 __global__ void k_debug_lane_shift(float* out_left, float* out_right) {
   float x = (float)threadIdx.x;
   out_left[threadIdx.x] = lane_left(x);

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, call, int_array, ptr_array
 
 __all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
-           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
+           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
 def _stream() -> int:
@@ -398,6 +398,50 @@ class _EluUpCatPad(torch.autograd.Function):
 def elu_up_cat_pad(a, skip=None):
     """reflect_pad1(cat(nearest_x2(elu(a)), skip)): (B,Ca,h,w) [+ (B,Cs,2h,2w)] -> (B,Ca+Cs,2h+2,2w+2)."""
     return _EluUpCatPad.apply(a, skip)
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """Training-mode BatchNorm2d + optional residual add + optional ReLU (`smd_bn_*`)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
+        x = _check('x', x)
+        if x.ndim != 4: raise ValueError(f'expected (N,C,H,W), got {tuple(x.shape)}')
+        N, C, H, W = x.shape
+        if N*H*W < 2: raise ValueError('Expected more than 1 value per channel when training')   # F.batch_norm's own check
+        if residual is not None: residual = _check('residual', residual, x.shape)
+        weight = _check('weight', weight, (C,)); bias = _check('bias', bias, (C,))
+        y = torch.empty_like(x)
+        save = torch.empty((2, C), device=x.device, dtype=torch.float32)
+        nbytes = _lib.lib.smd_bn_workspace_bytes(N, C, H*W)
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        call('smd_bn_fwd', x.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(), bias.data_ptr(),
+             running_mean.data_ptr() if running_mean is not None else None, running_var.data_ptr() if running_var is not None else None,
+             float(momentum), float(eps), int(relu), y.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), ws.data_ptr(), nbytes, N, C, H*W, _stream())
+        ctx.save_for_backward(x, y if relu else None, weight, save)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, y, weight, save = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g_y = g_y.contiguous()
+        g_x = torch.empty_like(x)
+        g_res = None
+        if ctx.has_res and ctx.needs_input_grad[1]: g_res = torch.empty_like(x) if ctx.relu else g_y   # without ReLU the branch gradient IS g_y
+        g_w = torch.empty_like(weight); g_b = torch.empty_like(weight)
+        nbytes = _lib.lib.smd_bn_workspace_bytes(N, C, H*W)
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        call('smd_bn_bwd', x.data_ptr(), y.data_ptr() if y is not None else None, g_y.data_ptr(), weight.data_ptr(), save[0].data_ptr(),
+             save[1].data_ptr(), int(ctx.relu), g_x.data_ptr(), g_res.data_ptr() if (g_res is not None and ctx.relu) else None,
+             g_w.data_ptr(), g_b.data_ptr(), ws.data_ptr(), nbytes, N, C, H*W, _stream())
+        return g_x, g_res, g_w, g_b, None, None, None, None, None
+
+
+def batch_norm_act(x, weight, bias, running_mean=None, running_var=None, *, residual=None, momentum: float = 0.1, eps: float = 1e-5, relu: bool = False):
+    """relu?(batch_norm_train(x) [+ residual]); running statistics are updated in place like `F.batch_norm(training=True)`."""
+    return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)
 
 
 # ---------------------------------------------------------------------------------------------------

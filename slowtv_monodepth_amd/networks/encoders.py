@@ -21,44 +21,78 @@ class FeatureInfo:
     def reduction(self): return list(self._r)
 
 
+class BatchNormAct2d(nn.BatchNorm2d):
+    """`nn.BatchNorm2d` (same parameters, buffers and state-dict keys) whose call can absorb the residual add and the ReLU
+    that follow it in a ResNet block.  On the GPU in fp32 training this is the `smd_bn_*` kernel pair (3 sweeps forward,
+    2 backward, for BN + add + ReLU together); anywhere else (CPU, eval, autocast, channels-last) it is the ATen composition."""
+    fused_enabled = True   # class-wide switch (tests compare the two evaluations of the same network)
+
+    def forward(self, x, residual=None, relu: bool = False):
+        fused = (self.fused_enabled and x.is_cuda and self.training and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.affine
+                 and self.track_running_stats and self.momentum is not None and x.is_contiguous())
+        if not fused:
+            y = super().forward(x)
+            if residual is not None: y = y + residual
+            return F.relu(y, inplace=True) if relu else y
+        from .. import functional as HF
+        self._pending_batches = getattr(self, '_pending_batches', 0) + 1   # num_batches_tracked, materialised lazily (see below)
+        return HF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, residual=residual,
+                                 momentum=self.momentum, eps=self.eps, relu=relu)
+
+    def flush_counter(self):
+        """`num_batches_tracked` only matters with momentum=None (cumulative average), which the fused path excludes; it is
+        kept exact but written when someone looks (state_dict / eval) instead of by one tiny launch per layer per step."""
+        n = getattr(self, '_pending_batches', 0)
+        if n and self.num_batches_tracked is not None: self.num_batches_tracked += n
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def train(self, mode: bool = True):
+        if not mode: self.flush_counter()
+        return super().train(mode)
+
+
 class BasicBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(cout)
-        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(cout)
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False); self.bn1 = BatchNormAct2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False); self.bn2 = BatchNormAct2d(cout)
         self.down = None
         if stride != 1 or cin != cout:
-            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), BatchNormAct2d(cout))
 
     def forward(self, x):
         idt = x if self.down is None else self.down(x)
-        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
-        return F.relu(self.bn2(self.conv2(x)) + idt, inplace=True)
+        x = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(x), residual=idt, relu=True)
 
 
 class Bottleneck(nn.Module):
     def __init__(self, cin, mid, stride):
         super().__init__()
         cout = mid*4
-        self.conv1 = nn.Conv2d(cin, mid, 1, bias=False); self.bn1 = nn.BatchNorm2d(mid)
-        self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False); self.bn2 = nn.BatchNorm2d(mid)
-        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False); self.bn3 = nn.BatchNorm2d(cout)
+        self.conv1 = nn.Conv2d(cin, mid, 1, bias=False); self.bn1 = BatchNormAct2d(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False); self.bn2 = BatchNormAct2d(mid)
+        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False); self.bn3 = BatchNormAct2d(cout)
         self.down = None
         if stride != 1 or cin != cout:
-            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), BatchNormAct2d(cout))
 
     def forward(self, x):
         idt = x if self.down is None else self.down(x)
-        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
-        x = F.relu(self.bn2(self.conv2(x)), inplace=True)
-        return F.relu(self.bn3(self.conv3(x)) + idt, inplace=True)
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
+        return self.bn3(self.conv3(x), residual=idt, relu=True)
 
 
 class ResNetFeatures(nn.Module):
     """ResNet trunk returning [stem (1/2), layer1 (1/4), layer2 (1/8), layer3 (1/16), layer4 (1/32)]."""
     def __init__(self, layers=(2, 2, 2, 2), bottleneck=False, in_chans=3):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_chans, 64, 7, 2, 3, bias=False); self.bn1 = nn.BatchNorm2d(64)
+        self.conv1 = nn.Conv2d(in_chans, 64, 7, 2, 3, bias=False); self.bn1 = BatchNormAct2d(64)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         widths, exp = (64, 128, 256, 512), (4 if bottleneck else 1)
         stages, cin = [], 64
@@ -75,7 +109,7 @@ class ResNetFeatures(nn.Module):
             if isinstance(m, nn.Conv2d): nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
 
     def forward(self, x):
-        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = self.bn1(self.conv1(x), relu=True)
         feats = [x]
         x = self.maxpool(x)
         for layer in self.layers:

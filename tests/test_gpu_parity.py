@@ -509,3 +509,55 @@ def _plain_decoder(dec, feat):
         x = dec.up1[str(i)](x)
         if i in dec.out_sc: out[i] = dec.act(dec.out[str(i)](x))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Producer side: BatchNorm (+ residual, + ReLU) kernels against ATen's batch_norm / add / relu
+@pytest.mark.parametrize('shape', [(4, 8, 6, 20), (3, 5, 7, 9), (12, 64, 24, 80), (2, 130, 3, 5)])
+@pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True), (False, True)])
+def test_batch_norm_act_kernel(F, shape, relu, res):
+    import torch.nn.functional as TF
+    gen = torch.Generator().manual_seed(8)
+    N, C, H, W = shape
+    x = (torch.randn(*shape, generator=gen)*2 + 3*torch.randn(1, C, 1, 1, generator=gen)).cuda()   # per-channel offsets: mean >> std for some
+    r = torch.randn(*shape, generator=gen).cuda() if res else None
+    w, b = (torch.rand(C, generator=gen) + 0.5).cuda(), torch.randn(C, generator=gen).cuda()
+    g = torch.randn(*shape, generator=gen).cuda()
+    outs = []
+    for fused in (True, False):
+        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rr = r.clone().requires_grad_(True) if res else None
+        rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        if fused: y = F.batch_norm_act(xx, ww, bb, rm, rv, residual=rr, momentum=0.1, eps=1e-5, relu=relu)
+        else:
+            y = TF.batch_norm(xx, rm, rv, ww, bb, True, 0.1, 1e-5)
+            if res: y = y + rr
+            if relu: y = TF.relu(y)
+        y.backward(g)
+        outs.append((y.detach(), xx.grad, ww.grad, bb.grad, rr.grad if res else None, rm, rv))
+    names = ('y', 'g_x', 'g_weight', 'g_bias', 'g_residual', 'running_mean', 'running_var')
+    for nm, a, e in zip(names, outs[0], outs[1]):
+        if e is None: continue
+        assert rel_to_max(a, e) < 2e-5, f'{nm}: {rel_to_max(a, e):.3e}'
+
+
+def test_resnet_encoder_with_fused_batch_norm_equals_aten(F):
+    from slowtv_monodepth_amd.networks import encoders as E
+    torch.manual_seed(1)
+    net = E.create_encoder('resnet18', in_chans=3).cuda().train()
+    x = torch.randn(4, 3, 64, 96, device='cuda')
+    res = []
+    for fused in (True, False):
+        E.BatchNormAct2d.fused_enabled = fused
+        try:
+            net.zero_grad()
+            state = {k: v.clone() for k, v in net.state_dict().items()}
+            feats = net(x)
+            sum((f*f).mean() for f in feats).backward()
+            res.append(([f.detach() for f in feats], [p.grad.clone() for p in net.parameters()], {k: v.clone() for k, v in net.state_dict().items()}))
+            net.load_state_dict(state)   # same running statistics for the second evaluation
+        finally:
+            E.BatchNormAct2d.fused_enabled = True
+    for a, b in zip(res[0][0], res[1][0]): assert rel_to_max(a, b) < 1e-4
+    for a, b in zip(res[0][1], res[1][1]): assert rel_to_max(a, b) < 2e-3
+    for k in res[0][2]: assert rel_to_max(res[0][2][k].float(), res[1][2][k].float()) < 1e-4, k
