@@ -4,8 +4,9 @@
 // element-wise ops around it were the largest non-convolution item of the step (MIOpen's spatial BN kernels launch one
 // workgroup per channel: 64 workgroups on a 256-CU device for the stem).
 //
-//   forward : stats sweep (shifted sums, many blocks per channel) -> finalize (fp64 combine, running stats) -> apply sweep
-//   backward: reduce sweep (sum dz, sum dz*(x-mean)) -> finalize (g_gamma, g_beta, coefficients) -> apply sweep
+//   forward : stats sweep (shifted sums, many blocks per channel) -> apply sweep (each block combines the channel's partials in fp64)
+//   backward: reduce sweep (sum dz, sum dz*(x-mean))               -> apply sweep (same; block 0 of a channel writes g_gamma, g_beta)
+//   layers with N*HW <= 16384 (layer3/4 of the encoders): ONE launch per direction, one block per channel
 // where dz = g_y masked by (y > 0) when the ReLU is fused.  NCHW fp32; float4 path when HW % 4 == 0.
 #include "smd_common.h"
 #include "smd_kernels.h"
@@ -66,46 +67,150 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_stats(const float* __restrict__
   if (threadIdx.x == 0) { partial[((size_t)c*chunks + k)*2] = r1; partial[((size_t)c*chunks + k)*2 + 1] = r2; }
 }
 
-__global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ x, const float* __restrict__ partial, int N, int C, int HW, int chunks,
-                                                    float momentum, float eps, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int c = blockIdx.x*64 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < chunks; ++k) { s1 += (double)partial[((size_t)c*chunks + k)*2]; s2 += (double)partial[((size_t)c*chunks + k)*2 + 1]; }
-  const double M = (double)N*HW, m1 = s1/M;
-  const double mean = (double)x[(size_t)c*HW] + m1;
+// fp64 combine of a channel's partial pairs by the whole block (every block of the apply sweeps does this for itself:
+// <= 128 pairs, so the separate one-thread-per-channel finalize launch is gone and nothing needs an atomic).
+__device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int c, int chunks, double* red, double& s1, double& s2) {
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < chunks; k += kBnBlock) { a += (double)partial[((size_t)c*chunks + k)*2]; b += (double)partial[((size_t)c*chunks + k)*2 + 1]; }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+  const int wv = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[wv*2] = a; red[wv*2 + 1] = b; }
+  __syncthreads();
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < kBnBlock/64; ++k) { s1 += red[k*2]; s2 += red[k*2 + 1]; }
+}
+
+struct BnStat { float mean, invstd; };
+__device__ __forceinline__ BnStat finish_stats(double s1, double s2, double shift, int N, int HW, float momentum, float eps, int c, bool writer,
+                                               float* running_mean, float* running_var, float* save_mean, float* save_invstd) {
+  const double M = (double)N*HW, m1 = s1/M, mean = shift + m1;
   double var = s2/M - m1*m1;
   if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)(1.0/sqrt(var + (double)eps));
-  if (running_mean) running_mean[c] = (float)((1.0 - momentum)*(double)running_mean[c] + momentum*mean);
-  if (running_var) running_var[c] = (float)((1.0 - momentum)*(double)running_var[c] + momentum*var*(M > 1.0 ? M/(M - 1.0) : 1.0));
+  const double invstd = 1.0/sqrt(var + (double)eps);
+  if (writer) {
+    save_mean[c] = (float)mean; save_invstd[c] = (float)invstd;
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum)*(double)running_mean[c] + momentum*mean);
+    if (running_var) running_var[c] = (float)((1.0 - momentum)*(double)running_var[c] + momentum*var*(M > 1.0 ? M/(M - 1.0) : 1.0));
+  }
+  return {(float)mean, (float)invstd};
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(kBnBlock) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ residual, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                       int C, int HW, size_t total, int relu, float* __restrict__ y) {
+__device__ __forceinline__ void apply_range(const float* __restrict__ x, const float* __restrict__ residual, float* __restrict__ y, int C, int HW, int c,
+                                            long long lo, long long hi, float sc, float sh, int relu) {
   constexpr int W = VEC ? 4 : 1;
-  for (size_t e = ((size_t)blockIdx.x*kBnBlock + threadIdx.x)*W; e < total; e += (size_t)gridDim.x*kBnBlock*W) {
-    const int c = (int)((e/HW) % C);
-    const float sc = gamma[c]*invstd[c], sh = fmaf(-mean[c], sc, beta[c]);
+  for (long long i = lo + (long long)threadIdx.x*W; i < hi; i += kBnBlock*W) {
+    const int n = (int)(i/HW), p = (int)(i - (long long)n*HW);
+    const size_t off = ((size_t)n*C + c)*HW + p;
     if (VEC) {
-      f4 v = *(const f4*)(x + e);
+      const f4 v = *(const f4*)(x + off);
       f4 o;
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = fmaf(v[q], sc, sh);
-      if (residual) { const f4 r = *(const f4*)(residual + e); o += r; }
+      if (residual) { const f4 r = *(const f4*)(residual + off); o += r; }
       if (relu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.f);
       }
-      *(f4*)(y + e) = o;
+      *(f4*)(y + off) = o;
     } else {
-      float o = fmaf(x[e], sc, sh);
-      if (residual) o += residual[e];
-      y[e] = relu ? fmaxf(o, 0.f) : o;
+      float o = fmaf(x[off], sc, sh);
+      if (residual) o += residual[off];
+      y[off] = relu ? fmaxf(o, 0.f) : o;
+    }
+  }
+}
+
+// Apply sweep of the chunked path: grid (chunks, C), the same ranges as the stats sweep.
+template <bool VEC>
+__global__ __launch_bounds__(kBnBlock) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ residual, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ partial, int N, int C, int HW, int chunks,
+                                                       float momentum, float eps, int relu, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ y) {
+  __shared__ double red[2*kBnBlock/64];
+  const int c = blockIdx.y, k = blockIdx.x;
+  double s1, s2;
+  combine_partials(partial, c, chunks, red, s1, s2);
+  const BnStat st = finish_stats(s1, s2, (double)x[(size_t)c*HW], N, HW, momentum, eps, c, k == 0 && threadIdx.x == 0, running_mean, running_var,
+                                 save_mean, save_invstd);
+  const float sc = gamma[c]*st.invstd, sh = fmaf(-st.mean, sc, beta[c]);
+  long long lo, hi;
+  chunk_range((long long)N*HW, chunks, k, lo, hi);
+  apply_range<VEC>(x, residual, y, C, HW, c, lo, hi, sc, sh, relu);
+}
+
+// Single-launch path for small channels (N*HW <= kBnSmall): one block per channel does stats, finalize and apply (second read from L2).
+template <bool VEC>
+__global__ __launch_bounds__(kBnBlock) void k_bn_fwd_small(const float* __restrict__ x, const float* __restrict__ residual, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int N, int C, int HW, float momentum, float eps, int relu,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ y) {
+  __shared__ float red[2*kBnBlock/64];
+  const int c = blockIdx.x;
+  const long long total = (long long)N*HW;
+  const float shift = x[(size_t)c*HW];
+  constexpr int W = VEC ? 4 : 1;
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = (long long)threadIdx.x*W; i < total; i += kBnBlock*W) {
+    const int n = (int)(i/HW), p = (int)(i - (long long)n*HW);
+    const size_t off = ((size_t)n*C + c)*HW + p;
+    if (VEC) {
+      const f4 v = *(const f4*)(x + off);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float d = v[q] - shift; s1 += d; s2 = fmaf(d, d, s2); }
+    } else { const float d = x[off] - shift; s1 += d; s2 = fmaf(d, d, s2); }
+  }
+  float r1, r2;
+  block_sum2(s1, s2, red, r1, r2);
+  const BnStat st = finish_stats((double)r1, (double)r2, (double)shift, N, HW, momentum, eps, c, threadIdx.x == 0, running_mean, running_var,
+                                 save_mean, save_invstd);
+  const float sc = gamma[c]*st.invstd, sh = fmaf(-st.mean, sc, beta[c]);
+  apply_range<VEC>(x, residual, y, C, HW, c, 0, total, sc, sh, relu);
+}
+
+template <bool VEC>
+__device__ __forceinline__ void bwd_reduce_range(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g_y, int C, int HW, int c,
+                                                 long long lo, long long hi, float mu, int relu, float& s1, float& s2) {
+  constexpr int W = VEC ? 4 : 1;
+  for (long long i = lo + (long long)threadIdx.x*W; i < hi; i += kBnBlock*W) {
+    const int n = (int)(i/HW), p = (int)(i - (long long)n*HW);
+    const size_t off = ((size_t)n*C + c)*HW + p;
+    if (VEC) {
+      const f4 xv = *(const f4*)(x + off), gv = *(const f4*)(g_y + off);
+      f4 yv = {1.f, 1.f, 1.f, 1.f};
+      if (relu) yv = *(const f4*)(y + off);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float dz = (yv[q] > 0.f) ? gv[q] : 0.f; s1 += dz; s2 = fmaf(dz, xv[q] - mu, s2); }
+    } else {
+      const float dz = (!relu || y[off] > 0.f) ? g_y[off] : 0.f;
+      s1 += dz; s2 = fmaf(dz, x[off] - mu, s2);
+    }
+  }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void bwd_apply_range(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g_y, float* __restrict__ g_x,
+                                                float* __restrict__ g_res, int C, int HW, int c, long long lo, long long hi, float mu, float a, float b,
+                                                float k2, int relu) {
+  constexpr int W = VEC ? 4 : 1;
+  for (long long i = lo + (long long)threadIdx.x*W; i < hi; i += kBnBlock*W) {
+    const int n = (int)(i/HW), p = (int)(i - (long long)n*HW);
+    const size_t off = ((size_t)n*C + c)*HW + p;
+    if (VEC) {
+      const f4 xv = *(const f4*)(x + off), gv = *(const f4*)(g_y + off);
+      f4 yv = {1.f, 1.f, 1.f, 1.f};
+      if (relu) yv = *(const f4*)(y + off);
+      f4 dz, dx;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dz[q] = (yv[q] > 0.f) ? gv[q] : 0.f; dx[q] = a*(dz[q] - b - (xv[q] - mu)*k2); }
+      *(f4*)(g_x + off) = dx;
+      if (g_res) *(f4*)(g_res + off) = dz;
+    } else {
+      const float dz = (!relu || y[off] > 0.f) ? g_y[off] : 0.f;
+      g_x[off] = a*(dz - b - (x[off] - mu)*k2);
+      if (g_res) g_res[off] = dz;
     }
   }
 }
@@ -116,100 +221,92 @@ __global__ __launch_bounds__(kBnBlock) void k_bn_bwd_reduce(const float* __restr
                                                             float* __restrict__ partial) {
   __shared__ float red[2*kBnBlock/64];
   const int c = blockIdx.y, k = blockIdx.x;
-  const long long total = (long long)N*HW;
   long long lo, hi;
-  chunk_range(total, chunks, k, lo, hi);
-  const float mu = mean[c];
+  chunk_range((long long)N*HW, chunks, k, lo, hi);
   float s1 = 0.f, s2 = 0.f;
-  if (VEC) {
-    for (long long i = lo + (long long)threadIdx.x*4; i < hi; i += kBnBlock*4) {
-      const int n = (int)(i/HW), p = (int)(i - (long long)n*HW);
-      const size_t off = ((size_t)n*C + c)*HW + p;
-      const f4 xv = *(const f4*)(x + off), gv = *(const f4*)(g_y + off);
-      f4 yv = {1.f, 1.f, 1.f, 1.f};
-      if (relu) yv = *(const f4*)(y + off);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const float dz = (yv[q] > 0.f) ? gv[q] : 0.f; s1 += dz; s2 = fmaf(dz, xv[q] - mu, s2); }
-    }
-  } else {
-    for (long long i = lo + threadIdx.x; i < hi; i += kBnBlock) {
-      const int n = (int)(i/HW), p = (int)(i - (long long)n*HW);
-      const size_t off = ((size_t)n*C + c)*HW + p;
-      const float dz = (!relu || y[off] > 0.f) ? g_y[off] : 0.f;
-      s1 += dz; s2 = fmaf(dz, x[off] - mu, s2);
-    }
-  }
+  bwd_reduce_range<VEC>(x, y, g_y, C, HW, c, lo, hi, mean[c], relu, s1, s2);
   float r1, r2;
   block_sum2(s1, s2, red, r1, r2);
   if (threadIdx.x == 0) { partial[((size_t)c*chunks + k)*2] = r1; partial[((size_t)c*chunks + k)*2 + 1] = r2; }
 }
 
-// coef[c] = {gamma*invstd, sum(dz)/M, invstd^2 * sum(dz*(x-mean))/M}
-__global__ __launch_bounds__(64) void k_bn_bwd_finalize(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                        int N, int C, int HW, int chunks, float* __restrict__ g_gamma, float* __restrict__ g_beta,
-                                                        float* __restrict__ coef) {
-  const int c = blockIdx.x*64 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < chunks; ++k) { s1 += (double)partial[((size_t)c*chunks + k)*2]; s2 += (double)partial[((size_t)c*chunks + k)*2 + 1]; }
+template <bool VEC>
+__global__ __launch_bounds__(kBnBlock) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g_y,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ partial, int N, int C, int HW, int chunks, int relu,
+                                                           float* __restrict__ g_x, float* __restrict__ g_res, float* __restrict__ g_gamma,
+                                                           float* __restrict__ g_beta) {
+  __shared__ double red[2*kBnBlock/64];
+  const int c = blockIdx.y, k = blockIdx.x;
+  double s1, s2;
+  combine_partials(partial, c, chunks, red, s1, s2);
   const double M = (double)N*HW, is = (double)invstd[c];
-  g_beta[c] = (float)s1; g_gamma[c] = (float)(s2*is);
-  coef[c*3] = (float)((double)gamma[c]*is); coef[c*3 + 1] = (float)(s1/M); coef[c*3 + 2] = (float)(s2*is*is/M);
+  if (k == 0 && threadIdx.x == 0) { g_beta[c] = (float)s1; g_gamma[c] = (float)(s2*is); }
+  long long lo, hi;
+  chunk_range((long long)N*HW, chunks, k, lo, hi);
+  bwd_apply_range<VEC>(x, y, g_y, g_x, g_res, C, HW, c, lo, hi, mean[c], (float)((double)gamma[c]*is), (float)(s1/M), (float)(s2*is*is/M), relu);
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(kBnBlock) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g_y,
-                                                           const float* __restrict__ mean, const float* __restrict__ coef, int C, int HW, size_t total,
-                                                           int relu, float* __restrict__ g_x, float* __restrict__ g_res) {
-  constexpr int W = VEC ? 4 : 1;
-  for (size_t e = ((size_t)blockIdx.x*kBnBlock + threadIdx.x)*W; e < total; e += (size_t)gridDim.x*kBnBlock*W) {
-    const int c = (int)((e/HW) % C);
-    const float a = coef[c*3], b = coef[c*3 + 1], k2 = coef[c*3 + 2], mu = mean[c];
-    if (VEC) {
-      const f4 xv = *(const f4*)(x + e), gv = *(const f4*)(g_y + e);
-      f4 yv = {1.f, 1.f, 1.f, 1.f};
-      if (relu) yv = *(const f4*)(y + e);
-      f4 dz, dx;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { dz[q] = (yv[q] > 0.f) ? gv[q] : 0.f; dx[q] = a*(dz[q] - b - (xv[q] - mu)*k2); }
-      *(f4*)(g_x + e) = dx;
-      if (g_res) *(f4*)(g_res + e) = dz;
-    } else {
-      const float dz = (!relu || y[e] > 0.f) ? g_y[e] : 0.f;
-      g_x[e] = a*(dz - b - (x[e] - mu)*k2);
-      if (g_res) g_res[e] = dz;
-    }
-  }
+__global__ __launch_bounds__(kBnBlock) void k_bn_bwd_small(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g_y,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           int N, int C, int HW, int relu, float* __restrict__ g_x, float* __restrict__ g_res,
+                                                           float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+  __shared__ float red[2*kBnBlock/64];
+  const int c = blockIdx.x;
+  const long long total = (long long)N*HW;
+  float s1 = 0.f, s2 = 0.f;
+  bwd_reduce_range<VEC>(x, y, g_y, C, HW, c, 0, total, mean[c], relu, s1, s2);
+  float r1, r2;
+  block_sum2(s1, s2, red, r1, r2);
+  const double M = (double)total, is = (double)invstd[c];
+  if (threadIdx.x == 0) { g_beta[c] = r1; g_gamma[c] = (float)((double)r2*is); }
+  bwd_apply_range<VEC>(x, y, g_y, g_x, g_res, C, HW, c, 0, total, mean[c], (float)((double)gamma[c]*is), (float)((double)r1/M),
+                       (float)((double)r2*is*is/M), relu);
 }
+
+constexpr long long kBnSmall = 16384;   // N*HW up to which one block per channel does the whole layer in one launch
 
 hipError_t launch_bn_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* running_mean, float* running_var,
                          float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd, float* ws, int N, int C, int HW,
                          hipStream_t st) {
-  const int chunks = bn_chunks(N, HW);
   const bool vec = (HW % 4) == 0;
-  const size_t total = (size_t)N*C*HW;
-  const unsigned ngrid = (unsigned)((total/(vec ? 4 : 1) + kBnBlock - 1)/kBnBlock < 16384 ? (total/(vec ? 4 : 1) + kBnBlock - 1)/kBnBlock : 16384);
-  if (vec) hipLaunchKernelGGL(k_bn_stats<true>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, N, C, HW, chunks, ws);
-  else hipLaunchKernelGGL(k_bn_stats<false>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, N, C, HW, chunks, ws);
-  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 64)), dim3(64), 0, st, x, ws, N, C, HW, chunks, momentum, eps, running_mean, running_var,
-                     save_mean, save_invstd);
-  if (vec) hipLaunchKernelGGL(k_bn_apply<true>, dim3(ngrid), dim3(kBnBlock), 0, st, x, residual, gamma, beta, save_mean, save_invstd, C, HW, total, relu, y);
-  else hipLaunchKernelGGL(k_bn_apply<false>, dim3(ngrid), dim3(kBnBlock), 0, st, x, residual, gamma, beta, save_mean, save_invstd, C, HW, total, relu, y);
+  if ((long long)N*HW <= kBnSmall) {
+    if (vec) hipLaunchKernelGGL(k_bn_fwd_small<true>, dim3(C), dim3(kBnBlock), 0, st, x, residual, gamma, beta, N, C, HW, momentum, eps, relu, running_mean, running_var, save_mean, save_invstd, y);
+    else hipLaunchKernelGGL(k_bn_fwd_small<false>, dim3(C), dim3(kBnBlock), 0, st, x, residual, gamma, beta, N, C, HW, momentum, eps, relu, running_mean, running_var, save_mean, save_invstd, y);
+    return hipGetLastError();
+  }
+  const int chunks = bn_chunks(N, HW);
+  if (vec) {
+    hipLaunchKernelGGL(k_bn_stats<true>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, N, C, HW, chunks, ws);
+    hipLaunchKernelGGL(k_bn_apply<true>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, residual, gamma, beta, ws, N, C, HW, chunks, momentum, eps, relu,
+                       running_mean, running_var, save_mean, save_invstd, y);
+  } else {
+    hipLaunchKernelGGL(k_bn_stats<false>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, N, C, HW, chunks, ws);
+    hipLaunchKernelGGL(k_bn_apply<false>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, residual, gamma, beta, ws, N, C, HW, chunks, momentum, eps, relu,
+                       running_mean, running_var, save_mean, save_invstd, y);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_bn_bwd(const float* x, const float* y, const float* g_y, const float* gamma, const float* save_mean, const float* save_invstd,
                          int relu, float* g_x, float* g_res, float* g_gamma, float* g_beta, float* ws, int N, int C, int HW, hipStream_t st) {
-  const int chunks = bn_chunks(N, HW);
   const bool vec = (HW % 4) == 0;
-  const size_t total = (size_t)N*C*HW;
-  const unsigned ngrid = (unsigned)((total/(vec ? 4 : 1) + kBnBlock - 1)/kBnBlock < 16384 ? (total/(vec ? 4 : 1) + kBnBlock - 1)/kBnBlock : 16384);
-  float* coef = ws + (size_t)C*chunks*2;
-  if (vec) hipLaunchKernelGGL(k_bn_bwd_reduce<true>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, y, g_y, save_mean, N, C, HW, chunks, relu, ws);
-  else hipLaunchKernelGGL(k_bn_bwd_reduce<false>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, y, g_y, save_mean, N, C, HW, chunks, relu, ws);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, gamma, save_invstd, N, C, HW, chunks, g_gamma, g_beta, coef);
-  if (vec) hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(ngrid), dim3(kBnBlock), 0, st, x, y, g_y, save_mean, coef, C, HW, total, relu, g_x, g_res);
-  else hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(ngrid), dim3(kBnBlock), 0, st, x, y, g_y, save_mean, coef, C, HW, total, relu, g_x, g_res);
+  if ((long long)N*HW <= kBnSmall) {
+    if (vec) hipLaunchKernelGGL(k_bn_bwd_small<true>, dim3(C), dim3(kBnBlock), 0, st, x, y, g_y, gamma, save_mean, save_invstd, N, C, HW, relu, g_x, g_res, g_gamma, g_beta);
+    else hipLaunchKernelGGL(k_bn_bwd_small<false>, dim3(C), dim3(kBnBlock), 0, st, x, y, g_y, gamma, save_mean, save_invstd, N, C, HW, relu, g_x, g_res, g_gamma, g_beta);
+    return hipGetLastError();
+  }
+  const int chunks = bn_chunks(N, HW);
+  if (vec) {
+    hipLaunchKernelGGL(k_bn_bwd_reduce<true>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, y, g_y, save_mean, N, C, HW, chunks, relu, ws);
+    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, y, g_y, gamma, save_mean, save_invstd, ws, N, C, HW, chunks, relu,
+                       g_x, g_res, g_gamma, g_beta);
+  } else {
+    hipLaunchKernelGGL(k_bn_bwd_reduce<false>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, y, g_y, save_mean, N, C, HW, chunks, relu, ws);
+    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(chunks, C), dim3(kBnBlock), 0, st, x, y, g_y, gamma, save_mean, save_invstd, ws, N, C, HW, chunks, relu,
+                       g_x, g_res, g_gamma, g_beta);
+  }
   return hipGetLastError();
 }
 

@@ -513,7 +513,7 @@ def _plain_decoder(dec, feat):
 
 # ---------------------------------------------------------------------------------------------------
 # Producer side: BatchNorm (+ residual, + ReLU) kernels against ATen's batch_norm / add / relu
-@pytest.mark.parametrize('shape', [(4, 8, 6, 20), (3, 5, 7, 9), (12, 64, 24, 80), (2, 130, 3, 5)])
+@pytest.mark.parametrize('shape', [(4, 8, 6, 20), (3, 5, 7, 9), (12, 64, 24, 80), (2, 130, 3, 5), (12, 6, 37, 41)])
 @pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True), (False, True)])
 def test_batch_norm_act_kernel(F, shape, relu, res):
     import torch.nn.functional as TF
@@ -524,17 +524,18 @@ def test_batch_norm_act_kernel(F, shape, relu, res):
     w, b = (torch.rand(C, generator=gen) + 0.5).cuda(), torch.randn(C, generator=gen).cuda()
     g = torch.randn(*shape, generator=gen).cuda()
     outs = []
-    for fused in (True, False):
-        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        rr = r.clone().requires_grad_(True) if res else None
-        rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    for fused in (True, False):   # the reference evaluation is ATen's batch_norm in fp64 on the CPU
+        cast = (lambda t: t.clone()) if fused else (lambda t: t.detach().double().cpu())
+        xx, ww, bb = cast(x).requires_grad_(True), cast(w).requires_grad_(True), cast(b).requires_grad_(True)
+        rr = cast(r).requires_grad_(True) if res else None
+        rm, rv = cast(torch.zeros(C, device='cuda')), cast(torch.ones(C, device='cuda'))
         if fused: y = F.batch_norm_act(xx, ww, bb, rm, rv, residual=rr, momentum=0.1, eps=1e-5, relu=relu)
         else:
             y = TF.batch_norm(xx, rm, rv, ww, bb, True, 0.1, 1e-5)
             if res: y = y + rr
             if relu: y = TF.relu(y)
-        y.backward(g)
-        outs.append((y.detach(), xx.grad, ww.grad, bb.grad, rr.grad if res else None, rm, rv))
+        y.backward(cast(g))
+        outs.append([t.detach().double().cpu() if t is not None else None for t in (y, xx.grad, ww.grad, bb.grad, rr.grad if res else None, rm, rv)])
     names = ('y', 'g_x', 'g_weight', 'g_bias', 'g_residual', 'running_mean', 'running_var')
     for nm, a, e in zip(names, outs[0], outs[1]):
         if e is None: continue
