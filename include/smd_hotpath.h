@@ -190,6 +190,11 @@ int smd_bn_bwd(const float* x, const float* y, const float* g_y, const float* ga
                int relu, float* g_x, float* g_residual, float* g_gamma, float* g_beta,
                void* workspace, size_t workspace_bytes, int N, int C, int HW, void* stream);
 
+/* smd_maxpool3x3s2_*: `nn.MaxPool2d(3, 2, 1)` of the ResNet stem.  x (N,C,H,W) -> y (N,C,Ho,Wo), Ho = (H-1)/2+1, and
+ * idx (N,C,Ho,Wo) uint8 = winning window position dh*3+dw (first maximum in scan order, as ATen).  Backward gathers. */
+int smd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream);
+int smd_maxpool3x3s2_bwd(const float* g_y, const uint8_t* idx, float* g_x, int N, int C, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pose / intrinsics prologue — one launch each instead of ~45 eager ATen launches.
  *

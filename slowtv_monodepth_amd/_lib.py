@@ -58,6 +58,8 @@ PROTOTYPES = {
     'smd_bn_workspace_bytes': (_sz, [_i, _i, _i]),
     'smd_bn_fwd': (_i, [_vp]*6 + [_f, _f, _i] + [_vp]*4 + [_sz] + [_i]*3 + [_vp]),
     'smd_bn_bwd': (_i, [_vp]*6 + [_i] + [_vp]*5 + [_sz] + [_i]*3 + [_vp]),
+    'smd_maxpool3x3s2_fwd': (_i, [_vp]*3 + [_i]*4 + [_vp]),
+    'smd_maxpool3x3s2_bwd': (_i, [_vp]*3 + [_i]*4 + [_vp]),
     'smd_pose_fwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     'smd_pose_bwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'smd_intrinsics_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

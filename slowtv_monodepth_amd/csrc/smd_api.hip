@@ -401,6 +401,17 @@ int smd_bn_bwd(const float* x, const float* y, const float* g_y, const float* ga
                                          N, C, HW, (hipStream_t)stream), "bn_bwd");
 }
 
+int smd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream) {
+  if (!x || !y || !idx) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || C < 1 || H < 1 || W < 1 || (long long)N*C*(((long long)H*W + 1023)/1024) >= (1ll << 31)) return fail(SMD_E_INVALID, "invalid sizes");
+  return check_launch(smd::launch_maxpool_fwd(x, y, idx, (size_t)N*C, H, W, (hipStream_t)stream), "maxpool_fwd");
+}
+int smd_maxpool3x3s2_bwd(const float* g_y, const uint8_t* idx, float* g_x, int N, int C, int H, int W, void* stream) {
+  if (!g_y || !idx || !g_x) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || C < 1 || H < 1 || W < 1 || (long long)N*C*(((long long)H*W + 1023)/1024) >= (1ll << 31)) return fail(SMD_E_INVALID, "invalid sizes");
+  return check_launch(smd::launch_maxpool_bwd(g_y, idx, g_x, (size_t)N*C, H, W, (hipStream_t)stream), "maxpool_bwd");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pose / intrinsics prologue
 int smd_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, void* stream) {

@@ -311,3 +311,81 @@ hipError_t launch_bn_bwd(const float* x, const float* y, const float* g_y, const
 }
 
 }  // namespace smd
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem.  Forward keeps the winning window position (0..8, first
+// maximum in row-major scan order, as ATen's max_pool2d_with_indices) in one byte instead of an int64 flat index; the
+// backward is a gather over the <= 4 windows that cover an input pixel, so g_input is written exactly once and never
+// zero-filled or scattered into.
+// ---------------------------------------------------------------------------------------------
+namespace smd {
+
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int H, int W, int Ho, int Wo,
+                                                     unsigned chunks) {
+  const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
+  const float* xp = x + (size_t)plane*H*W;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int o = chunk*1024 + k*256 + threadIdx.x;
+    if (o >= Ho*Wo) break;
+    const int oh = o/Wo, ow = o - oh*Wo;
+    float best = -INFINITY; int bi = 0;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = 2*oh - 1 + dh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = 2*ow - 1 + dw;
+        if (w < 0 || w >= W) continue;
+        const float v = xp[h*W + w];
+        if (v > best || v != v) { best = v; bi = dh*3 + dw; }
+      }
+    }
+    y[(size_t)plane*Ho*Wo + o] = best; idx[(size_t)plane*Ho*Wo + o] = (uint8_t)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g_y, const uint8_t* __restrict__ idx, float* __restrict__ g_x, int H, int W,
+                                                     int Ho, int Wo, unsigned chunks) {
+  const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
+  const float* gp = g_y + (size_t)plane*Ho*Wo; const uint8_t* ip = idx + (size_t)plane*Ho*Wo;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = chunk*1024 + k*256 + threadIdx.x;
+    if (i >= H*W) break;
+    const int h = i/W, w = i - h*W;
+    float acc = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int t = h + 1 - dh;             // = 2*oh
+      if (t < 0 || (t & 1)) continue;
+      const int oh = t >> 1;
+      if (oh >= Ho) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int s = w + 1 - dw;
+        if (s < 0 || (s & 1)) continue;
+        const int ow = s >> 1;
+        if (ow >= Wo) continue;
+        if (ip[oh*Wo + ow] == dh*3 + dw) acc += gp[oh*Wo + ow];
+      }
+    }
+    g_x[(size_t)plane*H*W + i] = acc;
+  }
+}
+
+hipError_t launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, size_t planes, int H, int W, hipStream_t st) {
+  const int Ho = (H - 1)/2 + 1, Wo = (W - 1)/2 + 1;
+  const unsigned chunks = ceil_div(Ho*Wo, 1024);
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)(planes*chunks)), dim3(256), 0, st, x, y, idx, H, W, Ho, Wo, chunks);
+  return hipGetLastError();
+}
+hipError_t launch_maxpool_bwd(const float* g_y, const uint8_t* idx, float* g_x, size_t planes, int H, int W, hipStream_t st) {
+  const int Ho = (H - 1)/2 + 1, Wo = (W - 1)/2 + 1;
+  const unsigned chunks = ceil_div(H*W, 1024);
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)(planes*chunks)), dim3(256), 0, st, g_y, idx, g_x, H, W, Ho, Wo, chunks);
+  return hipGetLastError();
+}
+
+}  // namespace smd

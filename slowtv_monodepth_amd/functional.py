@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, call, int_array, ptr_array
 
 __all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
-           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
+           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
 def _stream() -> int:
@@ -442,6 +442,33 @@ class _BatchNormAct(torch.autograd.Function):
 def batch_norm_act(x, weight, bias, running_mean=None, running_var=None, *, residual=None, momentum: float = 0.1, eps: float = 1e-5, relu: bool = False):
     """relu?(batch_norm_train(x) [+ residual]); running statistics are updated in place like `F.batch_norm(training=True)`."""
     return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)
+
+
+class _MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _check('x', x)
+        if x.ndim != 4: raise ValueError(f'expected (N,C,H,W), got {tuple(x.shape)}')
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1)//2 + 1, (W - 1)//2 + 1
+        y = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.uint8)
+        call('smd_maxpool3x3s2_fwd', x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, C, H, W, _stream())
+        ctx.save_for_backward(idx); ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        g_x = torch.empty((N, C, H, W), device=idx.device, dtype=torch.float32)
+        call('smd_maxpool3x3s2_bwd', g_y.contiguous().data_ptr(), idx.data_ptr(), g_x.data_ptr(), N, C, H, W, _stream())
+        return g_x
+
+
+def max_pool3x3s2(x):
+    """`F.max_pool2d(x, 3, 2, 1)` with a one-byte argmax and a gather backward."""
+    return _MaxPool3x3s2.apply(x)
 
 
 # ---------------------------------------------------------------------------------------------------

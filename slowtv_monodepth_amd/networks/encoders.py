@@ -111,7 +111,11 @@ class ResNetFeatures(nn.Module):
     def forward(self, x):
         x = self.bn1(self.conv1(x), relu=True)
         feats = [x]
-        x = self.maxpool(x)
+        if BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.is_contiguous():
+            from .. import functional as HF
+            x = HF.max_pool3x3s2(x)
+        else:
+            x = self.maxpool(x)
         for layer in self.layers:
             x = layer(x); feats.append(x)
         return feats

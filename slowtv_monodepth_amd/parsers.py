@@ -72,6 +72,10 @@ def get_opt(parameters, cfg: dict) -> optim.Optimizer:
     else:
         params = parameters
         cfg['weight_decay'] = wd
+    if name in ('adam', 'adamw') and 'fused' not in cfg and 'foreach' not in cfg:
+        ps = [p for g in params for p in g['params']] if is_module else list(params)
+        if is_module and ps and all(p.is_cuda and p.is_floating_point() for p in ps):
+            cfg['fused'] = True   # same update rule as the default (foreach) implementation, one launch instead of ~10 sweeps
     return _OPTS[name](params, **cfg)
 
 

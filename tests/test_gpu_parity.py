@@ -562,3 +562,16 @@ def test_resnet_encoder_with_fused_batch_norm_equals_aten(F):
     for a, b in zip(res[0][0], res[1][0]): assert rel_to_max(a, b) < 1e-4
     for a, b in zip(res[0][1], res[1][1]): assert rel_to_max(a, b) < 2e-3
     for k in res[0][2]: assert rel_to_max(res[0][2][k].float(), res[1][2][k].float()) < 1e-4, k
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 1, 1), (2, 3, 5, 8), (3, 4, 9, 7), (4, 16, 48, 160)])
+def test_max_pool_kernel(F, shape):
+    import torch.nn.functional as TF
+    gen = torch.Generator().manual_seed(2)
+    x = torch.relu(torch.randn(*shape, generator=gen)).cuda()     # post-ReLU input: many exact ties at 0, as in the stem
+    xr, xg = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ref = TF.max_pool2d(xr, 3, 2, 1); out = F.max_pool3x3s2(xg)
+    g = torch.randn(ref.shape, generator=gen).cuda()
+    ref.backward(g); out.backward(g)
+    assert torch.equal(out, ref)
+    torch.testing.assert_close(xg.grad, xr.grad, rtol=1e-6, atol=1e-6)
