@@ -165,14 +165,18 @@ int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_w
  * `MonodepthDecoder.forward` (src/networks/decoders/monodepth.py:71-89; conv_block / conv3x3 with reflection padding,
  * src/networks/decoders/utils.py:44-54) as one gather that writes the next convolution's padded input.
  *
- * smd_elu_pad_*:        out (B,C,h+2,w+2) = reflect_pad1(apply_elu ? elu(x) : x),  x (B,C,h,w) the raw conv output.
- * smd_elu_up_cat_pad_*: out (B,Ca+Cs,2h+2,2w+2) = reflect_pad1(cat(nearest_x2(elu(a)), skip)),  a (B,Ca,h,w),
- *                       skip (B,Cs,2h,2w) or NULL with Cs = 0.
- * Backward: g_out -> g_x / (g_a, g_skip) (either of the latter two may be NULL). */
-int smd_elu_pad_fwd(const float* x, float* out, int B, int C, int h, int w, int apply_elu, void* stream);
-int smd_elu_pad_bwd(const float* x, const float* g_out, float* g_x, int B, int C, int h, int w, int apply_elu, void* stream);
-int smd_elu_up_cat_pad_fwd(const float* a, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, void* stream);
-int smd_elu_up_cat_pad_bwd(const float* a, const float* g_out, float* g_a, float* g_skip, int B, int Ca, int Cs, int h, int w, void* stream);
+ * smd_elu_pad_*:        out (B,C,h+2,w+2) = reflect_pad1(apply_elu ? elu(x + bias) : x + bias),  x (B,C,h,w) the raw
+ *                       (bias-free) conv output, bias (C) or NULL.
+ * smd_elu_up_cat_pad_*: out (B,Ca+Cs,2h+2,2w+2) = reflect_pad1(cat(nearest_x2(elu(a + bias)), skip)),  a (B,Ca,h,w),
+ *                       bias (Ca) or NULL, skip (B,Cs,2h,2w) or NULL with Cs = 0.
+ * Backward: g_out -> g_x / (g_a, g_skip) and g_bias (C) or NULL (needs the workspace); g_a or g_skip may be NULL. */
+size_t smd_decoder_glue_workspace_bytes(int B, int C, int h, int w);
+int smd_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int h, int w, int apply_elu, void* stream);
+int smd_elu_pad_bwd(const float* x, const float* bias, const float* g_out, float* g_x, float* g_bias,
+                    void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int apply_elu, void* stream);
+int smd_elu_up_cat_pad_fwd(const float* a, const float* bias, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, void* stream);
+int smd_elu_up_cat_pad_bwd(const float* a, const float* bias, const float* g_out, float* g_a, float* g_skip, float* g_bias,
+                           void* workspace, size_t workspace_bytes, int B, int Ca, int Cs, int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Producer side of the path: training-mode BatchNorm2d of the ResNet encoders fused with the residual add and ReLU

@@ -25,7 +25,7 @@ for Ca, Cs, h, w in stages:
     def aten_pad(): return TF.pad(TF.elu(c), (1, 1, 1, 1), mode='reflect')
     rows = []
     for name, f_hip, f_aten, leaves in (('up_cat_pad', lambda: HF.elu_up_cat_pad(a, skip), aten_up, [a] + ([skip] if Cs else [])),
-                                        ('elu_pad', lambda: HF.elu_pad(c, True), aten_pad, [c])):
+                                        ('elu_pad', lambda: HF.elu_pad(c, None, True), aten_pad, [c])):
         o_h, o_a = f_hip(), f_aten()
         g = torch.randn_like(o_h)
         t_hf, t_af = timeit(f_hip), timeit(f_aten)

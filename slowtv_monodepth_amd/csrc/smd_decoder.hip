@@ -4,9 +4,11 @@
 //   reflect-pad -> conv3x3 -> ELU -> nearest x2 -> cat(skip) -> reflect-pad -> conv3x3 -> ELU -> [reflect-pad -> conv3x3 -> sigmoid]
 // as separate ATen kernels, each a full read + write of the activation.  The convolutions stay with MIOpen; everything
 // between them collapses into two gather kernels that write the NEXT convolution's already-padded input:
-//   k_elu_pad         out = reflect_pad1(elu(x))                              (B,C,h,w)           -> (B,C,h+2,w+2)
-//   k_elu_up_cat_pad  out = reflect_pad1(cat(nearest_x2(elu(a)), skip))       (B,Ca,h,w),(B,Cs,2h,2w) -> (B,Ca+Cs,2h+2,2w+2)
-// and two adjoint gathers (deterministic, no atomics).  ELU is recomputed from the saved pre-activation in the backward
+//   k_elu_pad         out = reflect_pad1(elu(x + bias))                              (B,C,h,w)           -> (B,C,h+2,w+2)
+//   k_elu_up_cat_pad  out = reflect_pad1(cat(nearest_x2(elu(a + bias)), skip))       (B,Ca,h,w),(B,Cs,2h,2w) -> (B,Ca+Cs,2h+2,2w+2)
+// and two adjoint gathers (deterministic, no atomics).  The convolution's bias is added here (the convolution itself runs
+// bias-free), so MIOpen's separate bias pass and ATen's bias-gradient reduction over the full tensor both disappear: the
+// adjoint gathers already hold the pre-activation gradient and emit its per-block channel sums.  ELU is recomputed from the saved pre-activation in the backward
 // (elu'(x) = x > 0 ? 1 : exp(x)), so no activated tensor is kept.
 #include "smd_common.h"
 #include "smd_kernels.h"
@@ -21,27 +23,50 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) 
 __device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : __expf(x); }
 __device__ __forceinline__ int unpad_reflect(int p, int n) { const int r = p - 1; return r < 0 ? -r : (r >= n ? 2*(n - 1) - r : r); }
 
+__device__ __forceinline__ void block_store_sum(float v, float* red, float* dst) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int k = 0; k < kDecBlock/64; ++k) t += red[k]; *dst = t; }
+}
+
+// g_bias[c] = sum over samples and chunks of the per-block partial sums of the pre-activation gradient (fp64, fixed order).
+__global__ __launch_bounds__(64) void k_bias_finalize(const float* __restrict__ partial, int B, int C, unsigned chunks, float* __restrict__ g_bias) {
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  const unsigned per = chunks, n = (unsigned)B*per;
+  for (unsigned i = threadIdx.x; i < n; i += 64) { const unsigned b = i/per, k = i - b*per; acc += (double)partial[((size_t)b*C + c)*per + k]; }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (threadIdx.x == 0) g_bias[c] = (float)acc;
+}
+
 // Sum of g over the padded positions that read un-padded index r along one axis of length n: p = r+1, plus the mirrored
 // border cell when r is the second / second-to-last element.
 #define SMD_PAD_ADJ_POS(r, n, p0, p1, p2) const int p0 = (r) + 1, p1 = ((r) == 1) ? 0 : -1, p2 = ((r) == (n) - 2) ? (n) + 1 : -1
 
-__global__ __launch_bounds__(kDecBlock) void k_elu_pad_fwd(const float* __restrict__ x, float* __restrict__ out, int h, int w, int apply_elu, unsigned chunks) {
+__global__ __launch_bounds__(kDecBlock) void k_elu_pad_fwd(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out, int C, int h, int w, int apply_elu,
+                                                           unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
   const int H = h + 2, W = w + 2;
+  const float bc = bias ? bias[plane % C] : 0.f;
 #pragma unroll
   for (int k = 0; k < kDecPerThread; ++k) {
     const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
     if (idx >= H*W) break;
     const int py = idx/W, px = idx - py*W;
-    const float v = x[(size_t)plane*h*w + unpad_reflect(py, h)*w + unpad_reflect(px, w)];
+    const float v = x[(size_t)plane*h*w + unpad_reflect(py, h)*w + unpad_reflect(px, w)] + bc;
     out[(size_t)plane*H*W + idx] = apply_elu ? elu1(v) : v;
   }
 }
 
-__global__ __launch_bounds__(kDecBlock) void k_elu_pad_bwd(const float* __restrict__ x, const float* __restrict__ g_out, float* __restrict__ g_x,
-                                                           int h, int w, int apply_elu, unsigned chunks) {
+__global__ __launch_bounds__(kDecBlock) void k_elu_pad_bwd(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ g_out,
+                                                           float* __restrict__ g_x, float* __restrict__ bias_partial, int C, int h, int w, int apply_elu,
+                                                           unsigned chunks) {
+  __shared__ float red[kDecBlock/64];
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
   const int W = w + 2;
+  const float bc = bias ? bias[plane % C] : 0.f;
+  float bsum = 0.f;
   const float* g = g_out + (size_t)plane*(h + 2)*W;
 #pragma unroll
   for (int k = 0; k < kDecPerThread; ++k) {
@@ -60,16 +85,19 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_pad_bwd(const float* __restri
         for (int b = 0; b < 3; ++b) if (xs[b] >= 0) acc += g[ys[a]*W + xs[b]];
       }
     }
-    g_x[(size_t)plane*h*w + idx] = apply_elu ? acc*elu1_grad(x[(size_t)plane*h*w + idx]) : acc;
+    const float gv = apply_elu ? acc*elu1_grad(x[(size_t)plane*h*w + idx] + bc) : acc;
+    g_x[(size_t)plane*h*w + idx] = gv; bsum += gv;
   }
+  if (bias_partial) block_store_sum(bsum, red, bias_partial + blockIdx.x);
 }
 
-__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_fwd(const float* __restrict__ a, const float* __restrict__ skip, float* __restrict__ out,
-                                                                  int Ca, int Cs, int h, int w, unsigned chunks) {
+__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_fwd(const float* __restrict__ a, const float* __restrict__ bias, const float* __restrict__ skip,
+                                                                  float* __restrict__ out, int Ca, int Cs, int h, int w, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*(Ca+Cs) + c
   const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, H = H2 + 2, W = W2 + 2;
   const unsigned b = plane/C, c = plane - b*C;
   const bool from_a = (int)c < Ca;
+  const float bc = (from_a && bias) ? bias[c] : 0.f;
   const float* src = from_a ? a + ((size_t)b*Ca + c)*h*w : skip + ((size_t)b*Cs + (c - Ca))*H2*W2;
 #pragma unroll
   for (int k = 0; k < kDecPerThread; ++k) {
@@ -77,18 +105,22 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_fwd(const float* _
     if (idx >= H*W) break;
     const int py = idx/W, px = idx - py*W;
     const int r = unpad_reflect(py, H2), q = unpad_reflect(px, W2);
-    out[(size_t)plane*H*W + idx] = from_a ? elu1(src[(r >> 1)*w + (q >> 1)]) : src[r*W2 + q];
+    out[(size_t)plane*H*W + idx] = from_a ? elu1(src[(r >> 1)*w + (q >> 1)] + bc) : src[r*W2 + q];
   }
 }
 
 // Adjoint w.r.t. `a` (low resolution): each source pixel feeds a 2x2 block of the up-sampled map, each cell of which
 // feeds its padded position plus (on the second / second-to-last row or column) the mirrored border cell.
-__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float* __restrict__ a, const float* __restrict__ g_out, float* __restrict__ g_a,
-                                                                    int Ca, int Cs, int h, int w, unsigned chunks) {
+__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float* __restrict__ a, const float* __restrict__ bias, const float* __restrict__ g_out,
+                                                                    float* __restrict__ g_a, float* __restrict__ bias_partial, int Ca, int Cs, int h, int w,
+                                                                    unsigned chunks) {
+  __shared__ float red[kDecBlock/64];
+  float bsum = 0.f;
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*Ca + c
   const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, W = W2 + 2;
   const unsigned b = plane/Ca, c = plane - b*Ca;
   const float* g = g_out + ((size_t)b*C + c)*(H2 + 2)*W;
+  const float bc = bias ? bias[c] : 0.f;
   for (int k = 0; k < kDecPerThread; ++k) {
   const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
   if (idx >= h*w) break;
@@ -116,8 +148,10 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float*
       }
     }
   }
-  g_a[(size_t)plane*h*w + idx] = acc*elu1_grad(a[(size_t)plane*h*w + idx]);
+  const float gv = acc*elu1_grad(a[(size_t)plane*h*w + idx] + bc);
+  g_a[(size_t)plane*h*w + idx] = gv; bsum += gv;
   }
+  if (bias_partial) block_store_sum(bsum, red, bias_partial + blockIdx.x);
 }
 
 // Adjoint w.r.t. the skip tensor (full resolution): plain reflection-pad adjoint of its channel slice.
@@ -148,25 +182,32 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_skip(const flo
   }
 }
 
-hipError_t launch_elu_pad_fwd(const float* x, float* out, size_t planes, int h, int w, int apply_elu, hipStream_t st) {
+hipError_t launch_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int h, int w, int apply_elu, hipStream_t st) {
   const unsigned chunks = ceil_div((h + 2)*(w + 2), kDecChunk);
-  hipLaunchKernelGGL(k_elu_pad_fwd, dim3((unsigned)(planes*chunks)), dim3(kDecBlock), 0, st, x, out, h, w, apply_elu, chunks);
+  hipLaunchKernelGGL(k_elu_pad_fwd, dim3((unsigned)((size_t)B*C*chunks)), dim3(kDecBlock), 0, st, x, bias, out, C, h, w, apply_elu, chunks);
   return hipGetLastError();
 }
-hipError_t launch_elu_pad_bwd(const float* x, const float* g_out, float* g_x, size_t planes, int h, int w, int apply_elu, hipStream_t st) {
+size_t decoder_bias_partials(int B, int C, int h, int w) { return (size_t)B*C*ceil_div(h*w, kDecChunk); }
+hipError_t launch_elu_pad_bwd(const float* x, const float* bias, const float* g_out, float* g_x, float* g_bias, float* ws, int B, int C, int h, int w,
+                              int apply_elu, hipStream_t st) {
   const unsigned chunks = ceil_div(h*w, kDecChunk);
-  hipLaunchKernelGGL(k_elu_pad_bwd, dim3((unsigned)(planes*chunks)), dim3(kDecBlock), 0, st, x, g_out, g_x, h, w, apply_elu, chunks);
+  hipLaunchKernelGGL(k_elu_pad_bwd, dim3((unsigned)((size_t)B*C*chunks)), dim3(kDecBlock), 0, st, x, bias, g_out, g_x, g_bias ? ws : nullptr, C, h, w,
+                     apply_elu, chunks);
+  if (g_bias) hipLaunchKernelGGL(k_bias_finalize, dim3(C), dim3(64), 0, st, ws, B, C, chunks, g_bias);
   return hipGetLastError();
 }
-hipError_t launch_elu_up_cat_pad_fwd(const float* a, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, hipStream_t st) {
+hipError_t launch_elu_up_cat_pad_fwd(const float* a, const float* bias, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, hipStream_t st) {
   const unsigned chunks = ceil_div((2*h + 2)*(2*w + 2), kDecChunk);
-  hipLaunchKernelGGL(k_elu_up_cat_pad_fwd, dim3((unsigned)((size_t)B*(Ca + Cs)*chunks)), dim3(kDecBlock), 0, st, a, skip, out, Ca, Cs, h, w, chunks);
+  hipLaunchKernelGGL(k_elu_up_cat_pad_fwd, dim3((unsigned)((size_t)B*(Ca + Cs)*chunks)), dim3(kDecBlock), 0, st, a, bias, skip, out, Ca, Cs, h, w, chunks);
   return hipGetLastError();
 }
-hipError_t launch_elu_up_cat_pad_bwd(const float* a, const float* g_out, float* g_a, float* g_skip, int B, int Ca, int Cs, int h, int w, hipStream_t st) {
+hipError_t launch_elu_up_cat_pad_bwd(const float* a, const float* bias, const float* g_out, float* g_a, float* g_skip, float* g_bias, float* ws,
+                                     int B, int Ca, int Cs, int h, int w, hipStream_t st) {
   if (g_a) {
     const unsigned chunks = ceil_div(h*w, kDecChunk);
-    hipLaunchKernelGGL(k_elu_up_cat_pad_bwd_a, dim3((unsigned)((size_t)B*Ca*chunks)), dim3(kDecBlock), 0, st, a, g_out, g_a, Ca, Cs, h, w, chunks);
+    hipLaunchKernelGGL(k_elu_up_cat_pad_bwd_a, dim3((unsigned)((size_t)B*Ca*chunks)), dim3(kDecBlock), 0, st, a, bias, g_out, g_a, g_bias ? ws : nullptr,
+                       Ca, Cs, h, w, chunks);
+    if (g_bias) hipLaunchKernelGGL(k_bias_finalize, dim3(Ca), dim3(64), 0, st, ws, B, Ca, chunks, g_bias);
   }
   if (g_skip && Cs > 0) {
     const unsigned chunks = ceil_div(4*h*w, kDecChunk);

@@ -342,62 +342,76 @@ def recon_reduce(err_warp, err_static=None, *, use_min: bool = False, noise=None
 
 # ---------------------------------------------------------------------------------------------------
 # ---------------------------------------------------------------------------------------------------
+def _glue_ws(B, C, h, w, device):
+    nbytes = _lib.lib.smd_decoder_glue_workspace_bytes(B, C, h, w)
+    return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
+
+
 class _EluPad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, apply_elu):
+    def forward(ctx, x, bias, apply_elu):
         x = _check('x', x)
         if x.ndim != 4: raise ValueError(f'expected (B,C,h,w), got {tuple(x.shape)}')
         B, C, h, w = x.shape
+        if bias is not None: bias = _check('bias', bias, (C,))
         out = torch.empty((B, C, h + 2, w + 2), device=x.device, dtype=torch.float32)
-        call('smd_elu_pad_fwd', x.data_ptr(), out.data_ptr(), B, C, h, w, int(apply_elu), _stream())
-        ctx.save_for_backward(x); ctx.apply_elu = int(apply_elu)
+        call('smd_elu_pad_fwd', x.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), B, C, h, w, int(apply_elu), _stream())
+        ctx.save_for_backward(x, bias); ctx.apply_elu = int(apply_elu)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        (x,) = ctx.saved_tensors
+        x, bias = ctx.saved_tensors
         B, C, h, w = x.shape
         g_x = torch.empty_like(x)
-        call('smd_elu_pad_bwd', x.data_ptr(), g_out.contiguous().data_ptr(), g_x.data_ptr(), B, C, h, w, ctx.apply_elu, _stream())
-        return g_x, None
+        g_b = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[1]) else None
+        ws, nbytes = _glue_ws(B, C, h, w, x.device) if g_b is not None else (None, 0)
+        call('smd_elu_pad_bwd', x.data_ptr(), bias.data_ptr() if bias is not None else None, g_out.contiguous().data_ptr(), g_x.data_ptr(),
+             g_b.data_ptr() if g_b is not None else None, ws.data_ptr() if ws is not None else None, nbytes, B, C, h, w, ctx.apply_elu, _stream())
+        return g_x, g_b, None
 
 
-def elu_pad(x, apply_elu: bool = True):
-    """reflect_pad1(elu(x)) (or just the padding): the input of the next 3x3 convolution of the decoder."""
-    return _EluPad.apply(x, apply_elu)
+def elu_pad(x, bias=None, apply_elu: bool = True):
+    """reflect_pad1(elu(x + bias)) (or just bias + padding): the input of the next 3x3 convolution of the decoder."""
+    return _EluPad.apply(x, bias, apply_elu)
 
 
 class _EluUpCatPad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, skip):
+    def forward(ctx, a, bias, skip):
         a = _check('a', a)
         if a.ndim != 4: raise ValueError(f'expected (B,C,h,w), got {tuple(a.shape)}')
         B, Ca, h, w = a.shape
+        if bias is not None: bias = _check('bias', bias, (Ca,))
         Cs = 0
         if skip is not None:
             Cs = skip.shape[1]
             skip = _check('skip', skip, (B, Cs, 2*h, 2*w))
         out = torch.empty((B, Ca + Cs, 2*h + 2, 2*w + 2), device=a.device, dtype=torch.float32)
-        call('smd_elu_up_cat_pad_fwd', a.data_ptr(), skip.data_ptr() if skip is not None else None, out.data_ptr(), B, Ca, Cs, h, w, _stream())
-        ctx.save_for_backward(a); ctx.Cs = Cs
+        call('smd_elu_up_cat_pad_fwd', a.data_ptr(), bias.data_ptr() if bias is not None else None, skip.data_ptr() if skip is not None else None,
+             out.data_ptr(), B, Ca, Cs, h, w, _stream())
+        ctx.save_for_backward(a, bias); ctx.Cs = Cs
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        (a,) = ctx.saved_tensors
+        a, bias = ctx.saved_tensors
         B, Ca, h, w = a.shape
         Cs = ctx.Cs
-        g_a = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        g_skip = torch.empty((B, Cs, 2*h, 2*w), device=a.device, dtype=torch.float32) if (Cs and ctx.needs_input_grad[1]) else None
-        if g_a is None and g_skip is None: return None, None
-        call('smd_elu_up_cat_pad_bwd', a.data_ptr(), g_out.contiguous().data_ptr(), g_a.data_ptr() if g_a is not None else None,
-             g_skip.data_ptr() if g_skip is not None else None, B, Ca, Cs, h, w, _stream())
-        return g_a, g_skip
+        g_b = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[1]) else None
+        g_a = torch.empty_like(a) if (ctx.needs_input_grad[0] or g_b is not None) else None
+        g_skip = torch.empty((B, Cs, 2*h, 2*w), device=a.device, dtype=torch.float32) if (Cs and ctx.needs_input_grad[2]) else None
+        if g_a is None and g_skip is None: return None, None, None
+        ws, nbytes = _glue_ws(B, Ca, h, w, a.device) if g_b is not None else (None, 0)
+        call('smd_elu_up_cat_pad_bwd', a.data_ptr(), bias.data_ptr() if bias is not None else None, g_out.contiguous().data_ptr(),
+             g_a.data_ptr() if g_a is not None else None, g_skip.data_ptr() if g_skip is not None else None,
+             g_b.data_ptr() if g_b is not None else None, ws.data_ptr() if ws is not None else None, nbytes, B, Ca, Cs, h, w, _stream())
+        return g_a, g_b, g_skip
 
 
-def elu_up_cat_pad(a, skip=None):
-    """reflect_pad1(cat(nearest_x2(elu(a)), skip)): (B,Ca,h,w) [+ (B,Cs,2h,2w)] -> (B,Ca+Cs,2h+2,2w+2)."""
-    return _EluUpCatPad.apply(a, skip)
+def elu_up_cat_pad(a, skip=None, bias=None):
+    """reflect_pad1(cat(nearest_x2(elu(a + bias)), skip)): (B,Ca,h,w) [+ (B,Cs,2h,2w)] -> (B,Ca+Cs,2h+2,2w+2)."""
+    return _EluUpCatPad.apply(a, bias, skip)
 
 
 class _BatchNormAct(torch.autograd.Function):

@@ -63,13 +63,13 @@ class MonodepthDecoder(nn.Module):
         the two gather kernels of `csrc/smd_decoder.hip`, each writing the next convolution's padded input, and the
         padded ELU output of a stage is shared by its output head and the next stage (the reference pads it twice)."""
         from .. import functional as HF
-        conv = lambda m, xp: F.conv2d(xp, m.weight, m.bias)     # input is already reflection-padded
+        conv = lambda m, xp: F.conv2d(xp, m.weight)            # input already reflection-padded; the bias is added by the next glue kernel
         out = {}
         xp = HF.elu_pad(feat[-1], apply_elu=False)
         for i in range(4, -1, -1):
-            a = conv(self.up0[str(i)][0], xp)
+            m0, m1 = self.up0[str(i)][0], self.up1[str(i)][0]
             skip = feat[self.enc_sc.index(2**i)] if (self.use_skip and 2**i in self.enc_sc) else None
-            c = conv(self.up1[str(i)][0], HF.elu_up_cat_pad(a, skip))
-            if i in self.out_sc or i > 0: xp = HF.elu_pad(c, apply_elu=True)
-            if i in self.out_sc: out[i] = self.act(conv(self.out[str(i)], xp))
+            c = conv(m1, HF.elu_up_cat_pad(conv(m0, xp), skip, bias=m0.bias))
+            if i in self.out_sc or i > 0: xp = HF.elu_pad(c, bias=m1.bias, apply_elu=True)
+            if i in self.out_sc: out[i] = self.act(F.conv2d(xp, self.out[str(i)].weight, self.out[str(i)].bias))
         return out

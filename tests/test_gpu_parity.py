@@ -456,7 +456,7 @@ def test_elu_pad_kernel(F, shape, apply_elu):
     x = torch.randn(*shape, generator=gen)
     xr = x.clone().requires_grad_(True); xg = x.cuda().requires_grad_(True)
     ref = TF.pad(TF.elu(xr) if apply_elu else xr, (1, 1, 1, 1), mode='reflect')
-    out = F.elu_pad(xg, apply_elu)
+    out = F.elu_pad(xg, None, apply_elu)
     g = torch.randn(ref.shape, generator=gen)
     ref.backward(g); out.backward(g.cuda())
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
@@ -575,3 +575,27 @@ def test_max_pool_kernel(F, shape):
     ref.backward(g); out.backward(g)
     assert torch.equal(out, ref)
     torch.testing.assert_close(xg.grad, xr.grad, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('B,Ca,Cs,h,w', [(2, 4, 3, 3, 5), (3, 16, 8, 24, 40)])
+def test_decoder_glue_with_bias(F, B, Ca, Cs, h, w):
+    """The glue kernels add the (bias-free) convolution's bias and return its gradient."""
+    import torch.nn.functional as TF
+    gen = torch.Generator().manual_seed(12)
+    a = torch.randn(B, Ca, h, w, generator=gen); skip = torch.randn(B, Cs, 2*h, 2*w, generator=gen); bias = torch.randn(Ca, generator=gen)
+    mk = lambda t, dev: t.clone().to(dev).requires_grad_(True)
+    res = []
+    for dev in ('cuda', 'cpu'):
+        aa, ss, bb = mk(a.double() if dev == 'cpu' else a, dev), mk(skip.double() if dev == 'cpu' else skip, dev), mk(bias.double() if dev == 'cpu' else bias, dev)
+        if dev == 'cuda':
+            o1 = F.elu_up_cat_pad(aa, ss, bias=bb); o2 = F.elu_pad(aa, bb, True); o3 = F.elu_pad(aa, bb, False)
+        else:
+            pre = aa + bb[None, :, None, None]
+            o1 = TF.pad(torch.cat((TF.interpolate(TF.elu(pre), scale_factor=2, mode='nearest'), ss), 1), (1, 1, 1, 1), mode='reflect')
+            o2 = TF.pad(TF.elu(pre), (1, 1, 1, 1), mode='reflect'); o3 = TF.pad(pre, (1, 1, 1, 1), mode='reflect')
+        g = torch.Generator().manual_seed(13)
+        loss = sum((o*torch.randn(o.shape, generator=g).to(o)).sum() for o in (o1, o2, o3))
+        loss.backward()
+        res.append([t.detach().double().cpu() for t in (o1, o2, o3, aa.grad, ss.grad, bb.grad)])
+    for nm, x, e in zip(('up_cat_pad', 'elu_pad', 'pad', 'g_a', 'g_skip', 'g_bias'), *res):
+        assert rel_to_max(x, e) < 1e-5, f'{nm}: {rel_to_max(x, e):.3e}'
