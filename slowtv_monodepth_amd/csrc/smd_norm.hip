@@ -346,32 +346,33 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x
   }
 }
 
+// One thread per 2x2 input block (rows 2k, 2k+1; columns 2j, 2j+1): the four windows A=(k,j), B=(k,j+1), C=(k+1,j),
+// D=(k+1,j+1) are the only ones that can have selected any of its pixels, each at a fixed window position:
+//   (2k,  2j)   <- A@4            (2k,  2j+1) <- A@5, B@3
+//   (2k+1,2j)   <- A@7, C@1       (2k+1,2j+1) <- A@8, B@6, C@2, D@0
 __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ g_y, const uint8_t* __restrict__ idx, float* __restrict__ g_x, int H, int W,
                                                      int Ho, int Wo, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
   const float* gp = g_y + (size_t)plane*Ho*Wo; const uint8_t* ip = idx + (size_t)plane*Ho*Wo;
+  float* out = g_x + (size_t)plane*H*W;
+  const int Hb = (H + 1)/2, Wb = (W + 1)/2;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = chunk*1024 + k*256 + threadIdx.x;
-    if (i >= H*W) break;
-    const int h = i/W, w = i - h*W;
-    float acc = 0.f;
-#pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int t = h + 1 - dh;             // = 2*oh
-      if (t < 0 || (t & 1)) continue;
-      const int oh = t >> 1;
-      if (oh >= Ho) continue;
-#pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const int s = w + 1 - dw;
-        if (s < 0 || (s & 1)) continue;
-        const int ow = s >> 1;
-        if (ow >= Wo) continue;
-        if (ip[oh*Wo + ow] == dh*3 + dw) acc += gp[oh*Wo + ow];
-      }
-    }
-    g_x[(size_t)plane*H*W + i] = acc;
+  for (int t = 0; t < 4; ++t) {
+    const int q = chunk*1024 + t*256 + threadIdx.x;
+    if (q >= Hb*Wb) break;
+    const int k = q/Wb, j = q - k*Wb;
+    const bool hasB = j + 1 < Wo, hasC = k + 1 < Ho;
+    const int ia = k*Wo + j;
+    const int sa = ip[ia], sb = hasB ? ip[ia + 1] : 255, sc = hasC ? ip[ia + Wo] : 255, sd = (hasB && hasC) ? ip[ia + Wo + 1] : 255;
+    const float ga = gp[ia], gb = hasB ? gp[ia + 1] : 0.f, gc = hasC ? gp[ia + Wo] : 0.f, gd = (hasB && hasC) ? gp[ia + Wo + 1] : 0.f;
+    const float o00 = (sa == 4) ? ga : 0.f;
+    const float o01 = ((sa == 5) ? ga : 0.f) + ((sb == 3) ? gb : 0.f);
+    const float o10 = ((sa == 7) ? ga : 0.f) + ((sc == 1) ? gc : 0.f);
+    const float o11 = (((sa == 8) ? ga : 0.f) + ((sb == 6) ? gb : 0.f)) + (((sc == 2) ? gc : 0.f) + ((sd == 0) ? gd : 0.f));
+    const int h0 = 2*k, w0 = 2*j;
+    out[h0*W + w0] = o00;
+    if (w0 + 1 < W) out[h0*W + w0 + 1] = o01;
+    if (h0 + 1 < H) { out[(h0 + 1)*W + w0] = o10; if (w0 + 1 < W) out[(h0 + 1)*W + w0 + 1] = o11; }
   }
 }
 
@@ -383,7 +384,7 @@ hipError_t launch_maxpool_fwd(const float* x, float* y, uint8_t* idx, size_t pla
 }
 hipError_t launch_maxpool_bwd(const float* g_y, const uint8_t* idx, float* g_x, size_t planes, int H, int W, hipStream_t st) {
   const int Ho = (H - 1)/2 + 1, Wo = (W - 1)/2 + 1;
-  const unsigned chunks = ceil_div(H*W, 1024);
+  const unsigned chunks = ceil_div(((H + 1)/2)*((W + 1)/2), 1024);
   hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)(planes*chunks)), dim3(256), 0, st, g_y, idx, g_x, H, W, Ho, Wo, chunks);
   return hipGetLastError();
 }
