@@ -83,16 +83,19 @@ def cpu_baseline(wl: dict, sample_b: int = 4, steps: int = 5) -> dict:
                       f'of the workload, after 1 warm-up; {dt*1e3:.0f} ms/step'}
 
 
-def measured_copy_ceiling(lib, device, nbytes=1 << 30, reps=10):
-    """GB/s (read + write) of a STREAM-style device copy of `nbytes` through the library's own copy kernel."""
+def measured_hbm_ceilings(lib, device, nbytes=1 << 30, reps=10):
+    """(copy GB/s counting read + write, read-only GB/s) of a STREAM-style sweep over `nbytes` through the library's own kernel."""
     src = torch.empty(nbytes, device=device, dtype=torch.uint8).fill_(1); dst = torch.empty_like(src)
     st = torch.cuda.current_stream().cuda_stream
-    for _ in range(2): lib.smd_debug_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, st)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps): lib.smd_debug_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, st)
-    e.record(); torch.cuda.synchronize()
-    return 2*nbytes*reps/(s.elapsed_time(e)*1e-3)/1e9
+    out = []
+    for mode, factor in ((0, 2), (1, 1)):
+        for _ in range(2): lib.smd_debug_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, mode, st)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps): lib.smd_debug_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, mode, st)
+        e.record(); torch.cuda.synchronize()
+        out.append(factor*nbytes*reps/(s.elapsed_time(e)*1e-3)/1e9)
+    return out
 
 
 def main():
@@ -159,7 +162,7 @@ def main():
         B_fwd, B_bwd = recon_bytes(wl['b'], wl['h'], wl['w'], n, S)
         avg = lambda v: sum(v)/max(len(v), 1)
         f_ms, b_ms = avg(fwd_ms), avg(bwd_ms)
-        copy_gbps = measured_copy_ceiling(_lib.lib, device)
+        copy_gbps, read_gbps = measured_hbm_ceilings(_lib.lib, device)
         traffic = None
         tf = ROOT/'profiles'/'traffic.json'   # per-launch HBM bytes from separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
         if tf.is_file():
@@ -179,7 +182,7 @@ def main():
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic,
                          'algorithmic_bytes': B_fwd, 'avg_kernel_ms': round(f_ms, 5), 'launches_timed': len(fwd_ms),
-                         'peak_measured_copy': round(copy_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
+                         'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
             'roofline_bwd': {'kernel': 'smd::k_recon_bwd (fused adjoint)', 'bound': 'hbm',
                              'achieved': round(B_bwd/(b_ms*1e-3)/1e9, 1) if b_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                              'frac': round(B_bwd/(b_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if b_ms else None,

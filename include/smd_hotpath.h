@@ -226,9 +226,9 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
 int smd_profile_enable(int which, int capacity);
 int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out);
 
-/* Measurement aid: STREAM-style device copy of nbytes (multiple of 16) src -> dst; bench.py times it to quote the measured
- * HBM copy ceiling of the box beside the datasheet peak. */
-int smd_debug_stream_copy(const void* src, void* dst, size_t nbytes, void* stream);
+/* Measurement aid: STREAM-style sweep over nbytes (multiple of 16): mode 0 copies src -> dst (read + write), mode 1 only
+ * reads src.  bench.py times both to quote the measured HBM ceilings of the box beside the datasheet peak. */
+int smd_debug_stream_copy(const void* src, void* dst, size_t nbytes, int mode, void* stream);
 
 /* Debug/self-test: out[l] = {value held by lane l-1, value held by lane l+1} for in[l] = l (64 lanes).
  * Used by the GPU tests to pin the cross-lane primitive the stencil kernels rely on. */

@@ -474,10 +474,10 @@ int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out) {
   return SMD_OK;
 }
 
-int smd_debug_stream_copy(const void* src, void* dst, size_t nbytes, void* stream) {
+int smd_debug_stream_copy(const void* src, void* dst, size_t nbytes, int mode, void* stream) {
   if (!src || !dst) return fail(SMD_E_INVALID, "null pointer");
   if (nbytes < 16 || (nbytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(SMD_E_INVALID, "size and pointers must be multiples of 16");
-  return check_launch(smd::launch_stream_copy(src, dst, nbytes, (hipStream_t)stream), "stream_copy");
+  return check_launch(smd::launch_stream_copy(src, dst, nbytes, mode, (hipStream_t)stream), "stream_copy");
 }
 
 int smd_debug_lane_shift(float* out_left, float* out_right, void* stream) {

@@ -94,7 +94,7 @@ hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_stati
 hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w,
                                    int flags, hipStream_t st);
 hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
-hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, hipStream_t st);
+hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, int mode, hipStream_t st);
 size_t decoder_bias_partials(int B, int C, int h, int w);
 hipError_t launch_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int h, int w, int apply_elu, hipStream_t st);
 hipError_t launch_elu_pad_bwd(const float* x, const float* bias, const float* g_out, float* g_x, float* g_bias, float* ws, int B, int C, int h, int w,
