@@ -599,3 +599,63 @@ def test_decoder_glue_with_bias(F, B, Ca, Cs, h, w):
         res.append([t.detach().double().cpu() for t in (o1, o2, o3, aa.grad, ss.grad, bb.grad)])
     for nm, x, e in zip(('up_cat_pad', 'elu_pad', 'pad', 'g_a', 'g_skip', 'g_bias'), *res):
         assert rel_to_max(x, e) < 1e-5, f'{nm}: {rel_to_max(x, e):.3e}'
+
+
+# ---------------------------------------------------------------------------------------------------
+# Strip-boundary sweep: a wave covers 62 interior columns forward and 60 backward, strips split the rows; widths and
+# heights around those boundaries (and degenerate 2-3 pixel images) against the oracle with random poses/depths.
+SWEEP = [(1, 2, 2, 1, 1), (2, 3, 5, 2, 1), (1, 5, 59, 1, 2), (1, 7, 60, 2, 1), (1, 4, 61, 2, 2), (2, 6, 62, 3, 1), (1, 9, 63, 2, 1),
+         (1, 5, 64, 1, 1), (1, 6, 65, 2, 2), (1, 3, 120, 2, 1), (1, 4, 121, 3, 1), (1, 5, 124, 2, 1), (1, 33, 125, 2, 2), (1, 70, 30, 4, 1)]
+
+
+@pytest.mark.parametrize('b,h,w,n,S', SWEEP)
+@pytest.mark.parametrize('mode', ['min_automask', 'mean'])
+def test_strip_boundary_shapes_match_oracle(F, b, h, w, n, S, mode):
+    from oracle import view_synth_oracle as O
+    gen = torch.Generator().manual_seed(1000*h + w + n)
+    imgs = torch.rand(b, 3, h, w, generator=gen); supp = (imgs[None] + 0.1*torch.randn(n, b, 3, h, w, generator=gen)).clamp(0, 1)
+    depth = 1 + 10*torch.rand(S, b, 1, h, w, generator=gen)
+    aa = 0.02*torch.randn(n*b, 3, generator=gen); t = 0.2*torch.randn(n*b, 3, generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(b, 1, 1)
+    noise = torch.randn(S*b, 1, h, w, generator=gen)
+    use_min = use_auto = mode == 'min_automask'
+    # oracle
+    d_c = depth.clone().requires_grad_(True); T_c = O.T_from_AAt(aa, t).unflatten(0, (n, b)).clone().requires_grad_(True)
+    loss_c, _, full = O.image_recon({s: d_c[s] for s in range(S)}, imgs, supp, T_c, K, 'ssim', use_min, use_auto, noise=noise)
+    loss_c.backward()
+    # HIP
+    d_g = depth.cuda().requires_grad_(True); T_g = T_c.detach().cuda().requires_grad_(True)
+    loss, err, sel, _ = F.image_recon_fused(d_g, imgs.cuda(), supp.cuda(), T_g, K.cuda(), flags=F.recon_flags('ssim', use_min, use_auto),
+                                            noise=noise.cuda())
+    loss.backward()
+    flips = (sel.cpu() != full['sel']).flatten()
+    assert flips.float().mean().item() <= 0.01, f'selection differs on {flips.float().mean().item():.2%} of pixels'
+    torch.testing.assert_close(err.cpu().flatten()[~flips], full['err'].detach().flatten()[~flips], rtol=0, atol=3e-4)
+    torch.testing.assert_close(loss.detach().cpu(), loss_c.detach(), rtol=1e-4, atol=1e-6)
+    tol = 5e-2 if flips.any() else 2e-3
+    assert rel_to_max(d_g.grad.cpu(), d_c.grad) < tol
+    assert rel_to_max(T_g.grad.cpu()[..., :3, :], T_c.grad[..., :3, :]) < tol
+
+
+@pytest.mark.parametrize('b,h,w,lows', [(2, 33, 47, [(33, 47), (16, 23), (8, 11)]), (1, 8, 12, [(8, 12), (4, 6), (2, 3), (1, 1)]),
+                                        (1, 192, 640, [(96, 320), (24, 80)]), (2, 21, 30, [(7, 10), (5, 30)])])
+@pytest.mark.parametrize('use_edges', [True, False])
+def test_k0_and_smoothness_at_non_integer_ratios(F, b, h, w, lows, use_edges):
+    """Disparity pyramids whose sizes are not exact halvings (odd images, anisotropic ratios): K0 forward/adjoint and the
+    smoothness sweep against the oracle."""
+    from oracle import view_synth_oracle as O
+    gen = torch.Generator().manual_seed(h*w)
+    imgs = torch.rand(b, 3, h, w, generator=gen)
+    disps = {s: 0.05 + 0.9*torch.rand(b, 1, hs, ws, generator=gen) for s, (hs, ws) in enumerate(lows)}
+    gup = torch.randn(len(lows), b, 1, h, w, generator=gen)
+    dc = {s: d.clone().requires_grad_(True) for s, d in disps.items()}; dg = {s: d.cuda().requires_grad_(True) for s, d in disps.items()}
+    _, dep_c = O.disp_to_depth_up(dc, (h, w), 0.1, 100)
+    l_c, _ = O.disp_smooth(dc, imgs, use_edges)
+    (sum((dep_c[s]*gup[s]).sum() for s in dc)*1e-3 + l_c).backward()
+    dep_g, _ = F.disp_to_depth([dg[s] for s in dg], (h, w), 0.1, 100)
+    l_g, _, _ = F.disp_smooth_fused(dg, imgs.cuda(), use_edges=use_edges, want_aux=False)
+    ((dep_g*gup.cuda()).sum()*1e-3 + l_g).backward()
+    for s in dc:
+        torch.testing.assert_close(dep_g[s].cpu(), dep_c[s].detach(), rtol=2e-5, atol=1e-5)
+        assert rel_to_max(dg[s].grad.cpu(), dc[s].grad) < 1e-3, s
+    torch.testing.assert_close(l_g.detach().cpu(), l_c.detach(), rtol=2e-5, atol=1e-7)
