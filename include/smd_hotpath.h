@@ -107,14 +107,17 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
  *   NULL -> key = s)
  *   loss (1) out;  stats (S,b,2) out: per (scale, sample) {mean disparity, un-normalised edge sum E} kept for backward
  *   disp_grad, image_grad: (b,1,hs[0],ws[0]) out or NULL (aux maps of the first scale, smooth.py:86,89)
+ *   edge_weights: out or NULL; smd_disp_smooth_edge_weight_bytes() bytes holding {exp(-|dI/dx|), exp(-|dI/dy|)} per pixel
+ *   of every scale (with SMD_USE_EDGES).  Handing the same buffer to the backward spares it every image access.
  * Backward: g_disp[s] (b,1,hs,ws) out. */
 size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int b);
+size_t smd_disp_smooth_edge_weight_bytes(const int* hs, const int* ws, int S, int b);
 int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
                         const float* img, int h, int w, int flags, float* loss, float* stats, float* disp_grad, float* image_grad,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        float* edge_weights, void* workspace, size_t workspace_bytes, void* stream);
 int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
-                        const float* img, int h, int w, int flags, const float* stats, const float* g_loss,
-                        float* const* g_disp, void* stream);
+                        const float* img, int h, int w, int flags, const float* stats, const float* edge_weights,
+                        const float* g_loss, float* const* g_disp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Un-fused operators (class-level drop-ins for callers that hold the intermediate tensors).

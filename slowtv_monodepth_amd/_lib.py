@@ -37,8 +37,9 @@ PROTOTYPES = {
     'smd_image_recon_fwd': (_i, [_vp]*7 + [_u64] + [_vp]*6 + [_sz] + [_i]*6 + [_vp]),
     'smd_image_recon_bwd': (_i, [_vp]*13 + [_sz] + [_i]*6 + [_vp]),
     'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
-    'smd_disp_smooth_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'smd_disp_smooth_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'smd_disp_smooth_edge_weight_bytes': (_sz, [_vp, _vp, _i, _i]),
+    'smd_disp_smooth_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'smd_disp_smooth_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'smd_view_synth_workspace_bytes': (_sz, [_i, _i, _i]),
     'smd_view_synth_fwd': (_i, [_vp]*8 + [_i]*4 + [_vp]),
     'smd_view_synth_bwd': (_i, [_vp]*13 + [_sz] + [_i]*4 + [_vp]),

@@ -234,9 +234,16 @@ size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int 
   return align256((size_t)S*b*smooth_chunks(hs, ws, S)*2*sizeof(float));
 }
 
+size_t smd_disp_smooth_edge_weight_bytes(const int* hs, const int* ws, int S, int b) {
+  if (!hs || !ws || S < 1 || S > SMD_MAX_SCALES || b < 1) return 0;
+  size_t px = 0;
+  for (int s = 0; s < S; ++s) px += (size_t)b*hs[s]*ws[s];
+  return align256(px*2*sizeof(float));
+}
+
 int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
                         const float* img, int h, int w, int flags, float* loss, float* stats, float* disp_grad, float* image_grad,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        float* edge_weights, void* workspace, size_t workspace_bytes, void* stream) {
   if (!disp || !img || !loss || !stats || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");
   smd::ScaleSet sc;
@@ -245,18 +252,18 @@ int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, 
   const size_t need = smd_disp_smooth_workspace_bytes(hs, ws, S, b);
   if (workspace_bytes < need) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
   return check_launch(smd::launch_smooth_fwd(sc, b, img, h, w, flags, loss, stats, disp_grad, image_grad, (float*)workspace,
-                                             (hipStream_t)stream), "disp_smooth_fwd");
+                                             edge_weights, (hipStream_t)stream), "disp_smooth_fwd");
 }
 
 int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
-                        const float* img, int h, int w, int flags, const float* stats, const float* g_loss,
+                        const float* img, int h, int w, int flags, const float* stats, const float* edge_weights, const float* g_loss,
                         float* const* g_disp, void* stream) {
   if (!disp || !img || !stats || !g_loss || !g_disp) return fail(SMD_E_INVALID, "null pointer");
   if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");
   smd::ScaleSet sc;
   if (int rc = fill_scales(sc, disp, g_disp, hs, ws, scale_keys, S)) return rc;
   for (int s = 0; s < S; ++s) if (!disp[s] || !g_disp[s]) return fail(SMD_E_INVALID, "null pointer for scale %d", s);
-  return check_launch(smd::launch_smooth_bwd(sc, b, img, h, w, flags, stats, g_loss, (hipStream_t)stream), "disp_smooth_bwd");
+  return check_launch(smd::launch_smooth_bwd(sc, b, img, h, w, flags, stats, g_loss, edge_weights, (hipStream_t)stream), "disp_smooth_bwd");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -76,9 +76,9 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
                                     const float* depth_up, const float* g_depth_up, float* tmp, hipStream_t st);
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
-                             float* disp_grad, float* image_grad, float* ws_sums, hipStream_t st);
+                             float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st);
 hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
-                             const float* g_loss, hipStream_t st);
+                             const float* g_loss, const float* edge_w, hipStream_t st);
 
 hipError_t launch_view_synth_fwd(const float* input, const float* depth, const float* T, const float* K, const float* Kinv,
                                  float* warp, float* depth_warp, uint8_t* mask_valid, int B, int C, int h, int w, hipStream_t st);

@@ -40,21 +40,16 @@ __device__ __forceinline__ void hsum_w3(float a, float b, float c, float wl, flo
 #ifdef SMD_NO_DPP
   ra = hsum3(a, wl, wr); rb = hsum3(b, wl, wr); rc = hsum3(c, wl, wr);
 #else
-  float ta, tb, tc;
+  // r = q + wl*left(q) + wr*right(q) as two DPP-sourced v_fmac per value (the shift rides on the FMA's first operand)
+  ra = a; rb = b; rc = c;
   asm volatile("s_nop 1\n\t"
-               "v_mov_b32_dpp %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_mov_b32_dpp %4, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_mov_b32_dpp %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_fma_f32 %0, %9, %3, %6\n\t"
-               "v_fma_f32 %1, %9, %4, %7\n\t"
-               "v_fma_f32 %2, %9, %5, %8\n\t"
-               "v_mov_b32_dpp %3, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_mov_b32_dpp %4, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_mov_b32_dpp %5, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_fma_f32 %0, %10, %3, %0\n\t"
-               "v_fma_f32 %1, %10, %4, %1\n\t"
-               "v_fma_f32 %2, %10, %5, %2"
-               : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(ta), "=&v"(tb), "=&v"(tc)
+               "v_fmac_f32_dpp %0, %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fmac_f32_dpp %1, %4, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fmac_f32_dpp %2, %5, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fmac_f32_dpp %0, %3, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fmac_f32_dpp %1, %4, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_fmac_f32_dpp %2, %5, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+               : "+&v"(ra), "+&v"(rb), "+&v"(rc)
                : "v"(a), "v"(b), "v"(c), "v"(wl), "v"(wr));
 #endif
 }

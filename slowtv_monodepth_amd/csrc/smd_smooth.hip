@@ -48,11 +48,18 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// Offset (in float2 units) of scale s in the per-pixel edge-weight buffer {exp(-|dI/dx|), exp(-|dI/dy|)}.
+__host__ __device__ inline size_t edge_offset(const ScaleSet& sc, int b, int s) {
+  size_t off = 0;
+  for (int k = 0; k < s; ++k) off += (size_t)b*sc.hs[k]*sc.ws[k];
+  return off;
+}
+
 // Pass 1: per block, partial sums of the UN-normalised edge energy E' = sum w |d_p - d_q| and of d itself.  Because
 // dhat = d / m with one m > 0 per image, E = E' / m: the mean is not needed inside the pixel loop, so the reference's
 // mean pass and its stencil pass collapse into one sweep.
 __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
-                                                     float* __restrict__ partial, int max_chunks) {
+                                                     float* __restrict__ partial, int max_chunks, float* __restrict__ edge_w) {
   __shared__ float red[4];
   const int s = blockIdx.z, bi = blockIdx.y, chunk = blockIdx.x;
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
@@ -60,6 +67,7 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
   const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
   const float* __restrict__ im = img + (size_t)bi*3*h*w;
   const bool edges = flags & SMD_USE_EDGES;
+  float2* __restrict__ ew = (edges && edge_w) ? (float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
   float accE = 0.f, accD = 0.f;
 #pragma unroll
   for (int k = 0; k < kSmoothChunk/256; ++k) {
@@ -79,7 +87,9 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
         gy = fabsf(dc - d[pix + ws]);
         if (edges) { float ib[3]; img_at(im, h, w, hs, ws, v + 1, u, ib); ay = (fabsf(ic[0] - ib[0]) + fabsf(ic[1] - ib[1]) + fabsf(ic[2] - ib[2]))*(1.f/3.f); }
       }
-      accE += edges ? (gx*__expf(-ax) + gy*__expf(-ay)) : (gx + gy);
+      const float wx = edges ? __expf(-ax) : 1.f, wy = edges ? __expf(-ay) : 1.f;
+      if (ew) ew[pix] = make_float2(wx, wy);       // kept for the adjoint: it then never touches the image
+      accE += gx*wx + gy*wy;
     }
   }
   const float totE = block_sum_256(accE, red);
@@ -148,11 +158,11 @@ __global__ __launch_bounds__(256) void k_smooth_aux(const ScaleSet sc, int b, co
 }
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
-                             float* disp_grad, float* image_grad, float* ws_sums, hipStream_t st) {
+                             float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st) {
   int maxpix = 0;
   for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
   const int max_chunks = ceil_div(maxpix, kSmoothChunk);
-  hipLaunchKernelGGL(k_smooth_main, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks);
+  hipLaunchKernelGGL(k_smooth_main, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks, edge_w);
   hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
   if (disp_grad || image_grad)
     hipLaunchKernelGGL(k_smooth_aux, dim3(min(ceil_div(sc.hs[0]*sc.ws[0], 256), 480), b), dim3(256), 0, st, sc, b, img, h, w, stats, disp_grad, image_grad);
@@ -160,7 +170,8 @@ hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h,
 }
 
 __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
-                                                    const float* __restrict__ stats, const float* __restrict__ g_loss) {
+                                                    const float* __restrict__ stats, const float* __restrict__ g_loss,
+                                                    const float* __restrict__ edge_w) {
   const int s = blockIdx.z, bi = blockIdx.y;
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
   const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
@@ -172,6 +183,25 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
   const float gs = g_loss[0]*exp2f(-(float)sc.key[s])/((float)sc.S*(float)b*(float)n);
   const float mean_term = (mean >= kEps32) ? E*inv_m/(float)n : 0.f;
   if ((int)blockIdx.x*kSmoothChunk >= n) return;
+  if (edges && edge_w) {   // weights cached by the forward sweep: 4 weight + 5 disparity loads per pixel, no image access, no exp
+    const float2* __restrict__ ew = (const float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n;
+    auto sg = [](float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); };
+#pragma unroll
+    for (int kk = 0; kk < kSmoothChunk/256; ++kk) {
+      const int pix = blockIdx.x*kSmoothChunk + kk*256 + threadIdx.x;
+      if (pix >= n) continue;
+      const int v = pix/ws, u = pix - v*ws;
+      const float dc = d[pix]*inv_m;
+      const float2 wc = ew[pix];
+      float G = 0.f;
+      if (u < ws - 1) G += wc.x*sg(dc - d[pix + 1]*inv_m);
+      if (u > 0) G -= ew[pix - 1].x*sg(d[pix - 1]*inv_m - dc);
+      if (v < hs - 1) G += wc.y*sg(dc - d[pix + ws]*inv_m);
+      if (v > 0) G -= ew[pix - ws].y*sg(d[pix - ws]*inv_m - dc);
+      gd[pix] = gs*(G*inv_m - mean_term);
+    }
+    return;
+  }
 #pragma unroll
   for (int kk = 0; kk < kSmoothChunk/256; ++kk) {
     const int pix = blockIdx.x*kSmoothChunk + kk*256 + threadIdx.x;
@@ -210,10 +240,10 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
 }
 
 hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
-                             const float* g_loss, hipStream_t st) {
+                             const float* g_loss, const float* edge_w, hipStream_t st) {
   int maxpix = 0;
   for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
-  hipLaunchKernelGGL(k_smooth_bwd, dim3(ceil_div(maxpix, kSmoothChunk), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, g_loss);
+  hipLaunchKernelGGL(k_smooth_bwd, dim3(ceil_div(maxpix, kSmoothChunk), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, g_loss, edge_w);
   return hipGetLastError();
 }
 

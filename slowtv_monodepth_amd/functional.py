@@ -160,22 +160,25 @@ class _DispSmooth(torch.autograd.Function):
         hs_a, ws_a, keys_a = int_array(hs), int_array(ws), int_array(keys)
         nbytes = _lib.lib.smd_disp_smooth_workspace_bytes(hs_a, ws_a, S, b)
         wsp = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+        need_bwd = any(ctx.needs_input_grad[4:]) and (int(flags) & FLAGS['use_edges'])
+        ew = torch.empty(_lib.lib.smd_disp_smooth_edge_weight_bytes(hs_a, ws_a, S, b), device=dev, dtype=torch.uint8) if need_bwd else None
         call('smd_disp_smooth_fwd', ptr_array([d.data_ptr() for d in disps]), hs_a, ws_a, keys_a, S, b, img.data_ptr(), h, w, int(flags),
              loss.data_ptr(), stats.data_ptr(), dg.data_ptr() if aux else None, ig.data_ptr() if aux else None,
-             wsp.data_ptr(), nbytes, _stream())
-        ctx.save_for_backward(img, stats, *disps)
+             ew.data_ptr() if ew is not None else None, wsp.data_ptr(), nbytes, _stream())
+        ctx.save_for_backward(img, stats, ew, *disps)
         ctx.meta = (hs, ws, list(keys), S, b, h, w, int(flags))
         if aux: ctx.mark_non_differentiable(dg, ig)
         return loss, dg, ig
 
     @staticmethod
     def backward(ctx, g_loss, *_):
-        img, stats, *disps = ctx.saved_tensors
+        img, stats, ew, *disps = ctx.saved_tensors
         hs, ws, keys, S, b, h, w, flags = ctx.meta
         g_loss = g_loss.to(torch.float32).contiguous()
         g_disps = [torch.empty_like(d) for d in disps]
         call('smd_disp_smooth_bwd', ptr_array([d.data_ptr() for d in disps]), int_array(hs), int_array(ws), int_array(keys), S, b,
-             img.data_ptr(), h, w, flags, stats.data_ptr(), g_loss.data_ptr(), ptr_array([g.data_ptr() for g in g_disps]), _stream())
+             img.data_ptr(), h, w, flags, stats.data_ptr(), ew.data_ptr() if ew is not None else None, g_loss.data_ptr(),
+             ptr_array([g.data_ptr() for g in g_disps]), _stream())
         return (None, None, None, None, *g_disps)
 
 
