@@ -13,6 +13,10 @@ namespace smd {
 constexpr int kFwdCols = 62;
 constexpr int kBwdCols = 60;
 constexpr int kWavesPerBlock = 4;
+#ifndef SMD_SMOOTH_CHUNK
+#define SMD_SMOOTH_CHUNK 1024
+#endif
+constexpr int kSmoothChunk = SMD_SMOOTH_CHUNK;   // pixels per block of the smoothness sweeps
 constexpr int kPoseSums = 12;  // accumulated d/d(H[9], a0, a1, tz) per (support, sample)
 
 struct ScaleSet {  // the multi-scale disparity pyramid, passed by value

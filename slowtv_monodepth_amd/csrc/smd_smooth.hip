@@ -13,7 +13,7 @@
 
 namespace smd {
 
-constexpr int kSmoothChunk = 1024;  // pixels per block in the main pass (4 per thread)
+// kSmoothChunk (pixels per block, smd_kernels.h) / 256 pixels per thread
 
 __device__ __forceinline__ void src_index_s(int dst, float scale, int n_in, int& i0, int& i1, float& l1) {
   float src = fmaxf(scale*((float)dst + 0.5f) - 0.5f, 0.f);
