@@ -202,6 +202,15 @@ int smd_bn_bwd(const float* x, const float* y, const float* g_y, const float* ga
 int smd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream);
 int smd_maxpool3x3s2_bwd(const float* g_y, const uint8_t* idx, float* g_x, int N, int C, int H, int W, void* stream);
 
+/* smd_dwconv7x7_*: the depthwise 7x7 convolution (stride 1, padding 3, groups = C) of the ConvNeXt blocks
+ * (timm convnext_* encoders of BASELINE configs 2-4, built at src/networks/depth.py:95-98).
+ * x, y (N,C,H,W); weight (C,1,7,7); bias (C) or NULL.  flip = 0: forward.  flip = 1: data gradient (call with x = g_y,
+ * bias = NULL; weights are read mirrored).  wrw: g_weight (C,1,7,7) and g_bias (C) or NULL from x and g_y. */
+size_t smd_dwconv7x7_workspace_bytes(int C, int H, int W);
+int smd_dwconv7x7_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int H, int W, int flip, void* stream);
+int smd_dwconv7x7_wrw(const float* x, const float* g_y, float* g_weight, float* g_bias, void* workspace, size_t workspace_bytes,
+                      int N, int C, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pose / intrinsics prologue — one launch each instead of ~45 eager ATen launches.
  *

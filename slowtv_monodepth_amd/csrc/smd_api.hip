@@ -429,6 +429,28 @@ int smd_maxpool3x3s2_bwd(const float* g_y, const uint8_t* idx, float* g_x, int N
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depthwise 7x7 convolution (ConvNeXt)
+static bool dw_sizes_ok(int N, int C, int H, int W) {
+  return N >= 1 && C >= 1 && H >= 1 && W >= 1 && (long long)N*C*smd::dwconv_tiles(H, W) < (1ll << 31) && (long long)H*W < (1ll << 30);
+}
+size_t smd_dwconv7x7_workspace_bytes(int C, int H, int W) {
+  if (C < 1 || H < 1 || W < 1) return 0;
+  return align256((size_t)C*smd::dwconv_tiles(H, W)*50*sizeof(float));
+}
+int smd_dwconv7x7_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int H, int W, int flip, void* stream) {
+  if (!x || !weight || !y) return fail(SMD_E_INVALID, "null pointer");
+  if (!dw_sizes_ok(N, C, H, W)) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d H=%d W=%d", N, C, H, W);
+  return check_launch(smd::launch_dwconv7(x, weight, bias, y, N, C, H, W, flip, (hipStream_t)stream), "dwconv7x7_fwd");
+}
+int smd_dwconv7x7_wrw(const float* x, const float* g_y, float* g_weight, float* g_bias, void* workspace, size_t workspace_bytes,
+                      int N, int C, int H, int W, void* stream) {
+  if (!x || !g_y || !g_weight || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (!dw_sizes_ok(N, C, H, W)) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d H=%d W=%d", N, C, H, W);
+  if (workspace_bytes < smd_dwconv7x7_workspace_bytes(C, H, W)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_dwconv7_wrw(x, g_y, g_weight, g_bias, (float*)workspace, N, C, H, W, (hipStream_t)stream), "dwconv7x7_wrw");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pose / intrinsics prologue
 int smd_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, void* stream) {
   if (!aa || !t || !T) return fail(SMD_E_INVALID, "null pointer");

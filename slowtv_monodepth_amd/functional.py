@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, call, int_array, ptr_array
 
 __all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
-           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
+           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
 def _stream() -> int:
@@ -486,6 +486,45 @@ class _MaxPool3x3s2(torch.autograd.Function):
 def max_pool3x3s2(x):
     """`F.max_pool2d(x, 3, 2, 1)` with a one-byte argmax and a gather backward."""
     return _MaxPool3x3s2.apply(x)
+
+
+class _DwConv7x7(torch.autograd.Function):
+    """Depthwise 7x7 convolution, stride 1, padding 3 (`smd_dwconv7x7_*`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _check('x', x)
+        if x.ndim != 4: raise ValueError(f'expected (N,C,H,W), got {tuple(x.shape)}')
+        N, C, H, W = x.shape
+        weight = _check('weight', weight, (C, 1, 7, 7))
+        if bias is not None: bias = _check('bias', bias, (C,))
+        y = torch.empty_like(x)
+        call('smd_dwconv7x7_fwd', x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), N, C, H, W, 0, _stream())
+        ctx.save_for_backward(x, weight); ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, weight = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g_y = g_y.contiguous()
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty_like(x)
+            call('smd_dwconv7x7_fwd', g_y.data_ptr(), weight.data_ptr(), None, g_x.data_ptr(), N, C, H, W, 1, _stream())
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            g_w = torch.empty_like(weight)
+            g_b = torch.empty((C,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            nbytes = _lib.lib.smd_dwconv7x7_workspace_bytes(C, H, W)
+            ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+            call('smd_dwconv7x7_wrw', x.data_ptr(), g_y.data_ptr(), g_w.data_ptr(), g_b.data_ptr() if g_b is not None else None, ws.data_ptr(), nbytes,
+                 N, C, H, W, _stream())
+        return g_x, g_w, g_b
+
+
+def dwconv7x7(x, weight, bias=None):
+    """`F.conv2d(x, weight (C,1,7,7), bias, padding=3, groups=C)`."""
+    return _DwConv7x7.apply(x, weight, bias)
 
 
 # ---------------------------------------------------------------------------------------------------

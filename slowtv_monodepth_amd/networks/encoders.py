@@ -136,7 +136,12 @@ class ConvNeXtBlock(nn.Module):
         self.gamma = nn.Parameter(ls_init*torch.ones(dim))
 
     def forward(self, x):
-        y = self.dw(x).permute(0, 2, 3, 1)
+        if BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
+            from .. import functional as HF   # depthwise 7x7 stencil in fp32 (also under autocast: it feeds a LayerNorm, which autocast runs in fp32)
+            with torch.autocast('cuda', enabled=False):
+                y = HF.dwconv7x7(x.float().contiguous(), self.dw.weight.float(), self.dw.bias.float()).permute(0, 2, 3, 1)
+        else:
+            y = self.dw(x).permute(0, 2, 3, 1)
         y = self.fc2(F.gelu(self.fc1(self.norm(y))))*self.gamma
         return x + y.permute(0, 3, 1, 2)
 

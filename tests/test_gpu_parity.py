@@ -659,3 +659,21 @@ def test_k0_and_smoothness_at_non_integer_ratios(F, b, h, w, lows, use_edges):
         torch.testing.assert_close(dep_g[s].cpu(), dep_c[s].detach(), rtol=2e-5, atol=1e-5)
         assert rel_to_max(dg[s].grad.cpu(), dc[s].grad) < 1e-3, s
     torch.testing.assert_close(l_g.detach().cpu(), l_c.detach(), rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 1, 1), (2, 5, 6, 20), (1, 4, 33, 65), (3, 8, 48, 160), (2, 6, 40, 70)])
+def test_depthwise_conv7x7_kernel(F, shape):
+    import torch.nn.functional as TF
+    gen = torch.Generator().manual_seed(21)
+    N, C, H, W = shape
+    x = torch.randn(*shape, generator=gen); w = torch.randn(C, 1, 7, 7, generator=gen)*0.2; b = torch.randn(C, generator=gen)
+    g = torch.randn(*shape, generator=gen)
+    res = []
+    for dev in ('cuda', 'cpu'):
+        cast = (lambda t: t.clone().cuda()) if dev == 'cuda' else (lambda t: t.clone().double())
+        xx, ww, bb = cast(x).requires_grad_(True), cast(w).requires_grad_(True), cast(b).requires_grad_(True)
+        y = F.dwconv7x7(xx, ww, bb) if dev == 'cuda' else TF.conv2d(xx, ww, bb, padding=3, groups=C)
+        y.backward(cast(g))
+        res.append([t.detach().double().cpu() for t in (y, xx.grad, ww.grad, bb.grad)])
+    for nm, a, e in zip(('y', 'g_x', 'g_weight', 'g_bias'), *res):
+        assert rel_to_max(a, e) < 2e-5, f'{nm}: {rel_to_max(a, e):.3e}'
