@@ -1,6 +1,9 @@
 """Pose / intrinsics prologue and the `ViewSynth` operator (reference: `src/tools/geometry.py`).
 
-The prologue (`T_from_AAt`, `resize_K`, `to_scaled`, `to_inv`) works on tiny tensors and stays in PyTorch autograd;
+`T_from_AAt` on GPU tensors is the `smd_pose_*` kernel pair (the training step goes through
+`functional.pose_matrices` / `functional.intrinsics` directly, which also fold in the inverse transforms and K^-1);
+on host tensors — dataset poses, fixtures — it is the same formula in PyTorch.  `to_scaled` / `to_inv` / `resize_K` /
+`build_K` are the reference's small helpers kept for API parity (the training step uses the K0 and intrinsics kernels).
 `ViewSynth` is the class-level drop-in whose forward/backward are HIP kernels (`smd_view_synth_*`).  The fused fast
 path (`handlers.image_recon`) never instantiates point clouds or sampling grids at all.
 """
@@ -34,6 +37,9 @@ def T_from_AAt(aa: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     if s1[-1] != 3: raise ValueError(f'Incorrect `axisangle` shape. ({s1} vs. (*, 3)')
     if s2[-1] != 3: raise ValueError(f'Incorrect `t` shape. ({s2} vs. (*, 3)')
     if s1 != s2: raise ValueError(f'Non-matching shapes. ({s1} vs. {s2}')
+    if aa.is_cuda and aa.dtype == torch.float32 and t.dtype == torch.float32:
+        from . import functional as F
+        return F.pose_matrices(aa.reshape(-1, 3), t.reshape(-1, 3)).reshape(*s1[:-1], 4, 4)
     angle = aa.norm(p=2, dim=-1, keepdim=True)
     x, y, z = (aa/angle.clip(min=ops.eps(angle))).unbind(-1)
     o = torch.zeros_like(x)

@@ -2,7 +2,7 @@
 
 Same cfg sections (`net`, `loss`, `optimizer`, `scheduler`, `trainer`), same phase structure
 (`forward` -> `forward_postprocess` -> `forward_loss`), same `fwd` / `loss_dict` keys.  What differs is what runs
-underneath: the post-process + loss phases are three HIP launches forward and three backward instead of ~300 ATen
+underneath: the pose prologue, post-process and loss phases are ~15 HIP launches forward + backward instead of ~350 ATen
 kernels, and the reference's per-phase `cuda.synchronize()` timers (src/utils/timers.py:178,195) are replaced by HIP
 events that are only read when someone asks for them.  The Lightning shell is replaced by `fit()` in `train.py`.
 """
