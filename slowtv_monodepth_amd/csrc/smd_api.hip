@@ -33,7 +33,8 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// Tuning knobs (read per call; unset = built-in heuristics): SMD_FWD_RH / SMD_BWD_RH rows per strip, SMD_FWD_NI supports
+// Tuning knobs (read per call; unset = built-in heuristics): SMD_BWD_SKIP (0..2, dead-row skipping of the fused backward,
+// default 2), SMD_FWD_RH / SMD_BWD_RH rows per strip, SMD_FWD_NI supports
 // held in registers per forward pass (1 or 2).
 StripPlan plan(int b, int S, int h, int w, int cols) {
   StripPlan p;
@@ -214,6 +215,7 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   const StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
+  a.skip_level = env_int("SMD_BWD_SKIP", 2);
   prof_mark(SMD_PROF_RECON_BWD, st, true);
   if (int rc = check_launch(smd::launch_recon_bwd(a, st), "image_recon_bwd")) return rc;
   prof_mark(SMD_PROF_RECON_BWD, st, false);

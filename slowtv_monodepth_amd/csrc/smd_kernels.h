@@ -62,6 +62,7 @@ struct ReconBwdArgs {
   int flags;
   int rh, nsx, nsy;
   float wscale, hscale;
+  int skip_level;         // 0..2, see k_recon_bwd
 };
 
 // launchers (return hipError_t from hipGetLastError after the launch)

@@ -9,6 +9,7 @@ default behaviour).  Opt out with SMD_NO_MIOPEN_DB=1 or by exporting MIOPEN_USER
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import tempfile
@@ -23,10 +24,13 @@ def install() -> str | None:
     """Copy the shipped db files to a per-user scratch dir (MIOpen appends to its user db; the tracked files stay pristine)
     and export MIOPEN_USER_DB_PATH.  Must run before the first convolution of the process.  Returns the directory used."""
     if os.environ.get('SMD_NO_MIOPEN_DB') == '1' or 'MIOPEN_USER_DB_PATH' in os.environ or not _SRC.is_dir(): return None
-    dst = Path(tempfile.gettempdir())/f'smd_miopen_db_{os.getuid()}'
+    files = sorted(_SRC.glob('*.txt'))
+    if not files: return None
+    tag = hashlib.sha1(b''.join(f.read_bytes() for f in files)).hexdigest()[:10]   # a new shipped db never meets a stale copy
+    dst = Path(tempfile.gettempdir())/f'smd_miopen_db_{os.getuid()}_{tag}'
     try:
         dst.mkdir(parents=True, exist_ok=True)
-        for f in _SRC.glob('*.txt'):
+        for f in files:
             out = dst/f.name
             if out.exists(): continue
             tmp = dst/f'.{f.name}.{os.getpid()}'
