@@ -43,7 +43,8 @@ def make_cfg(wl: dict, channels_last: bool = False) -> dict:
         'loss': {'img_recon': {'weight': 1, 'loss_name': 'ssim', 'use_min': True, 'use_automask': True},
                  'disp_smooth': {'weight': 0.001, 'use_edges': True}},
         'optimizer': {'type': 'adamw', 'lr': 1e-4, 'weight_decay': 1e-3},
-        'trainer': {'min_depth': 0.1, 'max_depth': 100, 'precision': wl['precision'], 'channels_last': channels_last},
+        'trainer': {'min_depth': 0.1, 'max_depth': 100, 'precision': wl['precision'], 'channels_last': channels_last,
+                    'overlap_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0'},
     }
 
 
@@ -177,7 +178,7 @@ def main():
             'config': {'workload': f'{args.workload}: {wl["depth"]} depth + {wl["pose"]} pose, {wl["w"]}x{wl["h"]}, {n} supports, 4 scales, '
                                    f'img_recon(ssim,min,automask)+disp_smooth(edges), AdamW, random init',
                        'global_batch': wl['b']*world, 'per_gpu_batch': wl['b'], 'parallelism': f'dp{world}',
-                       'loss_dtype': 'f32', 'channels_last': args.channels_last, 'final_loss': round(last_loss, 6)},
+                       'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6)},
             'roofline': {'kernel': 'smd::k_recon_fwd<2,true> (fused warp+SSIM+L1+min-reproj+automask forward)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic,

@@ -99,6 +99,8 @@ class MonoDepthModule(nn.Module):
         self.amp_dtype = {'32': None, '32-true': None, 'bf16': torch.bfloat16, 'bf16-mixed': torch.bfloat16}.get(prec, None)
         self.channels_last = bool(tcfg.get('channels_last', False))
         self.want_aux = bool(tcfg.get('log_images', False))  # supp_imgs_warp etc. are only for the image logger
+        self.overlap_nets = bool(tcfg.get('overlap_nets', True))   # pose network on a second HIP stream, concurrent with the depth network
+        self._side_streams = {}
         self.timer = EventTimer(enabled=bool(tcfg.get('profile_phases', False)))
         if self.channels_last: self.nets.to(memory_format=torch.channels_last)
 
@@ -113,29 +115,49 @@ class MonoDepthModule(nn.Module):
         imgs = x['imgs']
         if self.channels_last: imgs = imgs.contiguous(memory_format=torch.channels_last)
         idxs_all = [int(i) for i in x['supp_idxs']]
-        for key, net in self.nets.items():
+        # The two networks are independent until the loss.  Their deep stages launch kernels of a few dozen workgroups on a
+        # 256-CU device, so the pose network is enqueued on a second HIP stream and runs concurrently with the depth
+        # network (autograd replays each backward node on its forward stream, so the backward overlaps the same way).
+        side = None
+        if self.overlap_nets and imgs.is_cuda and 'pose' in self.nets and 'depth' in self.nets:
+            main = torch.cuda.current_stream(imgs.device)
+            side = self._side_streams.setdefault(imgs.device.index, torch.cuda.Stream(device=imgs.device))
+            side.wait_stream(main)
+            x['imgs'].record_stream(side); x['supp_imgs'].record_stream(side)
+        for key in sorted(self.nets.keys(), key=lambda k: k != 'pose'):   # enqueue the side-stream branch first
+            net = self.nets[key]
             if key == 'depth':
                 with self._autocast(imgs.device.type): out = net(imgs)
                 fwd.update(out)
             elif key == 'pose':
-                inv = lambda i: self.always_fwd_pose and i < 0
-                pairs = torch.stack([torch.cat([supp, x['imgs']] if inv(i) else [x['imgs'], supp], dim=1)
-                                     for i, supp in zip(idxs_all, x['supp_imgs']) if i != 0])   # (n,b,6,h,w)
-                sh = pairs.shape[:2]
-                pin = pairs.flatten(0, 1)
-                if self.channels_last: pin = pin.contiguous(memory_format=torch.channels_last)
-                with self._autocast(imgs.device.type): pose = net(pin)
-                pose = {k: v.float() for k, v in pose.items()}
-                idxs = [i for i in idxs_all if i != 0]
-                flags = [bool(inv(i)) for i in idxs for _ in range(sh[1])]
-                Ts = self.backend.pose_matrices(pose['R'][:, 0], pose['t'][:, 0], flags).unflatten(0, sh)
-                for i, T in zip(idxs, Ts): fwd[f'T_{i}'] = T
-                if 'fs' in pose and 'fs' not in fwd:
-                    fwd['fs'], fwd['cs'] = pose['fs'].unflatten(0, sh), pose['cs'].unflatten(0, sh)
-                    fwd['K'], fwd['K_inv'] = self.backend.intrinsics(fwd['fs'][0], fwd['cs'][0], x['imgs'].shape[-2:])  # first support's prediction only
+                with (torch.cuda.stream(side) if side is not None else nullcontext()):
+                    produced = self._forward_pose(net, x, idxs_all)
+                if side is not None:
+                    for v in produced.values(): v.record_stream(main)
+                fwd.update(produced)
             else:
                 raise KeyError(f'Unrecognized key: {key}.')
+        if side is not None: main.wait_stream(side)
         return fwd
+
+    def _forward_pose(self, net, x: dict, idxs_all) -> dict:
+        out = {}
+        inv = lambda i: self.always_fwd_pose and i < 0
+        pairs = torch.stack([torch.cat([supp, x['imgs']] if inv(i) else [x['imgs'], supp], dim=1)
+                             for i, supp in zip(idxs_all, x['supp_imgs']) if i != 0])   # (n,b,6,h,w)
+        sh = pairs.shape[:2]
+        pin = pairs.flatten(0, 1)
+        if self.channels_last: pin = pin.contiguous(memory_format=torch.channels_last)
+        with self._autocast(pin.device.type): pose = net(pin)
+        pose = {k: v.float() for k, v in pose.items()}
+        idxs = [i for i in idxs_all if i != 0]
+        flags = [bool(inv(i)) for i in idxs for _ in range(sh[1])]
+        Ts = self.backend.pose_matrices(pose['R'][:, 0], pose['t'][:, 0], flags).unflatten(0, sh)
+        for i, T in zip(idxs, Ts): out[f'T_{i}'] = T
+        if 'fs' in pose:
+            out['fs'], out['cs'] = pose['fs'].unflatten(0, sh), pose['cs'].unflatten(0, sh)
+            out['K'], out['K_inv'] = self.backend.intrinsics(out['fs'][0], out['cs'][0], x['imgs'].shape[-2:])  # first support's prediction only
+        return out
 
     def forward_postprocess(self, fwd: dict, x: dict, y: dict) -> dict:
         """Upsample + to-depth of every scale in one launch, and stack the poses (src/core/trainer.py:280-348)."""
