@@ -1,5 +1,6 @@
 """world_size-2 `gloo` test of the data-parallel path on CPU (the 8-GPU RCCL run is the driver's): sharded synthetic
-batches, DDP gradient averaging with `no_sync()` on accumulation micro-steps, identical replicas after every optimizer step."""
+batches, gradient averaging (flat-bucket all-reduce and torch DDP) with no collective on accumulation micro-steps, identical
+replicas after every optimizer step, identical trajectories between the two implementations."""
 import copy
 import os
 import socket
@@ -18,41 +19,46 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, accumulate, out_dir):
+def _worker(rank, world, port, accumulate, out_dir, impl):
     import sys
     sys.path.insert(0, str(ROOT))
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), SMD_DP_IMPL=impl)
     torch.set_num_threads(2)
     from oracle.backend import OracleBackend
     from slowtv_monodepth_amd.synthetic import make_batch
-    from slowtv_monodepth_amd.train import StepModule, init_distributed, train_steps, wrap_ddp
+    from slowtv_monodepth_amd.train import FlatAllReduce, StepModule, init_distributed, train_steps, wrap_ddp
     from slowtv_monodepth_amd.trainer import MonoDepthModule
     r, _, w = init_distributed(backend='gloo')
     assert (r, w) == (rank, world)
     cfg = {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False}, 'pose': {'enc_name': 'resnet18'}},
            'loss': {'img_recon': {'weight': 1, 'use_min': True, 'use_automask': True}, 'disp_smooth': {'weight': 0.001, 'use_edges': True}},
            'optimizer': {'type': 'adamw', 'lr': 1e-3, 'weight_decay': 1e-3}, 'trainer': {'min_depth': 0.1, 'max_depth': 100}}
-    torch.manual_seed(0)   # same initial replica on every rank (DDP would broadcast rank 0's anyway)
+    torch.manual_seed(rank)   # DIFFERENT initial replicas: the wrapper must broadcast rank 0's
     module = MonoDepthModule(copy.deepcopy(cfg), loss_backend=OracleBackend())
     opt = module.configure_optimizers()['optimizer']
     model = wrap_ddp(StepModule(module), torch.device('cpu'))
-    assert isinstance(model, torch.nn.parallel.DistributedDataParallel)
+    assert isinstance(model, torch.nn.parallel.DistributedDataParallel if impl == 'ddp' else FlatAllReduce)
     batches = [make_batch(1, 64, 96, (-1, 1), seed=100*rank + k) for k in range(2*accumulate)]   # a different shard per rank
     losses = train_steps(model, opt, lambda it: batches[it], len(batches), accumulate=accumulate)
     vec = torch.cat([p.detach().flatten() for p in module.nets.parameters()])
     gathered = [torch.empty_like(vec) for _ in range(world)]
     dist.all_gather(gathered, vec)
     torch.save({'params_equal': all(torch.equal(gathered[0], g) for g in gathered), 'moved': float((vec - vec.mean()).abs().sum()),
-                'losses': [l.item() for l in losses]}, os.path.join(out_dir, f'rank{rank}.pt'))
+                'losses': [l.item() for l in losses], 'params': vec}, os.path.join(out_dir, f'{impl}_rank{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('accumulate', [1, 2])
-def test_ddp_replicas_stay_identical(tmp_path, accumulate):
-    world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, accumulate, str(tmp_path)), nprocs=world, join=True)
-    res = [torch.load(tmp_path/f'rank{r}.pt') for r in range(world)]
-    assert all(r['params_equal'] for r in res), 'replicas diverged: gradients were not averaged identically'
-    assert res[0]['losses'] != res[1]['losses'], 'ranks must see different shards'
-    assert all(all(l == l for l in r['losses']) for r in res)
+def test_replicas_stay_identical_and_flat_allreduce_equals_ddp(tmp_path, accumulate):
+    world, out = 2, {}
+    for impl in ('flat', 'ddp'):
+        mp.spawn(_worker, args=(world, _free_port(), accumulate, str(tmp_path), impl), nprocs=world, join=True)
+        res = [torch.load(tmp_path/f'{impl}_rank{r}.pt') for r in range(world)]
+        assert all(r['params_equal'] for r in res), f'{impl}: replicas diverged: gradients were not averaged identically'
+        assert res[0]['losses'] != res[1]['losses'], 'ranks must see different shards'
+        assert all(all(l == l for l in r['losses']) for r in res)
+        out[impl] = res[0]
+    # the flat-bucket all-reduce and torch DDP implement the same averaging: same trajectory from the same start
+    torch.testing.assert_close(out['flat']['params'], out['ddp']['params'], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(torch.tensor(out['flat']['losses']), torch.tensor(out['ddp']['losses']), rtol=1e-4, atol=1e-6)
