@@ -65,6 +65,31 @@ struct ReconBwdArgs {
   int skip_level;         // 0..2, see k_recon_bwd
 };
 
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1)/b; }
+
+// XCD-aware block -> (strip block, sample, scale) mapping for the two fused kernels (1-D grid of nbx*b*S blocks).
+// MI355X dispatches workgroup p to XCD p % 8, each XCD with its own 4 MB L2.  The S scales of one image region gather from
+// the same support texels, so they are placed on ONE XCD in consecutive dispatch slots: the texels are fetched from HBM once
+// and re-read from that L2 by the other scales (with blockIdx.z = scale they ran a whole batch apart, on any XCD).
+__device__ __forceinline__ void decode_tile(unsigned p, int nbx, int b, int S, int& xb, int& bi, int& s) {
+  const unsigned nq = (unsigned)nbx*(unsigned)b, full = nq & ~7u;
+  unsigned q;
+  if (p < full*(unsigned)S) { const unsigned slot = p >> 3; q = (slot/(unsigned)S)*8u + (p & 7u); s = (int)(slot % (unsigned)S); }
+  else { const unsigned r = p - full*(unsigned)S; q = full + r/(unsigned)S; s = (int)(r % (unsigned)S); }
+  bi = (int)(q/(unsigned)nbx); xb = (int)(q - (unsigned)bi*(unsigned)nbx);
+}
+
+// (Tried and dropped: one block = the four scales of ONE strip, so that they also share the CU's vector L1.  L2 requests fell
+// by 20 %, but neighbouring strips then land on different XCDs and HBM reads went back up from 143 to 196 MB; no gain in time.)
+__host__ __device__ inline unsigned recon_grid_blocks(int nstrips, int b, int S) {
+  return (unsigned)ceil_div(nstrips, kWavesPerBlock)*(unsigned)b*(unsigned)S;
+}
+__device__ __forceinline__ void decode_wave(unsigned p, int wid, int nstrips, int b, int S, int& strip, int& bi, int& s) {
+  int xb;
+  decode_tile(p, ceil_div(nstrips, kWavesPerBlock), b, S, xb, bi, s);
+  strip = xb*kWavesPerBlock + wid;
+}
+
 // launchers (return hipError_t from hipGetLastError after the launch)
 hipError_t launch_recon_fwd(const ReconFwdArgs& a, int ni, bool warp, hipStream_t st);
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st);
@@ -129,7 +154,7 @@ hipError_t launch_intrinsics_fwd(const float* fs, const float* cs, const float* 
 hipError_t launch_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, const float* g_K, const float* g_Kinv,
                                  float* g_fs, float* g_cs, hipStream_t st);
 
-inline int ceil_div(int a, int b) { return (a + b - 1)/b; }
+
 
 // Rows per strip: enough strips to give every SIMD several waves, few enough that the halo rows stay cheap.
 inline int pick_rows_per_strip(int b, int S, int h, int w, int cols, int halo) {

@@ -68,11 +68,11 @@ template <int SKIP>
 __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int strip = blockIdx.x*kWavesPerBlock + wid;
   const int nstrips = a.nsx*a.nsy;
+  int strip, bi, s;
+  decode_wave(blockIdx.x, wid, nstrips, a.b, a.S, strip, bi, s);
   if (strip >= nstrips) return;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
-  const int bi = blockIdx.y, s = blockIdx.z;
   const int h = a.h, w = a.w;
   const int c0 = sxi*kBwdCols;
   const int r0 = syi*a.rh, r1 = min(r0 + a.rh, h);
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
 }
 
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
-  dim3 grid(ceil_div(a.nsx*a.nsy, kWavesPerBlock), a.b, a.S), block(64*kWavesPerBlock);
+  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b, a.S)), block(64*kWavesPerBlock);
   if (a.skip_level >= 2) hipLaunchKernelGGL(k_recon_bwd<2>, grid, block, 0, st, a);
   else if (a.skip_level == 1) hipLaunchKernelGGL(k_recon_bwd<1>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(k_recon_bwd<0>, grid, block, 0, st, a);

@@ -248,12 +248,13 @@ template <int NI, bool WARP, bool SSIM, bool SINGLE>
 __device__ __forceinline__ void recon_fwd_body(const ReconFwdArgs& a) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int strip = blockIdx.x*kWavesPerBlock + wid;
+  int strip, bi_, s_;
+  decode_wave(blockIdx.x, wid, a.nsx*a.nsy, a.b, a.S, strip, bi_, s_);
   if (strip >= a.nsx*a.nsy) return;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
 
   FwdCtx<NI, WARP, SSIM, SINGLE> cx{a};
-  cx.lane = lane; cx.bi = blockIdx.y; cx.s = blockIdx.z; cx.h = a.h; cx.w = a.w;
+  cx.lane = lane; cx.bi = bi_; cx.s = s_; cx.h = a.h; cx.w = a.w;
   const int c0 = sxi*kFwdCols;
   cx.r0 = syi*a.rh; cx.r1 = min(cx.r0 + a.rh, a.h);
   cx.u = c0 - 1 + lane;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void k_recon_fwd(const ReconFwdArgs a) { recon
 __global__ __launch_bounds__(256, 5) void k_recon_fwd_w4(const ReconFwdArgs a) { recon_fwd_body<2, true, true, true>(a); }
 
 hipError_t launch_recon_fwd(const ReconFwdArgs& a, int ni, bool warp, hipStream_t st) {
-  dim3 grid(ceil_div(a.nsx*a.nsy, kWavesPerBlock), a.b, a.S), block(64*kWavesPerBlock);
+  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b, a.S)), block(64*kWavesPerBlock);
   const bool ssim = !(a.flags & SMD_LOSS_L1);
   const bool single = a.first_pass && a.last_pass;
 #define SMD_LAUNCH(NI_, WARP_, SSIM_, SINGLE_) hipLaunchKernelGGL((k_recon_fwd<NI_, WARP_, SSIM_, SINGLE_>), grid, block, 0, st, a)
