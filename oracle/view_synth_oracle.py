@@ -16,7 +16,6 @@ heavy primitives to the ATen ops the reference itself calls (used for the timed 
 """
 from __future__ import annotations
 
-import math
 
 import torch
 import torch.nn.functional as F

@@ -53,8 +53,9 @@ ProfSlot g_prof[2];
 void prof_mark(int which, hipStream_t st, bool begin) {
   ProfSlot& p = g_prof[which];
   if (!p.ev || p.used >= p.cap) return;
-  if (begin) hipEventRecord(p.ev[2*p.used], st);
-  else { hipEventRecord(p.ev[2*p.used + 1], st); ++p.used; }
+  // a failed record only loses one timing sample (collect() reports the pairs that completed)
+  if (begin) (void)hipEventRecord(p.ev[2*p.used], st);
+  else { (void)hipEventRecord(p.ev[2*p.used + 1], st); ++p.used; }
 }
 
 int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil_div(h, 8); }
@@ -479,7 +480,7 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
 int smd_profile_enable(int which, int capacity) {
   if (which < 0 || which > 1 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
   ProfSlot& p = g_prof[which];
-  for (int i = 0; i < 2*p.cap; ++i) hipEventDestroy(p.ev[i]);
+  for (int i = 0; i < 2*p.cap; ++i) (void)hipEventDestroy(p.ev[i]);
   delete[] p.ev;
   p = ProfSlot();
   if (capacity == 0) return SMD_OK;
