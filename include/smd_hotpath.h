@@ -211,6 +211,16 @@ int smd_dwconv7x7_fwd(const float* x, const float* weight, const float* bias, fl
 int smd_dwconv7x7_wrw(const float* x, const float* g_y, float* g_weight, float* g_bias, void* workspace, size_t workspace_bytes,
                       int N, int C, int H, int W, void* stream);
 
+/* smd_layernorm_cf_*: LayerNorm over the channel dimension of an NCHW tensor, i.e. timm's `LayerNorm2d` and the block norm
+ * of ConvNeXt evaluated without the NCHW <-> NHWC permutes (`F.layer_norm(x.permute(0,2,3,1), (C,), gamma, beta, eps)`).
+ * x, y (N,C,H,W) with HW = H*W; gamma, beta (C); mean, rstd (N*HW) kept for the backward.
+ * Backward: g_y -> g_x, g_gamma, g_beta. */
+size_t smd_layernorm_cf_workspace_bytes(int N, int C, int HW);
+int smd_layernorm_cf_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                         int N, int C, int HW, float eps, void* stream);
+int smd_layernorm_cf_bwd(const float* x, const float* g_y, const float* gamma, const float* mean, const float* rstd,
+                         float* g_x, float* g_gamma, float* g_beta, void* workspace, size_t workspace_bytes, int N, int C, int HW, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pose / intrinsics prologue — one launch each instead of ~45 eager ATen launches.
  *

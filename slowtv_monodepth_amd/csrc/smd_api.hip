@@ -454,6 +454,27 @@ int smd_dwconv7x7_wrw(const float* x, const float* g_y, float* g_weight, float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Channel LayerNorm on NCHW (ConvNeXt)
+size_t smd_layernorm_cf_workspace_bytes(int N, int C, int HW) {
+  if (N < 1 || C < 1 || HW < 1) return 0;
+  return align256((size_t)smd::ln_cf_chunks((size_t)N*HW)*C*2*sizeof(float));
+}
+int smd_layernorm_cf_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int N, int C, int HW, float eps,
+                         void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || C < 1 || HW < 1 || (long long)N*HW >= (1ll << 38)) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d HW=%d", N, C, HW);
+  return check_launch(smd::launch_ln_cf_fwd(x, gamma, beta, y, mean, rstd, N, C, HW, eps, (hipStream_t)stream), "layernorm_cf_fwd");
+}
+int smd_layernorm_cf_bwd(const float* x, const float* g_y, const float* gamma, const float* mean, const float* rstd, float* g_x, float* g_gamma,
+                         float* g_beta, void* workspace, size_t workspace_bytes, int N, int C, int HW, void* stream) {
+  if (!x || !g_y || !gamma || !mean || !rstd || !g_x || !g_gamma || !g_beta || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (N < 1 || C < 1 || C > 32767 || HW < 1) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d HW=%d", N, C, HW);
+  if (workspace_bytes < smd_layernorm_cf_workspace_bytes(N, C, HW)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_ln_cf_bwd(x, g_y, gamma, mean, rstd, g_x, g_gamma, g_beta, (float*)workspace, N, C, HW, (hipStream_t)stream),
+                      "layernorm_cf_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pose / intrinsics prologue
 int smd_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, void* stream) {
   if (!aa || !t || !T) return fail(SMD_E_INVALID, "null pointer");

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, call, int_array, ptr_array
 
 __all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
-           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
+           'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'layer_norm_cf', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
 def _stream() -> int:
@@ -525,6 +525,39 @@ class _DwConv7x7(torch.autograd.Function):
 def dwconv7x7(x, weight, bias=None):
     """`F.conv2d(x, weight (C,1,7,7), bias, padding=3, groups=C)`."""
     return _DwConv7x7.apply(x, weight, bias)
+
+
+class _LayerNormCF(torch.autograd.Function):
+    """LayerNorm over the channel dimension of an NCHW tensor (`smd_layernorm_cf_*`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = _check('x', x)
+        if x.ndim != 4: raise ValueError(f'expected (N,C,H,W), got {tuple(x.shape)}')
+        N, C, H, W = x.shape
+        weight = _check('weight', weight, (C,)); bias = _check('bias', bias, (C,))
+        y = torch.empty_like(x)
+        stats = torch.empty((2, N*H*W), device=x.device, dtype=torch.float32)
+        call('smd_layernorm_cf_fwd', x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+             N, C, H*W, float(eps), _stream())
+        ctx.save_for_backward(x, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, weight, stats = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g_x = torch.empty_like(x); g_w = torch.empty_like(weight); g_b = torch.empty_like(weight)
+        nbytes = _lib.lib.smd_layernorm_cf_workspace_bytes(N, C, H*W)
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        call('smd_layernorm_cf_bwd', x.data_ptr(), g_y.contiguous().data_ptr(), weight.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+             g_x.data_ptr(), g_w.data_ptr(), g_b.data_ptr(), ws.data_ptr(), nbytes, N, C, H*W, _stream())
+        return g_x, g_w, g_b, None
+
+
+def layer_norm_cf(x, weight, bias, eps: float = 1e-6):
+    """`F.layer_norm(x.permute(0,2,3,1), (C,), weight, bias, eps).permute(0,3,1,2)` without the permutes."""
+    return _LayerNormCF.apply(x, weight, bias, eps)
 
 
 # ---------------------------------------------------------------------------------------------------

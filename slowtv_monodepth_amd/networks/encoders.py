@@ -121,9 +121,17 @@ class ResNetFeatures(nn.Module):
         return feats
 
 
+def _use_nchw_kernels(x) -> bool:
+    return BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+
+
 class LayerNorm2d(nn.LayerNorm):
-    """LayerNorm over the channel dim of an NCHW tensor."""
+    """LayerNorm over the channel dim of an NCHW tensor (on the GPU: `smd_layernorm_cf_*`, no permutes)."""
     def forward(self, x):
+        if _use_nchw_kernels(x):
+            from .. import functional as HF
+            with torch.autocast('cuda', enabled=False):
+                return HF.layer_norm_cf(x.float().contiguous(), self.weight.float(), self.bias.float(), self.eps)
         return F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
 
 
@@ -136,14 +144,22 @@ class ConvNeXtBlock(nn.Module):
         self.gamma = nn.Parameter(ls_init*torch.ones(dim))
 
     def forward(self, x):
-        if BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
-            from .. import functional as HF   # depthwise 7x7 stencil in fp32 (also under autocast: it feeds a LayerNorm, which autocast runs in fp32)
-            with torch.autocast('cuda', enabled=False):
-                y = HF.dwconv7x7(x.float().contiguous(), self.dw.weight.float(), self.dw.bias.float()).permute(0, 2, 3, 1)
-        else:
-            y = self.dw(x).permute(0, 2, 3, 1)
+        if _use_nchw_kernels(x): return self._forward_nchw(x)
+        y = self.dw(x).permute(0, 2, 3, 1)
         y = self.fc2(F.gelu(self.fc1(self.norm(y))))*self.gamma
         return x + y.permute(0, 3, 1, 2)
+
+    def _forward_nchw(self, x):
+        """The same block without leaving NCHW (timm's `conv_mlp` formulation on the SAME parameters): depthwise 7x7 stencil
+        and channel LayerNorm as HIP kernels in fp32 (autocast runs layer_norm in fp32 anyway), the MLP as two 1x1
+        convolutions on views of the Linear weights, layer scale + residual as one addcmul.  No layout copies."""
+        from .. import functional as HF
+        with torch.autocast('cuda', enabled=False):
+            y = HF.dwconv7x7(x.float().contiguous(), self.dw.weight.float(), self.dw.bias.float())
+            y = HF.layer_norm_cf(y, self.norm.weight.float(), self.norm.bias.float(), self.norm.eps)
+        y = F.conv2d(y, self.fc1.weight[:, :, None, None], self.fc1.bias)
+        y = F.conv2d(F.gelu(y), self.fc2.weight[:, :, None, None], self.fc2.bias)
+        return torch.addcmul(x, y, self.gamma.view(1, -1, 1, 1).to(y.dtype))
 
 
 class ConvNeXtFeatures(nn.Module):

@@ -677,3 +677,43 @@ def test_depthwise_conv7x7_kernel(F, shape):
         res.append([t.detach().double().cpu() for t in (y, xx.grad, ww.grad, bb.grad)])
     for nm, a, e in zip(('y', 'g_x', 'g_weight', 'g_bias'), *res):
         assert rel_to_max(a, e) < 2e-5, f'{nm}: {rel_to_max(a, e):.3e}'
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 1, 1), (2, 96, 6, 20), (1, 7, 33, 65), (3, 128, 24, 40), (2, 1030, 5, 7)])
+def test_channel_layer_norm_kernel(F, shape):
+    import torch.nn.functional as TF
+    gen = torch.Generator().manual_seed(31)
+    N, C, H, W = shape
+    x = torch.randn(*shape, generator=gen)*2 + 3*torch.randn(N, 1, H, W, generator=gen); w = torch.rand(C, generator=gen) + 0.5; b = torch.randn(C, generator=gen)
+    g = torch.randn(*shape, generator=gen)
+    res = []
+    for dev in ('cuda', 'cpu'):
+        cast = (lambda t: t.clone().cuda()) if dev == 'cuda' else (lambda t: t.clone().double())
+        xx, ww, bb = cast(x).requires_grad_(True), cast(w).requires_grad_(True), cast(b).requires_grad_(True)
+        y = F.layer_norm_cf(xx, ww, bb, 1e-6) if dev == 'cuda' else TF.layer_norm(xx.permute(0, 2, 3, 1), (C,), ww, bb, 1e-6).permute(0, 3, 1, 2)
+        y.backward(cast(g))
+        res.append([t.detach().double().cpu() for t in (y, xx.grad, ww.grad, bb.grad)])
+    for nm, a, e in zip(('y', 'g_x', 'g_weight', 'g_bias'), *res):
+        assert rel_to_max(a, e) < 3e-5, f'{nm}: {rel_to_max(a, e):.3e}'
+
+
+def test_convnext_encoder_nchw_path_equals_reference_formulation(F):
+    """ConvNeXt-T with the NCHW block (HIP depthwise + channel LayerNorm, 1x1-conv MLP) against the permute/Linear formulation."""
+    from slowtv_monodepth_amd.networks import encoders as E
+    torch.manual_seed(2)
+    net = E.create_encoder('convnext_tiny', in_chans=3).cuda().train()
+    for m in net.modules():
+        if isinstance(m, E.ConvNeXtBlock): m.gamma.data.fill_(0.5)   # make the residual branch matter (layer scale starts at 1e-6)
+    x = torch.randn(2, 3, 64, 96, device='cuda')
+    res = []
+    for fused in (True, False):
+        E.BatchNormAct2d.fused_enabled = fused
+        try:
+            net.zero_grad()
+            feats = net(x)
+            sum((f*f).mean() for f in feats).backward()
+            res.append(([f.detach() for f in feats], [p.grad.clone() for p in net.parameters()]))
+        finally:
+            E.BatchNormAct2d.fused_enabled = True
+    for a, b in zip(res[0][0], res[1][0]): assert rel_to_max(a, b) < 2e-4
+    for a, b in zip(res[0][1], res[1][1]): assert rel_to_max(a, b) < 5e-3
