@@ -88,6 +88,10 @@ class FlatAllReduce(nn.Module):
         self._left = [len(bk) for bk in self.buckets]
         self._works = [None]*len(self.buckets)
         self._streams = [set() for _ in self.buckets]   # streams on which the gradients of a bucket were accumulated
+        # Collectives must be issued in the same order on every rank.  The first synchronised step issues them after backward
+        # in index order and records the order in which the buckets completed; rank 0's record is broadcast and from then on
+        # a completed bucket is only launched once all of its predecessors in that order have been.
+        self._order, self._arrival, self._next, self._ready = None, [], 0, set()
         if self.overlap:
             for p in params: p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -98,14 +102,20 @@ class FlatAllReduce(nn.Module):
         i = self._bucket_of[p]
         if p.is_cuda: self._streams[i].add(torch.cuda.current_stream(p.device))
         self._left[i] -= 1
-        if self._left[i] == 0: self._launch(i, in_backward=True)
+        if self._left[i] == 0:
+            self._arrival.append(i)
+            if self._order is not None:
+                self._ready.add(i)
+                while self._next < len(self._order) and self._order[self._next] in self._ready:
+                    self._launch(self._order[self._next], in_backward=True)
+                    self._next += 1
 
     @torch.no_grad()
     def _launch(self, i: int, in_backward: bool) -> None:
         bk = self.buckets[i]
         for p in bk:
             if p.grad is None: p.grad = torch.zeros_like(p)
-        if in_backward and bk[0].is_cuda and len(self._streams[i]) > 1:   # mixed bucket (not expected): order the pack after all of them
+        if in_backward and bk[0].is_cuda:   # launched from another stream's hook (deferred) or mixed bucket: order the pack after its producers
             cur = torch.cuda.current_stream(bk[0].device)
             for st in self._streams[i]:
                 if st != cur: cur.wait_stream(st)
@@ -115,8 +125,17 @@ class FlatAllReduce(nn.Module):
     @torch.no_grad()
     def sync_gradients(self) -> None:
         """Finish the gradient average (call after the last backward of an optimizer step, before the optimizer)."""
-        for i in range(len(self.buckets)):
+        order = self._order if self._order is not None else list(range(len(self.buckets)))
+        for i in order:
             if self._works[i] is None: self._launch(i, in_backward=False)
+        if self._order is None and self.overlap:
+            seen = list(dict.fromkeys(self._arrival))
+            seen += [i for i in range(len(self.buckets)) if i not in seen]
+            t = torch.tensor(seen, dtype=torch.int64, device=self.flats[0].device)
+            dist.broadcast(t, 0)
+            self._order = [int(v) for v in t.tolist()]
+        self._arrival, self._next = [], 0
+        self._ready.clear()
         for i, bk in enumerate(self.buckets):
             self._works[i].wait()
             if self.avg_op == dist.ReduceOp.SUM: self.flats[i].div_(self.world)
