@@ -1,0 +1,69 @@
+"""Two ranks sharing ONE MI355X (backend gloo on GPU tensors — RCCL refuses two ranks per device): the data-parallel wrapper on
+the product path, i.e. HIP loss kernels, two network streams, gradient hooks firing on both streams, ordered asynchronous
+all-reduces.  The 8-GPU RCCL run is the driver's; this pins the parts that do not depend on the transport."""
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir, overlap):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world),
+                      SMD_DP_OVERLAP='1' if overlap else '0')
+    import torch.distributed as dist
+    from slowtv_monodepth_amd.synthetic import make_batch
+    from slowtv_monodepth_amd.train import FlatAllReduce, StepModule, init_distributed, train_steps, wrap_ddp
+    from slowtv_monodepth_amd.trainer import MonoDepthModule
+    init_distributed(backend='gloo')
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    cfg = {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False}, 'pose': {'enc_name': 'resnet18'}},
+           'loss': {'img_recon': {'weight': 1, 'use_min': True, 'use_automask': True}, 'disp_smooth': {'weight': 0.001, 'use_edges': True}},
+           'optimizer': {'type': 'adamw', 'lr': 1e-4, 'weight_decay': 1e-3}, 'trainer': {'min_depth': 0.1, 'max_depth': 100}}
+    torch.manual_seed(rank)   # different initial replicas: the wrapper broadcasts rank 0's
+    module = MonoDepthModule(copy.deepcopy(cfg)).to(dev)
+    opt = module.configure_optimizers()['optimizer']
+    model = wrap_ddp(StepModule(module), dev)
+    assert isinstance(model, FlatAllReduce) and model.overlap == overlap
+    batches = [make_batch(2, 64, 96, (-1, 1), seed=100*rank + k, device=dev) for k in range(4)]
+    losses = train_steps(model, opt, lambda it: batches[it], len(batches))
+    torch.cuda.synchronize()
+    vec = torch.cat([p.detach().flatten() for p in module.nets.parameters()]).cpu()
+    gathered = [torch.empty_like(vec) for _ in range(world)]
+    dist.all_gather(gathered, vec)
+    torch.save({'params_equal': all(torch.equal(gathered[0], g) for g in gathered), 'losses': [l.item() for l in losses], 'params': vec,
+                'order': model._order}, os.path.join(out_dir, f'ov{int(overlap)}_rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_stay_identical_and_overlap_equals_deferred(tmp_path):
+    world, out = 2, {}
+    for overlap in (True, False):
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap), nprocs=world, join=True)
+        res = [torch.load(tmp_path/f'ov{int(overlap)}_rank{r}.pt') for r in range(world)]
+        assert all(r['params_equal'] for r in res), 'replicas diverged'
+        assert res[0]['losses'] != res[1]['losses'], 'ranks must see different shards'
+        assert all(all(l == l for l in r['losses']) for r in res)
+        out[overlap] = res[0]
+    assert out[True]['order'] is not None and sorted(out[True]['order']) == list(range(len(out[True]['order'])))
+    # All-reducing during backward and after backward are the same computation.  The two runs are separate processes on a GPU
+    # whose convolution weight-gradient kernels accumulate atomically, and AdamW's first updates are ~lr*sign(g): tiny gradient
+    # differences move a parameter by up to 2*lr per step, hence the loose bound (4 steps at lr 1e-4 against |p| ~ 1).
+    assert ((out[True]['params'] - out[False]['params']).abs().max()/out[False]['params'].abs().max()).item() < 2e-3
+    torch.testing.assert_close(torch.tensor(out[True]['losses']), torch.tensor(out[False]['losses']), rtol=2e-2, atol=1e-4)
