@@ -717,3 +717,14 @@ def test_convnext_encoder_nchw_path_equals_reference_formulation(F):
             E.BatchNormAct2d.fused_enabled = True
     for a, b in zip(res[0][0], res[1][0]): assert rel_to_max(a, b) < 2e-4
     for a, b in zip(res[0][1], res[1][1]): assert rel_to_max(a, b) < 5e-3
+
+
+def test_training_cli_runs_and_the_loss_decreases(tmp_path, capsys):
+    """`python -m slowtv_monodepth_amd.train` on the shipped cfg: two short epochs on a fixed synthetic batch."""
+    from slowtv_monodepth_amd import train
+    from conftest import ROOT
+    train.main(['-c', str(ROOT/'cfg'/'kitti_resnet18.yaml'), '-o', str(tmp_path), '-n', 'cli', '--steps', '12', '--shape', '96', '160'])
+    out = capsys.readouterr().out
+    losses = [float(l.split('loss ')[1].split()[0]) for l in out.splitlines() if l.startswith('epoch')]
+    assert len(losses) == 2 and all(l == l for l in losses) and losses[1] < losses[0]
+    assert (tmp_path/'cli'/'000'/'last.ckpt').is_file()
