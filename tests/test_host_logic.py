@@ -1,6 +1,7 @@
 """CPU tests of the host side: registry / cfg surface, pose + intrinsics prologue, networks' output contract, the
 training step driven through the oracle backend, and the C-ABI library's symbol table (no compute calls without a GPU)."""
 import copy
+import os
 import re
 from pathlib import Path
 
@@ -219,3 +220,19 @@ def test_scale_dict_is_a_dict_of_views():
     st = torch.rand(3, 2, 1, 4, 5)
     sd = ScaleDict.from_stack([0, 1, 3], st)
     assert list(sd) == [0, 1, 3] and sd.stacked is st and sd[3].data_ptr() == st[2].data_ptr()
+
+
+def test_miopen_db_is_installed_to_a_private_versioned_copy(tmp_path, monkeypatch):
+    """The shipped find-db must never be written to in place: MIOPEN_USER_DB_PATH points at a per-user copy keyed by content."""
+    import importlib
+    from slowtv_monodepth_amd import miopen_tuning
+    monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+    monkeypatch.delenv('SMD_NO_MIOPEN_DB', raising=False)
+    monkeypatch.setattr(miopen_tuning.tempfile, 'gettempdir', lambda: str(tmp_path))
+    dst = miopen_tuning.install()
+    assert dst is not None and dst.startswith(str(tmp_path)) and os.environ['MIOPEN_USER_DB_PATH'] == dst
+    shipped = sorted(p.name for p in (ROOT/'slowtv_monodepth_amd'/'miopen_db').glob('*.txt'))
+    assert shipped and sorted(os.listdir(dst)) == shipped
+    monkeypatch.setenv('MIOPEN_USER_DB_PATH', '/somewhere/else')
+    assert miopen_tuning.install() is None and os.environ['MIOPEN_USER_DB_PATH'] == '/somewhere/else'   # the user's choice wins
+    importlib.reload(miopen_tuning)
