@@ -227,9 +227,9 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
 
 // ------------------------------------------------------------------------------------------------
 static int smooth_chunks(const int* hs, const int* ws, int S) {
-  int maxpix = 0;
-  for (int s = 0; s < S; ++s) maxpix = hs[s]*ws[s] > maxpix ? hs[s]*ws[s] : maxpix;
-  return smd::ceil_div(maxpix, smd::kSmoothChunk);
+  int mx = 1;
+  for (int s = 0; s < S; ++s) mx = smd::smooth_chunks_of(hs[s]*ws[s]) > mx ? smd::smooth_chunks_of(hs[s]*ws[s]) : mx;
+  return mx;
 }
 
 size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int b) {

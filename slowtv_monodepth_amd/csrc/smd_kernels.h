@@ -16,7 +16,11 @@ constexpr int kWavesPerBlock = 4;
 #ifndef SMD_SMOOTH_CHUNK
 #define SMD_SMOOTH_CHUNK 1024
 #endif
-constexpr int kSmoothChunk = SMD_SMOOTH_CHUNK;   // pixels per block of the smoothness sweeps
+constexpr int kSmoothChunk = SMD_SMOOTH_CHUNK;   // pixels per block of the smoothness sweeps at the large scales
+// Pixels per block for a scale with n pixels: the coarse scales have few pixels but the longest latency chains (their
+// image taps are strided gathers from the full-resolution frame), so they get one pixel per thread and start first.
+__host__ __device__ inline int smooth_chunk_px(int n) { return n > 32768 ? kSmoothChunk : 256; }
+__host__ __device__ inline int smooth_chunks_of(int n) { return (n + smooth_chunk_px(n) - 1)/smooth_chunk_px(n); }
 constexpr int kPoseSums = 12;  // accumulated d/d(H[9], a0, a1, tz) per (support, sample)
 
 struct ScaleSet {  // the multi-scale disparity pyramid, passed by value

@@ -61,35 +61,34 @@ __host__ __device__ inline size_t edge_offset(const ScaleSet& sc, int b, int s) 
 __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
                                                      float* __restrict__ partial, int max_chunks, float* __restrict__ edge_w) {
   __shared__ float red[4];
-  const int s = blockIdx.z, bi = blockIdx.y, chunk = blockIdx.x;
+  const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y, chunk = blockIdx.x;   // coarse scales first
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
-  if (chunk*kSmoothChunk >= n) return;
+  const int cpx = smooth_chunk_px(n), ppt = cpx/256;
+  if (chunk*cpx >= n) return;
   const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
   const float* __restrict__ im = img + (size_t)bi*3*h*w;
   const bool edges = flags & SMD_USE_EDGES;
   float2* __restrict__ ew = (edges && edge_w) ? (float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
   float accE = 0.f, accD = 0.f;
-#pragma unroll
-  for (int k = 0; k < kSmoothChunk/256; ++k) {
-    const int pix = chunk*kSmoothChunk + k*256 + threadIdx.x;
-    if (pix < n) {
-      const int v = pix/ws, u = pix - v*ws;
-      const float dc = d[pix];
-      accD += dc;
-      float gx = 0.f, gy = 0.f, ax = 0.f, ay = 0.f;
-      float ic[3];
-      if (edges) img_at(im, h, w, hs, ws, v, u, ic);
-      if (u < ws - 1) {
-        gx = fabsf(dc - d[pix + 1]);
-        if (edges) { float ir[3]; img_at(im, h, w, hs, ws, v, u + 1, ir); ax = (fabsf(ic[0] - ir[0]) + fabsf(ic[1] - ir[1]) + fabsf(ic[2] - ir[2]))*(1.f/3.f); }
-      }
-      if (v < hs - 1) {
-        gy = fabsf(dc - d[pix + ws]);
-        if (edges) { float ib[3]; img_at(im, h, w, hs, ws, v + 1, u, ib); ay = (fabsf(ic[0] - ib[0]) + fabsf(ic[1] - ib[1]) + fabsf(ic[2] - ib[2]))*(1.f/3.f); }
-      }
-      const float wx = edges ? __expf(-ax) : 1.f, wy = edges ? __expf(-ay) : 1.f;
+  // Branch-free body: neighbours are addressed with clamped indices (the last column / row then pairs a pixel with itself and
+  // contributes |d - d| = 0), so all loads of the thread's pixels are independent of any comparison and can be in flight together.
+  for (int k = 0; k < ppt; ++k) {
+    const int pix = min(chunk*cpx + k*256 + (int)threadIdx.x, n - 1);
+    const bool live = chunk*cpx + k*256 + (int)threadIdx.x < n;
+    const int v = pix/ws, u = pix - v*ws;
+    const int ur = min(u + 1, ws - 1), vb = min(v + 1, hs - 1);
+    const float dc = d[pix], dr = d[v*ws + ur], db = d[vb*ws + u];
+    float wx = 1.f, wy = 1.f;
+    if (edges) {
+      float ic[3], ir[3], ib[3];
+      img_at(im, h, w, hs, ws, v, u, ic); img_at(im, h, w, hs, ws, v, ur, ir); img_at(im, h, w, hs, ws, vb, u, ib);
+      wx = __expf(-(fabsf(ic[0] - ir[0]) + fabsf(ic[1] - ir[1]) + fabsf(ic[2] - ir[2]))*(1.f/3.f));
+      wy = __expf(-(fabsf(ic[0] - ib[0]) + fabsf(ic[1] - ib[1]) + fabsf(ic[2] - ib[2]))*(1.f/3.f));
+    }
+    if (live) {
       if (ew) ew[pix] = make_float2(wx, wy);       // kept for the adjoint: it then never touches the image
-      accE += gx*wx + gy*wy;
+      accD += dc;
+      accE += fabsf(dc - dr)*wx + fabsf(dc - db)*wy;
     }
   }
   const float totE = block_sum_256(accE, red);
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int
   for (int pair = wv; pair < sc.S*b; pair += 16) {
     const int s = pair/b;
     const int n = sc.hs[s]*sc.ws[s];
-    const int chunks = (n + kSmoothChunk - 1)/kSmoothChunk;
+    const int chunks = smooth_chunks_of(n);
     double e = 0.0, dsum = 0.0;
     for (int c = lane; c < chunks; c += 64) { e += (double)partial[((size_t)pair*max_chunks + c)*2]; dsum += (double)partial[((size_t)pair*max_chunks + c)*2 + 1]; }
 #pragma unroll
@@ -159,9 +158,8 @@ __global__ __launch_bounds__(256) void k_smooth_aux(const ScaleSet sc, int b, co
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st) {
-  int maxpix = 0;
-  for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
-  const int max_chunks = ceil_div(maxpix, kSmoothChunk);
+  int max_chunks = 1;
+  for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_chunks_of(sc.hs[s]*sc.ws[s]));
   hipLaunchKernelGGL(k_smooth_main, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks, edge_w);
   hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
   if (disp_grad || image_grad)
@@ -182,13 +180,13 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
   const bool edges = flags & SMD_USE_EDGES;
   const float gs = g_loss[0]*exp2f(-(float)sc.key[s])/((float)sc.S*(float)b*(float)n);
   const float mean_term = (mean >= kEps32) ? E*inv_m/(float)n : 0.f;
-  if ((int)blockIdx.x*kSmoothChunk >= n) return;
+  const int cpx = smooth_chunk_px(n), ppt = cpx/256;
+  if ((int)blockIdx.x*cpx >= n) return;
   if (edges && edge_w) {   // weights cached by the forward sweep: 4 weight + 5 disparity loads per pixel, no image access, no exp
     const float2* __restrict__ ew = (const float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n;
     auto sg = [](float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); };
-#pragma unroll
-    for (int kk = 0; kk < kSmoothChunk/256; ++kk) {
-      const int pix = blockIdx.x*kSmoothChunk + kk*256 + threadIdx.x;
+    for (int kk = 0; kk < ppt; ++kk) {
+      const int pix = blockIdx.x*cpx + kk*256 + threadIdx.x;
       if (pix >= n) continue;
       const int v = pix/ws, u = pix - v*ws;
       const float dc = d[pix]*inv_m;
@@ -202,9 +200,8 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
     }
     return;
   }
-#pragma unroll
-  for (int kk = 0; kk < kSmoothChunk/256; ++kk) {
-    const int pix = blockIdx.x*kSmoothChunk + kk*256 + threadIdx.x;
+  for (int kk = 0; kk < ppt; ++kk) {
+    const int pix = blockIdx.x*cpx + kk*256 + threadIdx.x;
     if (pix >= n) continue;
     const int v = pix/ws, u = pix - v*ws;
     const float dc = d[pix]*inv_m;
@@ -241,9 +238,9 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
 
 hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
                              const float* g_loss, const float* edge_w, hipStream_t st) {
-  int maxpix = 0;
-  for (int s = 0; s < sc.S; ++s) maxpix = max(maxpix, sc.hs[s]*sc.ws[s]);
-  hipLaunchKernelGGL(k_smooth_bwd, dim3(ceil_div(maxpix, kSmoothChunk), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, g_loss, edge_w);
+  int max_chunks = 1;
+  for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_chunks_of(sc.hs[s]*sc.ws[s]));
+  hipLaunchKernelGGL(k_smooth_bwd, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, g_loss, edge_w);
   return hipGetLastError();
 }
 
