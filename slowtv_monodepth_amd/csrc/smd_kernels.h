@@ -165,13 +165,16 @@ hipError_t launch_intrinsics_bwd(const float* fs, const float* cs, int b, int h,
 
 
 
-// Rows per strip: enough strips to give every SIMD several waves, few enough that the halo rows stay cheap.
+// Rows per strip.  More, shorter waves than fit at once balance better than one resident round (the waves of a round do
+// not finish together), and the forward kernel gains from short strips even though each pays two halo rows.  Measured
+// (scripts/dev/microbench.py, rh sweep 4..64): cfg 2 forward 93 -> 87 us, backward 221 -> 203 us; cfg 4 forward 229 -> 188 us,
+// backward 422 -> 397 us; cfg 5 forward 513 -> 430 us.  Rule: about 8k waves; the forward never longer than 16 rows.
 inline int pick_rows_per_strip(int b, int S, int h, int w, int cols, int halo) {
   const int nsx = ceil_div(w, cols);
-  // 256 CUs x 4 SIMDs x ~4-5 resident waves; measured optimum on cfg 2 (scripts/dev/microbench.py): fwd rh=24, bwd rh=20
-  const long target_waves = (cols == kFwdCols) ? 1024L*4 : 1024L*5;
+  const long target_waves = 8192;
+  const int rh_max = (cols == kFwdCols) ? 16 : 64;
   int best = 8;
-  for (int rh = 64; rh >= 8; rh -= 4) {
+  for (int rh = rh_max; rh >= 8; rh -= 4) {
     long waves = (long)nsx*ceil_div(h, rh)*b*S;
     best = rh;
     if (waves >= target_waves) break;
