@@ -12,7 +12,10 @@ namespace smd {
 // side are halo (their stencil results are incomplete), so a strip advances by 62 / 60 columns.
 constexpr int kFwdCols = 62;
 constexpr int kBwdCols = 60;
-constexpr int kWavesPerBlock = 4;
+#ifndef SMD_WAVES_PER_BLOCK
+#define SMD_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = SMD_WAVES_PER_BLOCK;
 #ifndef SMD_SMOOTH_CHUNK
 #define SMD_SMOOTH_CHUNK 1024
 #endif

@@ -65,7 +65,7 @@ struct BwdPending {   // loads in flight for the next row
 // selection / automask regions (any partly trained network) make 2 the fastest (-20 % at the microbenchmark's poses);
 // on noise-like masks (random initialisation) the branches cost ~5 %.
 template <int SKIP>
-__global__ __launch_bounds__(256) void k_recon_bwd(const ReconBwdArgs a) {
+__global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nstrips = a.nsx*a.nsy;

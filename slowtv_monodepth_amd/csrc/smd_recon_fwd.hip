@@ -286,10 +286,10 @@ __device__ __forceinline__ void recon_fwd_body(const ReconFwdArgs& a) {
 }
 
 template <int NI, bool WARP, bool SSIM, bool SINGLE>
-__global__ __launch_bounds__(256) void k_recon_fwd(const ReconFwdArgs a) { recon_fwd_body<NI, WARP, SSIM, SINGLE>(a); }
+__global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_fwd(const ReconFwdArgs a) { recon_fwd_body<NI, WARP, SSIM, SINGLE>(a); }
 
 // Same body for the headline configuration with the register budget capped at 128 (4 waves per SIMD).
-__global__ __launch_bounds__(256, 5) void k_recon_fwd_w4(const ReconFwdArgs a) { recon_fwd_body<2, true, true, true>(a); }
+__global__ __launch_bounds__(64*kWavesPerBlock, 5) void k_recon_fwd_w4(const ReconFwdArgs a) { recon_fwd_body<2, true, true, true>(a); }
 
 hipError_t launch_recon_fwd(const ReconFwdArgs& a, int ni, bool warp, hipStream_t st) {
   dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b, a.S)), block(64*kWavesPerBlock);
