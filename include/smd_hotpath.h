@@ -213,12 +213,13 @@ int smd_dwconv7x7_wrw(const float* x, const float* g_y, float* g_weight, float* 
 
 /* smd_layernorm_cf_*: LayerNorm over the channel dimension of an NCHW tensor, i.e. timm's `LayerNorm2d` and the block norm
  * of ConvNeXt evaluated without the NCHW <-> NHWC permutes (`F.layer_norm(x.permute(0,2,3,1), (C,), gamma, beta, eps)`).
- * x, y (N,C,H,W) with HW = H*W; gamma, beta (C); mean, rstd (N*HW) kept for the backward.
- * Backward: g_y -> g_x, g_gamma, g_beta. */
+ * x, y (N,C,H,W) with HW = H*W; gamma, beta (C); mean, rstd (N*HW) kept for the backward.  y may be written as bfloat16
+ * (y_is_bf16 != 0) and g_y read as bfloat16 (g_y_is_bf16 != 0) when the consumer is a bf16 convolution under autocast;
+ * the arithmetic is fp32 either way.  Backward: g_y -> g_x, g_gamma, g_beta (fp32). */
 size_t smd_layernorm_cf_workspace_bytes(int N, int C, int HW);
-int smd_layernorm_cf_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+int smd_layernorm_cf_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_is_bf16, float* mean, float* rstd,
                          int N, int C, int HW, float eps, void* stream);
-int smd_layernorm_cf_bwd(const float* x, const float* g_y, const float* gamma, const float* mean, const float* rstd,
+int smd_layernorm_cf_bwd(const float* x, const void* g_y, int g_y_is_bf16, const float* gamma, const float* mean, const float* rstd,
                          float* g_x, float* g_gamma, float* g_beta, void* workspace, size_t workspace_bytes, int N, int C, int HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

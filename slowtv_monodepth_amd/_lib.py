@@ -66,8 +66,8 @@ PROTOTYPES = {
     'smd_dwconv7x7_fwd': (_i, [_vp]*4 + [_i]*5 + [_vp]),
     'smd_dwconv7x7_wrw': (_i, [_vp]*5 + [_sz] + [_i]*4 + [_vp]),
     'smd_layernorm_cf_workspace_bytes': (_sz, [_i]*3),
-    'smd_layernorm_cf_fwd': (_i, [_vp]*6 + [_i]*3 + [_f, _vp]),
-    'smd_layernorm_cf_bwd': (_i, [_vp]*9 + [_sz] + [_i]*3 + [_vp]),
+    'smd_layernorm_cf_fwd': (_i, [_vp]*4 + [_i] + [_vp]*2 + [_i]*3 + [_f, _vp]),
+    'smd_layernorm_cf_bwd': (_i, [_vp]*2 + [_i] + [_vp]*7 + [_sz] + [_i]*3 + [_vp]),
     'smd_pose_fwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     'smd_pose_bwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'smd_intrinsics_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -459,18 +459,18 @@ size_t smd_layernorm_cf_workspace_bytes(int N, int C, int HW) {
   if (N < 1 || C < 1 || HW < 1) return 0;
   return align256((size_t)smd::ln_cf_chunks((size_t)N*HW)*C*2*sizeof(float));
 }
-int smd_layernorm_cf_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int N, int C, int HW, float eps,
-                         void* stream) {
+int smd_layernorm_cf_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_is_bf16, float* mean, float* rstd, int N, int C, int HW,
+                         float eps, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd) return fail(SMD_E_INVALID, "null pointer");
   if (N < 1 || C < 1 || HW < 1 || (long long)N*HW >= (1ll << 38)) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d HW=%d", N, C, HW);
-  return check_launch(smd::launch_ln_cf_fwd(x, gamma, beta, y, mean, rstd, N, C, HW, eps, (hipStream_t)stream), "layernorm_cf_fwd");
+  return check_launch(smd::launch_ln_cf_fwd(x, gamma, beta, y, y_is_bf16, mean, rstd, N, C, HW, eps, (hipStream_t)stream), "layernorm_cf_fwd");
 }
-int smd_layernorm_cf_bwd(const float* x, const float* g_y, const float* gamma, const float* mean, const float* rstd, float* g_x, float* g_gamma,
+int smd_layernorm_cf_bwd(const float* x, const void* g_y, int g_y_is_bf16, const float* gamma, const float* mean, const float* rstd, float* g_x, float* g_gamma,
                          float* g_beta, void* workspace, size_t workspace_bytes, int N, int C, int HW, void* stream) {
   if (!x || !g_y || !gamma || !mean || !rstd || !g_x || !g_gamma || !g_beta || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (N < 1 || C < 1 || C > 32767 || HW < 1) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d HW=%d", N, C, HW);
   if (workspace_bytes < smd_layernorm_cf_workspace_bytes(N, C, HW)) return fail(SMD_E_WORKSPACE, "workspace too small");
-  return check_launch(smd::launch_ln_cf_bwd(x, g_y, gamma, mean, rstd, g_x, g_gamma, g_beta, (float*)workspace, N, C, HW, (hipStream_t)stream),
+  return check_launch(smd::launch_ln_cf_bwd(x, g_y, g_y_is_bf16, gamma, mean, rstd, g_x, g_gamma, g_beta, (float*)workspace, N, C, HW, (hipStream_t)stream),
                       "layernorm_cf_bwd");
 }
 

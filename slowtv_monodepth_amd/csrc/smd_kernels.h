@@ -151,9 +151,9 @@ int dwconv_tiles(int H, int W);
 hipError_t launch_dwconv7(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int flip, hipStream_t st);
 hipError_t launch_dwconv7_wrw(const float* x, const float* gy, float* gw, float* gb, float* ws, int N, int C, int H, int W, hipStream_t st);
 int ln_cf_chunks(size_t npix);
-hipError_t launch_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int N, int C, int HW, float eps,
-                            hipStream_t st);
-hipError_t launch_ln_cf_bwd(const float* x, const float* g_y, const float* gamma, const float* mean, const float* rstd, float* g_x, float* g_gamma,
+hipError_t launch_ln_cf_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, float* mean, float* rstd, int N, int C, int HW,
+                            float eps, hipStream_t st);
+hipError_t launch_ln_cf_bwd(const float* x, const void* g_y, int g_bf16, const float* gamma, const float* mean, const float* rstd, float* g_x, float* g_gamma,
                             float* g_beta, float* ws, int N, int C, int HW, hipStream_t st);
 int regr_blocks(size_t N);
 hipError_t launch_regression_fwd(const float* pred, const float* target, const uint8_t* mask, size_t N, int flags, float* loss, float* err,

@@ -12,7 +12,18 @@
 #include "smd_common.h"
 #include "smd_kernels.h"
 
+#include <hip/hip_bf16.h>
+
 namespace smd {
+
+// The normalised output feeds a bf16 1x1 convolution under autocast and its gradient arrives in bf16: writing / reading those
+// two tensors in bf16 directly removes a full-tensor cast kernel per block and direction.  Arithmetic stays fp32.
+template <typename T> __device__ __forceinline__ float ld_as_float(const T* p, size_t i);
+template <> __device__ __forceinline__ float ld_as_float<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_as_float<__hip_bfloat16>(const __hip_bfloat16* p, size_t i) { return __bfloat162float(p[i]); }
+template <typename T> __device__ __forceinline__ void st_from_float(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void st_from_float<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st_from_float<__hip_bfloat16>(__hip_bfloat16* p, size_t i, float v) { p[i] = __float2bfloat16(v); }
 
 constexpr int kLnWaves = 4;                 // waves of a block share 64 pixels and split the channels
 constexpr int kLnBlock = 64*kLnWaves;
@@ -29,8 +40,9 @@ __device__ __forceinline__ void combine_waves(float& a, float& b, float (*red)[6
   for (int k = 0; k < kLnWaves; ++k) { a += red[k][lane][0]; b += red[k][lane][1]; }
 }
 
+template <typename TY>
 __global__ __launch_bounds__(kLnBlock) void k_ln_cf_fwd(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                        TY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                         int C, int HW, size_t npix, float eps) {
   __shared__ float red[kLnWaves][64][2];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -47,12 +59,13 @@ __global__ __launch_bounds__(kLnBlock) void k_ln_cf_fwd(const float* __restrict_
   const float mu = shift + m1, rs = rsqrtf(var + eps);
   if (!ok) return;
   if (wv == 0) { mean[pix] = mu; rstd[pix] = rs; }
-  float* __restrict__ yp = y + n*(size_t)C*HW + p;
-  for (int c = wv; c < C; c += kLnWaves) yp[(size_t)c*HW] = fmaf((xp[(size_t)c*HW] - mu)*rs, gamma[c], beta[c]);
+  TY* __restrict__ yp = y + n*(size_t)C*HW + p;
+  for (int c = wv; c < C; c += kLnWaves) st_from_float<TY>(yp, (size_t)c*HW, fmaf((xp[(size_t)c*HW] - mu)*rs, gamma[c], beta[c]));
 }
 
 // dx: per pixel a = sum_c g*gamma, b = sum_c g*gamma*xhat;  dx = rstd*(g*gamma - (a + xhat*b)/C).
-__global__ __launch_bounds__(kLnBlock) void k_ln_cf_bwd_dx(const float* __restrict__ x, const float* __restrict__ g_y, const float* __restrict__ gamma,
+template <typename TG>
+__global__ __launch_bounds__(kLnBlock) void k_ln_cf_bwd_dx(const float* __restrict__ x, const TG* __restrict__ g_y, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            float* __restrict__ g_x, int C, int HW, size_t npix) {
   __shared__ float red[kLnWaves][64][2];
@@ -61,11 +74,11 @@ __global__ __launch_bounds__(kLnBlock) void k_ln_cf_bwd_dx(const float* __restri
   const bool ok = pix < npix;
   const size_t q = ok ? pix : 0, n = q/HW, p = q - n*HW;
   const float* __restrict__ xp = x + n*(size_t)C*HW + p;
-  const float* __restrict__ gp = g_y + n*(size_t)C*HW + p;
+  const TG* __restrict__ gp = g_y + n*(size_t)C*HW + p;
   const float mu = mean[q], rs = rstd[q];
   float a = 0.f, b = 0.f;
   for (int c = wv; c < C; c += kLnWaves) {
-    const float g = gp[(size_t)c*HW]*gamma[c];
+    const float g = ld_as_float<TG>(gp, (size_t)c*HW)*gamma[c];
     a += g; b = fmaf(g, (xp[(size_t)c*HW] - mu)*rs, b);
   }
   combine_waves(a, b, red);
@@ -74,12 +87,13 @@ __global__ __launch_bounds__(kLnBlock) void k_ln_cf_bwd_dx(const float* __restri
   float* __restrict__ dp = g_x + n*(size_t)C*HW + p;
   for (int c = wv; c < C; c += kLnWaves) {
     const float xh = (xp[(size_t)c*HW] - mu)*rs;
-    dp[(size_t)c*HW] = rs*(gp[(size_t)c*HW]*gamma[c] - rc*(a + xh*b));
+    dp[(size_t)c*HW] = rs*(ld_as_float<TG>(gp, (size_t)c*HW)*gamma[c] - rc*(a + xh*b));
   }
 }
 
 // d gamma / d beta: per channel sums over all pixels of g*xhat and g — the BatchNorm-style reduction (grid (chunks, C)).
-__global__ __launch_bounds__(256) void k_ln_cf_bwd_wb(const float* __restrict__ x, const float* __restrict__ g_y, const float* __restrict__ mean,
+template <typename TG>
+__global__ __launch_bounds__(256) void k_ln_cf_bwd_wb(const float* __restrict__ x, const TG* __restrict__ g_y, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, int N, int C, int HW, int chunks, float* __restrict__ partial) {
   __shared__ float red[8];
   const int c = blockIdx.y, k = blockIdx.x;
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(256) void k_ln_cf_bwd_wb(const float* __restrict__ 
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const long long n = i/HW, p = i - n*HW;
     const size_t off = ((size_t)n*C + c)*HW + p;
-    const float g = g_y[off];
+    const float g = ld_as_float<TG>(g_y, off);
     s1 = fmaf(g, (x[off] - mean[i])*rstd[i], s1); s2 += g;
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -112,18 +126,26 @@ int ln_cf_chunks(size_t npix) {
   return (int)(c < 1 ? 1 : (c > (size_t)kLnMaxChunks ? kLnMaxChunks : c));
 }
 
-hipError_t launch_ln_cf_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int N, int C, int HW, float eps,
-                            hipStream_t st) {
+hipError_t launch_ln_cf_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, float* mean, float* rstd, int N, int C, int HW,
+                            float eps, hipStream_t st) {
   const size_t npix = (size_t)N*HW;
-  hipLaunchKernelGGL(k_ln_cf_fwd, dim3((unsigned)((npix + 63)/64)), dim3(kLnBlock), 0, st, x, gamma, beta, y, mean, rstd, C, HW, npix, eps);
+  const dim3 grid((unsigned)((npix + 63)/64));
+  if (y_bf16) hipLaunchKernelGGL(k_ln_cf_fwd<__hip_bfloat16>, grid, dim3(kLnBlock), 0, st, x, gamma, beta, (__hip_bfloat16*)y, mean, rstd, C, HW, npix, eps);
+  else hipLaunchKernelGGL(k_ln_cf_fwd<float>, grid, dim3(kLnBlock), 0, st, x, gamma, beta, (float*)y, mean, rstd, C, HW, npix, eps);
   return hipGetLastError();
 }
-hipError_t launch_ln_cf_bwd(const float* x, const float* g_y, const float* gamma, const float* mean, const float* rstd, float* g_x, float* g_gamma,
+hipError_t launch_ln_cf_bwd(const float* x, const void* g_y, int g_bf16, const float* gamma, const float* mean, const float* rstd, float* g_x, float* g_gamma,
                             float* g_beta, float* ws, int N, int C, int HW, hipStream_t st) {
   const size_t npix = (size_t)N*HW;
   const int chunks = ln_cf_chunks(npix);
-  hipLaunchKernelGGL(k_ln_cf_bwd_dx, dim3((unsigned)((npix + 63)/64)), dim3(kLnBlock), 0, st, x, g_y, gamma, mean, rstd, g_x, C, HW, npix);
-  hipLaunchKernelGGL(k_ln_cf_bwd_wb, dim3(chunks, C), dim3(256), 0, st, x, g_y, mean, rstd, N, C, HW, chunks, ws);
+  const dim3 grid((unsigned)((npix + 63)/64));
+  if (g_bf16) {
+    hipLaunchKernelGGL(k_ln_cf_bwd_dx<__hip_bfloat16>, grid, dim3(kLnBlock), 0, st, x, (const __hip_bfloat16*)g_y, gamma, mean, rstd, g_x, C, HW, npix);
+    hipLaunchKernelGGL(k_ln_cf_bwd_wb<__hip_bfloat16>, dim3(chunks, C), dim3(256), 0, st, x, (const __hip_bfloat16*)g_y, mean, rstd, N, C, HW, chunks, ws);
+  } else {
+    hipLaunchKernelGGL(k_ln_cf_bwd_dx<float>, grid, dim3(kLnBlock), 0, st, x, (const float*)g_y, gamma, mean, rstd, g_x, C, HW, npix);
+    hipLaunchKernelGGL(k_ln_cf_bwd_wb<float>, dim3(chunks, C), dim3(256), 0, st, x, (const float*)g_y, mean, rstd, N, C, HW, chunks, ws);
+  }
   hipLaunchKernelGGL(k_ln_cf_bwd_finalize, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, chunks, C, g_gamma, g_beta);
   return hipGetLastError();
 }

@@ -531,15 +531,15 @@ class _LayerNormCF(torch.autograd.Function):
     """LayerNorm over the channel dimension of an NCHW tensor (`smd_layernorm_cf_*`)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, out_bf16):
         x = _check('x', x)
         if x.ndim != 4: raise ValueError(f'expected (N,C,H,W), got {tuple(x.shape)}')
         N, C, H, W = x.shape
         weight = _check('weight', weight, (C,)); bias = _check('bias', bias, (C,))
-        y = torch.empty_like(x)
+        y = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32)
         stats = torch.empty((2, N*H*W), device=x.device, dtype=torch.float32)
-        call('smd_layernorm_cf_fwd', x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-             N, C, H*W, float(eps), _stream())
+        call('smd_layernorm_cf_fwd', x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), int(out_bf16), stats[0].data_ptr(),
+             stats[1].data_ptr(), N, C, H*W, float(eps), _stream())
         ctx.save_for_backward(x, weight, stats)
         return y
 
@@ -547,17 +547,21 @@ class _LayerNormCF(torch.autograd.Function):
     def backward(ctx, g_y):
         x, weight, stats = ctx.saved_tensors
         N, C, H, W = x.shape
+        if g_y.dtype not in (torch.float32, torch.bfloat16): g_y = g_y.float()
+        g_y = g_y.contiguous()
         g_x = torch.empty_like(x); g_w = torch.empty_like(weight); g_b = torch.empty_like(weight)
         nbytes = _lib.lib.smd_layernorm_cf_workspace_bytes(N, C, H*W)
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-        call('smd_layernorm_cf_bwd', x.data_ptr(), g_y.contiguous().data_ptr(), weight.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-             g_x.data_ptr(), g_w.data_ptr(), g_b.data_ptr(), ws.data_ptr(), nbytes, N, C, H*W, _stream())
-        return g_x, g_w, g_b, None
+        call('smd_layernorm_cf_bwd', x.data_ptr(), g_y.data_ptr(), int(g_y.dtype == torch.bfloat16), weight.data_ptr(), stats[0].data_ptr(),
+             stats[1].data_ptr(), g_x.data_ptr(), g_w.data_ptr(), g_b.data_ptr(), ws.data_ptr(), nbytes, N, C, H*W, _stream())
+        return g_x, g_w, g_b, None, None
 
 
-def layer_norm_cf(x, weight, bias, eps: float = 1e-6):
-    """`F.layer_norm(x.permute(0,2,3,1), (C,), weight, bias, eps).permute(0,3,1,2)` without the permutes."""
-    return _LayerNormCF.apply(x, weight, bias, eps)
+def layer_norm_cf(x, weight, bias, eps: float = 1e-6, out_dtype=torch.float32):
+    """`F.layer_norm(x.permute(0,2,3,1), (C,), weight, bias, eps).permute(0,3,1,2)` without the permutes.  `out_dtype=bfloat16`
+    writes the result (and reads its gradient) in bf16 for a bf16 consumer; the arithmetic is fp32."""
+    if out_dtype not in (torch.float32, torch.bfloat16): raise TypeError(f'out_dtype must be float32 or bfloat16, got {out_dtype}')
+    return _LayerNormCF.apply(x, weight, bias, eps, out_dtype == torch.bfloat16)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -154,9 +154,11 @@ class ConvNeXtBlock(nn.Module):
         and channel LayerNorm as HIP kernels in fp32 (autocast runs layer_norm in fp32 anyway), the MLP as two 1x1
         convolutions on views of the Linear weights, layer scale + residual as one addcmul.  No layout copies."""
         from .. import functional as HF
+        to_bf16 = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16   # the 1x1 convolution will run in bf16
         with torch.autocast('cuda', enabled=False):
             y = HF.dwconv7x7(x.float().contiguous(), self.dw.weight.float(), self.dw.bias.float())
-            y = HF.layer_norm_cf(y, self.norm.weight.float(), self.norm.bias.float(), self.norm.eps)
+            y = HF.layer_norm_cf(y, self.norm.weight.float(), self.norm.bias.float(), self.norm.eps,
+                                 out_dtype=torch.bfloat16 if to_bf16 else torch.float32)
         y = F.conv2d(y, self.fc1.weight[:, :, None, None], self.fc1.bias)
         y = F.conv2d(F.gelu(y), self.fc2.weight[:, :, None, None], self.fc2.bias)
         return torch.addcmul(x, y, self.gamma.view(1, -1, 1, 1).to(y.dtype))

@@ -728,3 +728,19 @@ def test_training_cli_runs_and_the_loss_decreases(tmp_path, capsys):
     losses = [float(l.split('loss ')[1].split()[0]) for l in out.splitlines() if l.startswith('epoch')]
     assert len(losses) == 2 and all(l == l for l in losses) and losses[1] < losses[0]
     assert (tmp_path/'cli'/'000'/'last.ckpt').is_file()
+
+
+def test_channel_layer_norm_bf16_io(F):
+    """bf16 output / bf16 incoming gradient (autocast consumer): same fp32 arithmetic, rounded once at the boundary."""
+    gen = torch.Generator().manual_seed(33)
+    x = torch.randn(2, 48, 9, 11, generator=gen).cuda(); w = (torch.rand(48, generator=gen) + 0.5).cuda(); b = torch.randn(48, generator=gen).cuda()
+    g = torch.randn(2, 48, 9, 11, generator=gen).cuda()
+    res = []
+    for dt in (torch.float32, torch.bfloat16):
+        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = F.layer_norm_cf(xx, ww, bb, 1e-6, out_dtype=dt)
+        assert y.dtype == dt
+        y.backward(g.to(dt))
+        res.append((y.float(), xx.grad, ww.grad, bb.grad))
+    assert rel_to_max(res[1][0], res[0][0]) < 1e-2     # bf16 rounding of the output
+    for a, e in zip(res[1][1:], res[0][1:]): assert rel_to_max(a, e) < 2e-2   # gradient was rounded to bf16 on the way in
