@@ -67,3 +67,13 @@ def test_two_ranks_on_one_gpu_stay_identical_and_overlap_equals_deferred(tmp_pat
     # differences move a parameter by up to 2*lr per step, hence the loose bound (4 steps at lr 1e-4 against |p| ~ 1).
     assert ((out[True]['params'] - out[False]['params']).abs().max()/out[False]['params'].abs().max()).item() < 2e-3
     torch.testing.assert_close(torch.tensor(out[True]['losses']), torch.tensor(out[False]['losses']), rtol=2e-2, atol=1e-4)
+
+
+def test_four_ranks_on_one_gpu(tmp_path):
+    """Same path at world size 4 (ordering agreement and broadcast with more than two ranks)."""
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    res = [torch.load(tmp_path/f'ov1_rank{r}.pt') for r in range(world)]
+    assert all(r['params_equal'] for r in res), 'replicas diverged'
+    assert len({tuple(r['order']) for r in res}) == 1, 'ranks disagree on the collective order'
+    assert len({tuple(r['losses']) for r in res}) == world, 'ranks must see different shards'
