@@ -157,10 +157,11 @@ def wrap_ddp(step: StepModule, device: torch.device, bucket_cap_mb: int = 25) ->
                                                bucket_cap_mb=bucket_cap_mb)  # (static_graph would forbid no_sync() on the first micro-step)
 
 
-def train_steps(model: nn.Module, opt: torch.optim.Optimizer, batch_fn, steps: int, accumulate: int = 1, clip=None):
+def train_steps(model: nn.Module, opt: torch.optim.Optimizer, batch_fn, steps: int, accumulate: int = 1, clip=None, detect_anomaly: bool = False):
     """Run `steps` optimizer micro-steps (each = forward + backward on one batch; the optimizer fires every `accumulate`).
     LR schedulers step per epoch in the reference (Lightning's default interval), so they are the caller's business.
-    Returns the list of (detached) loss tensors; nothing in here synchronises with the host."""
+    Returns the list of (detached) loss tensors; nothing in here synchronises with the host unless `detect_anomaly` is set, which
+    mirrors the reference's `DetectAnomaly` callback (src/utils/callbacks.py:27-31): raise on a non-finite loss, every batch."""
     losses = []
     ddp = isinstance(model, nn.parallel.DistributedDataParallel)
     flat = isinstance(model, FlatAllReduce)
@@ -170,6 +171,7 @@ def train_steps(model: nn.Module, opt: torch.optim.Optimizer, batch_fn, steps: i
         if flat: model.require_sync = boundary
         with ctx:
             loss, _ = model(batch_fn(it))
+            if detect_anomaly and not torch.isfinite(loss).item(): raise ValueError(f'Detected NaN/Infinite loss: "{loss.item()}"')
             (loss/accumulate).backward()
         if boundary:
             if flat: model.sync_gradients()
@@ -211,7 +213,8 @@ def main(argv=None):
     if rank == 0: save_dir.mkdir(parents=True, exist_ok=True)
     for epoch in range(tcfg.get('max_epochs', 1)):
         t0 = time.time()
-        losses = train_steps(model, opt, lambda it: batch, args.steps, accumulate=acc, clip=tcfg.get('gradient_clip_val'))
+        losses = train_steps(model, opt, lambda it: batch, args.steps, accumulate=acc, clip=tcfg.get('gradient_clip_val'),
+                             detect_anomaly=bool(tcfg.get('detect_anomaly', False)))
         if sched is not None: sched.step()
         last = losses[-1].item()
         if rank == 0:
