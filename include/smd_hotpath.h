@@ -172,14 +172,20 @@ int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_w
  *                       (bias-free) conv output, bias (C) or NULL.
  * smd_elu_up_cat_pad_*: out (B,Ca+Cs,2h+2,2w+2) = reflect_pad1(cat(nearest_x2(elu(a + bias)), skip)),  a (B,Ca,h,w),
  *                       bias (Ca) or NULL, skip (B,Cs,2h,2w) or NULL with Cs = 0.
- * Backward: g_out -> g_x / (g_a, g_skip) and g_bias (C) or NULL (needs the workspace); g_a or g_skip may be NULL. */
+ * Backward: g_out -> g_x / (g_a, g_skip) and g_bias (C) or NULL (needs the workspace); g_a or g_skip may be NULL.
+ * dtypes: bit 0 (SMD_GLUE_A_BF16) x / a and their gradients are bfloat16, bit 1 (SMD_GLUE_SKIP_BF16) skip and its gradient,
+ * bit 2 (SMD_GLUE_OUT_BF16) out and its gradient — for decoders running under bf16 autocast; bias, g_bias and the arithmetic are fp32. */
+#define SMD_GLUE_A_BF16 1
+#define SMD_GLUE_SKIP_BF16 2
+#define SMD_GLUE_OUT_BF16 4
 size_t smd_decoder_glue_workspace_bytes(int B, int C, int h, int w);
-int smd_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int h, int w, int apply_elu, void* stream);
-int smd_elu_pad_bwd(const float* x, const float* bias, const float* g_out, float* g_x, float* g_bias,
-                    void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int apply_elu, void* stream);
-int smd_elu_up_cat_pad_fwd(const float* a, const float* bias, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, void* stream);
-int smd_elu_up_cat_pad_bwd(const float* a, const float* bias, const float* g_out, float* g_a, float* g_skip, float* g_bias,
-                           void* workspace, size_t workspace_bytes, int B, int Ca, int Cs, int h, int w, void* stream);
+int smd_elu_pad_fwd(const void* x, const float* bias, void* out, int B, int C, int h, int w, int apply_elu, int dtypes, void* stream);
+int smd_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g_x, float* g_bias,
+                    void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int apply_elu, int dtypes, void* stream);
+int smd_elu_up_cat_pad_fwd(const void* a, const float* bias, const void* skip, void* out, int B, int Ca, int Cs, int h, int w, int dtypes,
+                           void* stream);
+int smd_elu_up_cat_pad_bwd(const void* a, const float* bias, const void* g_out, void* g_a, void* g_skip, float* g_bias,
+                           void* workspace, size_t workspace_bytes, int B, int Ca, int Cs, int h, int w, int dtypes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Producer side of the path: training-mode BatchNorm2d of the ResNet encoders fused with the residual add and ReLU

@@ -53,10 +53,10 @@ PROTOTYPES = {
     'smd_recon_reduce_fwd': (_i, [_vp]*3 + [_u64] + [_vp]*4 + [_sz] + [_i]*5 + [_vp]),
     'smd_recon_reduce_bwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
     'smd_decoder_glue_workspace_bytes': (_sz, [_i]*4),
-    'smd_elu_pad_fwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
-    'smd_elu_pad_bwd': (_i, [_vp]*6 + [_sz] + [_i]*5 + [_vp]),
-    'smd_elu_up_cat_pad_fwd': (_i, [_vp]*4 + [_i]*5 + [_vp]),
-    'smd_elu_up_cat_pad_bwd': (_i, [_vp]*7 + [_sz] + [_i]*5 + [_vp]),
+    'smd_elu_pad_fwd': (_i, [_vp]*3 + [_i]*6 + [_vp]),
+    'smd_elu_pad_bwd': (_i, [_vp]*6 + [_sz] + [_i]*6 + [_vp]),
+    'smd_elu_up_cat_pad_fwd': (_i, [_vp]*4 + [_i]*6 + [_vp]),
+    'smd_elu_up_cat_pad_bwd': (_i, [_vp]*7 + [_sz] + [_i]*6 + [_vp]),
     'smd_bn_workspace_bytes': (_sz, [_i, _i, _i]),
     'smd_bn_fwd': (_i, [_vp]*6 + [_f, _f, _i] + [_vp]*4 + [_sz] + [_i]*3 + [_vp]),
     'smd_bn_bwd': (_i, [_vp]*6 + [_i] + [_vp]*5 + [_sz] + [_i]*3 + [_vp]),

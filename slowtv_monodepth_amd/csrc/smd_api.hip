@@ -366,31 +366,31 @@ size_t smd_decoder_glue_workspace_bytes(int B, int C, int h, int w) {
   if (B < 1 || C < 1 || h < 1 || w < 1) return 0;
   return align256(smd::decoder_bias_partials(B, C, h, w)*sizeof(float));
 }
-int smd_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int h, int w, int apply_elu, void* stream) {
+int smd_elu_pad_fwd(const void* x, const float* bias, void* out, int B, int C, int h, int w, int apply_elu, int dtypes, void* stream) {
   if (!x || !out) return fail(SMD_E_INVALID, "null pointer");
   if (B < 1 || C < 1 || !dec_sizes_ok((long long)B*C, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
-  return check_launch(smd::launch_elu_pad_fwd(x, bias, out, B, C, h, w, apply_elu, (hipStream_t)stream), "elu_pad_fwd");
+  return check_launch(smd::launch_elu_pad_fwd(x, bias, out, B, C, h, w, apply_elu, dtypes, (hipStream_t)stream), "elu_pad_fwd");
 }
-int smd_elu_pad_bwd(const float* x, const float* bias, const float* g_out, float* g_x, float* g_bias, void* workspace, size_t workspace_bytes,
-                    int B, int C, int h, int w, int apply_elu, void* stream) {
+int smd_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g_x, float* g_bias, void* workspace, size_t workspace_bytes,
+                    int B, int C, int h, int w, int apply_elu, int dtypes, void* stream) {
   if (!x || !g_out || !g_x || (g_bias && !workspace)) return fail(SMD_E_INVALID, "null pointer");
   if (B < 1 || C < 1 || !dec_sizes_ok((long long)B*C, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
   if (g_bias && workspace_bytes < smd_decoder_glue_workspace_bytes(B, C, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
-  return check_launch(smd::launch_elu_pad_bwd(x, bias, g_out, g_x, g_bias, (float*)workspace, B, C, h, w, apply_elu, (hipStream_t)stream), "elu_pad_bwd");
+  return check_launch(smd::launch_elu_pad_bwd(x, bias, g_out, g_x, g_bias, (float*)workspace, B, C, h, w, apply_elu, dtypes, (hipStream_t)stream), "elu_pad_bwd");
 }
-int smd_elu_up_cat_pad_fwd(const float* a, const float* bias, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, void* stream) {
+int smd_elu_up_cat_pad_fwd(const void* a, const float* bias, const void* skip, void* out, int B, int Ca, int Cs, int h, int w, int dtypes, void* stream) {
   if (!a || !out || (Cs > 0 && !skip)) return fail(SMD_E_INVALID, "null pointer");
   if (B < 1 || Ca < 1 || Cs < 0 || h < 1 || w < 1 || !dec_sizes_ok((long long)B*(Ca + Cs), 2*h, 2*w))
     return fail(SMD_E_INVALID, "invalid sizes B=%d Ca=%d Cs=%d h=%d w=%d", B, Ca, Cs, h, w);
-  return check_launch(smd::launch_elu_up_cat_pad_fwd(a, bias, skip, out, B, Ca, Cs, h, w, (hipStream_t)stream), "elu_up_cat_pad_fwd");
+  return check_launch(smd::launch_elu_up_cat_pad_fwd(a, bias, skip, out, B, Ca, Cs, h, w, dtypes, (hipStream_t)stream), "elu_up_cat_pad_fwd");
 }
-int smd_elu_up_cat_pad_bwd(const float* a, const float* bias, const float* g_out, float* g_a, float* g_skip, float* g_bias,
-                           void* workspace, size_t workspace_bytes, int B, int Ca, int Cs, int h, int w, void* stream) {
+int smd_elu_up_cat_pad_bwd(const void* a, const float* bias, const void* g_out, void* g_a, void* g_skip, float* g_bias,
+                           void* workspace, size_t workspace_bytes, int B, int Ca, int Cs, int h, int w, int dtypes, void* stream) {
   if (!a || !g_out || (!g_a && !g_skip) || (g_bias && (!workspace || !g_a))) return fail(SMD_E_INVALID, "null pointer");
   if (B < 1 || Ca < 1 || Cs < 0 || h < 1 || w < 1 || !dec_sizes_ok((long long)B*(Ca + Cs), 2*h, 2*w))
     return fail(SMD_E_INVALID, "invalid sizes B=%d Ca=%d Cs=%d h=%d w=%d", B, Ca, Cs, h, w);
   if (g_bias && workspace_bytes < smd_decoder_glue_workspace_bytes(B, Ca, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
-  return check_launch(smd::launch_elu_up_cat_pad_bwd(a, bias, g_out, g_a, g_skip, g_bias, (float*)workspace, B, Ca, Cs, h, w, (hipStream_t)stream),
+  return check_launch(smd::launch_elu_up_cat_pad_bwd(a, bias, g_out, g_a, g_skip, g_bias, (float*)workspace, B, Ca, Cs, h, w, dtypes, (hipStream_t)stream),
                       "elu_up_cat_pad_bwd");
 }
 

@@ -8,7 +8,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <hip/hip_bf16.h>
+
 namespace smd {
+
+// Typed element access for kernels whose I/O tensors may be bf16 at an autocast boundary (arithmetic stays fp32).
+typedef __hip_bfloat16 bf16;
+template <typename T> __device__ __forceinline__ float ld_as_float(const T* p, size_t i);
+template <> __device__ __forceinline__ float ld_as_float<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_as_float<bf16>(const bf16* p, size_t i) { return __bfloat162float(p[i]); }
+template <typename T> __device__ __forceinline__ void st_from_float(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void st_from_float<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st_from_float<bf16>(bf16* p, size_t i, float v) { p[i] = __float2bfloat16(v); }
+
 
 constexpr float kEps32 = 1.1920929e-07f;  // torch.finfo(float32).eps  (src/tools/ops.py:63-66)
 constexpr float kC1 = 1e-4f;              // SSIM eps1 = 0.01^2        (src/losses/photometric.py:30)

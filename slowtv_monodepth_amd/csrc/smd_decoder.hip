@@ -44,7 +44,8 @@ __global__ __launch_bounds__(64) void k_bias_finalize(const float* __restrict__ 
 // border cell when r is the second / second-to-last element.
 #define SMD_PAD_ADJ_POS(r, n, p0, p1, p2) const int p0 = (r) + 1, p1 = ((r) == 1) ? 0 : -1, p2 = ((r) == (n) - 2) ? (n) + 1 : -1
 
-__global__ __launch_bounds__(kDecBlock) void k_elu_pad_fwd(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out, int C, int h, int w, int apply_elu,
+template <typename TA, typename TO>
+__global__ __launch_bounds__(kDecBlock) void k_elu_pad_fwd(const TA* __restrict__ x, const float* __restrict__ bias, TO* __restrict__ out, int C, int h, int w, int apply_elu,
                                                            unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
   const int H = h + 2, W = w + 2;
@@ -54,26 +55,27 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_pad_fwd(const float* __restri
     const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
     if (idx >= H*W) break;
     const int py = idx/W, px = idx - py*W;
-    const float v = x[(size_t)plane*h*w + unpad_reflect(py, h)*w + unpad_reflect(px, w)] + bc;
-    out[(size_t)plane*H*W + idx] = apply_elu ? elu1(v) : v;
+    const float v = ld_as_float<TA>(x, (size_t)plane*h*w + unpad_reflect(py, h)*w + unpad_reflect(px, w)) + bc;
+    st_from_float<TO>(out, (size_t)plane*H*W + idx, apply_elu ? elu1(v) : v);
   }
 }
 
-__global__ __launch_bounds__(kDecBlock) void k_elu_pad_bwd(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ g_out,
-                                                           float* __restrict__ g_x, float* __restrict__ bias_partial, int C, int h, int w, int apply_elu,
+template <typename TA, typename TO>
+__global__ __launch_bounds__(kDecBlock) void k_elu_pad_bwd(const TA* __restrict__ x, const float* __restrict__ bias, const TO* __restrict__ g_out,
+                                                           TA* __restrict__ g_x, float* __restrict__ bias_partial, int C, int h, int w, int apply_elu,
                                                            unsigned chunks) {
   __shared__ float red[kDecBlock/64];
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;
   const int W = w + 2;
   const float bc = bias ? bias[plane % C] : 0.f;
   float bsum = 0.f;
-  const float* g = g_out + (size_t)plane*(h + 2)*W;
+  const TO* g = g_out + (size_t)plane*(h + 2)*W;
 #pragma unroll
   for (int k = 0; k < kDecPerThread; ++k) {
     const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
     if (idx >= h*w) break;
     const int i = idx/w, j = idx - i*w;
-    float acc = g[(i + 1)*W + j + 1];
+    float acc = ld_as_float<TO>(g, (i + 1)*W + j + 1);
     if (i == 1 || i == h - 2 || j == 1 || j == w - 2) {   // rare: mirrored border cells
       SMD_PAD_ADJ_POS(i, h, y0, y1, y2); SMD_PAD_ADJ_POS(j, w, x0, x1, x2);
       const int ys[3] = {y0, y1, y2}, xs[3] = {x0, x1, x2};
@@ -82,44 +84,47 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_pad_bwd(const float* __restri
       for (int a = 0; a < 3; ++a) {
         if (ys[a] < 0) continue;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) if (xs[b] >= 0) acc += g[ys[a]*W + xs[b]];
+        for (int b = 0; b < 3; ++b) if (xs[b] >= 0) acc += ld_as_float<TO>(g, ys[a]*W + xs[b]);
       }
     }
-    const float gv = apply_elu ? acc*elu1_grad(x[(size_t)plane*h*w + idx] + bc) : acc;
-    g_x[(size_t)plane*h*w + idx] = gv; bsum += gv;
+    const float gv = apply_elu ? acc*elu1_grad(ld_as_float<TA>(x, (size_t)plane*h*w + idx) + bc) : acc;
+    st_from_float<TA>(g_x, (size_t)plane*h*w + idx, gv); bsum += gv;
   }
   if (bias_partial) block_store_sum(bsum, red, bias_partial + blockIdx.x);
 }
 
-__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_fwd(const float* __restrict__ a, const float* __restrict__ bias, const float* __restrict__ skip,
-                                                                  float* __restrict__ out, int Ca, int Cs, int h, int w, unsigned chunks) {
+template <typename TA, typename TS, typename TO>
+__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_fwd(const TA* __restrict__ a, const float* __restrict__ bias, const TS* __restrict__ skip,
+                                                                  TO* __restrict__ out, int Ca, int Cs, int h, int w, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*(Ca+Cs) + c
   const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, H = H2 + 2, W = W2 + 2;
   const unsigned b = plane/C, c = plane - b*C;
   const bool from_a = (int)c < Ca;
   const float bc = (from_a && bias) ? bias[c] : 0.f;
-  const float* src = from_a ? a + ((size_t)b*Ca + c)*h*w : skip + ((size_t)b*Cs + (c - Ca))*H2*W2;
+  const TA* src_a = a + ((size_t)b*Ca + (from_a ? c : 0))*h*w;
+  const TS* src_s = from_a ? nullptr : skip + ((size_t)b*Cs + (c - Ca))*H2*W2;
 #pragma unroll
   for (int k = 0; k < kDecPerThread; ++k) {
     const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
     if (idx >= H*W) break;
     const int py = idx/W, px = idx - py*W;
     const int r = unpad_reflect(py, H2), q = unpad_reflect(px, W2);
-    out[(size_t)plane*H*W + idx] = from_a ? elu1(src[(r >> 1)*w + (q >> 1)] + bc) : src[r*W2 + q];
+    st_from_float<TO>(out, (size_t)plane*H*W + idx, from_a ? elu1(ld_as_float<TA>(src_a, (r >> 1)*w + (q >> 1)) + bc) : ld_as_float<TS>(src_s, r*W2 + q));
   }
 }
 
 // Adjoint w.r.t. `a` (low resolution): each source pixel feeds a 2x2 block of the up-sampled map, each cell of which
 // feeds its padded position plus (on the second / second-to-last row or column) the mirrored border cell.
-__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float* __restrict__ a, const float* __restrict__ bias, const float* __restrict__ g_out,
-                                                                    float* __restrict__ g_a, float* __restrict__ bias_partial, int Ca, int Cs, int h, int w,
+template <typename TA, typename TO>
+__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const TA* __restrict__ a, const float* __restrict__ bias, const TO* __restrict__ g_out,
+                                                                    TA* __restrict__ g_a, float* __restrict__ bias_partial, int Ca, int Cs, int h, int w,
                                                                     unsigned chunks) {
   __shared__ float red[kDecBlock/64];
   float bsum = 0.f;
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*Ca + c
   const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, W = W2 + 2;
   const unsigned b = plane/Ca, c = plane - b*Ca;
-  const float* g = g_out + ((size_t)b*C + c)*(H2 + 2)*W;
+  const TO* g = g_out + ((size_t)b*C + c)*(H2 + 2)*W;
   const float bc = bias ? bias[c] : 0.f;
   for (int k = 0; k < kDecPerThread; ++k) {
   const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
@@ -127,8 +132,8 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float*
   const int i = idx/w, j = idx - i*w;
   float acc = 0.f;
   if (i > 0 && i < h - 1 && j > 0 && j < w - 1) {   // interior: the plain 2x2 block
-    const float* gp = g + (2*i + 1)*W + 2*j + 1;
-    acc = (gp[0] + gp[1]) + (gp[W] + gp[W + 1]);
+    const TO* gp = g + (2*i + 1)*W + 2*j + 1;
+    acc = (ld_as_float<TO>(gp, 0) + ld_as_float<TO>(gp, 1)) + (ld_as_float<TO>(gp, W) + ld_as_float<TO>(gp, W + 1));
   } else
 #pragma unroll
   for (int dr = 0; dr < 2; ++dr) {
@@ -144,29 +149,30 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_a(const float*
       for (int m = 0; m < 3; ++m) {
         if (ys[m] < 0) continue;
 #pragma unroll
-        for (int n = 0; n < 3; ++n) if (xs[n] >= 0) acc += g[ys[m]*W + xs[n]];
+        for (int n = 0; n < 3; ++n) if (xs[n] >= 0) acc += ld_as_float<TO>(g, ys[m]*W + xs[n]);
       }
     }
   }
-  const float gv = acc*elu1_grad(a[(size_t)plane*h*w + idx] + bc);
-  g_a[(size_t)plane*h*w + idx] = gv; bsum += gv;
+  const float gv = acc*elu1_grad(ld_as_float<TA>(a, (size_t)plane*h*w + idx) + bc);
+  st_from_float<TA>(g_a, (size_t)plane*h*w + idx, gv); bsum += gv;
   }
   if (bias_partial) block_store_sum(bsum, red, bias_partial + blockIdx.x);
 }
 
 // Adjoint w.r.t. the skip tensor (full resolution): plain reflection-pad adjoint of its channel slice.
-__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_skip(const float* __restrict__ g_out, float* __restrict__ g_skip,
+template <typename TS, typename TO>
+__global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_skip(const TO* __restrict__ g_out, TS* __restrict__ g_skip,
                                                                        int Ca, int Cs, int h, int w, unsigned chunks) {
   const unsigned plane = blockIdx.x/chunks, chunk = blockIdx.x - plane*chunks;   // plane = b*Cs + c
   const int C = Ca + Cs, H2 = 2*h, W2 = 2*w, W = W2 + 2;
   const unsigned b = plane/Cs, c = plane - b*Cs;
-  const float* g = g_out + ((size_t)b*C + Ca + c)*(H2 + 2)*W;
+  const TO* g = g_out + ((size_t)b*C + Ca + c)*(H2 + 2)*W;
 #pragma unroll
   for (int k = 0; k < kDecPerThread; ++k) {
     const int idx = chunk*kDecChunk + k*kDecBlock + threadIdx.x;
     if (idx >= H2*W2) break;
     const int r = idx/W2, q = idx - r*W2;
-    float acc = g[(r + 1)*W + q + 1];
+    float acc = ld_as_float<TO>(g, (r + 1)*W + q + 1);
     if (r == 1 || r == H2 - 2 || q == 1 || q == W2 - 2) {
       SMD_PAD_ADJ_POS(r, H2, y0, y1, y2); SMD_PAD_ADJ_POS(q, W2, x0, x1, x2);
       const int ys[3] = {y0, y1, y2}, xs[3] = {x0, x1, x2};
@@ -175,43 +181,71 @@ __global__ __launch_bounds__(kDecBlock) void k_elu_up_cat_pad_bwd_skip(const flo
       for (int m = 0; m < 3; ++m) {
         if (ys[m] < 0) continue;
 #pragma unroll
-        for (int n = 0; n < 3; ++n) if (xs[n] >= 0) acc += g[ys[m]*W + xs[n]];
+        for (int n = 0; n < 3; ++n) if (xs[n] >= 0) acc += ld_as_float<TO>(g, ys[m]*W + xs[n]);
       }
     }
-    g_skip[(size_t)plane*H2*W2 + idx] = acc;
+    st_from_float<TS>(g_skip, (size_t)plane*H2*W2 + idx, acc);
   }
 }
 
-hipError_t launch_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int h, int w, int apply_elu, hipStream_t st) {
+// dtypes: bit 0 = x / a (and their gradients) are bf16, bit 1 = skip (and its gradient), bit 2 = out (and its gradient).
+#define SMD_DT_A 1
+#define SMD_DT_S 2
+#define SMD_DT_O 4
+
+hipError_t launch_elu_pad_fwd(const void* x, const float* bias, void* out, int B, int C, int h, int w, int apply_elu, int dt, hipStream_t st) {
   const unsigned chunks = ceil_div((h + 2)*(w + 2), kDecChunk);
-  hipLaunchKernelGGL(k_elu_pad_fwd, dim3((unsigned)((size_t)B*C*chunks)), dim3(kDecBlock), 0, st, x, bias, out, C, h, w, apply_elu, chunks);
+  const dim3 grid((unsigned)((size_t)B*C*chunks)), blk(kDecBlock);
+#define SMD_GO(TA_, TO_) hipLaunchKernelGGL((k_elu_pad_fwd<TA_, TO_>), grid, blk, 0, st, (const TA_*)x, bias, (TO_*)out, C, h, w, apply_elu, chunks)
+  if (dt & SMD_DT_A) { if (dt & SMD_DT_O) SMD_GO(bf16, bf16); else SMD_GO(bf16, float); }
+  else { if (dt & SMD_DT_O) SMD_GO(float, bf16); else SMD_GO(float, float); }
+#undef SMD_GO
   return hipGetLastError();
 }
 size_t decoder_bias_partials(int B, int C, int h, int w) { return (size_t)B*C*ceil_div(h*w, kDecChunk); }
-hipError_t launch_elu_pad_bwd(const float* x, const float* bias, const float* g_out, float* g_x, float* g_bias, float* ws, int B, int C, int h, int w,
-                              int apply_elu, hipStream_t st) {
+hipError_t launch_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g_x, float* g_bias, float* ws, int B, int C, int h, int w,
+                              int apply_elu, int dt, hipStream_t st) {
   const unsigned chunks = ceil_div(h*w, kDecChunk);
-  hipLaunchKernelGGL(k_elu_pad_bwd, dim3((unsigned)((size_t)B*C*chunks)), dim3(kDecBlock), 0, st, x, bias, g_out, g_x, g_bias ? ws : nullptr, C, h, w,
-                     apply_elu, chunks);
+  const dim3 grid((unsigned)((size_t)B*C*chunks)), blk(kDecBlock);
+#define SMD_GO(TA_, TO_) hipLaunchKernelGGL((k_elu_pad_bwd<TA_, TO_>), grid, blk, 0, st, (const TA_*)x, bias, (const TO_*)g_out, (TA_*)g_x, g_bias ? ws : nullptr, C, h, w, apply_elu, chunks)
+  if (dt & SMD_DT_A) { if (dt & SMD_DT_O) SMD_GO(bf16, bf16); else SMD_GO(bf16, float); }
+  else { if (dt & SMD_DT_O) SMD_GO(float, bf16); else SMD_GO(float, float); }
+#undef SMD_GO
   if (g_bias) hipLaunchKernelGGL(k_bias_finalize, dim3(C), dim3(64), 0, st, ws, B, C, chunks, g_bias);
   return hipGetLastError();
 }
-hipError_t launch_elu_up_cat_pad_fwd(const float* a, const float* bias, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, hipStream_t st) {
+hipError_t launch_elu_up_cat_pad_fwd(const void* a, const float* bias, const void* skip, void* out, int B, int Ca, int Cs, int h, int w, int dt,
+                                     hipStream_t st) {
   const unsigned chunks = ceil_div((2*h + 2)*(2*w + 2), kDecChunk);
-  hipLaunchKernelGGL(k_elu_up_cat_pad_fwd, dim3((unsigned)((size_t)B*(Ca + Cs)*chunks)), dim3(kDecBlock), 0, st, a, bias, skip, out, Ca, Cs, h, w, chunks);
+  const dim3 grid((unsigned)((size_t)B*(Ca + Cs)*chunks)), blk(kDecBlock);
+#define SMD_GO(TA_, TS_, TO_) hipLaunchKernelGGL((k_elu_up_cat_pad_fwd<TA_, TS_, TO_>), grid, blk, 0, st, (const TA_*)a, bias, (const TS_*)skip, (TO_*)out, Ca, Cs, h, w, chunks)
+  switch (dt & 7) {
+    case 0: SMD_GO(float, float, float); break;  case 1: SMD_GO(bf16, float, float); break;
+    case 2: SMD_GO(float, bf16, float); break;   case 3: SMD_GO(bf16, bf16, float); break;
+    case 4: SMD_GO(float, float, bf16); break;   case 5: SMD_GO(bf16, float, bf16); break;
+    case 6: SMD_GO(float, bf16, bf16); break;    default: SMD_GO(bf16, bf16, bf16); break;
+  }
+#undef SMD_GO
   return hipGetLastError();
 }
-hipError_t launch_elu_up_cat_pad_bwd(const float* a, const float* bias, const float* g_out, float* g_a, float* g_skip, float* g_bias, float* ws,
-                                     int B, int Ca, int Cs, int h, int w, hipStream_t st) {
+hipError_t launch_elu_up_cat_pad_bwd(const void* a, const float* bias, const void* g_out, void* g_a, void* g_skip, float* g_bias, float* ws,
+                                     int B, int Ca, int Cs, int h, int w, int dt, hipStream_t st) {
   if (g_a) {
     const unsigned chunks = ceil_div(h*w, kDecChunk);
-    hipLaunchKernelGGL(k_elu_up_cat_pad_bwd_a, dim3((unsigned)((size_t)B*Ca*chunks)), dim3(kDecBlock), 0, st, a, bias, g_out, g_a, g_bias ? ws : nullptr,
-                       Ca, Cs, h, w, chunks);
+    const dim3 grid((unsigned)((size_t)B*Ca*chunks)), blk(kDecBlock);
+#define SMD_GO(TA_, TO_) hipLaunchKernelGGL((k_elu_up_cat_pad_bwd_a<TA_, TO_>), grid, blk, 0, st, (const TA_*)a, bias, (const TO_*)g_out, (TA_*)g_a, g_bias ? ws : nullptr, Ca, Cs, h, w, chunks)
+    if (dt & SMD_DT_A) { if (dt & SMD_DT_O) SMD_GO(bf16, bf16); else SMD_GO(bf16, float); }
+    else { if (dt & SMD_DT_O) SMD_GO(float, bf16); else SMD_GO(float, float); }
+#undef SMD_GO
     if (g_bias) hipLaunchKernelGGL(k_bias_finalize, dim3(Ca), dim3(64), 0, st, ws, B, Ca, chunks, g_bias);
   }
   if (g_skip && Cs > 0) {
     const unsigned chunks = ceil_div(4*h*w, kDecChunk);
-    hipLaunchKernelGGL(k_elu_up_cat_pad_bwd_skip, dim3((unsigned)((size_t)B*Cs*chunks)), dim3(kDecBlock), 0, st, g_out, g_skip, Ca, Cs, h, w, chunks);
+    const dim3 grid((unsigned)((size_t)B*Cs*chunks)), blk(kDecBlock);
+#define SMD_GO(TS_, TO_) hipLaunchKernelGGL((k_elu_up_cat_pad_bwd_skip<TS_, TO_>), grid, blk, 0, st, (const TO_*)g_out, (TS_*)g_skip, Ca, Cs, h, w, chunks)
+    if (dt & SMD_DT_S) { if (dt & SMD_DT_O) SMD_GO(bf16, bf16); else SMD_GO(bf16, float); }
+    else { if (dt & SMD_DT_O) SMD_GO(float, bf16); else SMD_GO(float, float); }
+#undef SMD_GO
   }
   return hipGetLastError();
 }

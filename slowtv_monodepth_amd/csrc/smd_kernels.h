@@ -133,12 +133,13 @@ hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, floa
 hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
 hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, int mode, hipStream_t st);
 size_t decoder_bias_partials(int B, int C, int h, int w);
-hipError_t launch_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int h, int w, int apply_elu, hipStream_t st);
-hipError_t launch_elu_pad_bwd(const float* x, const float* bias, const float* g_out, float* g_x, float* g_bias, float* ws, int B, int C, int h, int w,
-                              int apply_elu, hipStream_t st);
-hipError_t launch_elu_up_cat_pad_fwd(const float* a, const float* bias, const float* skip, float* out, int B, int Ca, int Cs, int h, int w, hipStream_t st);
-hipError_t launch_elu_up_cat_pad_bwd(const float* a, const float* bias, const float* g_out, float* g_a, float* g_skip, float* g_bias, float* ws,
-                                     int B, int Ca, int Cs, int h, int w, hipStream_t st);
+hipError_t launch_elu_pad_fwd(const void* x, const float* bias, void* out, int B, int C, int h, int w, int apply_elu, int dt, hipStream_t st);
+hipError_t launch_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g_x, float* g_bias, float* ws, int B, int C, int h, int w,
+                              int apply_elu, int dt, hipStream_t st);
+hipError_t launch_elu_up_cat_pad_fwd(const void* a, const float* bias, const void* skip, void* out, int B, int Ca, int Cs, int h, int w, int dt,
+                                     hipStream_t st);
+hipError_t launch_elu_up_cat_pad_bwd(const void* a, const float* bias, const void* g_out, void* g_a, void* g_skip, float* g_bias, float* ws,
+                                     int B, int Ca, int Cs, int h, int w, int dt, hipStream_t st);
 int bn_chunks(int N, int HW);
 hipError_t launch_bn_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* running_mean, float* running_var,
                          float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd, float* ws, int N, int C, int HW,

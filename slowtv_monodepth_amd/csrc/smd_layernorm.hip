@@ -12,19 +12,10 @@
 #include "smd_common.h"
 #include "smd_kernels.h"
 
-#include <hip/hip_bf16.h>
-
 namespace smd {
 
 // The normalised output feeds a bf16 1x1 convolution under autocast and its gradient arrives in bf16: writing / reading those
 // two tensors in bf16 directly removes a full-tensor cast kernel per block and direction.  Arithmetic stays fp32.
-template <typename T> __device__ __forceinline__ float ld_as_float(const T* p, size_t i);
-template <> __device__ __forceinline__ float ld_as_float<float>(const float* p, size_t i) { return p[i]; }
-template <> __device__ __forceinline__ float ld_as_float<__hip_bfloat16>(const __hip_bfloat16* p, size_t i) { return __bfloat162float(p[i]); }
-template <typename T> __device__ __forceinline__ void st_from_float(T* p, size_t i, float v);
-template <> __device__ __forceinline__ void st_from_float<float>(float* p, size_t i, float v) { p[i] = v; }
-template <> __device__ __forceinline__ void st_from_float<__hip_bfloat16>(__hip_bfloat16* p, size_t i, float v) { p[i] = __float2bfloat16(v); }
-
 constexpr int kLnWaves = 4;                 // waves of a block share 64 pixels and split the channels
 constexpr int kLnBlock = 64*kLnWaves;
 constexpr int kLnRedItems = 8192;           // pixels a block sweeps per channel in the gamma/beta reduction
@@ -130,7 +121,7 @@ hipError_t launch_ln_cf_fwd(const float* x, const float* gamma, const float* bet
                             float eps, hipStream_t st) {
   const size_t npix = (size_t)N*HW;
   const dim3 grid((unsigned)((npix + 63)/64));
-  if (y_bf16) hipLaunchKernelGGL(k_ln_cf_fwd<__hip_bfloat16>, grid, dim3(kLnBlock), 0, st, x, gamma, beta, (__hip_bfloat16*)y, mean, rstd, C, HW, npix, eps);
+  if (y_bf16) hipLaunchKernelGGL(k_ln_cf_fwd<bf16>, grid, dim3(kLnBlock), 0, st, x, gamma, beta, (bf16*)y, mean, rstd, C, HW, npix, eps);
   else hipLaunchKernelGGL(k_ln_cf_fwd<float>, grid, dim3(kLnBlock), 0, st, x, gamma, beta, (float*)y, mean, rstd, C, HW, npix, eps);
   return hipGetLastError();
 }
@@ -140,8 +131,8 @@ hipError_t launch_ln_cf_bwd(const float* x, const void* g_y, int g_bf16, const f
   const int chunks = ln_cf_chunks(npix);
   const dim3 grid((unsigned)((npix + 63)/64));
   if (g_bf16) {
-    hipLaunchKernelGGL(k_ln_cf_bwd_dx<__hip_bfloat16>, grid, dim3(kLnBlock), 0, st, x, (const __hip_bfloat16*)g_y, gamma, mean, rstd, g_x, C, HW, npix);
-    hipLaunchKernelGGL(k_ln_cf_bwd_wb<__hip_bfloat16>, dim3(chunks, C), dim3(256), 0, st, x, (const __hip_bfloat16*)g_y, mean, rstd, N, C, HW, chunks, ws);
+    hipLaunchKernelGGL(k_ln_cf_bwd_dx<bf16>, grid, dim3(kLnBlock), 0, st, x, (const bf16*)g_y, gamma, mean, rstd, g_x, C, HW, npix);
+    hipLaunchKernelGGL(k_ln_cf_bwd_wb<bf16>, dim3(chunks, C), dim3(256), 0, st, x, (const bf16*)g_y, mean, rstd, N, C, HW, chunks, ws);
   } else {
     hipLaunchKernelGGL(k_ln_cf_bwd_dx<float>, grid, dim3(kLnBlock), 0, st, x, (const float*)g_y, gamma, mean, rstd, g_x, C, HW, npix);
     hipLaunchKernelGGL(k_ln_cf_bwd_wb<float>, dim3(chunks, C), dim3(256), 0, st, x, (const float*)g_y, mean, rstd, N, C, HW, chunks, ws);

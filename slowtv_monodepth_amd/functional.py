@@ -350,16 +350,29 @@ def _glue_ws(B, C, h, w, device):
     return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
 
 
+def _check_fb(name: str, t: torch.Tensor, shape=None) -> torch.Tensor:
+    """Like `_check`, for the operators that also take bfloat16 tensors at an autocast boundary."""
+    if not isinstance(t, torch.Tensor): raise TypeError(f'{name} must be a Tensor, got {type(t)}')
+    if not t.is_cuda: raise RuntimeError(f'{name} must live on the GPU')
+    if t.dtype not in (torch.float32, torch.bfloat16): raise TypeError(f'{name} must be float32 or bfloat16, got {t.dtype}')
+    if shape is not None and tuple(t.shape) != tuple(shape): raise ValueError(f'{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
+    return t.contiguous()
+
+
+_BF = torch.bfloat16
+
+
 class _EluPad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias, apply_elu):
-        x = _check('x', x)
+    def forward(ctx, x, bias, apply_elu, out_dtype):
+        x = _check_fb('x', x)
         if x.ndim != 4: raise ValueError(f'expected (B,C,h,w), got {tuple(x.shape)}')
         B, C, h, w = x.shape
         if bias is not None: bias = _check('bias', bias, (C,))
-        out = torch.empty((B, C, h + 2, w + 2), device=x.device, dtype=torch.float32)
-        call('smd_elu_pad_fwd', x.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), B, C, h, w, int(apply_elu), _stream())
-        ctx.save_for_backward(x, bias); ctx.apply_elu = int(apply_elu)
+        out = torch.empty((B, C, h + 2, w + 2), device=x.device, dtype=out_dtype)
+        dt = (1 if x.dtype == _BF else 0) | (4 if out_dtype == _BF else 0)
+        call('smd_elu_pad_fwd', x.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), B, C, h, w, int(apply_elu), dt, _stream())
+        ctx.save_for_backward(x, bias); ctx.apply_elu, ctx.dt, ctx.out_dtype = int(apply_elu), dt, out_dtype
         return out
 
     @staticmethod
@@ -369,31 +382,35 @@ class _EluPad(torch.autograd.Function):
         g_x = torch.empty_like(x)
         g_b = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[1]) else None
         ws, nbytes = _glue_ws(B, C, h, w, x.device) if g_b is not None else (None, 0)
-        call('smd_elu_pad_bwd', x.data_ptr(), bias.data_ptr() if bias is not None else None, g_out.contiguous().data_ptr(), g_x.data_ptr(),
-             g_b.data_ptr() if g_b is not None else None, ws.data_ptr() if ws is not None else None, nbytes, B, C, h, w, ctx.apply_elu, _stream())
-        return g_x, g_b, None
+        call('smd_elu_pad_bwd', x.data_ptr(), bias.data_ptr() if bias is not None else None, g_out.to(ctx.out_dtype).contiguous().data_ptr(),
+             g_x.data_ptr(), g_b.data_ptr() if g_b is not None else None, ws.data_ptr() if ws is not None else None, nbytes, B, C, h, w,
+             ctx.apply_elu, ctx.dt, _stream())
+        return g_x, g_b, None, None
 
 
-def elu_pad(x, bias=None, apply_elu: bool = True):
-    """reflect_pad1(elu(x + bias)) (or just bias + padding): the input of the next 3x3 convolution of the decoder."""
-    return _EluPad.apply(x, bias, apply_elu)
+def elu_pad(x, bias=None, apply_elu: bool = True, out_dtype=None):
+    """reflect_pad1(elu(x + bias)) (or just bias + padding): the input of the next 3x3 convolution of the decoder.
+    x float32 or bfloat16; `out_dtype` (default: x's) may be bfloat16 for a bf16 consumer; bias and arithmetic are fp32."""
+    return _EluPad.apply(x, bias, apply_elu, out_dtype or x.dtype)
 
 
 class _EluUpCatPad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, bias, skip):
-        a = _check('a', a)
+    def forward(ctx, a, bias, skip, out_dtype):
+        a = _check_fb('a', a)
         if a.ndim != 4: raise ValueError(f'expected (B,C,h,w), got {tuple(a.shape)}')
         B, Ca, h, w = a.shape
         if bias is not None: bias = _check('bias', bias, (Ca,))
         Cs = 0
         if skip is not None:
             Cs = skip.shape[1]
-            skip = _check('skip', skip, (B, Cs, 2*h, 2*w))
-        out = torch.empty((B, Ca + Cs, 2*h + 2, 2*w + 2), device=a.device, dtype=torch.float32)
+            skip = _check_fb('skip', skip, (B, Cs, 2*h, 2*w))
+        out = torch.empty((B, Ca + Cs, 2*h + 2, 2*w + 2), device=a.device, dtype=out_dtype)
+        dt = (1 if a.dtype == _BF else 0) | (2 if (skip is not None and skip.dtype == _BF) else 0) | (4 if out_dtype == _BF else 0)
         call('smd_elu_up_cat_pad_fwd', a.data_ptr(), bias.data_ptr() if bias is not None else None, skip.data_ptr() if skip is not None else None,
-             out.data_ptr(), B, Ca, Cs, h, w, _stream())
-        ctx.save_for_backward(a, bias); ctx.Cs = Cs
+             out.data_ptr(), B, Ca, Cs, h, w, dt, _stream())
+        ctx.save_for_backward(a, bias)
+        ctx.Cs, ctx.dt, ctx.out_dtype, ctx.skip_dtype = Cs, dt, out_dtype, (skip.dtype if skip is not None else None)
         return out
 
     @staticmethod
@@ -403,18 +420,19 @@ class _EluUpCatPad(torch.autograd.Function):
         Cs = ctx.Cs
         g_b = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[1]) else None
         g_a = torch.empty_like(a) if (ctx.needs_input_grad[0] or g_b is not None) else None
-        g_skip = torch.empty((B, Cs, 2*h, 2*w), device=a.device, dtype=torch.float32) if (Cs and ctx.needs_input_grad[2]) else None
-        if g_a is None and g_skip is None: return None, None, None
+        g_skip = torch.empty((B, Cs, 2*h, 2*w), device=a.device, dtype=ctx.skip_dtype) if (Cs and ctx.needs_input_grad[2]) else None
+        if g_a is None and g_skip is None: return None, None, None, None
         ws, nbytes = _glue_ws(B, Ca, h, w, a.device) if g_b is not None else (None, 0)
-        call('smd_elu_up_cat_pad_bwd', a.data_ptr(), bias.data_ptr() if bias is not None else None, g_out.contiguous().data_ptr(),
+        call('smd_elu_up_cat_pad_bwd', a.data_ptr(), bias.data_ptr() if bias is not None else None, g_out.to(ctx.out_dtype).contiguous().data_ptr(),
              g_a.data_ptr() if g_a is not None else None, g_skip.data_ptr() if g_skip is not None else None,
-             g_b.data_ptr() if g_b is not None else None, ws.data_ptr() if ws is not None else None, nbytes, B, Ca, Cs, h, w, _stream())
-        return g_a, g_b, g_skip
+             g_b.data_ptr() if g_b is not None else None, ws.data_ptr() if ws is not None else None, nbytes, B, Ca, Cs, h, w, ctx.dt, _stream())
+        return g_a, g_b, g_skip, None
 
 
-def elu_up_cat_pad(a, skip=None, bias=None):
-    """reflect_pad1(cat(nearest_x2(elu(a + bias)), skip)): (B,Ca,h,w) [+ (B,Cs,2h,2w)] -> (B,Ca+Cs,2h+2,2w+2)."""
-    return _EluUpCatPad.apply(a, bias, skip)
+def elu_up_cat_pad(a, skip=None, bias=None, out_dtype=None):
+    """reflect_pad1(cat(nearest_x2(elu(a + bias)), skip)): (B,Ca,h,w) [+ (B,Cs,2h,2w)] -> (B,Ca+Cs,2h+2,2w+2).
+    a / skip float32 or bfloat16 (independently); `out_dtype` defaults to a's."""
+    return _EluUpCatPad.apply(a, bias, skip, out_dtype or a.dtype)
 
 
 class _BatchNormAct(torch.autograd.Function):

@@ -48,8 +48,9 @@ class MonodepthDecoder(nn.Module):
 
     def forward(self, feat):
         x = feat[-1]
-        if x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.upsample_mode == 'nearest':
-            return self._forward_glued(feat)
+        amp_bf16 = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and (amp_bf16 or not torch.is_autocast_enabled()) and self.upsample_mode == 'nearest':
+            return self._forward_glued(feat, torch.bfloat16 if amp_bf16 else None)
         out = {}
         for i in range(4, -1, -1):
             x = F.interpolate(self.up0[str(i)](x), scale_factor=2, mode=self.upsample_mode)
@@ -58,18 +59,18 @@ class MonodepthDecoder(nn.Module):
             if i in self.out_sc: out[i] = self.act(self.out[str(i)](x))
         return out
 
-    def _forward_glued(self, feat):
+    def _forward_glued(self, feat, out_dtype=None):
         """Same network, same parameters; the ops BETWEEN the convolutions (ELU, nearest x2, cat, reflection pad) run as
         the two gather kernels of `csrc/smd_decoder.hip`, each writing the next convolution's padded input, and the
         padded ELU output of a stage is shared by its output head and the next stage (the reference pads it twice)."""
         from .. import functional as HF
         conv = lambda m, xp: F.conv2d(xp, m.weight)            # input already reflection-padded; the bias is added by the next glue kernel
         out = {}
-        xp = HF.elu_pad(feat[-1], apply_elu=False)
+        xp = HF.elu_pad(feat[-1], apply_elu=False, out_dtype=out_dtype)   # under bf16 autocast the glue writes bf16 for the bf16 convolutions
         for i in range(4, -1, -1):
             m0, m1 = self.up0[str(i)][0], self.up1[str(i)][0]
             skip = feat[self.enc_sc.index(2**i)] if (self.use_skip and 2**i in self.enc_sc) else None
-            c = conv(m1, HF.elu_up_cat_pad(conv(m0, xp), skip, bias=m0.bias))
-            if i in self.out_sc or i > 0: xp = HF.elu_pad(c, bias=m1.bias, apply_elu=True)
+            c = conv(m1, HF.elu_up_cat_pad(conv(m0, xp), skip, bias=m0.bias.float(), out_dtype=out_dtype))
+            if i in self.out_sc or i > 0: xp = HF.elu_pad(c, bias=m1.bias.float(), apply_elu=True, out_dtype=out_dtype)
             if i in self.out_sc: out[i] = self.act(F.conv2d(xp, self.out[str(i)].weight, self.out[str(i)].bias))
         return out

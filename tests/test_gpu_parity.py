@@ -744,3 +744,22 @@ def test_channel_layer_norm_bf16_io(F):
         res.append((y.float(), xx.grad, ww.grad, bb.grad))
     assert rel_to_max(res[1][0], res[0][0]) < 1e-2     # bf16 rounding of the output
     for a, e in zip(res[1][1:], res[0][1:]): assert rel_to_max(a, e) < 2e-2   # gradient was rounded to bf16 on the way in
+
+
+def test_decoder_glue_bf16_io(F):
+    """bf16 conv outputs in, bf16 padded tensors out (decoder under bf16 autocast), fp32 skip: same arithmetic, rounded at the boundary."""
+    gen = torch.Generator().manual_seed(14)
+    B, Ca, Cs, h, w = 2, 6, 3, 5, 7
+    a = torch.randn(B, Ca, h, w, generator=gen).cuda(); skip = torch.randn(B, Cs, 2*h, 2*w, generator=gen).cuda(); bias = torch.randn(Ca, generator=gen).cuda()
+    res = []
+    for bf in (False, True):
+        aa = (a.bfloat16() if bf else a.clone()).requires_grad_(True); ss = skip.clone().requires_grad_(True); bb = bias.clone().requires_grad_(True)
+        od = torch.bfloat16 if bf else None
+        o1 = F.elu_up_cat_pad(aa, ss, bias=bb, out_dtype=od); o2 = F.elu_pad(aa, bb, True, out_dtype=od)
+        assert o1.dtype == (torch.bfloat16 if bf else torch.float32) and o2.dtype == o1.dtype
+        g = torch.Generator(device='cuda').manual_seed(15)
+        (sum((o.float()*torch.randn(o.shape, generator=g, device='cuda')).sum() for o in (o1, o2))).backward()
+        assert aa.grad.dtype == aa.dtype and ss.grad.dtype == torch.float32 and bb.grad.dtype == torch.float32
+        res.append([t.detach().float() for t in (o1, o2, aa.grad, ss.grad, bb.grad)])
+    for nm, x, e in zip(('up_cat_pad', 'elu_pad', 'g_a', 'g_skip', 'g_bias'), res[1], res[0]):
+        assert rel_to_max(x, e) < 3e-2, f'{nm}: {rel_to_max(x, e):.3e}'
