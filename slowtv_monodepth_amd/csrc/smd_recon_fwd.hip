@@ -214,7 +214,8 @@ struct FwdCtx {
   // The row loop.  Ring: A = row j-2, B = row j-1, C = row j.  Software pipeline per step j:
   //   finish(C <- loads of row j, issued during step j-1) | issue(loads of row j+1; needs depth(j+1), loaded during
   //   step j-1) | load depth(j+2) | emit(row j-1)  — so a row's gathers are in flight under the previous row's SSIM math.
-  // (Unrolling by 3 to avoid shifting the ring was measured slower: 114 VGPRs / 4 waves and 3x the code vs 95 / 5.)
+  // (Unrolling by 3 to avoid shifting the ring — 54 v_mov per row — was measured slower twice: the three role assignments keep
+  //  more values live; 128 VGPRs / 4 waves: 137 us, capped at 96 VGPRs it spills: 483 us, against 87 us for the shifting loop.)
   __device__ __forceinline__ void run() {
     RowState<NI> A = {}, B = {}, C = {};
     Pending<NI, WARP> P = {};
