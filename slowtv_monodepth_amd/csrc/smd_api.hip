@@ -27,6 +27,9 @@ int check_launch(hipError_t e, const char* what) {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct StripPlan { int rh, nsx, nsy; };
+constexpr int kMinStripRows = 4;   // lower bound of the rows-per-strip override; the workspace is sized for it
+int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil_div(h, kMinStripRows); }
+
 
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -34,13 +37,12 @@ int env_int(const char* name, int dflt) {
 }
 
 // Tuning knobs (read per call; unset = built-in heuristics): SMD_BWD_SKIP (0..2, dead-row skipping of the fused backward,
-// default 2), SMD_FWD_RH / SMD_BWD_RH rows per strip, SMD_FWD_NI supports
-// held in registers per forward pass (1 or 2).
+// default 2), SMD_FWD_RH / SMD_BWD_RH rows per strip (>= 4).
 StripPlan plan(int b, int S, int h, int w, int cols) {
   StripPlan p;
   p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
   const int ov = env_int(cols == smd::kFwdCols ? "SMD_FWD_RH" : "SMD_BWD_RH", 0);
-  if (ov >= 1) p.rh = ov;
+  if (ov >= 1) p.rh = ov < kMinStripRows ? kMinStripRows : ov;
   p.nsx = smd::ceil_div(w, cols);
   p.nsy = smd::ceil_div(h, p.rh);
   return p;
@@ -58,15 +60,13 @@ void prof_mark(int which, hipStream_t st, bool begin) {
   else { (void)hipEventRecord(p.ev[2*p.used + 1], st); ++p.used; }
 }
 
-int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil_div(h, 8); }
 
-struct ReconWs { float* e_static; float* loss_partial; float* pose_partial; size_t bytes; };
+struct ReconWs { float* loss_partial; float* pose_partial; size_t bytes; };
 
 ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
   ReconWs r;
   size_t off = 0;
   char* p = (char*)base;
-  r.e_static = (float*)(p + off); off += align256((size_t)b*h*w*sizeof(float));
   r.loss_partial = (float*)(p + off); off += align256((size_t)S*b*max_strips(h, w, smd::kFwdCols)*sizeof(float));
   r.pose_partial = (float*)(p + off); off += align256((size_t)n*b*S*max_strips(h, w, smd::kBwdCols)*smd::kPoseSums*sizeof(float));
   r.bytes = off;
@@ -144,7 +144,7 @@ size_t smd_image_recon_workspace_bytes(int b, int n, int S, int h, int w) {
 
 size_t smd_packed_supports_bytes(int b, int n, int h, int w) {
   if (b < 1 || n < 1 || h < 2 || w < 2) return 0;
-  return (size_t)n*b*h*w*4*sizeof(float);
+  return smd::packed_total_floats(b, n, h, w)*sizeof(float);
 }
 
 int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
@@ -153,43 +153,43 @@ int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp,
                         int b, int n, int S, int h, int w, int flags, void* stream) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
   if (!depth || !tgt || !supp || !T || !K || !K_inv || !supp_packed || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
-  if ((size_t)n*b*h*w*16 >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "n*b*h*w*16 must stay below 2^32");
+  if (smd_packed_supports_bytes(b, n, h, w) >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "the packed buffer (%zu bytes) must stay below 2^32", smd_packed_supports_bytes(b, n, h, w));
+  if ((size_t)n*b*3*h*w*4 >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "n*b*3*h*w*4 must stay below 2^32");
+  if ((size_t)(h + 1)*(size_t)(w + 1) >= ((size_t)1 << 24)) return fail(SMD_E_INVALID, "(h+1)*(w+1) must stay below 2^24");
   ReconWs ws = carve_recon(workspace, b, n, S, h, w);
   if (workspace_bytes < ws.bytes) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = check_launch(smd::launch_pack_supports(supp, supp_packed, n*b, h, w, st), "pack supports")) return rc;
+  constexpr int kMaxPerPass = 4;   // supports held in registers by one launch
 
-  smd::ReconFwdArgs a;
+  {  // once per sample: texel repack, target window sums, identity error (scale independent)
+    smd::ReconPrepArgs p;
+    memset(&p, 0, sizeof(p));
+    p.tgt = tgt; p.supp = supp; p.packed = supp_packed;
+    p.b = b; p.n = n; p.h = h; p.w = w; p.flags = flags & (SMD_USE_MIN | SMD_LOSS_L1 | SMD_USE_AUTOMASK);
+    const StripPlan ipl = plan(b, 1, h, w, smd::kFwdCols);  // one "scale" only: shorter strips keep the chip full
+    p.rh = ipl.rh; p.nsx = ipl.nsx; p.nsy = ipl.nsy;
+    for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
+      p.i0 = i0; p.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
+      p.first_pass = (i0 == 0); p.last_pass = (i0 + p.ni >= n);
+      if (int rc = check_launch(smd::launch_recon_prep(p, st), "recon prep")) return rc;
+    }
+  }
+
+  smd::ReconMainArgs a;
   memset(&a, 0, sizeof(a));
-  a.tgt = tgt; a.supp_pk = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv;
-  a.b = b; a.n = n; a.h = h; a.w = w;
+  a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv;
+  a.noise = noise; a.err = err; a.sel = sel; a.partial = ws.loss_partial; a.warp0 = warp0;
+  a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
+  a.inv_n = (float)(1.0/(double)n);
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
-  a.variant = env_int("SMD_FWD_VARIANT", 1);
-
-  if (flags & SMD_USE_AUTOMASK) {  // identity error, once per sample (scale independent)
-    smd::ReconFwdArgs id = a;
-    const StripPlan ipl = plan(b, 1, h, w, smd::kFwdCols);  // one "scale" only: shorter strips keep the chip full
-    id.rh = ipl.rh; id.nsx = ipl.nsx; id.nsy = ipl.nsy;
-    id.S = 1; id.err = ws.e_static; id.sel = nullptr; id.partial = nullptr;
-    id.flags = flags & (SMD_USE_MIN | SMD_LOSS_L1);
-    const int id_max = env_int("SMD_FWD_NI", 2) >= 2 ? 2 : 1;
-    for (int i0 = 0; i0 < n; i0 += id_max) {
-      const int ni = (n - i0 >= id_max) ? id_max : 1;
-      id.i0 = i0; id.first_pass = (i0 == 0); id.last_pass = (i0 + ni >= n);
-      if (int rc = check_launch(smd::launch_recon_fwd(id, ni, false, st), "identity error")) return rc;
-    }
-  }
-  a.depth = depth; a.S = S; a.err = err; a.sel = sel; a.partial = ws.loss_partial; a.warp0 = warp0;
-  a.e_static = ws.e_static; a.noise = noise; a.flags = flags;
-  const int ni_max = env_int("SMD_FWD_NI", 2) >= 2 ? 2 : 1;
-  for (int i0 = 0; i0 < n; i0 += ni_max) {
-    const int ni = (n - i0 >= ni_max) ? ni_max : 1;
-    a.i0 = i0; a.first_pass = (i0 == 0); a.last_pass = (i0 + ni >= n);
+  for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
+    a.i0 = i0; a.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
+    a.first_pass = (i0 == 0); a.last_pass = (i0 + a.ni >= n);
     if (i0 == 0) prof_mark(SMD_PROF_RECON_FWD, st, true);
-    if (int rc = check_launch(smd::launch_recon_fwd(a, ni, true, st), "image_recon_fwd")) return rc;
+    if (int rc = check_launch(smd::launch_recon_main(a, st), "image_recon_fwd")) return rc;
     if (a.last_pass) prof_mark(SMD_PROF_RECON_FWD, st, false);
   }
   const int count = S*b*pl.nsx*pl.nsy;

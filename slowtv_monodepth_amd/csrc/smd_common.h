@@ -30,7 +30,8 @@ constexpr float kZMin = 0.1f;             // z.clamp(min=0.1)          (src/tool
 constexpr int kWave = 64;
 
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load that is only 4-byte aligned
-typedef float f4 __attribute__((ext_vector_type(4)));               // one RGBX texel of a repacked support frame
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f3 __attribute__((ext_vector_type(3)));               // one RGB texel of a repacked support frame
 
 // ---------------------------------------------------------------------------------------------
 // Cross-lane neighbours (DPP wave shifts; one VALU op each, no LDS traffic).
@@ -124,12 +125,12 @@ __device__ __forceinline__ void make_cam(Cam& c, const float* __restrict__ T, co
 
 // Bilinear, border-clamped 4-tap gather setup (grid_sample(bilinear, border, align_corners=False)).
 struct Taps {
-  int off;        // iy*w + ix of the north-west tap (ix <= w-2, iy <= h-2 so the 2x2 block is in range)
+  int off;        // iy*stride + ix of the north-west tap (ix <= w-2, iy <= h-2 so the 2x2 block is in range)
   float fx, fy;   // fractional weights of the east / south taps
   float mx, my;   // d(clamped coord)/d(unclamped coord): 1 strictly inside (0, size-1), else 0
 };
 
-__device__ __forceinline__ Taps make_taps(float sx, float sy, int h, int w) {
+__device__ __forceinline__ Taps make_taps(float sx, float sy, int h, int w, int stride) {
   Taps t;
   const float xmax = (float)(w - 1), ymax = (float)(h - 1);
   t.mx = (sx > 0.f && sx < xmax) ? 1.f : 0.f;
@@ -138,7 +139,7 @@ __device__ __forceinline__ Taps make_taps(float sx, float sy, int h, int w) {
   float cx = fminf(fmaxf(sx, 0.f), xmax), cy = fminf(fmaxf(sy, 0.f), ymax);
   float x0 = fminf(floorf(cx), xmax - 1.f), y0 = fminf(floorf(cy), ymax - 1.f);
   t.fx = cx - x0; t.fy = cy - y0;
-  t.off = (int)y0*w + (int)x0;
+  t.off = (int)y0*stride + (int)x0;
   return t;
 }
 
@@ -160,6 +161,95 @@ __device__ __forceinline__ float bilerp(const float* __restrict__ plane, const T
 // Uniform base + 32-bit lane offset: lets the compiler use the saddr form (no 64-bit VALU address arithmetic).
 __device__ __forceinline__ float ld1(const float* base, unsigned idx) { return *(const float*)((const char*)base + (size_t)(idx*4u)); }
 __device__ __forceinline__ f4 ld4(const float* base, unsigned texel) { return *(const f4*)((const char*)base + (size_t)(texel*16u)); }
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ f3 ld3(const float* base, unsigned texel) { const f3u v = *(const f3u*)((const char*)base + (size_t)(texel*12u)); return v; }
+
+// Uniform base (SGPR pair) + per-lane 32-bit BYTE offset: the saddr addressing form, no 64-bit VALU address arithmetic.
+__device__ __forceinline__ float ldu(const float* base, unsigned byte_off) { return *(const float*)((const char*)base + (size_t)byte_off); }
+// Buffer resources (SRSRC): base + size in four SGPRs.  A row access is `buffer_load v, v_lane_offset, s[rsrc], s_row_offset offen`:
+// the per-lane column offset is a loop-invariant VGPR, the row / plane offset is a scalar the SALU advances, so the coalesced
+// loads and stores of the streaming kernels cost no VALU address arithmetic at all (with plain pointers LLVM re-associates
+// `row pointer + lane offset`, hoists `base + lane offset` out of the row loop as a 64-bit VGPR pair per array and pays
+// 64-bit VALU adds per access).  Out-of-range accesses read 0 / are dropped.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+}
+__device__ __forceinline__ float bld(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ unsigned bld8(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0); }
+__device__ __forceinline__ f4 bld4(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// 12-byte load of an RGB texel.  (Never a 16-byte load with an ignored fourth lane: the register allocator treats the
+// never-read .w register of an in-flight load as free, reuses it for address arithmetic and must then wait (s_waitcnt) for
+// that load to land first — which serialises a whole gather batch behind its first load.)
+__device__ __forceinline__ f3 bld3(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bst(rsrc_t r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void bst8(rsrc_t r, unsigned voff, unsigned soff, unsigned v) {
+  __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff, soff, 0);
+}
+__device__ __forceinline__ void bst3(rsrc_t r, unsigned voff, unsigned soff, f3 v) {
+  typedef unsigned u3 __attribute__((ext_vector_type(3)));
+  __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u3, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void bst4(rsrc_t r, unsigned voff, unsigned soff, f4 v) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
+}
+
+// Horizontal 3-tap sum through DPP wave shifts (each shift rides on a v_add_f32_dpp).  No weights are needed for the
+// reflection padding: the halo lane left of column 0 (right of column w-1) synthesises column 1 (w-2) itself, i.e. it
+// holds the reflected value.  Written as asm blocks so that each shift stays fused into its add and the pairs stay
+// adjacent: left to itself the compiler emits all the shifts of a row first (as v_mov_b32_dpp) and keeps their results
+// live, which costs a wave of occupancy.  Two or three independent sums share one block: one s_nop covers the
+// VALU-write -> DPP-read hazard (2 wait states) that the compiler cannot see inside asm, and the interleaving hides the
+// add latency.
+#define SMD_DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define SMD_DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void hsum2(float a, float b, float& ra, float& rb) {
+#ifdef SMD_NO_DPP
+  ra = (a + lane_left(a)) + lane_right(a); rb = (b + lane_left(b)) + lane_right(b);
+#else
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %2, %2" SMD_DPP_SHR
+               "v_add_f32_dpp %1, %3, %3" SMD_DPP_SHR
+               "v_add_f32_dpp %0, %2, %0" SMD_DPP_SHL
+               "v_add_f32_dpp %1, %3, %1" SMD_DPP_SHL
+               : "=&v"(ra), "=&v"(rb) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void hsum3(float a, float b, float c, float& ra, float& rb, float& rc) {
+#ifdef SMD_NO_DPP
+  ra = (a + lane_left(a)) + lane_right(a); rb = (b + lane_left(b)) + lane_right(b); rc = (c + lane_left(c)) + lane_right(c);
+#else
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %3, %3" SMD_DPP_SHR
+               "v_add_f32_dpp %1, %4, %4" SMD_DPP_SHR
+               "v_add_f32_dpp %2, %5, %5" SMD_DPP_SHR
+               "v_add_f32_dpp %0, %3, %0" SMD_DPP_SHL
+               "v_add_f32_dpp %1, %4, %1" SMD_DPP_SHL
+               "v_add_f32_dpp %2, %5, %2" SMD_DPP_SHL
+               : "=&v"(ra), "=&v"(rb), "=&v"(rc) : "v"(a), "v"(b), "v"(c));
+#endif
+}
+
+// SSIM error of one channel from UN-normalised (x9) window sums: ssim = N/D with N and D both scaled by 81*81.
+//   sx = S_x, sxx = S_xx, sxy = S_xy;  sy = S_y, cy1 = S_y^2 + 81 C1, cy2 = 9 S_yy - S_y^2 + 81 C2     (photometric.py:40-50)
+__device__ __forceinline__ float ssim_err81(float sx, float sxx, float sxy, float sy, float cy1, float cy2) {
+  constexpr float c1 = 81.f*kC1, c2 = 81.f*kC2;
+  const float t = sx*sy;
+  const float num = fmaf(2.f, t, c1)*fmaf(2.f, fmaf(9.f, sxy, -t), c2);
+  const float sx2 = sx*sx;
+  const float den = (sx2 + cy1)*(fmaf(9.f, sxx, -sx2) + cy2);
+  const float val = fmaf(-0.5f, num*__builtin_amdgcn_rcpf(den), 0.5f);
+  return fminf(fmaxf(val, 0.f), 1.f);
+}
 
 // SSIM error of one channel from the nine-tap window sums (already divided by 9 where noted).
 //   mx = E[x], exx = E[x^2], exy = E[xy];  my = E[y], cy1 = my^2 + C1, cy2 = var(y) + C2

@@ -35,28 +35,51 @@ struct ScaleSet {  // the multi-scale disparity pyramid, passed by value
   int S;
 };
 
-struct ReconFwdArgs {
-  const float* depth;     // (S,b,h,w); unused when WARP == false
-  const float* tgt;       // (b,3,h,w)
-  const float* supp_pk;   // (n,b,h,w,4) supports repacked as RGBX texels (16-byte aligned gathers)
-  const float* T;         // (n,b,4,4)
-  const float* K;         // (b,4,4)
-  const float* Kinv;      // (b,4,4)
-  const float* e_static;  // (b,h,w) identity error (automask) or null
-  const float* noise;     // (S,b,h,w) or null
-  float* err;             // (S,b,h,w) running / final error
-  uint8_t* sel;           // (S,b,h,w) running / final selection (may be null for the identity pass)
-  float* partial;         // [S*b*nstrips] per-wave loss sums (last pass only)
-  float* warp0;           // (n,b,3,h,w) or null
-  int b, n, S, h, w;
-  int i0;                 // first support handled by this launch
+// Layout of the caller-kept buffer `packed` (smd_packed_supports_bytes; below 4 GB so that one buffer resource spans it):
+//   texels (n,b,h+1,w+1,3): the supports as RGB texels (12 bytes: one dwordx3 load per bilinear tap, a wave's 64 adjacent taps
+//                           span 768 contiguous bytes), padded by one zero texel to the right and below so that the 2x2 tap
+//                           block of any clamped coordinate stays in range;
+//   ypix   (b,h,w,3):       the target as RGB texels (one 12-byte load per lane and row instead of three planar ones);
+//   ta     (b,h,w,4):       {S_y (3 channels), c_0}   with c = 9 S_yy - S_y^2 + 81 C2: what every scale and support shares
+//   tb     (b,h,w,4):       {c_1, c_2, identity error of the automask, 0}              at a target pixel.
+__host__ __device__ inline size_t packed_texel_floats(int b, int n, int h, int w) { return (size_t)n*b*(size_t)(h + 1)*(size_t)(w + 1)*3; }
+__host__ __device__ inline size_t packed_ypix_floats(int b, int h, int w) { return (size_t)b*(size_t)h*(size_t)w*3; }
+__host__ __device__ inline size_t packed_tpix_floats(int b, int h, int w) { return (size_t)b*(size_t)h*(size_t)w*4; }   // each of ta, tb
+__host__ __device__ inline size_t packed_total_floats(int b, int n, int h, int w) {
+  return packed_texel_floats(b, n, h, w) + packed_ypix_floats(b, h, w) + 2*packed_tpix_floats(b, h, w);
+}
+
+struct ReconPrepArgs {     // k_recon_prep: texel repack + target window sums + identity error, once per sample
+  const float* tgt;        // (b,3,h,w)
+  const float* supp;       // (n,b,3,h,w) planar
+  float* packed;           // out, layout above
+  int b, n, h, w;
+  int i0, ni;              // supports [i0, i0+ni) handled by this launch (ni <= 4)
   int flags;
-  int rh;                 // rows per strip
-  int nsx, nsy;           // strips per image in x / y
-  float wscale, hscale;   // w/(w-1), h/(h-1)
+  int rh, nsx, nsy;
+  int first_pass, last_pass;
+};
+
+struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over supports + automask, per (strip, sample, scale)
+  const float* depth;      // (S,b,h,w)
+  const float* packed;     // layout above
+  const float* T;          // (n,b,4,4)
+  const float* K;          // (b,4,4)
+  const float* Kinv;       // (b,4,4)
+  const float* noise;      // (S,b,h,w) or null
+  float* err;              // (S,b,h,w) running / final error
+  uint8_t* sel;            // (S,b,h,w) running / final selection
+  float* partial;          // [S*b*nstrips] per-wave loss sums (last pass only)
+  float* warp0;            // (n,b,3,h,w) or null
+  int b, n, S, h, w;
+  int i0, ni;              // supports [i0, i0+ni) handled by this launch (ni <= 4)
+  int flags;
+  int rh;                  // rows per strip
+  int nsx, nsy;            // strips per image in x / y
+  float wscale, hscale;    // w/(w-1), h/(h-1)
+  float inv_n;
   uint32_t seed_lo, seed_hi;
   int first_pass, last_pass;
-  int variant;            // code-generation variant of the hot instantiation (tuning)
 };
 
 struct ReconBwdArgs {
@@ -98,9 +121,9 @@ __device__ __forceinline__ void decode_wave(unsigned p, int wid, int nstrips, in
 }
 
 // launchers (return hipError_t from hipGetLastError after the launch)
-hipError_t launch_recon_fwd(const ReconFwdArgs& a, int ni, bool warp, hipStream_t st);
+hipError_t launch_recon_prep(const ReconPrepArgs& a, hipStream_t st);
+hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st);
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st);
-hipError_t launch_pack_supports(const float* supp, float* supp_pk, int nb, int h, int w, hipStream_t st);
 hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st);
 hipError_t launch_pose_finalize(const float* pose_partial, int entries, const float* T, const float* K, const float* Kinv,
                                 float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st);

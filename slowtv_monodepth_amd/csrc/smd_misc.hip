@@ -1,0 +1,61 @@
+// smd_misc.hip — small shared kernels: the deterministic second stage of the scalar reductions, the STREAM-style
+// bandwidth probe quoted by bench.py, and the cross-lane self-test.
+#include "smd_common.h"
+#include "smd_kernels.h"
+
+namespace smd {
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic second stage of every scalar reduction: one block, fp64 accumulation.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ partial, int count, double scale, float* out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) acc += (double)partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0]*scale);
+}
+
+hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, partial, count, scale, out);
+  return hipGetLastError();
+}
+
+// STREAM-style device copy (4 independent 16-B loads per lane in flight, grid-stride): the measured HBM ceiling quoted
+// beside the datasheet peak.  `mode` 0 = copy (read + write), 1 = read-only sum (writes one value per block).
+__global__ __launch_bounds__(256) void k_stream_copy(const f4* __restrict__ src, f4* __restrict__ dst, size_t n16, int mode) {
+  const size_t stride = (size_t)gridDim.x*256;
+  size_t i = (size_t)blockIdx.x*256 + threadIdx.x;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i + 3*stride < n16; i += 4*stride) {
+    const f4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const f4 c = __builtin_nontemporal_load(src + i + 2*stride), d = __builtin_nontemporal_load(src + i + 3*stride);
+    if (mode == 0) {
+      __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+      __builtin_nontemporal_store(c, dst + i + 2*stride); __builtin_nontemporal_store(d, dst + i + 3*stride);
+    } else acc += (a + b) + (c + d);
+  }
+  for (; i < n16; i += stride) { const f4 a = src[i]; if (mode == 0) dst[i] = a; else acc += a; }
+  if (mode != 0 && (acc[0] + acc[1] + acc[2] + acc[3]) == 12345.678f) dst[blockIdx.x] = acc;   // keeps the loads alive; practically never taken
+}
+hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_stream_copy, dim3(256*8), dim3(256), 0, st, (const f4*)src, (f4*)dst, nbytes/16, mode);
+  return hipGetLastError();
+}
+
+__global__ void k_debug_lane_shift(float* out_left, float* out_right) {
+  float x = (float)threadIdx.x;
+  out_left[threadIdx.x] = lane_left(x);
+  out_right[threadIdx.x] = lane_right(x);
+}
+hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st) {
+  hipLaunchKernelGGL(k_debug_lane_shift, dim3(1), dim3(64), 0, st, out_left, out_right);
+  return hipGetLastError();
+}
+
+}  // namespace smd

@@ -55,7 +55,7 @@ __device__ __forceinline__ void hsum_w3(float a, float b, float c, float wl, flo
 }
 
 struct BwdPending {   // loads in flight for the next row
-  f4 t[4];            // bilinear taps NW, NE, SW, SE (RGBX texels)
+  f3 t[4];            // bilinear taps NW, NE, SW, SE (RGB texels)
   float y[3];
   float fx, fy, kx, ky;
 };
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
   for (int i = 0; i < a.n; ++i) {
     Cam cm;
     make_cam(cm, a.T + ((size_t)i*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16);
-    const float* spk = a.supp_pk + ((size_t)i*a.b + bi)*4*hw;
+    const unsigned wp = (unsigned)w + 1u;   // padded texel rows (smd_kernels.h: packed_texel_floats)
+    const float* spk = a.supp_pk + ((size_t)i*a.b + bi)*3*(size_t)(h + 1)*wp;
 
     // rings of raw per-pixel values: index 0 = row j, 1 = row j-1, 2 = row j-2
     float x0[3] = {}, x1[3] = {}, x2[3] = {}, y0[3] = {}, y1[3] = {}, y2[3] = {};
@@ -123,10 +124,10 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
       float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hyy, cm.a1), yz = fmaf(D, hz, cm.tz);
       float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
       float sx = fmaf(nx*rz, a.wscale, -0.5f), sy = fmaf(ny*rz, a.hscale, -0.5f);
-      Taps tp = make_taps(sx, sy, h, w);
+      Taps tp = make_taps(sx, sy, h, w, (int)wp);
       P.fx = tp.fx; P.fy = tp.fy; P.kx = tp.mx*a.wscale; P.ky = tp.my*a.hscale;
       const unsigned o = (unsigned)tp.off;
-      P.t[0] = ld4(spk, o); P.t[1] = ld4(spk, o + 1u); P.t[2] = ld4(spk, o + (unsigned)w); P.t[3] = ld4(spk, o + (unsigned)w + 1u);
+      P.t[0] = ld3(spk, o); P.t[1] = ld3(spk, o + 1u); P.t[2] = ld3(spk, o + wp); P.t[3] = ld3(spk, o + wp + 1u);
 #pragma unroll
       for (int c = 0; c < 3; ++c) P.y[c] = ld1(tgt_b, c*hw + ro);
     };

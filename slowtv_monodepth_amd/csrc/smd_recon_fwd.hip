@@ -1,252 +1,465 @@
-// smd_recon_fwd.hip — fused forward of the view-synthesis photometric loss for gfx950.
+// smd_recon_fwd.hip — round-2 forward of the fused view-synthesis photometric loss for gfx950.
 //
-// One launch covers every (strip, sample, scale).  A wave owns 64 consecutive columns (62 interior + 1 halo
-// lane per side) of a `rh`-row strip and streams down the rows:
-//   per row    : depth + target row (coalesced), per support: 6 FMAs of projective geometry, one rcp, four aligned
-//                16-byte gathers from the RGBX-repacked support frame, bilinear blend             (K1c-K1g of SURVEY §2.2)
-//   pipeline   : the loads of row j+1 (and the depth of row j+2) are issued before the SSIM math of row j-1, so the
-//                dependent chain depth -> coordinates -> gather never stalls the wave on two memory latencies per row
-//   horizontal : 3-tap sums of {x, x^2, xy} (and {y, y^2}) through DPP wave shifts folded into v_add_f32_dpp; the
-//                reflection padding costs nothing: halo lanes outside the image synthesise the reflected column
-//   vertical   : a 3-row ring of the raw pixel values in registers;
-//                vertical taps are summed per lane, then the horizontal taps: the 3x3 SSIM window never touches
-//                LDS or HBM                                                                      (K2a-K2c)
-//   per pixel  : SSIM + L1, min/mean over supports in registers, automask against the identity error,
-//                error + selection written once, loss reduced per wave                           (K2d-K2f)
-// The identity ("static") error does not depend on the scale, so it is produced once per sample by the same
-// template with WARP = false instead of S times as in the reference (reconstruction.py:71).
-//
-// Template parameters: NI supports held in registers per pass (n > 2 runs several passes that carry the running
-// min / sum through `err`/`sel`), WARP (false = identity error), SSIM (false = loss_name 'l1'), SINGLE (one pass:
-// no carried state is read or written).
+// The round-1 kernel was VALU-issue bound (about 425 vector instructions per 64-pixel row at ~3.5 cycles each, see
+// profiles/r02_valu_rate2.txt for the issue rates this rewrite is priced against).  Same wave-strip streaming structure
+// (one wave = 64 consecutive columns, 62 interior + 1 halo lane per side, walking down `rh` rows; horizontal 3x3 taps through
+// DPP wave shifts, reflection by data in the halo lanes), but the instruction count per row is cut by:
+//   * sliding vertical sums: per (support, channel) the state is {x(j-1), P = r(j-2) + r(j-1) for r in x, x^2, x*y}; a new
+//     row costs V = P + r(j), P' = r(j-1) + r(j).  No 3-row ring, and with the row loop unrolled by two (the two state
+//     copies swap roles) not a single register move.  Image-border reflection in y is a wave-uniform multiplier on the
+//     new row (top) or one subtraction that recovers row h-2 from P (bottom).
+//   * target-side window sums (sum y, 9*sum y^2 - (sum y)^2 + C2) do not depend on scale or support: k_recon_prep computes them
+//     once per sample, together with the RGBX texel repack (padded by one texel right / below so that the bilinear tap
+//     block needs no clamp) and the identity ("static") error of the automask — one launch instead of round 1's pack +
+//     identity passes.  The main kernel reads them back (six coalesced loads per row, L2 hits for three of four scales).
+//   * geometry: grid normalisation folded into the homography, per-lane column part hoisted out of the row loop, med3
+//     clamps, one float->int conversion per tap block.
+//   * addressing: every array is a buffer resource; the per-lane column offset is a loop-invariant VGPR and the row / plane
+//     offset a scalar (soffset), so the coalesced loads and stores cost no VALU instruction.
+// Supports are processed in pairs inside one launch (n <= 4 in a single pass, no err/sel read-modify-write); the gathers
+// of the next pair / next row are in flight under the current pair's SSIM math.
+// Reference semantics: src/tools/geometry.py:285-391, src/losses/photometric.py:23-88, src/losses/reconstruction.py:43-126.
 #include "smd_common.h"
 #include "smd_kernels.h"
 
+#ifndef SMD_ABLATE
+#define SMD_ABLATE 0   // diagnosis builds only (scripts/dev/ablate.sh): bit 0 no tap gathers, bit 1 no row loads, bit 2 no stores
+#endif
+
 namespace smd {
 
-template <int NI>
-struct RowState {          // raw pixel values of one image row (one column per lane)
-  float yc[3];             // target
-  float xc[NI][3];         // warped (or, for the identity error, un-warped) support
-};
+// ---------------------------------------------------------------------------------------------
+// k_recon_prep: per (strip, sample).  Reads the planar target and support frames once and fills the caller-kept `packed`
+// buffer (layout: smd_kernels.h) that the main kernel and the backward read through ONE buffer resource:
+//   texels (n,b,h+1,w+1,3)   RGB texels of the supports, zero padding column w and row h
+//   ypix   (b,h,w,3)         the target as RGB texels
+//   ta, tb (b,h,w,4) each    {S_y[3], c_0}, {c_1, c_2, identity error, 0}: S_y = 3x3 reflect-padded window sum of the target
+//                            channel, c = 9*S_yy - S_y^2 + 81*C2 (x81 variance term of photometric.py:44-47); identity error =
+//                            min / mean over supports of the photometric error of the UN-warped support (reconstruction.py:70-71).
+// ---------------------------------------------------------------------------------------------
+template <int N, bool SSIM>
+struct PrepCtx {
+  const ReconPrepArgs& a;
+  int h, w, u, r0, r1;
+  unsigned lane4;          // byte offset of this lane's (reflected) column inside a row of floats
+  bool interior;
+  unsigned hw4, w4;        // bytes per plane / per row
+  unsigned so_sup[N], so_tex[N], so_y, so_ta, so_tb;   // wave-uniform byte offsets: planar support k, its texel image, this sample's ypix / ta / tb
+  rsrc_t rs_tgt, rs_sup, rs_pk;
+  float Px[N][3], Pxx[N][3], Pxy[N][3], Py[3], Pyy[3];
+  float ny[3], nx[N][3];   // loads in flight for the next row
 
-template <int NI, bool WARP>
-struct Pending {           // loads in flight for the NEXT row (software pipeline: issued one row ahead of their use)
-  float y[3];
-  f4 t[NI][WARP ? 4 : 1];  // WARP: the 2x2 bilinear taps (NW, NE, SW, SE) as RGBX texels; !WARP: the un-warped support texel
-  float fx[NI], fy[NI];
-};
-
-// Horizontal 3-tap sum through DPP wave shifts (the compiler folds each shift into a v_add_f32_dpp).  No weights are
-// needed for the reflection padding: the halo lane left of column 0 (right of column w-1) synthesises column 1
-// (w-2) itself, i.e. it holds the reflected value.
-// Written as asm blocks so that each shift stays fused into its add (v_add_f32_dpp) and the pairs stay adjacent: left to
-// itself the compiler emits all 48 shifts of a row first (as v_mov_b32_dpp) and keeps their results live, which costs
-// a wave of occupancy.  Two or three independent sums share one block: one s_nop covers the VALU-write -> DPP-read
-// hazard (2 wait states) that the compiler cannot see inside asm, and the interleaving hides the add latency.
-#define SMD_DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define SMD_DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-__device__ __forceinline__ void hsum2(float a, float b, float& ra, float& rb) {
-#ifdef SMD_NO_DPP
-  ra = (a + lane_left(a)) + lane_right(a); rb = (b + lane_left(b)) + lane_right(b);
-#else
-  asm volatile("s_nop 1\n\t"
-               "v_add_f32_dpp %0, %2, %2" SMD_DPP_SHR
-               "v_add_f32_dpp %1, %3, %3" SMD_DPP_SHR
-               "v_add_f32_dpp %0, %2, %0" SMD_DPP_SHL
-               "v_add_f32_dpp %1, %3, %1" SMD_DPP_SHL
-               : "=&v"(ra), "=&v"(rb) : "v"(a), "v"(b));
-#endif
-}
-__device__ __forceinline__ void hsum3(float a, float b, float c, float& ra, float& rb, float& rc) {
-#ifdef SMD_NO_DPP
-  ra = (a + lane_left(a)) + lane_right(a); rb = (b + lane_left(b)) + lane_right(b); rc = (c + lane_left(c)) + lane_right(c);
-#else
-  asm volatile("s_nop 1\n\t"
-               "v_add_f32_dpp %0, %3, %3" SMD_DPP_SHR
-               "v_add_f32_dpp %1, %4, %4" SMD_DPP_SHR
-               "v_add_f32_dpp %2, %5, %5" SMD_DPP_SHR
-               "v_add_f32_dpp %0, %3, %0" SMD_DPP_SHL
-               "v_add_f32_dpp %1, %4, %1" SMD_DPP_SHL
-               "v_add_f32_dpp %2, %5, %2" SMD_DPP_SHL
-               : "=&v"(ra), "=&v"(rb), "=&v"(rc) : "v"(a), "v"(b), "v"(c));
-#endif
-}
-
-template <int NI, bool WARP, bool SSIM, bool SINGLE>
-struct FwdCtx {
-  const ReconFwdArgs& a;
-  int lane, bi, s, h, w, u, uc, r0, r1;
-  bool interior, use_min, automask;
-  float wl, wr, uf;
-  unsigned hw;
-  Cam cam[NI];
-  const float* splane[NI];
-  const float* tgt_b;
-  const float* depth_sb;
-  unsigned out_base;
-  float lsum;
-
-  // ---- stage 1: issue the loads of row j (depth value D already in a register) -------------------
-  __device__ __forceinline__ void issue_row(Pending<NI, WARP>& P, int j, float D) {
-    const unsigned ro = (unsigned)j*(unsigned)w + (unsigned)uc;
+  __device__ __forceinline__ void load_row(int j) {
+    const unsigned ro = (unsigned)j*w4;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) P.y[c] = ld1(tgt_b, c*hw + ro);
-    const float vf = (float)j;
+    for (int c = 0; c < 3; ++c) ny[c] = bld(rs_tgt, lane4, ro + (unsigned)c*hw4);
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      if (WARP) {
-        const Cam& cm = cam[k];
-        float hx = fmaf(cm.H[0], uf, fmaf(cm.H[1], vf, cm.H[2]));
-        float hy_ = fmaf(cm.H[3], uf, fmaf(cm.H[4], vf, cm.H[5]));
-        float hz = fmaf(cm.H[6], uf, fmaf(cm.H[7], vf, cm.H[8]));
-        float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hy_, cm.a1), yz = fmaf(D, hz, cm.tz);
-        float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
-        float sx = fmaf(nx*rz, a.wscale, -0.5f), sy = fmaf(ny*rz, a.hscale, -0.5f);
-        Taps tp = make_taps(sx, sy, h, w);
-        P.fx[k] = tp.fx; P.fy[k] = tp.fy;
-        const unsigned o = (unsigned)tp.off;
-        P.t[k][0] = ld4(splane[k], o); P.t[k][1] = ld4(splane[k], o + 1u);
-        P.t[k][2] = ld4(splane[k], o + (unsigned)w); P.t[k][3] = ld4(splane[k], o + (unsigned)w + 1u);
-      } else {
-        P.t[k][0] = ld4(splane[k], ro);
-      }
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nx[k][c] = bld(rs_sup, lane4, so_sup[k] + ro + (unsigned)c*hw4);
+  }
+  __device__ __forceinline__ void pack_row(int j, const float (&X)[N][3], const float (&Y)[3]) {   // repack of row j (interior lanes)
+    if (a.first_pass) { f3 t; t.x = Y[0]; t.y = Y[1]; t.z = Y[2]; bst3(rs_pk, lane4*3u, so_y + (unsigned)j*w4*3u, t); }
+    const unsigned ro = (unsigned)j*((unsigned)w + 1u)*12u;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      f3 t; t.x = X[k][0]; t.y = X[k][1]; t.z = X[k][2];
+      bst3(rs_pk, lane4*3u, so_tex[k] + ro, t);
+      if (u == w - 1) { const f3 z = {0.f, 0.f, 0.f}; bst3(rs_pk, lane4*3u + 12u, so_tex[k] + ro, z); }
     }
   }
 
-  // ---- stage 2: consume the loads -> raw pixel values of row j ------------------------------------
-  __device__ __forceinline__ void finish_row(RowState<NI>& R, const Pending<NI, WARP>& P, int j) {
+  // One row step: row j becomes the NEW row (Xn, Yn), the centre row is j-1 (Xo, Yo), P holds r(j-2) + r(j-1).
+  // VIRT: j == h, the row below the image is row h-2 (ReflectionPad2d(1)) = P - r(h-1).
+  template <bool EMIT, bool VIRT>
+  __device__ __forceinline__ void step(int j, float (&Xo)[N][3], float (&Xn)[N][3], float (&Yo)[3], float (&Yn)[3]) {
+    const int v = j - 1;
+    if (!VIRT) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) R.yc[c] = P.y[c];
+      for (int c = 0; c < 3; ++c) Yn[c] = ny[c];
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      if (WARP) {
-        const float w11 = P.fx[k]*P.fy[k], w01 = P.fx[k] - w11, w10 = P.fy[k] - w11, w00 = (1.f - P.fx[k]) - w10;
+      for (int k = 0; k < N; ++k)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          R.xc[k][c] = fmaf(w11, P.t[k][3][c], fmaf(w10, P.t[k][2][c], fmaf(w01, P.t[k][1][c], w00*P.t[k][0][c])));
-      } else {
+        for (int c = 0; c < 3; ++c) Xn[k][c] = nx[k][c];
+      if (j >= r0 && j < r1 && interior) pack_row(j, Xn, Yn);   // each row is interior to exactly one strip
+      if (j + 1 <= min(r1, h - 1)) load_row(j + 1);
+    } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) R.xc[k][c] = P.t[k][0][c];
-      }
-      if (WARP && a.warp0 != nullptr && s == 0 && interior && j >= r0 && j < r1) {
-        float* wo = a.warp0 + ((size_t)(a.i0 + k)*a.b + bi)*3*hw + (size_t)j*w + u;
+      for (int c = 0; c < 3; ++c) Yn[c] = Py[c] - Yo[c];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) wo[(size_t)c*hw] = R.xc[k][c];
-      }
+      for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Xn[k][c] = Px[k][c] - Xo[k][c];
     }
-  }
-
-  // ---- emit row v from the ring (A = row v-1, B = row v, C = row v+1) --------------------------
-  // Vertical 3-tap sums first (per lane, from the raw ring), then the horizontal taps through DPP: the ring holds
-  // 3 + 3*NI values per row instead of the 6 + 9*NI horizontal sums.  Reflection in y is done by the caller
-  // (A := C for the first image row, C := A for the last), so every window is a plain sum.
-  __device__ __forceinline__ float vsum(float qa, float qb, float qc) { return (qa + qb) + qc; }
-  __device__ __forceinline__ float vdot(float pa, float qa, float pb, float qb, float pc, float qc) { return fmaf(pc, qc, fmaf(pa, qa, pb*qb)); }
-
-  __device__ __forceinline__ void emit_row(const RowState<NI>& A, const RowState<NI>& B, const RowState<NI>& C, int v) {
-    // window sums are kept un-normalised (x9): ssim = N/D with both N and D scaled by 81*81
+    const float m = (v == 0) ? 2.f : 1.f;  // row -1 is row 1: the new row counts twice for the first image row
     constexpr float c1 = 81.f*kC1, c2 = 81.f*kC2;
-    float sy[3], cy1[3], cy2[3];
+    float sy[3] = {0.f, 0.f, 0.f}, cy1[3], cy2[3] = {0.f, 0.f, 0.f};
     if (SSIM) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float s1, s2;
-        hsum2(vsum(A.yc[c], B.yc[c], C.yc[c]), vdot(A.yc[c], A.yc[c], B.yc[c], B.yc[c], C.yc[c], C.yc[c]), s1, s2);
-        sy[c] = s1; cy1[c] = fmaf(s1, s1, c1); cy2[c] = fmaf(9.f, s2, c2) - s1*s1;
+        const float yy = Yn[c]*Yn[c];
+        const float Vy = fmaf(m, Yn[c], Py[c]), Vyy = fmaf(m, yy, Pyy[c]);
+        Py[c] = Yo[c] + Yn[c]; Pyy[c] = fmaf(Yo[c], Yo[c], yy);
+        if (EMIT) {
+          float s1, s2;
+          hsum2(Vy, Vyy, s1, s2);
+          sy[c] = s1; cy2[c] = fmaf(9.f, s2, c2) - s1*s1; cy1[c] = fmaf(s1, s1, c1);
+        }
       }
     }
     float best = 0.f, acc = 0.f;
-    int bsel = a.i0;
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
+    for (int k = 0; k < N; ++k) {
       float es = 0.f, el = 0.f;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        el += fabsf(B.xc[k][c] - B.yc[c]);
+        const float xn = Xn[k][c], xo = Xo[k][c];
+        if (EMIT) el += fabsf(xo - Yo[c]);
         if (SSIM) {
-          float sx, sxx, sxy;
-          hsum3(vsum(A.xc[k][c], B.xc[k][c], C.xc[k][c]),
-                vdot(A.xc[k][c], A.xc[k][c], B.xc[k][c], B.xc[k][c], C.xc[k][c], C.xc[k][c]),
-                vdot(A.xc[k][c], A.yc[c], B.xc[k][c], B.yc[c], C.xc[k][c], C.yc[c]), sx, sxx, sxy);
-          float t = sx*sy[c];
-          float num = fmaf(2.f, t, c1)*fmaf(2.f, fmaf(9.f, sxy, -t), c2);
-          float sx2 = sx*sx;
-          float den = (sx2 + cy1[c])*(fmaf(9.f, sxx, -sx2) + cy2[c]);
-          float val = fmaf(-0.5f, num*__builtin_amdgcn_rcpf(den), 0.5f);
-          es += fminf(fmaxf(val, 0.f), 1.f);
+          const float xx = xn*xn, xy = xn*Yn[c];
+          const float Vx = fmaf(m, xn, Px[k][c]), Vxx = fmaf(m, xx, Pxx[k][c]), Vxy = fmaf(m, xy, Pxy[k][c]);
+          Px[k][c] = xo + xn; Pxx[k][c] = fmaf(xo, xo, xx); Pxy[k][c] = fmaf(xo, Yo[c], xy);
+          if (EMIT) {
+            float sx, sxx, sxy;
+            hsum3(Vx, Vxx, Vxy, sx, sxx, sxy);
+            es += ssim_err81(sx, sxx, sxy, sy[c], cy1[c], cy2[c]);
+          }
         }
       }
-      float e = SSIM ? fmaf(kWSsim/3.f, es, ((1.f - kWSsim)/3.f)*el) : el*(1.f/3.f);
-      if (k == 0) { best = e; acc = e; }
-      else {
-        acc += e;
-        if (e < best) { best = e; bsel = a.i0 + k; }
+      if (EMIT) {
+        const float e = SSIM ? fmaf(kWSsim/3.f, es, ((1.f - kWSsim)/3.f)*el) : el*(1.f/3.f);
+        if (k == 0) { best = e; acc = e; } else { acc += e; best = fminf(best, e); }
       }
     }
-    if (interior) {
-      const unsigned idx = out_base + (unsigned)v*(unsigned)w + (unsigned)u;
+    if (EMIT && interior) {
+      const unsigned to = (unsigned)v*w4*4u;
+      const bool use_min = a.flags & SMD_USE_MIN;
+      float e = use_min ? best : acc;
+      if (!a.first_pass) { const float prev = bld(rs_pk, lane4*4u + 8u, so_tb + to); e = use_min ? fminf(e, prev) : e + prev; }
+      if (a.last_pass && !use_min) e = e/(float)a.n;
+      if (a.first_pass) {
+        f4 t0, t1; t0.x = sy[0]; t0.y = sy[1]; t0.z = sy[2]; t0.w = cy2[0]; t1.x = cy2[1]; t1.y = cy2[2]; t1.z = e; t1.w = 0.f;
+        bst4(rs_pk, lane4*4u, so_ta + to, t0); bst4(rs_pk, lane4*4u, so_tb + to, t1);
+      } else bst(rs_pk, lane4*4u + 8u, so_tb + to, e);
+    }
+  }
+
+  __device__ __forceinline__ void init(float (&X)[N][3], float (&Y)[3]) {   // first row of the strip: P = r(jstart) alone
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { Y[c] = ny[c]; Py[c] = Y[c]; Pyy[c] = Y[c]*Y[c]; }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { X[k][c] = nx[k][c]; Px[k][c] = X[k][c]; Pxx[k][c] = X[k][c]*X[k][c]; Pxy[k][c] = X[k][c]*Y[c]; }
+  }
+};
+
+template <int N, bool SSIM>
+__global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_prep(const ReconPrepArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nstrips = a.nsx*a.nsy;
+  const int nbx = ceil_div(nstrips, kWavesPerBlock);
+  const int bi = blockIdx.x/nbx, strip = (blockIdx.x - bi*nbx)*kWavesPerBlock + wid;
+  if (strip >= nstrips) return;
+  const int sxi = strip % a.nsx, syi = strip/a.nsx;
+  PrepCtx<N, SSIM> cx{a};
+  cx.h = a.h; cx.w = a.w;
+  cx.r0 = syi*a.rh; cx.r1 = min(cx.r0 + a.rh, a.h);
+  cx.u = sxi*kFwdCols - 1 + lane;
+  const int uc = (cx.u < 0) ? min(-cx.u, a.w - 1) : ((cx.u >= a.w) ? max(2*(a.w - 1) - cx.u, 0) : cx.u);
+  cx.lane4 = (unsigned)uc*4u;
+  cx.interior = (lane >= 1) && (lane <= kFwdCols) && (cx.u < a.w);
+  const size_t hw = (size_t)a.h*a.w;
+  cx.hw4 = (unsigned)hw*4u; cx.w4 = (unsigned)a.w*4u;
+  cx.rs_tgt = make_rsrc(a.tgt + (size_t)bi*3*hw, 3*hw*4);
+  cx.rs_sup = make_rsrc(a.supp, (size_t)a.n*a.b*3*hw*4);
+  cx.rs_pk = make_rsrc(a.packed, packed_total_floats(a.b, a.n, a.h, a.w)*4);
+  const unsigned texel_bytes = (unsigned)(a.h + 1)*(unsigned)(a.w + 1)*12u;
+  cx.so_y = (unsigned)(packed_texel_floats(a.b, a.n, a.h, a.w)*4) + (unsigned)bi*cx.hw4*3u;
+  cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, a.h, a.w) + packed_ypix_floats(a.b, a.h, a.w))*4) + (unsigned)bi*cx.hw4*4u;
+  cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, a.h, a.w)*4);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    cx.so_sup[k] = (unsigned)((a.i0 + k)*a.b + bi)*3u*cx.hw4;
+    cx.so_tex[k] = (unsigned)((a.i0 + k)*a.b + bi)*texel_bytes;
+  }
+
+  float XA[N][3], XB[N][3], YA[3], YB[3];
+  const int jstart = max(cx.r0 - 1, 0), jlast = min(cx.r1, a.h - 1);
+  cx.load_row(jstart);
+  int j = jstart + 1;
+  if (jstart >= cx.r0 && cx.interior) cx.pack_row(jstart, cx.nx, cx.ny);   // jstart == r0 == 0
+  if (cx.r0 > 0) {
+    cx.init(XB, YB);
+    if (jstart + 1 <= jlast) cx.load_row(jstart + 1);
+    cx.template step<false, false>(j, XB, XA, YB, YA);   // centre r0-1 belongs to the strip above
+    ++j;
+  } else {
+    cx.init(XA, YA);
+    if (jstart + 1 <= jlast) cx.load_row(jstart + 1);
+  }
+  bool cur_is_a = true;
+  for (; j <= jlast; j += 2) {
+    cx.template step<true, false>(j, XA, XB, YA, YB);
+    if (j + 1 > jlast) { cur_is_a = false; ++j; break; }
+    cx.template step<true, false>(j + 1, XB, XA, YB, YA);
+  }
+  if (cx.r1 == a.h) {   // the strip owns the last image row: one more step whose new row is the reflected row h-2
+    if (!cur_is_a) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) YA[c] = YB[c];
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) XA[k][c] = XB[k][c];
+    }
+    cx.template step<true, true>(a.h, XA, XB, YA, YB);
+    // zero padding row h of the texel array
+    if (cx.interior) {
+      const unsigned ro = (unsigned)a.h*((unsigned)a.w + 1u)*12u;
+      const f3 z = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        bst3(cx.rs_pk, cx.lane4*3u, cx.so_tex[k] + ro, z);
+        if (cx.u == a.w - 1) bst3(cx.rs_pk, cx.lane4*3u + 12u, cx.so_tex[k] + ro, z);
+      }
+    }
+  }
+}
+
+hipError_t launch_recon_prep(const ReconPrepArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(a.nsx*a.nsy, kWavesPerBlock)*(unsigned)a.b), block(64*kWavesPerBlock);
+  const bool ssim = !(a.flags & SMD_LOSS_L1);
+#define SMD_PREP(N_) do { if (ssim) hipLaunchKernelGGL((k_recon_prep<N_, true>), grid, block, 0, st, a); \
+                          else hipLaunchKernelGGL((k_recon_prep<N_, false>), grid, block, 0, st, a); } while (0)
+  switch (a.ni) { case 1: SMD_PREP(1); break; case 2: SMD_PREP(2); break; case 3: SMD_PREP(3); break; default: SMD_PREP(4); break; }
+#undef SMD_PREP
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_recon_main: per (strip, sample, scale).
+// Template parameters: N supports of this launch (1..4); SSIM (false = loss_name 'l1'); SINGLE (one launch covers all supports:
+// no carried min / sum is read or written); AUX (the rarely used extras: caller-supplied tie-break noise, `supp_imgs_warp`
+// output — kept out of the hot instantiation because their wave-uniform addresses would sit in SGPRs for the whole loop).
+// ---------------------------------------------------------------------------------------------
+struct Cam2 {              // wave-uniform part of the folded homography (SGPRs); rows 0/1 carry the grid scale w/(w-1), h/(h-1)
+  float H1, H4, H7;        // d(hx, hy, hz)/dv
+  float a0, a1, tz;
+};
+
+template <int N>
+struct MainPend {          // gathers in flight for one pair of supports
+  f3 t[(N > 1) ? 2 : 1][4];
+  float fx[(N > 1) ? 2 : 1], fy[(N > 1) ? 2 : 1];
+};
+
+template <int N, bool SSIM, bool SINGLE, bool AUX>
+struct MainCtx {
+  static constexpr int NG = (N + 1)/2;
+  const ReconMainArgs& a;
+  int bi, s, h, w, r0, r1, jlast;
+  unsigned lane4;          // byte offset of this lane's (reflected) column inside a row of floats
+  bool interior, use_min, automask, has_noise, want_w0;
+  unsigned hw4, w4, rowbytes;
+  float xmax, ymax, wpf;
+  Cam2 cam[N];
+  float hx0[N], hy0[N], hz0[N];
+  unsigned so_tex[N], so_y, so_ta, so_tb;   // wave-uniform byte offsets into `packed`: texel image of support k, this sample's ypix / ta / tb
+  const float* nz_sb;               // noise of this (scale, sample) (AUX)
+  rsrc_t rs_pk, rs_depth, rs_err, rs_sel;
+  float lsum;
+  float Px[N][3], Pxx[N][3], Pxy[N][3];
+  MainPend<N> P;
+  f3 py;                   // target row in flight
+  float Dcur, Dnext;       // depth of rows j and j+1
+  float vfn;               // (float)(j+1)
+
+  // ---- coordinates + the four tap loads of one pair of supports -----------------------------------------
+  __device__ __forceinline__ void issue(int g, float D, float vf) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = 2*g + kk;
+      if (k < N) {
+        const Cam2& cm = cam[k];
+        const float hx = fmaf(cm.H1, vf, hx0[k]), hy = fmaf(cm.H4, vf, hy0[k]), hz = fmaf(cm.H7, vf, hz0[k]);
+        const float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hy, cm.a1), yz = fmaf(D, hz, cm.tz);
+        const float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
+        const float sx = fmaf(nx, rz, -0.5f), sy = fmaf(ny, rz, -0.5f);
+        const float cx = __builtin_amdgcn_fmed3f(sx, 0.f, xmax), cy = __builtin_amdgcn_fmed3f(sy, 0.f, ymax);
+        const float x0 = floorf(cx), y0 = floorf(cy);
+        P.fx[kk] = cx - x0; P.fy[kk] = cy - y0;
+        const unsigned o = __umul24((unsigned)fmaf(y0, wpf, x0), 12u);   // texel index exact in fp32: (h+1)*(w+1) < 2^24 (checked by the C ABI)
+#if (SMD_ABLATE & 1)
+        const float fo = __builtin_bit_cast(float, (o & 0x7fffffu) | 0x3f000000u);
+        P.t[kk][0] = f3{fo, fo*0.5f, fo*0.25f}; P.t[kk][1] = f3{fo*0.3f, fo, fo}; P.t[kk][2] = f3{fo, fo*0.7f, fo}; P.t[kk][3] = f3{fo*0.9f, fo, fo*0.1f};
+#else
+        P.t[kk][0] = bld3(rs_pk, o, so_tex[k]); P.t[kk][1] = bld3(rs_pk, o + 12u, so_tex[k]);
+        P.t[kk][2] = bld3(rs_pk, o, so_tex[k] + rowbytes); P.t[kk][3] = bld3(rs_pk, o + 12u, so_tex[k] + rowbytes);
+#endif
+      }
+    }
+  }
+
+  // The loads that follow the last pair of row j: first pair of row j+1, its target row, the depth of row j+2.  Issued
+  // unconditionally — also after the last row of the strip, where nothing consumes them: the tap coordinates are clamped, a
+  // depth row below the image reads 0 (buffer bounds), and a conditional issue would make every pending register a loop phi
+  // with a second copy (36 more VGPRs).
+  __device__ __forceinline__ void issue_next_row(int j) {
+    issue(0, Dnext, vfn);
+#if (SMD_ABLATE & 2)
+    py = f3{vfn*0.001f, 0.5f, vfn*0.002f};
+    Dcur = Dnext;
+    Dnext = 1.f + vfn*0.01f;
+#else
+    py = bld3(rs_pk, lane4*3u, so_y + (unsigned)(j + 1)*w4*3u);
+    Dcur = Dnext;
+    Dnext = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
+#endif
+    vfn += 1.f;
+  }
+
+  __device__ __forceinline__ void finish(int g, float (&Xn)[N][3], int j) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = 2*g + kk;
+      if (k < N) {
+        const float w11 = P.fx[kk]*P.fy[kk], w01 = P.fx[kk] - w11, w10 = P.fy[kk] - w11, w00 = (1.f - P.fx[kk]) - w10;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          Xn[k][c] = fmaf(w11, P.t[kk][3][c], fmaf(w10, P.t[kk][2][c], fmaf(w01, P.t[kk][1][c], w00*P.t[kk][0][c])));
+      }
+    }
+    if (AUX && want_w0 && j >= r0 && j < r1 && interior) {     // loss_dict['supp_imgs_warp'] (scale 0 only; logging path)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int k = 2*g + kk;
+        if (k < N) {
+          float* wo = a.warp0 + ((size_t)(a.i0 + k)*a.b + bi)*3*(size_t)(hw4/4u) + (size_t)j*w + (lane4 >> 2);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) wo[(size_t)c*(hw4/4u)] = Xn[k][c];
+        }
+      }
+    }
+  }
+
+  // One row step: row j is the NEW row, centre row v = j-1.  EMIT = false only updates the sliding sums.
+  // VIRT (j == h): the new row is the reflected row h-2: the target row is read again, the warped row is P - x(h-1).
+  template <bool EMIT, bool VIRT>
+  __device__ __forceinline__ void step(int j, float (&Xo)[N][3], float (&Xn)[N][3], float (&Yo)[3], float (&Yn)[3]) {
+    const int v = j - 1;
+    constexpr float c1 = 81.f*kC1;
+    f4 t0 = {0.f, 0.f, 0.f, 0.f};
+    f3 t1 = {0.f, 0.f, 0.f};
+    float nz = 0.f;
+    if (EMIT) {   // what the centre row shares across scales and supports: {S_y[3], cy2[3], identity error, -}
+      const unsigned to = (unsigned)v*w4*4u;
+#if (SMD_ABLATE & 2)
+      t0 = f4{4.5f + vfn*0.01f, 4.4f, 4.3f, 0.2f}; t1 = f3{0.25f, 0.3f, 0.05f}; (void)to;
+#else
+      if (SSIM) t0 = bld4(rs_pk, lane4*4u, so_ta + to);
+      t1 = bld3(rs_pk, lane4*4u, so_tb + to);
+#endif
+      if (AUX && has_noise) nz = nz_sb[(size_t)v*w + (lane4 >> 2)];
+    }
+    if (!VIRT) { Yn[0] = py.x; Yn[1] = py.y; Yn[2] = py.z; }
+    else { const f3 yy = bld3(rs_pk, lane4*3u, so_y + (unsigned)(h - 2)*w4*3u); Yn[0] = yy.x; Yn[1] = yy.y; Yn[2] = yy.z; }
+    const float m = (v == 0) ? 2.f : 1.f;                 // row -1 is row 1: the new row counts twice for the first image row
+    float best = 0.f, acc = 0.f;
+    int bsel = a.i0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (!VIRT) finish(g, Xn, j);
+      else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { const int k = 2*g + kk; if (k < N) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Xn[k][c] = Px[k][c] - Xo[k][c]; } }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // keep the memory pipe busy: next pair of this row, or the first pair of the next row
+      if (!VIRT) {
+        if (g + 1 < NG) issue(g + 1, Dcur, vfn - 1.f);
+        else issue_next_row(j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int k = 2*g + kk;
+        if (k < N) {
+          float es = 0.f, el = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float xn = Xn[k][c], xo = Xo[k][c];
+            if (EMIT) el += fabsf(xo - Yo[c]);
+            if (SSIM) {
+              const float xx = xn*xn, xy = xn*Yn[c];
+              const float Vx = fmaf(m, xn, Px[k][c]), Vxx = fmaf(m, xx, Pxx[k][c]), Vxy = fmaf(m, xy, Pxy[k][c]);
+              Px[k][c] = xo + xn; Pxx[k][c] = fmaf(xo, xo, xx); Pxy[k][c] = fmaf(xo, Yo[c], xy);
+              if (EMIT) {
+                float sx, sxx, sxy;
+                hsum3(Vx, Vxx, Vxy, sx, sxx, sxy);
+                const float sy = t0[c], cy2 = (c == 0) ? t0.w : ((c == 1) ? t1.x : t1.y);
+                es += ssim_err81(sx, sxx, sxy, sy, fmaf(sy, sy, c1), cy2);
+              }
+            }
+          }
+          if (EMIT) {
+            const float e = SSIM ? fmaf(kWSsim/3.f, es, ((1.f - kWSsim)/3.f)*el) : el*(1.f/3.f);
+            if (k == 0) { best = e; acc = e; }
+            else { acc += e; if (e < best) { best = e; bsel = a.i0 + k; } }
+          }
+        }
+      }
+    }
+    if (EMIT && interior) {
+      const unsigned lane1 = lane4 >> 2, cro = (unsigned)v*w4, cro1 = (unsigned)v*(unsigned)w;
       if (!SINGLE && !a.first_pass) {
-        float prev = a.err[idx];
-        if (use_min) { if (!(best < prev)) { best = prev; bsel = a.sel ? a.sel[idx] : 0; } }
+        const float prev = bld(rs_err, lane4, cro);
+        if (use_min) { if (!(best < prev)) { best = prev; bsel = (int)bld8(rs_sel, lane1, cro1); } }
         else acc += prev;
       }
       if (!SINGLE && !a.last_pass) {
-        a.err[idx] = use_min ? best : acc;
-        if (a.sel) a.sel[idx] = (uint8_t)bsel;
+        bst(rs_err, lane4, cro, use_min ? best : acc);
+        bst8(rs_sel, lane1, cro1, (unsigned)bsel);
       } else {
-        float e = use_min ? best : acc/(float)a.n;
+        float e = use_min ? best : acc*a.inv_n;
         if (!use_min) bsel = 0;
-        if (automask) {
-          float est = a.e_static[(unsigned)bi*hw + (unsigned)v*(unsigned)w + (unsigned)u];
-          // the tie-break noise is eps*N(0,1): it can only matter when the two errors are within a few eps of each other
-          if (a.noise) est = fmaf(kEps32, a.noise[idx], est);
-          else if (fabsf(est - e) < 1e-5f) est = fmaf(kEps32, gauss_noise(a.seed_lo, a.seed_hi, (uint32_t)idx), est);
-          if (est < e) { e = est; bsel = SMD_SEL_MASKED; }
-        }
-        a.err[idx] = e;
-        if (a.sel) a.sel[idx] = (uint8_t)bsel;
+        float est = automask ? t1.z : __builtin_inff();
+        // the tie-break noise is eps*N(0,1): it can only matter when the two errors are within a few eps of each other
+        if (AUX && has_noise) est = fmaf(kEps32, nz, est);
+        else if (fabsf(est - e) < 1e-5f)
+          est = fmaf(kEps32, gauss_noise(a.seed_lo, a.seed_hi, (uint32_t)(((unsigned)s*(unsigned)a.b + (unsigned)bi)*(hw4 >> 2) + cro1 + lane1)), est);
+        if (est < e) { e = est; bsel = SMD_SEL_MASKED; }
+#if (SMD_ABLATE & 4)
+        if (e == 123.456f) bst(rs_err, lane4, cro, e + (float)bsel);
+#else
+        bst(rs_err, lane4, cro, e);
+        bst8(rs_sel, lane1, cro1, (unsigned)bsel);
+#endif
         lsum += e;
       }
     }
   }
 
-  // The row loop.  Ring: A = row j-2, B = row j-1, C = row j.  Software pipeline per step j:
-  //   finish(C <- loads of row j, issued during step j-1) | issue(loads of row j+1; needs depth(j+1), loaded during
-  //   step j-1) | load depth(j+2) | emit(row j-1)  — so a row's gathers are in flight under the previous row's SSIM math.
-  // (Unrolling by 3 to avoid shifting the ring — 54 v_mov per row — was measured slower twice: the three role assignments keep
-  //  more values live; 128 VGPRs / 4 waves: 137 us, capped at 96 VGPRs it spills: 483 us, against 87 us for the shifting loop.)
-  __device__ __forceinline__ void run() {
-    RowState<NI> A = {}, B = {}, C = {};
-    Pending<NI, WARP> P = {};
-    const int jstart = max(r0 - 1, 0);
-    const int jlast = min(r1, h - 1);  // last row that is read (row r1 is halo when r1 < h)
-    float Dn = 0.f;
-    if (WARP) Dn = ld1(depth_sb, (unsigned)jstart*(unsigned)w + (unsigned)uc);
-    issue_row(P, jstart, Dn);
-    if (WARP && jstart + 1 <= jlast) Dn = ld1(depth_sb, (unsigned)(jstart + 1)*(unsigned)w + (unsigned)uc);
-    for (int j = jstart; j <= r1; ++j) {  // j == r1 == h is the virtual row below the image: it only emits row h-1
-      if (j <= jlast) finish_row(C, P, j);
-      __builtin_amdgcn_sched_barrier(0);
-      if (j + 1 <= jlast) {
-        issue_row(P, j + 1, Dn);
-        if (WARP && j + 2 <= jlast) Dn = ld1(depth_sb, (unsigned)(j + 2)*(unsigned)w + (unsigned)uc);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const int v = j - 1;
-      if (v >= r0 && v < r1) {
-        if (v == 0) A = C;        // ReflectionPad2d(1): row -1 is row 1
-        if (j == h) C = A;        //                     row h is row h-2
-        emit_row(A, B, C, v);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      A = B; B = C;
+  __device__ __forceinline__ void init(float (&X)[N][3], float (&Y)[3], int j) {   // P = r(jstart) alone
+    Y[0] = py.x; Y[1] = py.y; Y[2] = py.z;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      finish(g, X, j);
+      if (g + 1 < NG) issue(g + 1, Dcur, vfn - 1.f);
+      else issue_next_row(j);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) { const int k = 2*g + kk; if (k < N) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { Px[k][c] = X[k][c]; Pxx[k][c] = X[k][c]*X[k][c]; Pxy[k][c] = X[k][c]*Y[c]; } } }
     }
   }
 };
 
-template <int NI, bool WARP, bool SSIM, bool SINGLE>
-__device__ __forceinline__ void recon_fwd_body(const ReconFwdArgs& a) {
+template <int N, bool SSIM, bool SINGLE, bool AUX>
+__device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int strip, bi_, s_;
@@ -254,132 +467,122 @@ __device__ __forceinline__ void recon_fwd_body(const ReconFwdArgs& a) {
   if (strip >= a.nsx*a.nsy) return;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
 
-  FwdCtx<NI, WARP, SSIM, SINGLE> cx{a};
-  cx.lane = lane; cx.bi = bi_; cx.s = s_; cx.h = a.h; cx.w = a.w;
-  const int c0 = sxi*kFwdCols;
+  MainCtx<N, SSIM, SINGLE, AUX> cx{a};
+  cx.bi = bi_; cx.s = s_; cx.h = a.h; cx.w = a.w;
   cx.r0 = syi*a.rh; cx.r1 = min(cx.r0 + a.rh, a.h);
-  cx.u = c0 - 1 + lane;
+  cx.jlast = min(cx.r1, a.h - 1);
+  const int u = sxi*kFwdCols - 1 + lane;
   // The pixel column this lane synthesises: its own, or — for the halo lane just outside the image — the reflected one.
-  cx.uc = (cx.u < 0) ? min(-cx.u, a.w - 1) : ((cx.u >= a.w) ? max(2*(a.w - 1) - cx.u, 0) : cx.u);
-  cx.interior = (lane >= 1) && (lane <= kFwdCols) && (cx.u < a.w);
-  cx.wl = cx.wr = 1.f;
-  cx.uf = (float)cx.uc;
+  const int uc = (u < 0) ? min(-u, a.w - 1) : ((u >= a.w) ? max(2*(a.w - 1) - u, 0) : u);
+  cx.lane4 = (unsigned)uc*4u;
+  cx.interior = (lane >= 1) && (lane <= kFwdCols) && (u < a.w);
   cx.use_min = a.flags & SMD_USE_MIN;
   cx.automask = a.flags & SMD_USE_AUTOMASK;
-  cx.hw = (unsigned)a.h*(unsigned)a.w;
+  cx.has_noise = cx.automask && a.noise != nullptr;
+  cx.want_w0 = a.warp0 != nullptr && s_ == 0;
+  const size_t hw = (size_t)a.h*a.w;
+  cx.hw4 = (unsigned)hw*4u; cx.w4 = (unsigned)a.w*4u;
+  cx.rowbytes = ((unsigned)a.w + 1u)*12u;
+  cx.xmax = (float)(a.w - 1); cx.ymax = (float)(a.h - 1); cx.wpf = (float)(a.w + 1);
+  const float uf = (float)uc;
+  const unsigned texel_bytes = (unsigned)(a.h + 1)*(unsigned)(a.w + 1)*12u;
 #pragma unroll
-  for (int k = 0; k < NI; ++k) {
+  for (int k = 0; k < N; ++k) {
     const int i = a.i0 + k;
-    if (WARP) make_cam(cx.cam[k], a.T + ((size_t)i*a.b + cx.bi)*16, a.K + (size_t)cx.bi*16, a.Kinv + (size_t)cx.bi*16);
-    cx.splane[k] = a.supp_pk + ((size_t)i*a.b + cx.bi)*4*cx.hw;
+    const float* T = a.T + ((size_t)i*a.b + bi_)*16;
+    const float* K = a.K + (size_t)bi_*16;
+    const float* Ki = a.Kinv + (size_t)bi_*16;
+    float M[9];  // R * Kinv3
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) M[r*3 + q] = T[r*4 + 0]*Ki[0*4 + q] + T[r*4 + 1]*Ki[1*4 + q] + T[r*4 + 2]*Ki[2*4 + q];
+    float H[9];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      H[q] = (K[0]*M[q] + K[1]*M[3 + q] + K[2]*M[6 + q])*a.wscale;
+      H[3 + q] = (K[4]*M[q] + K[5]*M[3 + q] + K[6]*M[6 + q])*a.hscale;
+      H[6 + q] = M[6 + q];
+    }
+    cx.cam[k].H1 = uniform(H[1]); cx.cam[k].H4 = uniform(H[4]); cx.cam[k].H7 = uniform(H[7]);
+    cx.cam[k].a0 = uniform((K[0]*T[3] + K[1]*T[7] + K[2]*T[11])*a.wscale);
+    cx.cam[k].a1 = uniform((K[4]*T[3] + K[5]*T[7] + K[6]*T[11])*a.hscale);
+    cx.cam[k].tz = uniform(T[11]);
+    cx.hx0[k] = fmaf(uniform(H[0]), uf, uniform(H[2]));
+    cx.hy0[k] = fmaf(uniform(H[3]), uf, uniform(H[5]));
+    cx.hz0[k] = fmaf(uniform(H[6]), uf, uniform(H[8]));
+    cx.so_tex[k] = (unsigned)(i*a.b + bi_)*texel_bytes;
   }
-  cx.tgt_b = a.tgt + (size_t)cx.bi*3*cx.hw;
-  cx.depth_sb = WARP ? a.depth + ((size_t)cx.s*a.b + cx.bi)*cx.hw : nullptr;
-  cx.out_base = ((unsigned)cx.s*(unsigned)a.b + (unsigned)cx.bi)*cx.hw;
+  const size_t sb = ((size_t)s_*a.b + bi_)*hw;
+  cx.so_y = (unsigned)(packed_texel_floats(a.b, a.n, a.h, a.w)*4) + (unsigned)bi_*cx.hw4*3u;
+  cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, a.h, a.w) + packed_ypix_floats(a.b, a.h, a.w))*4) + (unsigned)bi_*cx.hw4*4u;
+  cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, a.h, a.w)*4);
+  cx.rs_pk = make_rsrc(a.packed, packed_total_floats(a.b, a.n, a.h, a.w)*4);
+  cx.rs_depth = make_rsrc(a.depth + sb, hw*4);
+  cx.nz_sb = (AUX && a.noise) ? a.noise + sb : nullptr;
+  cx.rs_err = make_rsrc(a.err + sb, hw*4);
+  cx.rs_sel = make_rsrc(a.sel + sb, hw);
   cx.lsum = 0.f;
 
-  cx.run();
+  // prologue: row jstart's loads, depth two rows ahead
+  const int jstart = max(cx.r0 - 1, 0);
+  cx.vfn = (float)jstart;
+  cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)jstart*cx.w4);
+  cx.Dcur = cx.Dnext;
+  cx.issue(0, cx.Dnext, cx.vfn);
+  cx.py = bld3(cx.rs_pk, cx.lane4*3u, cx.so_y + (unsigned)jstart*cx.w4*3u);
+  cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)(jstart + 1)*cx.w4);
+  cx.vfn += 1.f;
+
+  float XA[N][3], XB[N][3], YA[3], YB[3];
+  int j = jstart + 1;
+  if (cx.r0 > 0) {
+    cx.init(XB, YB, jstart);
+    cx.template step<false, false>(j, XB, XA, YB, YA);
+    ++j;
+  } else {
+    cx.init(XA, YA, jstart);
+  }
+  bool cur_is_a = true;
+  for (; j <= cx.jlast; j += 2) {
+    cx.template step<true, false>(j, XA, XB, YA, YB);
+    if (j + 1 > cx.jlast) { cur_is_a = false; break; }
+    cx.template step<true, false>(j + 1, XB, XA, YB, YA);
+  }
+  if (cx.r1 == a.h) {   // the strip owns the last image row: one more step whose new row is the reflected row h-2
+    if (!cur_is_a) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) YA[c] = YB[c];
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) XA[k][c] = XB[k][c];
+    }
+    cx.template step<true, true>(a.h, XA, XB, YA, YB);
+  }
 
   if ((SINGLE || a.last_pass) && a.partial != nullptr) {
-    float tot = wave_sum(cx.lsum);
+    const float tot = wave_sum(cx.lsum);
     if (lane == 0) a.partial[((size_t)cx.s*a.b + cx.bi)*(a.nsx*a.nsy) + strip] = tot;
   }
 }
 
-template <int NI, bool WARP, bool SSIM, bool SINGLE>
-__global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_fwd(const ReconFwdArgs a) { recon_fwd_body<NI, WARP, SSIM, SINGLE>(a); }
+// register budget: 128 VGPRs (4 waves per SIMD) up to two supports, 168 (3 waves) for three and four
+// register budget: up to two supports fit 128 VGPRs (4 waves per SIMD) unaided; three and four are held to 168 (3 waves)
+template <int N, bool SSIM, bool SINGLE, bool AUX>
+__global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 1 : 3)) void k_recon_main(const ReconMainArgs a) { recon_main_body<N, SSIM, SINGLE, AUX>(a); }
 
-// Same body for the headline configuration with the register budget capped at 128 (4 waves per SIMD).
-__global__ __launch_bounds__(64*kWavesPerBlock, 5) void k_recon_fwd_w4(const ReconFwdArgs a) { recon_fwd_body<2, true, true, true>(a); }
-
-hipError_t launch_recon_fwd(const ReconFwdArgs& a, int ni, bool warp, hipStream_t st) {
+hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
   dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b, a.S)), block(64*kWavesPerBlock);
   const bool ssim = !(a.flags & SMD_LOSS_L1);
   const bool single = a.first_pass && a.last_pass;
-#define SMD_LAUNCH(NI_, WARP_, SSIM_, SINGLE_) hipLaunchKernelGGL((k_recon_fwd<NI_, WARP_, SSIM_, SINGLE_>), grid, block, 0, st, a)
-#define SMD_PICK(NI_, WARP_)                                                    \
-  do {                                                                          \
-    if (ssim) { if (single) SMD_LAUNCH(NI_, WARP_, true, true); else SMD_LAUNCH(NI_, WARP_, true, false); } \
-    else { SMD_LAUNCH(NI_, WARP_, false, false); }                              \
-  } while (0)
-  if (warp && ni == 2 && ssim && single && a.variant == 1) hipLaunchKernelGGL(k_recon_fwd_w4, grid, block, 0, st, a);
-  else if (warp) { if (ni == 1) SMD_PICK(1, true); else SMD_PICK(2, true); }
-  else { if (ni == 1) SMD_PICK(1, false); else SMD_PICK(2, false); }
-#undef SMD_PICK
-#undef SMD_LAUNCH
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Planar (n,b,3,h,w) support frames -> RGBX texels (n,b,h,w,4).  One aligned 16-byte load per bilinear tap instead of
-// three unaligned 8-byte ones: the texture-data path of a CU returns aligned wide accesses at full rate, while the
-// planar gather ran it at a quarter of that (profiles/, DESIGN.md "Kernels").  Used by forward and backward.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_supports(const float* __restrict__ supp, f4* __restrict__ out, unsigned hw, unsigned total) {
-  for (unsigned p = blockIdx.x*256u + threadIdx.x; p < total; p += gridDim.x*256u) {
-    const unsigned img = p/hw, px = p - img*hw;
-    const float* src = supp + (size_t)img*3*hw + px;
-    f4 t; t.x = src[0]; t.y = src[hw]; t.z = src[2*(size_t)hw]; t.w = 0.f;
-    out[p] = t;
-  }
-}
-
-hipError_t launch_pack_supports(const float* supp, float* supp_pk, int nb, int h, int w, hipStream_t st) {
-  const unsigned hw = (unsigned)h*(unsigned)w, total = (unsigned)nb*hw;
-  hipLaunchKernelGGL(k_pack_supports, dim3(min(ceil_div((int)total, 256), 8192)), dim3(256), 0, st, supp, (f4*)supp_pk, hw, total);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Deterministic second stage of every scalar reduction: one block, fp64 accumulation.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ partial, int count, double scale, float* out) {
-  __shared__ double red[256];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < count; i += 256) acc += (double)partial[i];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int sft = 128; sft > 0; sft >>= 1) {
-    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = (float)(red[0]*scale);
-}
-
-hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, partial, count, scale, out);
-  return hipGetLastError();
-}
-
-// STREAM-style device copy (4 independent 16-B loads per lane in flight, grid-stride): the measured HBM ceiling quoted
-// beside the datasheet peak.  `mode` 0 = copy (read + write), 1 = read-only sum (writes one value per block).
-__global__ __launch_bounds__(256) void k_stream_copy(const f4* __restrict__ src, f4* __restrict__ dst, size_t n16, int mode) {
-  const size_t stride = (size_t)gridDim.x*256;
-  size_t i = (size_t)blockIdx.x*256 + threadIdx.x;
-  f4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (; i + 3*stride < n16; i += 4*stride) {
-    const f4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-    const f4 c = __builtin_nontemporal_load(src + i + 2*stride), d = __builtin_nontemporal_load(src + i + 3*stride);
-    if (mode == 0) {
-      __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
-      __builtin_nontemporal_store(c, dst + i + 2*stride); __builtin_nontemporal_store(d, dst + i + 3*stride);
-    } else acc += (a + b) + (c + d);
-  }
-  for (; i < n16; i += stride) { const f4 a = src[i]; if (mode == 0) dst[i] = a; else acc += a; }
-  if (mode != 0 && (acc[0] + acc[1] + acc[2] + acc[3]) == 12345.678f) dst[blockIdx.x] = acc;   // keeps the loads alive; practically never taken
-}
-hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_stream_copy, dim3(256*8), dim3(256), 0, st, (const f4*)src, (f4*)dst, nbytes/16, mode);
-  return hipGetLastError();
-}
-
-__global__ void k_debug_lane_shift(float* out_left, float* out_right) {
-  float x = (float)threadIdx.x;
-  out_left[threadIdx.x] = lane_left(x);
-  out_right[threadIdx.x] = lane_right(x);
-}
-hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st) {
-  hipLaunchKernelGGL(k_debug_lane_shift, dim3(1), dim3(64), 0, st, out_left, out_right);
+  const bool aux = a.warp0 != nullptr || a.noise != nullptr;
+#define SMD_MAIN(N_) do { \
+    if (ssim && single && !aux) hipLaunchKernelGGL((k_recon_main<N_, true, true, false>), grid, block, 0, st, a); \
+    else if (ssim) hipLaunchKernelGGL((k_recon_main<N_, true, false, true>), grid, block, 0, st, a); \
+    else hipLaunchKernelGGL((k_recon_main<N_, false, false, true>), grid, block, 0, st, a); } while (0)
+  switch (a.ni) { case 1: SMD_MAIN(1); break; case 2: SMD_MAIN(2); break; case 3: SMD_MAIN(3); break; default: SMD_MAIN(4); break; }
+#undef SMD_MAIN
   return hipGetLastError();
 }
 

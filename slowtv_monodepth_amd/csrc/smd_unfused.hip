@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kUfBlock) void k_view_synth_fwd(const float* __rest
   const int v = pix/w, u = pix - v*w;
   const size_t hw = (size_t)h*w;
   const PixGeom g = pix_geom(cm, depth[(size_t)bi*hw + pix], (float)u, (float)v, wscale, hscale);
-  const Taps tp = make_taps(g.sx, g.sy, h, w);
+  const Taps tp = make_taps(g.sx, g.sy, h, w, w);
   const float* in_b = input + (size_t)bi*C*hw;
   for (int c = 0; c < C; ++c) warp[((size_t)bi*C + c)*hw + pix] = bilerp(in_b + (size_t)c*hw, tp, w);
   if (depth_warp) depth_warp[(size_t)bi*hw + pix] = fmaxf(g.yz, kEps32);                      // geometry.py:340
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kUfBlock) void k_view_synth_bwd(const float* __rest
     const float D = depth[(size_t)bi*hw + pix];
     const float uf = (float)u, vf = (float)v;
     const PixGeom g = pix_geom(cm, D, uf, vf, wscale, hscale);
-    const Taps tp = make_taps(g.sx, g.sy, h, w);
+    const Taps tp = make_taps(g.sx, g.sy, h, w, w);
     const float* in_b = input + (size_t)bi*C*hw;
     float gsx = 0.f, gsy = 0.f;
     for (int c = 0; c < C; ++c) {

@@ -97,7 +97,8 @@ class _ImageRecon(torch.autograd.Function):
         warp0 = torch.empty((n, b, 3, h, w), device=dev, dtype=torch.float32) if want_warp else None
         nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        supp_pk = torch.empty((n, b, h, w, 4), device=dev, dtype=torch.float32)  # RGBX texels, reused by the backward
+        # padded RGBX texels of the supports + the target's SSIM window sums; written by the forward, reused by the backward
+        supp_pk = torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32)
         call('smd_image_recon_fwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), supp_pk.data_ptr(), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
              warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, int(flags), _stream())
