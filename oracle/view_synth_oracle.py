@@ -222,14 +222,26 @@ def compute_photo(pred, target, loss_name='ssim', use_min=False, aten=False):
     return red, err
 
 
-def recon_loss(pred, target, source=None, loss_name='ssim', use_min=False, use_automask=False, noise=None, aten=False):
+def recon_loss(pred, target, source=None, loss_name='ssim', use_min=False, use_automask=False, noise=None, aten=False,
+               force_sel=None):
     """`ReconstructionLoss.forward` (src/losses/reconstruction.py:98-126).
     `noise` replaces the `torch.randn_like` draw of :72 (must be (B,1,h,w)); pass None to draw it here.
     Returns loss, dict(automask, err (after automask), err_warp, sel) — sel: index of the winning support, or
-    255 where the static (un-warped) error won."""
+    255 where the static (un-warped) error won.
+    `force_sel` (B,1,h,w uint8; test aid, not part of the reference): take the min-reprojection / automask decisions from this
+    map instead of the arg-min.  The parity tests use it to compare GRADIENTS under identical routing when a handful of
+    near-ties (errors equal to ~1e-7) are decided differently by fp32 rounding; out['tie_gap'] reports how close they were."""
     err_warp, per = compute_photo(pred, target, loss_name, use_min, aten)
     sel = per.argmin(dim=1, keepdim=True) if use_min else torch.zeros_like(err_warp, dtype=torch.long)
-    out = {'err_warp': err_warp}
+    out = {}
+    if force_sel is not None and use_min:
+        pick = force_sel.long().clamp(max=per.shape[1] - 1)
+        forced = per.gather(1, pick)
+        warped = force_sel != 255
+        out['tie_gap'] = ((forced - err_warp)*warped).detach()       # >= 0: how much worse the forced support is than the best one
+        err_warp = torch.where(warped, forced, err_warp)
+        sel = torch.where(warped, pick, sel)
+    out['err_warp'] = err_warp
     err = err_warp
     if use_automask:
         if source is None: raise ValueError("Must provide the original 'source' images when automasking...")
@@ -237,6 +249,11 @@ def recon_loss(pred, target, source=None, loss_name='ssim', use_min=False, use_a
         if noise is None: noise = torch.randn_like(err_static)
         err_static = err_static + EPS32*noise                                                # :72
         err, idx = torch.min(torch.cat((err_warp, err_static), dim=1), dim=1, keepdim=True)  # :74-75
+        if force_sel is not None:
+            masked = force_sel == 255
+            gap = torch.where(masked, err_static - err, err_warp - err).detach()
+            out['tie_gap'] = torch.maximum(out['tie_gap'], gap) if 'tie_gap' in out else gap
+            err, idx = torch.where(masked, err_static, err_warp), masked.long()
         out['automask'] = idx == 0                                                           # :76
         sel = torch.where(out['automask'], sel, torch.full_like(sel, 255))
     out['err'] = err
@@ -271,7 +288,7 @@ def smooth_reg(disp, img, use_edges=False):
 # a5/a11: handlers, a13: combination
 # ---------------------------------------------------------------------------------------------------
 def image_recon(depths: dict, imgs, supp_imgs, Ts, Ks, loss_name='ssim', use_min=False, use_automask=False,
-                noise=None, aten=False):
+                noise=None, aten=False, force_sel=None):
     """`handlers.image_recon` (src/core/handlers.py:14-67).  depths {s: (b,1,h,w)}, imgs (b,3,h,w),
     supp_imgs (n,b,3,h,w), Ts (n,b,4,4), Ks (b,4,4).  Flattened batch order is n-major, then scale, then b."""
     n, S = supp_imgs.shape[0], len(depths)
@@ -284,11 +301,12 @@ def image_recon(depths: dict, imgs, supp_imgs, Ts, Ks, loss_name='ssim', use_min
     warp = view_synth(src.flatten(0, 1), dep[None].expand(n, *dep.shape).flatten(0, 1), T, K, aten=aten)[0]
     warp = warp.unflatten(0, (n, S*b))
     loss, out = recon_loss(warp, tgt, source=src, loss_name=loss_name, use_min=use_min, use_automask=use_automask,
-                           noise=noise, aten=aten)
+                           noise=noise, aten=aten, force_sel=force_sel)
     ld = {'supp_imgs_warp': warp.unflatten(1, (S, b))[:, 0]}
     if use_automask: ld['automask'] = out['automask'].unflatten(0, (S, b))[0]
     full = {'warp': warp, 'err': out['err'].unflatten(0, (S, b)), 'err_warp': out['err_warp'].unflatten(0, (S, b)),
             'sel': out['sel'].unflatten(0, (S, b))}
+    if 'tie_gap' in out: full['tie_gap'] = out['tie_gap'].unflatten(0, (S, b))
     return loss, ld, full
 
 
@@ -300,12 +318,12 @@ def disp_smooth(disps: dict, imgs, use_edges=False, aten=False):
 
 
 def loss_path(disps: dict, imgs, supp_imgs, Ts, Ks, *, min_depth=0.1, max_depth=100, loss_name='ssim', use_min=True,
-              use_automask=True, use_edges=True, w_recon=1.0, w_smooth=0.001, noise=None, aten=False):
+              use_automask=True, use_edges=True, w_recon=1.0, w_smooth=0.001, noise=None, aten=False, force_sel=None):
     """The whole hot path as one call: forward_postprocess (src/core/trainer.py:316-321) + forward_loss for the
     keys `img_recon` and `disp_smooth` (:388-392, :436-437) + weighted sum (:462-464).
     `w_smooth=None` drops the regulariser."""
     _, depth_up = disp_to_depth_up(disps, imgs.shape[-2:], min_depth, max_depth, aten=aten)
-    l_rec, ld, full = image_recon(depth_up, imgs, supp_imgs, Ts, Ks, loss_name, use_min, use_automask, noise, aten)
+    l_rec, ld, full = image_recon(depth_up, imgs, supp_imgs, Ts, Ks, loss_name, use_min, use_automask, noise, aten, force_sel)
     loss = w_recon*l_rec
     out = {'loss_img_recon': l_rec, **ld, 'depth_up': depth_up, 'full': full}
     if w_smooth is not None:

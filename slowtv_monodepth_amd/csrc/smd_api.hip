@@ -159,7 +159,8 @@ int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp,
   ReconWs ws = carve_recon(workspace, b, n, S, h, w);
   if (workspace_bytes < ws.bytes) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
   hipStream_t st = (hipStream_t)stream;
-  constexpr int kMaxPerPass = 4;   // supports held in registers by one launch
+  int kMaxPerPass = env_int("SMD_FWD_NI", 4);   // supports held in registers by one launch (1..4)
+  if (kMaxPerPass < 1 || kMaxPerPass > 4) kMaxPerPass = 4;
 
   {  // once per sample: texel repack, target window sums, identity error (scale independent)
     smd::ReconPrepArgs p;

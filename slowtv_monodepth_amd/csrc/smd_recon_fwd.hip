@@ -579,6 +579,7 @@ hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
   const bool aux = a.warp0 != nullptr || a.noise != nullptr;
 #define SMD_MAIN(N_) do { \
     if (ssim && single && !aux) hipLaunchKernelGGL((k_recon_main<N_, true, true, false>), grid, block, 0, st, a); \
+    else if (ssim && !aux) hipLaunchKernelGGL((k_recon_main<N_, true, false, false>), grid, block, 0, st, a); \
     else if (ssim) hipLaunchKernelGGL((k_recon_main<N_, true, false, true>), grid, block, 0, st, a); \
     else hipLaunchKernelGGL((k_recon_main<N_, false, false, true>), grid, block, 0, st, a); } while (0)
   switch (a.ni) { case 1: SMD_MAIN(1); break; case 2: SMD_MAIN(2); break; case 3: SMD_MAIN(3); break; default: SMD_MAIN(4); break; }

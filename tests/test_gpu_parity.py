@@ -8,7 +8,7 @@ Tolerances (fp32 path, stated per BASELINE.json: loss within 1e-4 relative of th
 import pytest
 import torch
 
-from conftest import TRAIN_CASES, case_inputs, rel_to_max
+from conftest import TRAIN_CASES, case_inputs, parity_note, rel_to_max
 from oracle import view_synth_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -101,7 +101,7 @@ def test_fused_path_matches_oracle_and_reference(F, golden, name):
     errs['Ts'] = rel_to_max(Ts.grad.cpu()[..., :3, :], Ts_c.grad[..., :3, :])
     errs['K'] = rel_to_max(K.grad.cpu(), K_c.grad)
     report.append('  grad rel-to-max errors: ' + ' '.join(f'{k}={v:.2e}' for k, v in errs.items()))
-    print('\n'.join(report))
+    parity_note('\n'.join(report))
     # The pure-L1 error has a sign() gradient: the l1 fixture contains one pixel whose warped green channel equals the target
     # to 6e-8 (9.6e-9 in fp64), so its sign is decided by rounding and flips one +-2*w*slope term (scripts/dev/dbg_l1.py).
     tol = 1e-2 if g['meta_loss_name'] == 'l1' else 1e-3
@@ -135,9 +135,135 @@ def test_rejects_cpu_tensors_and_bad_shapes(F):
     with pytest.raises(NotImplementedError): F.recon_flags('l2')
 
 
+# ---------------------------------------------------------------------------------------------------
+# BASELINE sizes, value for value against the oracle (ATen primitives on the CPU: ~5 s per sample pair at 640x192)
+# ---------------------------------------------------------------------------------------------------
+def _baseline_inputs(b, h, w, supp, S, seed):
+    from slowtv_monodepth_amd.synthetic import make_batch
+    import torch.nn.functional as Fn
+    n = len(supp)
+    _, y, _ = make_batch(b, h, w, supp, seed=seed, device='cpu')
+    g = torch.Generator().manual_seed(seed + 1)
+    disps = {}
+    for s in range(S):   # smooth field + pixel noise, like a partly trained network's output
+        hs, ws = h >> s, w >> s
+        low = 0.02 + 0.25*torch.rand(b, 1, 4, 10, generator=g)      # depth 0.4 .. 5: no pixel so close that it alone moves a pose gradient
+        disps[s] = (Fn.interpolate(low, size=(hs, ws), mode='bilinear', align_corners=False) + 0.01*torch.rand(b, 1, hs, ws, generator=g))
+    aa, t = 0.01*torch.randn(n, b, 3, generator=g), 0.08*torch.randn(n, b, 3, generator=g)
+    noise = torch.randn(S*b, 1, h, w, generator=g)
+    return y, disps, aa, t, noise
+
+
+BASELINE_CASES = {
+    # name: (b, h, w, supports, S, learned K)
+    'cfg2_b12_192x640_n2': (12, 192, 640, (-1, 1), 4, False),       # the configuration the metric is quoted on, full batch
+    'cfg4_b2_384x640_n2_learnK': (2, 384, 640, (-1, 1), 4, True),   # learned intrinsics: K gradient (SMD_NEED_K_GRAD)
+    'cfg5_b2_384x640_n4': (2, 384, 640, (-2, -1, 1, 2), 4, False),  # four supports in one launch
+}
+
+
+@pytest.mark.parametrize('name', list(BASELINE_CASES))
+def test_baseline_size_matches_oracle(F, name):
+    """HIP vs oracle at the BASELINE shapes: loss 1e-4 relative (BASELINE.json; asserted at 2e-5), error map, selection flips,
+    gradients w.r.t. every disparity scale, the pose vectors and (cfg 4) the intrinsics' network outputs."""
+    b, h, w, supp, S, learn_k = BASELINE_CASES[name]
+    n = len(supp)
+    y, disps, aa, t, noise = _baseline_inputs(b, h, w, supp, S, seed=7)
+    g = torch.Generator().manual_seed(99)
+    fs, cs = 0.3*torch.randn(b, 2, generator=g), 0.2*torch.randn(b, 2, generator=g)
+
+    def run(dev, hip, force_sel=None):
+        leaf = lambda v: v.detach().clone().to(dev).requires_grad_(True)
+        d = {s: leaf(v) for s, v in disps.items()}
+        a_, t_, fs_, cs_ = leaf(aa), leaf(t), leaf(fs), leaf(cs)
+        imgs, sup = y['imgs'].to(dev), y['supp_imgs'].to(dev)
+        gap = None
+        if hip:
+            Ts = F.pose_matrices(a_.flatten(0, 1), t_.flatten(0, 1)).unflatten(0, (n, b))
+            K, K_inv = F.intrinsics(fs_, cs_, (h, w)) if learn_k else (y['K'].to(dev), None)
+            depth_up, _ = F.disp_to_depth(list(d.values()), (h, w), 0.1, 100)
+            l_rec, err, sel, _ = F.image_recon_fused(depth_up, imgs, sup, Ts, K, K_inv, flags=F.recon_flags('ssim', True, True), noise=noise.to(dev))
+            l_sm, *_ = F.disp_smooth_fused(d, imgs, use_edges=True, want_aux=False)
+            loss = l_rec + 0.001*l_sm
+        else:
+            Ts = O.T_from_AAt(a_.flatten(0, 1), t_.flatten(0, 1)).unflatten(0, (n, b))
+            K = O.resize_K(O.build_K(fs_, cs_), (h, w)) if learn_k else y['K']
+            loss, out = O.loss_path(d, imgs, sup, Ts, K, noise=noise, aten=True, force_sel=force_sel)
+            err, sel, gap = out['full']['err'], out['full']['sel'], out['full'].get('tie_gap')
+        loss.backward()
+        grads = {f'disp_{s}': v.grad.cpu() for s, v in d.items()}
+        grads['aa'], grads['t'] = a_.grad.cpu(), t_.grad.cpu()
+        if learn_k: grads['fs'], grads['cs'] = fs_.grad.cpu(), cs_.grad.cpu()
+        return loss.item(), err.detach().cpu().reshape(S, b, h, w), sel.cpu().reshape(S, b, h, w), grads, gap
+
+    l_hip, e_hip, s_hip, g_hip, _ = run('cuda', True)
+    torch.cuda.synchronize()
+    # The oracle routes the gradient through ITS arg-min.  At this size a handful of pixels (a few per million) have two
+    # candidate errors equal to within the fp32 noise of the error map (~1e-5) and rounding decides them differently; a flipped pixel close to the camera moves a
+    # pose gradient by percents.  So: (1) free-running oracle -> loss, error map, selection flips; (2) oracle again with the
+    # kernel's decisions imposed (and the proof that every imposed decision was a tie) -> gradients under identical routing.
+    l_ref, e_ref, s_ref, g_free, _ = run('cpu', False)
+    flips = (s_hip != s_ref)
+    bad = ((e_hip - e_ref).abs() > 2e-4).float().mean().item()
+    _, _, _, g_ref, gap = run('cpu', False, force_sel=s_hip.reshape(S*b, 1, h, w)) if flips.any() else (None, None, None, g_free, None)
+    tie = gap.abs().max().item() if gap is not None else 0.0
+    # The loss has more discontinuities than the arg-min (clamp(0,1) of the SSIM term, sign() of the L1 term, border clamps): a
+    # pixel sitting on one of them gets a different one-sided derivative from rounding alone.  Dense gradients are therefore
+    # judged by their bulk (99.9 % quantile of the difference) plus a count of outliers tied to the number of decision flips;
+    # the pose / intrinsics gradients (sums over all pixels) by their relative error.
+    n_flips = int(flips.sum())
+    report, ok = [], True
+    for k in g_ref:
+        diff, mx = (g_hip[k] - g_ref[k]).abs(), g_ref[k].abs().max()
+        if k.startswith('disp_'):
+            allow = 30*(n_flips + 3)                     # a flip touches its 3x3 window, at most 5x5 low-resolution pixels
+            level = 1.0 - max(1e-3, 2.0*allow/diff.numel())
+            q = torch.quantile(diff.flatten()[:: max(1, diff.numel()//2_000_000)], level).item()/mx.item()
+            outl = int((diff > 1e-3*mx).sum())
+            report.append(f'{k}: q{100*level:.1f}={q:.1e} outliers={outl}')
+            ok &= q < 2e-4 and outl <= allow
+        else:
+            e = (diff.max()/mx).item()
+            report.append(f'{k}={e:.1e}')
+            ok &= e < 5e-3                               # two samples only (cfg 4/5 cases): one outlier pixel weighs 1e-3
+    free = {k: rel_to_max(g_hip[k], g_free[k]) for k in g_free}
+    parity_note(f'{name}: loss hip={l_hip:.8f} oracle={l_ref:.8f} (rel {abs(l_hip - l_ref)/abs(l_ref):.2e}); sel flips {n_flips} of {flips.numel()} '
+          f'({flips.float().mean().item():.2e}, largest gap between the tied errors {tie:.1e}); |err diff| > 2e-4 on {bad:.2e} of pixels '
+          f'(max {(e_hip - e_ref).abs().max():.2e})\n  gradients, same routing: ' + ' '.join(report)
+          + '\n  max-norm rel-to-max against the free-running oracle: ' + ' '.join(f'{k}={v:.1e}' for k, v in free.items()))
+    assert abs(l_hip - l_ref) <= 2e-5*abs(l_ref)
+    assert bad <= 3e-3 and flips.float().mean().item() <= 1e-4
+    assert tie <= 1e-4, 'a selection that differs from the oracle must be a tie within the error-map tolerance (2e-4)'
+    assert ok, f'{name}: gradients differ: ' + ' '.join(report)
+
+
+def test_baseline_size_in_kernel_noise_matches_oracle_off_the_ties(F):
+    """The product path (noise=None: counter-based Gaussian drawn in the kernel) at cfg-2 size against the oracle run WITHOUT
+    noise: errors agree everywhere, selection may differ only where the warped and the static error tie (|diff| < 1e-5)."""
+    b, h, w, supp, S = 2, 192, 640, (-1, 1), 4
+    y, disps, aa, t, _ = _baseline_inputs(b, h, w, supp, S, seed=11)
+    Ts_c = O.T_from_AAt(aa.flatten(0, 1), t.flatten(0, 1)).unflatten(0, (2, b))
+    with torch.no_grad():
+        l_ref, out = O.loss_path(disps, y['imgs'], y['supp_imgs'], Ts_c, y['K'], noise=torch.zeros(S*b, 1, h, w), aten=True)
+    e_ref, s_ref = out['full']['err'].reshape(S, b, h, w), out['full']['sel'].reshape(S, b, h, w)
+    dev = 'cuda'
+    Ts = F.pose_matrices(aa.to(dev).flatten(0, 1), t.to(dev).flatten(0, 1)).unflatten(0, (2, b))
+    depth_up, _ = F.disp_to_depth([d.to(dev) for d in disps.values()], (h, w), 0.1, 100)
+    l_hip, err, sel, _ = F.image_recon_fused(depth_up, y['imgs'].to(dev), y['supp_imgs'].to(dev), Ts, y['K'].to(dev),
+                                              flags=F.recon_flags('ssim', True, True), noise=None, seed=2024)
+    e_hip, s_hip = err.cpu().reshape(S, b, h, w), sel.cpu().reshape(S, b, h, w)
+    with torch.no_grad(): l_rec_ref = e_ref.mean().item()
+    assert abs(l_hip.item() - l_rec_ref) <= 2e-5*abs(l_rec_ref)
+    differ = s_hip != s_ref
+    close = (e_hip - e_ref).abs() <= 2e-4
+    parity_note(f'in-kernel noise: {int(differ.sum())} selection differences of {differ.numel()}, {int((~close).sum())} pixels with |err diff| > 2e-4')
+    assert (~close).float().mean().item() <= 3e-3
+    assert differ.float().mean().item() <= 3e-3
+
+
 @pytest.mark.parametrize('shape', [(12, 192, 640, 2, 4), (3, 384, 640, 4, 4), (1, 50, 70, 3, 2)])
 def test_full_size_properties(F, shape):
-    """Size-independent properties at BASELINE sizes (no oracle: it would take minutes on the CPU):
+    """Size-independent properties at BASELINE sizes (on top of the value-for-value comparisons above):
     (1) identity pose + constant depth + fixed K: warped support == bilinear resample with the known w/(w-1) stretch,
         so err is finite, within [0, 1], and `loss == err.mean()`;
     (2) swapping the support order leaves the min-reprojection error unchanged and permutes `sel`;
