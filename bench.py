@@ -61,8 +61,21 @@ def collect_profile(lib, which: int, cap: int):
     return [buf[i] for i in range(n.value)]
 
 
-def cpu_baseline(wl: dict, sample_b: int = 4, steps: int = 5) -> dict:
-    """The same training step on the host cores: PyTorch CPU networks + the CPU oracle as loss path (kind 'port')."""
+def cpu_model() -> str:
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'): return line.split(':', 1)[1].strip()
+    except OSError: pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
+def cpu_baseline(wl: dict, sample_b: int = 2, steps: int = 10, warmup: int = 3) -> dict:
+    """the same work on the host cores, median of `steps` after `warmup` — (1) the loss path alone (oracle,
+    forward + backward from given network outputs), (2) the full training step (PyTorch-CPU networks + the oracle loss path,
+    kind 'port').  Bounded sample: `sample_b` of the workload's triplets, so the default run stays within a few minutes."""
+    import statistics
+    from oracle import view_synth_oracle as O
     from oracle.backend import OracleBackend
     from slowtv_monodepth_amd.synthetic import make_batch
     from slowtv_monodepth_amd.train import StepModule, train_steps
@@ -71,17 +84,41 @@ def cpu_baseline(wl: dict, sample_b: int = 4, steps: int = 5) -> dict:
     cores = int(os.environ.get('SMD_CPU_THREADS', min(avail, 16)))   # measured on the 256-thread GPU host: 16 threads is the fastest setting (8: 3.1, 16: 4.7, 32: 3.3, 64: 1.8 img/s)
     torch.set_num_threads(cores)
     torch.manual_seed(42)
+    h, w, n, S = wl['h'], wl['w'], len(wl['supp']), 4
+    batch = make_batch(sample_b, h, w, wl['supp'], seed=42)
+    # (1) loss path only
+    g = torch.Generator().manual_seed(0)
+    disps = {s: (0.05 + 0.9*torch.rand(sample_b, 1, h >> s, w >> s, generator=g)).requires_grad_(True) for s in range(S)}
+    Ts = torch.eye(4).repeat(n, sample_b, 1, 1); Ts[..., :3, 3] = 0.05*torch.randn(n, sample_b, 3, generator=g); Ts.requires_grad_(True)
+    y = batch[1]
+
+    def loss_step():
+        for v in disps.values(): v.grad = None
+        Ts.grad = None
+        t0 = time.perf_counter()
+        loss, _ = O.loss_path(disps, y['imgs'], y['supp_imgs'], Ts, y['K'], aten=True)
+        loss.backward()
+        return time.perf_counter() - t0
+    for _ in range(warmup): loss_step()
+    t_loss = statistics.median(loss_step() for _ in range(steps))
+    B_fwd, B_bwd = recon_bytes(sample_b, h, w, n, S)
+    # (2) full training step
     module = MonoDepthModule(make_cfg({**wl, 'precision': 32}), loss_backend=OracleBackend(aten=True))
     opt = module.configure_optimizers()['optimizer']
-    batch = make_batch(sample_b, wl['h'], wl['w'], wl['supp'], seed=42)
     model = StepModule(module)
-    train_steps(model, opt, lambda it: batch, 1)
-    t0 = time.perf_counter()
-    train_steps(model, opt, lambda it: batch, steps)
-    dt = (time.perf_counter() - t0)/steps
-    return {'value': round(sample_b/dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{steps} full training steps (PyTorch-CPU nets + oracle loss path, fp32) on {sample_b} of the {wl["b"]} triplets '
-                      f'of the workload, after 1 warm-up; {dt*1e3:.0f} ms/step'}
+    train_steps(model, opt, lambda it: batch, warmup)
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        train_steps(model, opt, lambda it: batch, 1)
+        ts.append(time.perf_counter() - t0)
+    dt = statistics.median(ts)
+    return {'value': round(sample_b/dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(), 'host_threads_available': avail,
+            'loss_path_only': {'value': round(sample_b/t_loss, 3), 'unit': 'images/s', 'ms_per_step': round(t_loss*1e3, 1),
+                               'effective_GBps': round((B_fwd + B_bwd)/t_loss/1e9, 3)},
+            'sample': f'median of {steps} steps after {warmup} warm-ups on {sample_b} of the {wl["b"]} triplets of the workload, fp32: '
+                      f'loss path only (oracle forward + backward, {t_loss*1e3:.0f} ms) and full training step (PyTorch-CPU nets + oracle '
+                      f'loss path, {dt*1e3:.0f} ms)'}
 
 
 BASELINE_METRIC = 'training images/sec (640\u00d7192, 3-frame) at 1/2/4/8 MI355X; warp+SSIM HBM GB/s'   # BASELINE.json's metric, verbatim
@@ -91,14 +128,14 @@ def measured_hbm_ceilings(lib, device, nbytes=1 << 30, reps=10):
     """(copy GB/s counting read + write, read-only GB/s) of a STREAM-style sweep over `nbytes` through the library's own kernel."""
     src = torch.empty(nbytes, device=device, dtype=torch.uint8).fill_(1); dst = torch.empty_like(src)
     st = torch.cuda.current_stream().cuda_stream
-    out = []
-    for mode, factor in ((0, 2), (1, 1)):
+    out = [0.0, 0.0]
+    for mode, factor in ((0, 2), (1, 1), (2, 2), (3, 1)):   # modes 2, 3: the deeper-unrolled variant; quote the better one
         for _ in range(2): lib.smd_debug_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, mode, st)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(reps): lib.smd_debug_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, mode, st)
         e.record(); torch.cuda.synchronize()
-        out.append(factor*nbytes*reps/(s.elapsed_time(e)*1e-3)/1e9)
+        out[mode & 1] = max(out[mode & 1], factor*nbytes*reps/(s.elapsed_time(e)*1e-3)/1e9)
     return out
 
 
@@ -119,8 +156,16 @@ def main():
     from slowtv_monodepth_amd.trainer import MonoDepthModule
 
     t_start = time.perf_counter()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # not under a launcher: start one rank per GPU ourselves (one process per GPU, RCCL process group)
+        import socket, subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env={**os.environ, 'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')}).returncode)
     rank, local, world = init_distributed()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})'
+    if world != args.gpus: raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     # NOTE: cudnn.benchmark (MIOpen exhaustive find) is left OFF: on a fresh box every candidate solver would be JIT-compiled
@@ -147,7 +192,7 @@ def main():
         if i == 0: fence(); note('first step done')
     fence()
     note('warm-up done; timing')
-    _lib.lib.smd_profile_enable(0, args.steps); _lib.lib.smd_profile_enable(1, args.steps)
+    for which in range(4): _lib.lib.smd_profile_enable(which, args.steps)
     t0 = time.perf_counter()
     losses = train_steps(model, opt, batch_fn, args.steps)
     fence()
@@ -157,7 +202,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     fwd_ms = collect_profile(_lib.lib, 0, args.steps); bwd_ms = collect_profile(_lib.lib, 1, args.steps)
-    _lib.lib.smd_profile_enable(0, 0); _lib.lib.smd_profile_enable(1, 0)
+    fwd_all_ms = collect_profile(_lib.lib, 2, args.steps); bwd_all_ms = collect_profile(_lib.lib, 3, args.steps)
+    for which in range(4): _lib.lib.smd_profile_enable(which, 0)
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
     last_loss = losses[-1].item()
     assert last_loss == last_loss, 'loss is NaN'
 
@@ -165,12 +212,17 @@ def main():
         n, S = len(wl['supp']), 4
         B_fwd, B_bwd = recon_bytes(wl['b'], wl['h'], wl['w'], n, S)
         avg = lambda v: sum(v)/max(len(v), 1)
-        f_ms, b_ms = avg(fwd_ms), avg(bwd_ms)
+        f_ms, b_ms, fa_ms, ba_ms = avg(fwd_ms), avg(bwd_ms), avg(fwd_all_ms), avg(bwd_all_ms)
         copy_gbps, read_gbps = measured_hbm_ceilings(_lib.lib, device)
-        traffic = None
-        tf = ROOT/'profiles'/'traffic.json'   # per-launch HBM bytes from separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
+        # HBM traffic cannot be measured inside this run (it needs rocprofv3 --pmc passes, which serialise the kernels): it is
+        # read from the committed summary of such passes over THIS command (scripts/pmc_traffic.sh -> profiles/traffic.json).
+        traffic, traffic_source = None, None
+        tf = ROOT/'profiles'/'traffic.json'
         if tf.is_file():
-            try: traffic = json.loads(tf.read_text()).get(args.workload, {}).get('recon_fwd_bytes')
+            try:
+                tj = json.loads(tf.read_text())
+                traffic = tj.get(args.workload, {}).get('recon_fwd_bytes')
+                if traffic: traffic_source = f"profiles/traffic.json ({tj.get('_source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})"
             except Exception: traffic = None
         out = {
             'metric': BASELINE_METRIC,
@@ -181,16 +233,20 @@ def main():
             'config': {'workload': f'{args.workload}: {wl["depth"]} depth + {wl["pose"]} pose, {wl["w"]}x{wl["h"]}, {n} supports, 4 scales, '
                                    f'img_recon(ssim,min,automask)+disp_smooth(edges), AdamW, random init',
                        'global_batch': wl['b']*world, 'per_gpu_batch': wl['b'], 'parallelism': f'dp{world}',
-                       'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6)},
-            'roofline': {'kernel': 'smd::k_recon_fwd<2,true> (fused warp+SSIM+L1+min-reproj+automask forward)', 'bound': 'hbm',
+                       'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6),
+                       'rccl_ranks': rccl_ranks},
+            'roofline': {'kernel': f'smd::k_recon_main<{n}, true, true, false> (fused warp+SSIM+L1+min-reproj+automask forward; name as rocprofv3 prints it)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic,
+                         'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,
+                         'whole_forward_ms': round(fa_ms, 5), 'whole_forward_launches': 'k_recon_prep + k_recon_main + k_sum_partials',
+                         'whole_forward_frac': round(B_fwd/(fa_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
                          'algorithmic_bytes': B_fwd, 'avg_kernel_ms': round(f_ms, 5), 'launches_timed': len(fwd_ms),
                          'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
             'roofline_bwd': {'kernel': 'smd::k_recon_bwd (fused adjoint)', 'bound': 'hbm',
                              'achieved': round(B_bwd/(b_ms*1e-3)/1e9, 1) if b_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                              'frac': round(B_bwd/(b_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if b_ms else None,
-                             'algorithmic_bytes': B_bwd, 'avg_kernel_ms': round(b_ms, 5), 'launches_timed': len(bwd_ms)},
+                             'algorithmic_bytes': B_bwd, 'avg_kernel_ms': round(b_ms, 5), 'launches_timed': len(bwd_ms),
+                             'whole_backward_ms': round(ba_ms, 5), 'whole_backward_launches': 'k_recon_bwd + k_pose_finalize'},
         }
         note(f'timed region done: {out["value"]} img/s')
         if world == 1 and not args.no_cpu_baseline:

@@ -246,17 +246,21 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
                        float* g_fs, float* g_cs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Kernel timing hooks for bench.py: while enabled, every call of the named entry point records a HIP event pair
- * around its DOMINANT kernel (the fused strip kernel; not the identity-error pass or the scalar reductions) on
- * the caller's stream.  smd_profile_collect() waits for the recorded events and returns their durations in ms.
- * which: 0 = smd_image_recon_fwd, 1 = smd_image_recon_bwd.  Not thread-safe; one device. */
-#define SMD_PROF_RECON_FWD 0
-#define SMD_PROF_RECON_BWD 1
+ * Kernel timing hooks for bench.py: while enabled, every call of the named entry point records a HIP event pair on the
+ * caller's stream, either around its DOMINANT kernel (the fused strip kernel k_recon_main / k_recon_bwd) or around ALL
+ * of its launches (forward: per-sample prep + main + loss reduction; backward: main + pose finalize).
+ * smd_profile_collect() waits for the recorded events and returns their durations in ms.  Not thread-safe; one device. */
+#define SMD_PROF_RECON_FWD 0       /* smd_image_recon_fwd, dominant kernel */
+#define SMD_PROF_RECON_BWD 1       /* smd_image_recon_bwd, dominant kernel */
+#define SMD_PROF_RECON_FWD_ALL 2   /* smd_image_recon_fwd, every launch */
+#define SMD_PROF_RECON_BWD_ALL 3   /* smd_image_recon_bwd, every launch */
 int smd_profile_enable(int which, int capacity);
 int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out);
 
 /* Measurement aid: STREAM-style sweep over nbytes (multiple of 16): mode 0 copies src -> dst (read + write), mode 1 only
- * reads src.  bench.py times both to quote the measured HBM ceilings of the box beside the datasheet peak. */
+ * reads src; add 2 (modes 2, 3) for the variant with eight instead of four 16-byte loads in flight per lane and plain instead of
+ * non-temporal accesses.  bench.py times all of them and quotes the best as the measured HBM ceiling of the box beside the
+ * datasheet peak. */
 int smd_debug_stream_copy(const void* src, void* dst, size_t nbytes, int mode, void* stream);
 
 /* Debug/self-test: out[l] = {value held by lane l-1, value held by lane l+1} for in[l] = l (64 lanes).

@@ -50,7 +50,7 @@ StripPlan plan(int b, int S, int h, int w, int cols) {
 
 // ---- optional event-pair recording around the dominant kernels (bench.py roofline measurement) ----
 struct ProfSlot { hipEvent_t* ev = nullptr; int cap = 0, used = 0; };
-ProfSlot g_prof[2];
+ProfSlot g_prof[4];   // SMD_PROF_*: dominant forward kernel, dominant backward kernel, whole forward entry point, whole backward entry point
 
 void prof_mark(int which, hipStream_t st, bool begin) {
   ProfSlot& p = g_prof[which];
@@ -159,6 +159,7 @@ int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp,
   ReconWs ws = carve_recon(workspace, b, n, S, h, w);
   if (workspace_bytes < ws.bytes) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
   hipStream_t st = (hipStream_t)stream;
+  prof_mark(SMD_PROF_RECON_FWD_ALL, st, true);
   int kMaxPerPass = env_int("SMD_FWD_NI", 4);   // supports held in registers by one launch (1..4)
   if (kMaxPerPass < 1 || kMaxPerPass > 4) kMaxPerPass = 4;
 
@@ -194,7 +195,9 @@ int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp,
     if (a.last_pass) prof_mark(SMD_PROF_RECON_FWD, st, false);
   }
   const int count = S*b*pl.nsx*pl.nsy;
-  return check_launch(smd::launch_sum_partials(ws.loss_partial, count, 1.0/((double)S*b*h*w), loss, st), "loss reduction");
+  const int rc = check_launch(smd::launch_sum_partials(ws.loss_partial, count, 1.0/((double)S*b*h*w), loss, st), "loss reduction");
+  prof_mark(SMD_PROF_RECON_FWD_ALL, st, false);
+  return rc;
 }
 
 int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_packed, const float* T, const float* K,
@@ -218,12 +221,15 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
   const StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
   a.skip_level = env_int("SMD_BWD_SKIP", 2);
+  prof_mark(SMD_PROF_RECON_BWD_ALL, st, true);
   prof_mark(SMD_PROF_RECON_BWD, st, true);
   if (int rc = check_launch(smd::launch_recon_bwd(a, st), "image_recon_bwd")) return rc;
   prof_mark(SMD_PROF_RECON_BWD, st, false);
-  return check_launch(smd::launch_pose_finalize(ws.pose_partial, S*pl.nsx*pl.nsy, T, K, K_inv, g_T,
-                                                (flags & SMD_NEED_K_GRAD) ? g_K : nullptr, (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr,
-                                                b, n, st), "pose finalize");
+  const int rc = check_launch(smd::launch_pose_finalize(ws.pose_partial, S*pl.nsx*pl.nsy, T, K, K_inv, g_T,
+                                                        (flags & SMD_NEED_K_GRAD) ? g_K : nullptr, (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr,
+                                                        b, n, st), "pose finalize");
+  prof_mark(SMD_PROF_RECON_BWD_ALL, st, false);
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -500,7 +506,7 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
 }
 
 int smd_profile_enable(int which, int capacity) {
-  if (which < 0 || which > 1 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
+  if (which < 0 || which > 3 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
   ProfSlot& p = g_prof[which];
   for (int i = 0; i < 2*p.cap; ++i) (void)hipEventDestroy(p.ev[i]);
   delete[] p.ev;
@@ -514,7 +520,7 @@ int smd_profile_enable(int which, int capacity) {
 }
 
 int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out) {
-  if (which < 0 || which > 1 || !ms_out || !n_out) return fail(SMD_E_INVALID, "bad profile arguments");
+  if (which < 0 || which > 3 || !ms_out || !n_out) return fail(SMD_E_INVALID, "bad profile arguments");
   ProfSlot& p = g_prof[which];
   int n = 0;
   for (int i = 0; i < p.used && n < max_out; ++i) {
