@@ -214,7 +214,7 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
 
   smd::ReconBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.depth = depth; a.tgt = tgt; a.supp_pk = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
+  a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
   a.g_depth = g_depth; a.pose_partial = ws.pose_partial;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));

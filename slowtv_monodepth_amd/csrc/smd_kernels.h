@@ -83,7 +83,7 @@ struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over suppo
 };
 
 struct ReconBwdArgs {
-  const float* depth; const float* tgt; const float* supp_pk; const float* T; const float* K; const float* Kinv;
+  const float* depth; const float* packed; const float* T; const float* K; const float* Kinv;
   const uint8_t* sel;
   const float* g_loss;    // device scalar
   float* g_depth;         // (S,b,h,w)

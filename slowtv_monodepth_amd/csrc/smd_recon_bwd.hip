@@ -1,46 +1,30 @@
-// smd_recon_bwd.hip — hand-written adjoint of the fused view-synthesis photometric loss (gfx950).
+// smd_recon_bwd.hip — hand-written adjoint of the fused view-synthesis photometric loss (gfx950), round-2 structure.
 //
-// Same wave-strip streaming structure as the forward (smd_recon_fwd.hip) with a three-stage software pipeline
-// per row step j (60 interior columns, 2 halo lanes per side, rows r0-2 .. r1+1):
-//   stage A (row j)   : re-synthesise the warped pixel x and its bilinear partials dx/dsx, dx/dsy from the four RGBX
-//                       taps whose loads were issued one row earlier (software pipeline); issue row j+1's loads
-//   stage B (row j-1) : window sums from the 3-row ring of raw values (vertical taps per lane, horizontal taps via DPP),
-//                       SSIM partials d e/d(Sx, Sxx, Sxy) times the upstream gradient routed by `sel`
-//                       (min-reprojection / automask), box-summed with the ADJOINT reflection weights
-//                       (avg_pool2d + reflection_pad2d backward) -> complete for row j-2
-//   stage C (row j-2) : dL/dx -> dL/d(sx, sy) (zero where the border clamp is active) -> projective chain rule
-//                       -> dL/d depth (written once per pixel) and twelve per-lane sums dL/d(H, a) that a tiny
-//                       epilogue kernel turns into dL/dT, dL/dK and dL/dK^-1.
-// Nothing is re-read from HBM except the inputs themselves; no intermediate tensor of the forward is stored.
+// Same wave-strip streaming as the forward (smd_recon_fwd.hip): 60 interior columns + 2 halo lanes per side, rows
+// r0-2 .. r1+1, one support per pass of the row loop (the state of one support is ~75 registers; two at once would halve the
+// occupancy of a kernel that is bound by memory latency), three stages per row step j:
+//   stage A (row j)   : re-synthesise the warped pixel x and its bilinear partials dx/dsx, dx/dsy from the four RGB taps
+//                       whose loads were issued one step earlier; issue the loads of row j+1
+//   stage B (row j-1) : window sums by the forward's sliding scheme (P = r(j-2) + r(j-1); reflection by data in the halo
+//                       lanes, by a multiplier / a recovered row at the image's top / bottom), the target-side sums read
+//                       back from the packed buffer the forward filled; SSIM partials d e/d(Sx, Sxx, Sxy) times the upstream
+//                       gradient routed by `sel` (min-reprojection / automask); box-summed horizontally with the ADJOINT
+//                       reflection weights (avg_pool2d + reflection_pad2d backward) and accumulated vertically
+//   stage C (row j-2) : dL/dx -> dL/d(sx, sy) (zero where the border clamp is active) -> projective chain rule ->
+//                       dL/d depth (read-modify-written across supports) and nine per-lane sums that become dL/d(H, a);
+//                       a tiny epilogue kernel turns them into dL/dT, dL/dK and dL/dK^-1.
+// Nothing of the forward is stored except the packed texels / target sums (which the forward needs itself) and `sel`.
 #include "smd_common.h"
 #include "smd_kernels.h"
 
 namespace smd {
 
-// Reflection-weighted horizontal 3-tap through DPP wave shifts, as ONE asm block: keeps shift and FMA adjacent (left
-// alone the compiler batches every shift of a row first and keeps ~50 results live).  s_nop covers the VALU-write ->
-// DPP-read hazard the compiler cannot see inside asm.
-__device__ __forceinline__ float hsum_w(float q, float wl, float wr) {
-#ifdef SMD_NO_DPP
-  return hsum3(q, wl, wr);
-#else
-  float r, t;
-  asm volatile("s_nop 1\n\t"
-               "v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_fma_f32 %0, %3, %1, %2\n\t"
-               "v_mov_b32_dpp %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_fma_f32 %0, %4, %1, %0"
-               : "=&v"(r), "=&v"(t) : "v"(q), "v"(wl), "v"(wr));
-  return r;
-#endif
-}
-
-// Three independent weighted sums in one block: one hazard nop, interleaved shifts and FMAs.
+// Three independent reflection-weighted horizontal 3-tap sums in one asm block: r = q + wl*left(q) + wr*right(q) as two
+// DPP-sourced v_fmac per value (the shift rides on the FMA's first operand); one hazard nop covers all of them.
 __device__ __forceinline__ void hsum_w3(float a, float b, float c, float wl, float wr, float& ra, float& rb, float& rc) {
 #ifdef SMD_NO_DPP
   ra = hsum3(a, wl, wr); rb = hsum3(b, wl, wr); rc = hsum3(c, wl, wr);
 #else
-  // r = q + wl*left(q) + wr*right(q) as two DPP-sourced v_fmac per value (the shift rides on the FMA's first operand)
   ra = a; rb = b; rc = c;
   asm volatile("s_nop 1\n\t"
                "v_fmac_f32_dpp %0, %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -54,17 +38,10 @@ __device__ __forceinline__ void hsum_w3(float a, float b, float c, float wl, flo
 #endif
 }
 
-struct BwdPending {   // loads in flight for the next row
-  f3 t[4];            // bilinear taps NW, NE, SW, SE (RGB texels)
-  float y[3];
-  float fx, fy, kx, ky;
-};
-
-// SKIP: 0 = every row does the full adjoint; 1 = rows where no pixel of the wave selected the current support skip the SSIM
-// partials; 2 = additionally skip the chain rule of rows whose three coefficient rows and L1 term are all dead.  Coherent
-// selection / automask regions (any partly trained network) make 2 the fastest (-20 % at the microbenchmark's poses);
-// on noise-like masks (random initialisation) the branches cost ~5 %.
-template <int SKIP>
+// SKIP: 0 = every row does the full adjoint; 2 = rows where no pixel of the wave selected the current support skip the SSIM
+// partials, and rows whose three coefficient rows and L1 term are all dead skip the chain rule.  Coherent selection /
+// automask regions (any partly trained network) make 2 the fastest; on noise-like masks the branches cost a few percent.
+template <bool SSIM, int SKIP>
 __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -74,185 +51,214 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
   if (strip >= nstrips) return;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
   const int h = a.h, w = a.w;
-  const int c0 = sxi*kBwdCols;
   const int r0 = syi*a.rh, r1 = min(r0 + a.rh, h);
 
-  const int u = c0 - 2 + lane;
+  const int u = sxi*kBwdCols - 2 + lane;
   const bool col_ok = (u >= 0) && (u < w);
-  const unsigned uc = (unsigned)min(max(u, 0), w - 1);
+  // data column: the lane's own, or the reflected one for the halo lanes outside the image (reflection by data)
+  const int uc = (u < 0) ? min(-u, w - 1) : ((u >= w) ? max(2*(w - 1) - u, 0) : u);
   const bool interior = (lane >= 2) && (lane < 2 + kBwdCols) && (u < w);
-  float wl, wr, wla, wra;
-  reflect_weights((int)uc, w, wl, wr);
-  reflect_weights_adj((int)uc, w, wla, wra);
-  if (!col_ok) { wl = wr = wla = wra = 0.f; }
-  const float uf = (float)u;
+  const unsigned lane4 = (unsigned)uc*4u, lane1 = (unsigned)uc;
+  float wla, wra;                                   // adjoint reflection weights: how much column u receives from u-1 / u+1
+  reflect_weights_adj(min(max(u, 0), w - 1), w, wla, wra);
+  if (!col_ok) { wla = 0.f; wra = 0.f; }
+  const float uf = (float)uc;
 
   const bool use_min = a.flags & SMD_USE_MIN;
-  const bool l1_only = a.flags & SMD_LOSS_L1;
-  const unsigned hw = (unsigned)h*(unsigned)w;
-  const float w_ssim = l1_only ? 0.f : kWSsim/3.f;
-  const float w_l1 = l1_only ? 1.f/3.f : (1.f - kWSsim)/3.f;
+  const size_t hw = (size_t)h*w;
+  const unsigned hw4 = (unsigned)hw*4u, w4 = (unsigned)w*4u;
+  const float w_ssim = SSIM ? kWSsim/3.f : 0.f, w_l1 = SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f;
   float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
   if (!use_min) gscale /= (float)a.n;
-  constexpr float c1 = 81.f*kC1, c2 = 81.f*kC2;   // window sums stay un-normalised (x9), see smd_recon_fwd.hip
+  constexpr float c1 = 81.f*kC1;   // window sums stay un-normalised (x9), see smd_recon_fwd.hip
+  const float xmax = (float)(w - 1), ymax = (float)(h - 1), wpf = (float)(w + 1);
 
-  const float* tgt_b = a.tgt + (size_t)bi*3*hw;
-  const float* depth_sb = a.depth + ((size_t)s*a.b + bi)*hw;
-  const uint8_t* sel_sb = a.sel + ((size_t)s*a.b + bi)*hw;
-  float* gd_sb = a.g_depth + ((size_t)s*a.b + bi)*hw;
+  const size_t sb = ((size_t)s*a.b + bi)*hw;
+  const rsrc_t rs_pk = make_rsrc(a.packed, packed_total_floats(a.b, a.n, h, w)*4);
+  const rsrc_t rs_depth = make_rsrc(a.depth + sb, hw*4);
+  const rsrc_t rs_sel = make_rsrc(a.sel + sb, hw);
+  const rsrc_t rs_gd = make_rsrc(a.g_depth + sb, hw*4);
+  const unsigned texel_bytes = (unsigned)(h + 1)*(unsigned)(w + 1)*12u, rowbytes = ((unsigned)w + 1u)*12u;
+  const unsigned so_y = (unsigned)(packed_texel_floats(a.b, a.n, h, w)*4) + (unsigned)bi*hw4*3u;
+  const unsigned so_ta = (unsigned)((packed_texel_floats(a.b, a.n, h, w) + packed_ypix_floats(a.b, h, w))*4) + (unsigned)bi*hw4*4u;
+  const unsigned so_tb = so_ta + (unsigned)(packed_tpix_floats(a.b, h, w)*4);
+
+  const int jstart = max(r0 - 2, 0);
+  const int jlast = min(r1 + 1, h - 1);             // last real row that is loaded
+  const int pb0 = max(r0 - 1, 0), pb1 = min(r1, h - 1);   // centre rows whose coefficients are needed
 
   for (int i = 0; i < a.n; ++i) {
     Cam cm;
     make_cam(cm, a.T + ((size_t)i*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16);
-    const unsigned wp = (unsigned)w + 1u;   // padded texel rows (smd_kernels.h: packed_texel_floats)
-    const float* spk = a.supp_pk + ((size_t)i*a.b + bi)*3*(size_t)(h + 1)*wp;
+    const float hx0 = fmaf(cm.H[0], uf, cm.H[2]), hy0 = fmaf(cm.H[3], uf, cm.H[5]), hz0 = fmaf(cm.H[6], uf, cm.H[8]);
+    const unsigned so_tex = (unsigned)(i*a.b + bi)*texel_bytes;
 
-    // rings of raw per-pixel values: index 0 = row j, 1 = row j-1, 2 = row j-2
-    float x0[3] = {}, x1[3] = {}, x2[3] = {}, y0[3] = {}, y1[3] = {}, y2[3] = {};
-    float gx0[3] = {}, gx1[3] = {}, gx2[3] = {}, gy0[3] = {}, gy1[3] = {}, gy2[3] = {};  // dx/dpx, dx/dpy (clamp mask, grid scale folded in)
-    float ac1[3][3] = {}, ac0[3][3] = {};      // vertical accumulators of the h-summed coefficient maps {A, B, C}
-    float psum[kPoseSums] = {};
-    unsigned live_hist = 0;   // bit k: stage B of the k-th most recent row produced coefficients (wave-uniform)
-    BwdPending P = {};
+    // state: rows j-1 (o) and j-2 (q) of the raw values, the sliding sums, the bilinear partials of rows j, j-1, j-2
+    float xo[3] = {}, xq[3] = {}, yo[3] = {}, yq[3] = {};
+    float Px[3] = {}, Pxx[3] = {}, Pxy[3] = {};
+    float gx0[3] = {}, gx1[3] = {}, gx2[3] = {}, gy0[3] = {}, gy1[3] = {}, gy2[3] = {};   // dx/dpx, dx/dpy (clamp mask, grid scale folded in)
+    float ac1[3][3] = {}, ac0[3][3] = {};             // vertical accumulators of the h-summed coefficient maps {A, B, C}
+    float ps[9] = {};                                 // per-lane sums of {dnx, dnx*v, dny, dny*v, dz, dz*v, gnx, gny, gz}
+    float D0 = 0.f, D1 = 0.f, D2 = 0.f;               // depth of rows j, j-1, j-2
+    unsigned selp = SMD_SEL_MASKED, selq = SMD_SEL_MASKED;
+    unsigned live_hist = 0;                           // bit k: stage B of the k-th most recent row produced coefficients (wave-uniform)
+    f3 t0 = {}, t1 = {}, t2 = {}, t3 = {}, py = {};   // loads in flight for the next row
+    float pfx = 0.f, pfy = 0.f, pkx = 0.f, pky = 0.f;
 
-    auto issue = [&](int jr, float D) {   // stage 1 of row jr: coordinates + gathers
-      const unsigned ro = (unsigned)jr*(unsigned)w + uc;
+    auto issue = [&](int jr, float D) {               // coordinates + gathers + target row of row jr
       const float vf = (float)jr;
-      float hx = fmaf(cm.H[0], uf, fmaf(cm.H[1], vf, cm.H[2]));
-      float hyy = fmaf(cm.H[3], uf, fmaf(cm.H[4], vf, cm.H[5]));
-      float hz = fmaf(cm.H[6], uf, fmaf(cm.H[7], vf, cm.H[8]));
-      float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hyy, cm.a1), yz = fmaf(D, hz, cm.tz);
-      float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
-      float sx = fmaf(nx*rz, a.wscale, -0.5f), sy = fmaf(ny*rz, a.hscale, -0.5f);
-      Taps tp = make_taps(sx, sy, h, w, (int)wp);
-      P.fx = tp.fx; P.fy = tp.fy; P.kx = tp.mx*a.wscale; P.ky = tp.my*a.hscale;
-      const unsigned o = (unsigned)tp.off;
-      P.t[0] = ld3(spk, o); P.t[1] = ld3(spk, o + 1u); P.t[2] = ld3(spk, o + wp); P.t[3] = ld3(spk, o + wp + 1u);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) P.y[c] = ld1(tgt_b, c*hw + ro);
+      const float hx = fmaf(cm.H[1], vf, hx0), hyy = fmaf(cm.H[4], vf, hy0), hz = fmaf(cm.H[7], vf, hz0);
+      const float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hyy, cm.a1), yz = fmaf(D, hz, cm.tz);
+      const float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
+      const float sx = fmaf(nx*rz, a.wscale, -0.5f), sy = fmaf(ny*rz, a.hscale, -0.5f);
+      pkx = (sx > 0.f && sx < xmax) ? a.wscale : 0.f;   // d(clamped coordinate)/d(unclamped), times the grid scale
+      pky = (sy > 0.f && sy < ymax) ? a.hscale : 0.f;
+      const float cx = __builtin_amdgcn_fmed3f(sx, 0.f, xmax), cy = __builtin_amdgcn_fmed3f(sy, 0.f, ymax);
+      const float x0 = floorf(cx), y0 = floorf(cy);
+      pfx = cx - x0; pfy = cy - y0;
+      const unsigned o = __umul24((unsigned)fmaf(y0, wpf, x0), 12u);
+      t0 = bld3(rs_pk, o, so_tex); t1 = bld3(rs_pk, o + 12u, so_tex);
+      t2 = bld3(rs_pk, o, so_tex + rowbytes); t3 = bld3(rs_pk, o + 12u, so_tex + rowbytes);
+      py = bld3(rs_pk, lane4*3u, so_y + (unsigned)jr*w4*3u);
     };
 
-    const int jstart = max(r0 - 2, 0);
-    const int jlast = min(r1 + 1, h - 1);
-    float Dn = ld1(depth_sb, (unsigned)jstart*(unsigned)w + uc);
-    issue(jstart, Dn);
-    if (jstart + 1 <= jlast) Dn = ld1(depth_sb, (unsigned)(jstart + 1)*(unsigned)w + uc);
+    float Da = bld(rs_depth, lane4, (unsigned)jstart*w4);       // depth of the row whose loads are in flight
+    issue(jstart, Da);
+    float Db = bld(rs_depth, lane4, (unsigned)(jstart + 1)*w4); // ... and of the row after it (a row below the image reads 0)
 
     for (int j = jstart; j <= r1 + 1; ++j) {
-      // ================= stage A: row j — consume its loads, issue the next row's =================
-      if (j <= jlast) {
+      // ---- roll the two-row history (row j-1 -> j-2) before row j overwrites the "current" slots
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float dn = P.t[1][c] - P.t[0][c], ds = P.t[3][c] - P.t[2][c];
-          const float top = fmaf(P.fx, dn, P.t[0][c]), bot = fmaf(P.fx, ds, P.t[2][c]);
-          const float ddy = bot - top;
-          x0[c] = fmaf(P.fy, ddy, top);
-          gx0[c] = fmaf(P.fy, ds - dn, dn)*P.kx;
-          gy0[c] = ddy*P.ky;
-          y0[c] = P.y[c];
-        }
+      for (int c = 0; c < 3; ++c) { gx2[c] = gx1[c]; gx1[c] = gx0[c]; gy2[c] = gy1[c]; gy1[c] = gy0[c]; }
+      D2 = D1; D1 = D0; selq = selp;
+      const int p = j - 1, q = j - 2;
+      const bool doB = SSIM && p >= pb0 && p <= pb1;
+      const bool doC = q >= r0 && q < r1;
+      // ================= stage A: row j =================
+      float xn[3], yn[3];
+      f4 ta = {}; f3 tb = {};
+      if (doB || (!SSIM && p >= 0 && p < h)) selp = bld8(rs_sel, lane1, (unsigned)p*(unsigned)w);
+      if (doB) {
+        ta = bld4(rs_pk, lane4*4u, so_ta + (unsigned)p*w4*4u);
+        tb = bld3(rs_pk, lane4*4u, so_tb + (unsigned)p*w4*4u);
       }
-      if (j + 1 <= jlast) {
-        issue(j + 1, Dn);
-        if (j + 2 <= jlast) Dn = ld1(depth_sb, (unsigned)(j + 2)*(unsigned)w + uc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float dn = t1[c] - t0[c], ds = t3[c] - t2[c];
+        const float top = fmaf(pfx, dn, t0[c]), bot = fmaf(pfx, ds, t2[c]);
+        const float ddy = bot - top;
+        xn[c] = fmaf(pfy, ddy, top);
+        gx0[c] = fmaf(pfy, ds - dn, dn)*pkx;
+        gy0[c] = ddy*pky;
+        yn[c] = py[c];
+      }
+      D0 = Da;
+      // Next row's loads, unconditionally (also after the last row, where nothing consumes them): the tap coordinates are
+      // clamped, a depth row below the image reads 0 (buffer bounds), and a conditional issue would turn every register of
+      // the in-flight loads into a loop phi with a second copy.
+      issue(j + 1, Db);
+      Da = Db;
+      Db = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
+      if (j > jlast) {
+        // j == h: the row below the image is row h-2 (ReflectionPad2d(1)), which is still in the history; beyond that the
+        // values are never used
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xn[c] = xq[c]; yn[c] = yq[c]; }
       }
 
-      // ================= stage B: row p = j-1 — SSIM partials, h-summed with the adjoint weights =================
-      const int p = j - 1;
+      // ================= stage B: centre row p = j-1 — SSIM partials, h-summed with the adjoint weights =================
       float hc[3][3] = {};
-      if (!(!l1_only && p >= max(r0 - 1, 0) && p <= min(r1, h - 1))) live_hist <<= 1;
-      if (!l1_only && p >= max(r0 - 1, 0) && p <= min(r1, h - 1)) {
-        float lo_p, hi_p;
-        reflect_weights(p, h, lo_p, hi_p);   // vertical reflection weights of rows p-1 (ring 2) and p+1 (ring 0)
-        if (j >= h) hi_p = 0.f;              // row p+1 does not exist: ring 0 holds stale (finite) values
-        const uint8_t sl = sel_sb[(unsigned)p*(unsigned)w + uc];
-        const bool active = use_min ? (sl == (uint8_t)i) : (sl != (uint8_t)SMD_SEL_MASKED);
-        const float g = (active && col_ok) ? gscale*w_ssim : 0.f;
-        // Rows in which no pixel of this wave selected the current support carry no gradient through their windows:
-        // skip the SSIM partials (wave-uniform branch; coherent regions of the min-reprojection / automask are common).
-        const bool row_live = SKIP >= 1 ? (__builtin_amdgcn_ballot_w64(g != 0.f) != 0) : true;
-        live_hist = (live_hist << 1) | (row_live ? 1u : 0u);
-        if (row_live)
+      if (SSIM) {
+        const float m = (p == 0) ? 2.f : 1.f;         // row -1 is row 1
+        float Vx[3], Vxx[3], Vxy[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float ya = lo_p*y2[c], yc_ = hi_p*y0[c], xa = lo_p*x2[c], xc_ = hi_p*x0[c];
-          float sy, syy, sx, sxx, sxy, unused;
-          hsum_w3((xa + x1[c]) + xc_, fmaf(xc_, x0[c], fmaf(xa, x2[c], x1[c]*x1[c])), fmaf(xc_, y0[c], fmaf(xa, y2[c], x1[c]*y1[c])),
-                  wl, wr, sx, sxx, sxy);
-          hsum_w3((ya + y1[c]) + yc_, fmaf(yc_, y0[c], fmaf(ya, y2[c], y1[c]*y1[c])), 0.f, wl, wr, sy, syy, unused);
-          // e = (1 - N/Dn)/2 with N = a1*a2, Dn = b1*b2 on the x9 sums (both scaled by 81*81)
-          const float t = sx*sy;
-          const float a1 = fmaf(2.f, t, c1), a2 = fmaf(2.f, fmaf(9.f, sxy, -t), c2);
-          const float sx2 = sx*sx;
-          const float b1 = sx2 + fmaf(sy, sy, c1), b2 = fmaf(9.f, sxx, -sx2) + (fmaf(9.f, syy, c2) - sy*sy);
-          const float rden = __builtin_amdgcn_rcpf(b1*b2);
-          const float val = a1*a2*rden;
-          const float e = fmaf(-0.5f, val, 0.5f);
-          const float pass = (e >= 0.f && e <= 1.f) ? -0.5f*g : 0.f;   // d e/d val, gated by the clamp(0,1), times upstream
-          // partials w.r.t. the x9 sums Sx, Sxx, Sxy (a1, a2, b1, b2 as functions of them):
-          //   da1/dSx = 2 Sy, da2/dSx = -2 Sy, db1/dSx = 2 Sx, db2/dSx = -2 Sx, da2/dSxy = 18, db2/dSxx = 9
-          const float prd = pass*rden;
-          const float dSx = prd*(2.f*sy*(a2 - a1) - 2.f*sx*val*(b2 - b1));
-          const float dSxx = prd*(-9.f*val*b1);
-          const float dSxy = prd*(18.f*a1);
-          hsum_w3(dSx, dSxx, dSxy, wla, wra, hc[c][0], hc[c][1], hc[c][2]);
+          const float xx = xn[c]*xn[c], xy = xn[c]*yn[c];
+          Vx[c] = fmaf(m, xn[c], Px[c]); Vxx[c] = fmaf(m, xx, Pxx[c]); Vxy[c] = fmaf(m, xy, Pxy[c]);
+          Px[c] = xo[c] + xn[c]; Pxx[c] = fmaf(xo[c], xo[c], xx); Pxy[c] = fmaf(xo[c], yo[c], xy);
+        }
+        if (!doB) live_hist <<= 1;
+        else {
+          const bool active = use_min ? (selp == (unsigned)i) : (selp != (unsigned)SMD_SEL_MASKED);
+          const float g = (active && col_ok) ? gscale*w_ssim : 0.f;
+          // Rows in which no pixel of this wave selected the current support carry no gradient through their windows:
+          // skip the SSIM partials (wave-uniform branch; coherent regions of the min-reprojection / automask are common).
+          const bool row_live = SKIP >= 1 ? (__builtin_amdgcn_ballot_w64(g != 0.f) != 0) : true;
+          live_hist = (live_hist << 1) | (row_live ? 1u : 0u);
+          if (row_live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              float sx, sxx, sxy;
+              hsum3(Vx[c], Vxx[c], Vxy[c], sx, sxx, sxy);
+              const float sy = ta[c], cy2 = (c == 0) ? ta.w : ((c == 1) ? tb.x : tb.y), cy1 = fmaf(sy, sy, c1);
+              // e = (1 - N/Dn)/2 with N = a1*a2, Dn = b1*b2 on the x9 sums (both scaled by 81*81)
+              const float t = sx*sy;
+              const float a1 = fmaf(2.f, t, c1), a2 = fmaf(2.f, fmaf(9.f, sxy, -t), 81.f*kC2);
+              const float sx2 = sx*sx;
+              const float b1 = sx2 + cy1, b2 = fmaf(9.f, sxx, -sx2) + cy2;
+              const float rden = __builtin_amdgcn_rcpf(b1*b2);
+              const float val = a1*a2*rden;
+              const float e = fmaf(-0.5f, val, 0.5f);
+              const float pass = (e >= 0.f && e <= 1.f) ? -0.5f*g : 0.f;   // d e/d val, gated by the clamp(0,1), times upstream
+              // partials w.r.t. the x9 sums Sx, Sxx, Sxy (a1, a2, b1, b2 as functions of them):
+              //   da1/dSx = 2 Sy, da2/dSx = -2 Sy, db1/dSx = 2 Sx, db2/dSx = -2 Sx, da2/dSxy = 18, db2/dSxx = 9
+              const float prd = pass*rden;
+              const float dSx = prd*(2.f*sy*(a2 - a1) - 2.f*sx*val*(b2 - b1));
+              const float dSxx = prd*(-9.f*val*b1);
+              const float dSxy = prd*(18.f*a1);
+              hsum_w3(dSx, dSxx, dSxy, wla, wra, hc[c][0], hc[c][1], hc[c][2]);
+            }
+          }
         }
       }
 
       // ================= stage C: row q = j-2 — dL/dx -> dL/d(px,py) -> depth, pose sums =================
-      const int q = j - 2;
-      if (q >= r0 && q < r1) {
+      if (doC) {
         float lo_q, hi_q;
-        reflect_weights_adj(q, h, lo_q, hi_q);
-        const unsigned rq = (unsigned)q*(unsigned)w + uc;
-        const uint8_t sl = sel_sb[rq];
-        const bool active = use_min ? (sl == (uint8_t)i) : (sl != (uint8_t)SMD_SEL_MASKED);
+        reflect_weights_adj(q, h, lo_q, hi_q);        // hi_q: weight of coefficient row q+1 in the gradient of row q
+        const bool active = use_min ? (selq == (unsigned)i) : (selq != (unsigned)SMD_SEL_MASKED);
         const float gl = (active && col_ok) ? gscale*w_l1 : 0.f;
         // coefficient rows q-1, q, q+1 all skipped and no L1 term anywhere in the wave: the gradient of this row is zero
         const bool dead = SKIP >= 2 ? ((live_hist & 7u) == 0u && __builtin_amdgcn_ballot_w64(gl != 0.f) == 0) : false;
+        const unsigned qro = (unsigned)q*w4;
         if (dead) {
-          if (interior && i == 0) gd_sb[rq] = 0.f;
+          if (interior && i == 0) bst(rs_gd, lane4, qro, 0.f);
         } else {
-        float gpx = 0.f, gpy = 0.f;
+          float gpx = 0.f, gpy = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float d = x2[c] - y2[c];
-          float gxc = gl*((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
-          if (!l1_only) {
-            const float SA = fmaf(hi_q, hc[c][0], ac1[c][0]), SB = fmaf(hi_q, hc[c][1], ac1[c][1]), SC = fmaf(hi_q, hc[c][2], ac1[c][2]);
-            gxc += fmaf(2.f*x2[c], SB, fmaf(y2[c], SC, SA));   // d/dx_q of the x9 sums: 1, 2 x_q, y_q
+          for (int c = 0; c < 3; ++c) {
+            const float d = xq[c] - yq[c];
+            float gxc = gl*((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+            if (SSIM) {
+              const float SA = fmaf(hi_q, hc[c][0], ac1[c][0]), SB = fmaf(hi_q, hc[c][1], ac1[c][1]), SC = fmaf(hi_q, hc[c][2], ac1[c][2]);
+              gxc += fmaf(2.f*xq[c], SB, fmaf(yq[c], SC, SA));   // d/dx_q of the x9 sums: 1, 2 x_q, y_q
+            }
+            gpx = fmaf(gxc, gx2[c], gpx);
+            gpy = fmaf(gxc, gy2[c], gpy);
           }
-          gpx = fmaf(gxc, gx2[c], gpx);
-          gpy = fmaf(gxc, gy2[c], gpy);
-        }
-        // projective chain rule at (q, u): recompute the cheap geometry
-        const float D = ld1(depth_sb, rq);
-        const float vf = (float)q;
-        float hx = fmaf(cm.H[0], uf, fmaf(cm.H[1], vf, cm.H[2]));
-        float hyy = fmaf(cm.H[3], uf, fmaf(cm.H[4], vf, cm.H[5]));
-        float hz = fmaf(cm.H[6], uf, fmaf(cm.H[7], vf, cm.H[8]));
-        float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hyy, cm.a1), yz = fmaf(D, hz, cm.tz);
-        float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
-        float gnx = gpx*rz, gny = gpy*rz;
-        float gz = (yz >= kZMin) ? -(gpx*nx + gpy*ny)*rz*rz : 0.f;
-        if (!interior) { gnx = 0.f; gny = 0.f; gz = 0.f; }
-        float gD = fmaf(gnx, hx, fmaf(gny, hyy, gz*hz));
-        if (interior) {
-          float* gp = gd_sb + rq;
-          if (i == 0) *gp = gD; else *gp += gD;
-        }
-        float dnx = gnx*D, dny = gny*D, dz = gz*D;
-        psum[0] = fmaf(dnx, uf, psum[0]); psum[1] = fmaf(dnx, vf, psum[1]); psum[2] += dnx;
-        psum[3] = fmaf(dny, uf, psum[3]); psum[4] = fmaf(dny, vf, psum[4]); psum[5] += dny;
-        psum[6] = fmaf(dz, uf, psum[6]);  psum[7] = fmaf(dz, vf, psum[7]);  psum[8] += dz;
-        psum[9] += gnx; psum[10] += gny; psum[11] += gz;
+          // projective chain rule at (q, u): the cheap geometry is recomputed from the depth kept in the ring
+          const float vf = (float)q;
+          const float hx = fmaf(cm.H[1], vf, hx0), hyy = fmaf(cm.H[4], vf, hy0), hz = fmaf(cm.H[7], vf, hz0);
+          const float nx = fmaf(D2, hx, cm.a0), ny = fmaf(D2, hyy, cm.a1), yz = fmaf(D2, hz, cm.tz);
+          const float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
+          float gnx = gpx*rz, gny = gpy*rz;
+          float gz = (yz >= kZMin) ? -(gpx*nx + gpy*ny)*rz*rz : 0.f;
+          if (!interior) { gnx = 0.f; gny = 0.f; gz = 0.f; }
+          float gD = fmaf(gnx, hx, fmaf(gny, hyy, gz*hz));
+          if (interior) {
+            if (i != 0) gD += bld(rs_gd, lane4, qro);
+            bst(rs_gd, lane4, qro, gD);
+          }
+          const float dnx = gnx*D2, dny = gny*D2, dz = gz*D2;
+          ps[0] += dnx; ps[1] = fmaf(dnx, vf, ps[1]); ps[2] += dny; ps[3] = fmaf(dny, vf, ps[3]); ps[4] += dz; ps[5] = fmaf(dz, vf, ps[5]);
+          ps[6] += gnx; ps[7] += gny; ps[8] += gz;
         }
       }
 
       // ================= roll =================
-      if (!l1_only) {
+      if (SSIM) {
         float lo_na, hi_na;
-        reflect_weights_adj(min(max(p + 1, 0), h - 1), h, lo_na, hi_na);  // weight of coefficient row p in out(p+1)
+        reflect_weights_adj(min(max(p + 1, 0), h - 1), h, lo_na, hi_na);  // weight of coefficient row p in the gradient of row p+1
         if (p + 1 >= h || p < 0) lo_na = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -260,17 +266,15 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
           for (int k = 0; k < 3; ++k) { ac1[c][k] = ac0[c][k] + hc[c][k]; ac0[c][k] = lo_na*hc[c][k]; }
       }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        x2[c] = x1[c]; x1[c] = x0[c]; y2[c] = y1[c]; y1[c] = y0[c];
-        gx2[c] = gx1[c]; gx1[c] = gx0[c]; gy2[c] = gy1[c]; gy1[c] = gy0[c];
-      }
+      for (int c = 0; c < 3; ++c) { xq[c] = xo[c]; xo[c] = xn[c]; yq[c] = yo[c]; yo[c] = yn[c]; }
     }
 
-    // per-wave pose partials
+    // per-wave pose partials: d/d(H[0..8], a0, a1, tz); the column factor of H[.,0] is constant per lane
     float* pp = a.pose_partial + (((size_t)i*a.b + bi)*((size_t)a.S*nstrips) + (size_t)s*nstrips + strip)*kPoseSums;
+    const float psum[kPoseSums] = {ps[0]*uf, ps[1], ps[0], ps[2]*uf, ps[3], ps[2], ps[4]*uf, ps[5], ps[4], ps[6], ps[7], ps[8]};
 #pragma unroll
     for (int k = 0; k < kPoseSums; ++k) {
-      float tot = wave_sum(psum[k]);
+      const float tot = wave_sum(psum[k]);
       if (lane == 0) pp[k] = tot;
     }
   }
@@ -278,9 +282,11 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
 
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
   dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b, a.S)), block(64*kWavesPerBlock);
-  if (a.skip_level >= 2) hipLaunchKernelGGL(k_recon_bwd<2>, grid, block, 0, st, a);
-  else if (a.skip_level == 1) hipLaunchKernelGGL(k_recon_bwd<1>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(k_recon_bwd<0>, grid, block, 0, st, a);
+  const bool ssim = !(a.flags & SMD_LOSS_L1);
+  if (ssim) {
+    if (a.skip_level >= 1) hipLaunchKernelGGL((k_recon_bwd<true, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_recon_bwd<true, 0>), grid, block, 0, st, a);
+  } else hipLaunchKernelGGL((k_recon_bwd<false, 0>), grid, block, 0, st, a);
   return hipGetLastError();
 }
 
