@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 2
+#define SMD_ABI_VERSION 3
 
 #define SMD_OK 0
 #define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
@@ -77,8 +77,10 @@ int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int
  *   depth   (S,b,h,w)    tgt (b,3,h,w)    supp (n,b,3,h,w)    T (n,b,4,4)    K, K_inv (b,4,4)
  *   noise   (S,b,h,w) or NULL: the `randn_like` draw of reconstruction.py:72; NULL -> counter-based
  *           in-kernel Gaussian keyed by `seed` (statistically equivalent tie-break, different stream)
- *   supp_packed (n,b,h,w,4) out: the supports repacked as RGBX texels (smd_packed_supports_bytes() bytes); the
- *           forward fills it and the caller keeps it for the backward (aligned 16-byte bilinear taps)
+ *   supp_packed out, smd_packed_supports_bytes() bytes (< 4 GB): what every scale and support shares, produced once per
+ *           sample by the forward's prep kernel and kept by the caller for the backward — the supports as padded 12-byte
+ *           RGB texels (n,b,h+1,w+1,3), the target as RGB texels (b,h,w,3), and per target pixel the SSIM window sums of the
+ *           target and the identity error of the automask (2 x (b,h,w,4))
  *   err     (S,b,h,w) out: per-pixel error after min/mean-reprojection and automasking
  *   sel     (S,b,h,w) out uint8: winning support index, or SMD_SEL_MASKED where the static error won
  *   loss    (1) out: mean of err  (= `loss_img_recon`)
@@ -98,6 +100,25 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
                         const float* K_inv, const uint8_t* sel, const float* g_loss,
                         float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream);
+
+/* K0 fused into the reconstruction: the same operator fed with the network's multi-scale sigmoid
+ * disparity instead of the up-sampled depth.  Replaces, in one launch sequence, `forward_postprocess`' per-scale
+ * `ops.interpolate_like` + `to_scaled` / `to_inv` (src/core/trainer.py:316-321) AND `handlers.image_recon`
+ * (src/core/handlers.py:14-67): the fused kernel up-samples the disparity of the rows it is about to warp, converts it to
+ * depth and writes `depth_up` (S,b,h,w) once (the backward and `fwd['depth_up']` read it); no K0 launch is needed.
+ *   disp[s] (b,1,hs[s],ws[s]) host array of S device pointers;  min_depth / max_depth <= 0 mean "not set" (to_inv).
+ * Backward: recomputes nothing of K0 — it reads depth_up, adds `g_depth_up_in` (S,b,h,w; the gradient reaching depth_up from
+ * other consumers, or NULL), writes the gradient of a full-resolution scale 0 directly and the coarser scales through the
+ * bilinear adjoint -> g_disp[s] (b,1,hs,ws), overwritten.  Workspace: smd_image_recon_disp_workspace_bytes(). */
+size_t smd_image_recon_disp_workspace_bytes(const int* hs, const int* ws, int S, int b, int n, int h, int w);
+int smd_image_recon_disp_fwd(const float* const* disp, const int* hs, const int* ws, int S, float min_depth, float max_depth,
+                             const float* tgt, const float* supp, const float* T, const float* K, const float* K_inv,
+                             const float* noise, uint64_t seed, float* supp_packed, float* depth_up, float* err, uint8_t* sel, float* loss,
+                             float* warp0, void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream);
+int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_depth, float max_depth, const float* depth_up,
+                             const float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
+                             const float* g_loss, const float* g_depth_up_in, float* const* g_disp, float* g_T, float* g_K, float* g_Kinv,
+                             void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Edge-aware disparity smoothness over all scales.  Replaces `handlers.disp_smooth(crit, disps, imgs)`

@@ -23,9 +23,12 @@ def mk(s):
 disps = [mk(s).requires_grad_(True) for s in range(S)]
 T = torch.eye(4, device=dev).repeat(n, b, 1, 1); T[..., :3, 3] = 0.05*torch.randn(n, b, 3, device=dev, generator=g); T.requires_grad_(True)
 flags = F.recon_flags('ssim', True, True)
+fused_k0 = os.environ.get('MB_DISP', '1') == '1'   # 1: K0 fused into the reconstruction kernel (the product path); 0: separate K0 launch
 def step():
-    depth_up, _ = F.disp_to_depth(disps, (h, w), 0.1, 100)
-    loss, err, sel, _ = F.image_recon_fused(depth_up, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, seed=1)
+    if fused_k0: loss, err, sel, _, _ = F.image_recon_fused_disp(disps, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, min_depth=0.1, max_depth=100, seed=1)
+    else:
+        depth_up, _ = F.disp_to_depth(disps, (h, w), 0.1, 100)
+        loss, err, sel, _ = F.image_recon_fused(depth_up, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, seed=1)
     lsm, _, _ = F.disp_smooth_fused({s: d for s, d in enumerate(disps)}, y['imgs'], use_edges=True, want_aux=False)
     (loss + 0.001*lsm).backward()
     return loss
@@ -42,6 +45,6 @@ def col(which):
     return v[len(v)//2]*1e3, v[0]*1e3
 f, fb = col(0); bw, bb = col(1)
 B = b*h*w*(S*9 + 12*(1 + n))
-tag = ' '.join(f'{k}={v}' for k, v in os.environ.items() if k.startswith('SMD_'))
+tag = ' '.join(f'{k}={v}' for k, v in os.environ.items() if k.startswith('SMD_') or k.startswith('MB_'))
 print(f'{name} [{tag}] fwd med {f:.1f} us (min {fb:.1f}) = {B/f/1e3:.0f} GB/s | bwd med {bw:.1f} us (min {bb:.1f}) = {B/bw/1e3:.0f} GB/s | '
       f'whole loss path fwd+bwd {e0.elapsed_time(e1)/iters*1e3:.0f} us/iter | loss {l.item():.6f}')

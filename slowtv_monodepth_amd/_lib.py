@@ -36,6 +36,9 @@ PROTOTYPES = {
     'smd_packed_supports_bytes': (_sz, [_i, _i, _i, _i]),
     'smd_image_recon_fwd': (_i, [_vp]*7 + [_u64] + [_vp]*6 + [_sz] + [_i]*6 + [_vp]),
     'smd_image_recon_bwd': (_i, [_vp]*13 + [_sz] + [_i]*6 + [_vp]),
+    'smd_image_recon_disp_workspace_bytes': (_sz, [_vp, _vp, _i, _i, _i, _i, _i]),
+    'smd_image_recon_disp_fwd': (_i, [_vp, _vp, _vp, _i, _f, _f] + [_vp]*6 + [_u64] + [_vp]*7 + [_sz] + [_i]*5 + [_vp]),
+    'smd_image_recon_disp_bwd': (_i, [_vp, _vp, _i, _f, _f] + [_vp]*13 + [_sz] + [_i]*5 + [_vp]),
     'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_disp_smooth_edge_weight_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_disp_smooth_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -92,7 +95,7 @@ def _load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if handle.smd_abi_version() != 2: raise ImportError(f'ABI version mismatch in {lib_path}')
+    if handle.smd_abi_version() != 3: raise ImportError(f'ABI version mismatch in {lib_path}')
     return handle
 
 

@@ -61,7 +61,7 @@ void prof_mark(int which, hipStream_t st, bool begin) {
 }
 
 
-struct ReconWs { float* loss_partial; float* pose_partial; size_t bytes; };
+struct ReconWs { float* loss_partial; float* pose_partial; uint4* rowtab; size_t bytes; };
 
 ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
   ReconWs r;
@@ -69,6 +69,7 @@ ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
   char* p = (char*)base;
   r.loss_partial = (float*)(p + off); off += align256((size_t)S*b*max_strips(h, w, smd::kFwdCols)*sizeof(float));
   r.pose_partial = (float*)(p + off); off += align256((size_t)n*b*S*max_strips(h, w, smd::kBwdCols)*smd::kPoseSums*sizeof(float));
+  r.rowtab = (uint4*)(p + off); off += align256((size_t)S*(h + 2)*sizeof(uint4));
   r.bytes = off;
   return r;
 }
@@ -132,7 +133,7 @@ int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int
   for (int s = 0; s < S; ++s) if (!g_disp[s]) return fail(SMD_E_INVALID, "null gradient pointer for scale %d", s);
   const size_t need = smd_disp_to_depth_workspace_bytes(hs, ws, S, b, h, w);
   if (workspace_bytes < need) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
-  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth_up, (float*)workspace,
+  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth_up, (float*)workspace, false,
                                                     (hipStream_t)stream), "disp_to_depth_bwd");
 }
 
@@ -147,12 +148,15 @@ size_t smd_packed_supports_bytes(int b, int n, int h, int w) {
   return smd::packed_total_floats(b, n, h, w)*sizeof(float);
 }
 
-int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
-                        const float* K_inv, const float* noise, uint64_t seed, float* supp_packed, float* err, uint8_t* sel, float* loss,
-                        float* warp0, void* workspace, size_t workspace_bytes,
-                        int b, int n, int S, int h, int w, int flags, void* stream) {
+// Shared body of the two forward entry points.  `sc` != null: K0 fused — the first launch computes the depth from the
+// low-resolution disparity pyramid and writes it to `depth_out`; otherwise the depth is read from `depth`.
+static int recon_fwd_impl(const float* depth, float* depth_out, const smd::ScaleSet* sc, float min_depth, float max_depth,
+                          const float* tgt, const float* supp, const float* T, const float* K,
+                          const float* K_inv, const float* noise, uint64_t seed, float* supp_packed, float* err, uint8_t* sel, float* loss,
+                          float* warp0, void* workspace, size_t workspace_bytes,
+                          int b, int n, int S, int h, int w, int flags, void* stream) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
-  if (!depth || !tgt || !supp || !T || !K || !K_inv || !supp_packed || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if ((!depth && !sc) || !tgt || !supp || !T || !K || !K_inv || !supp_packed || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (smd_packed_supports_bytes(b, n, h, w) >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "the packed buffer (%zu bytes) must stay below 2^32", smd_packed_supports_bytes(b, n, h, w));
   if ((size_t)n*b*3*h*w*4 >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "n*b*3*h*w*4 must stay below 2^32");
   if ((size_t)(h + 1)*(size_t)(w + 1) >= ((size_t)1 << 24)) return fail(SMD_E_INVALID, "(h+1)*(w+1) must stay below 2^24");
@@ -170,15 +174,30 @@ int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp,
     p.b = b; p.n = n; p.h = h; p.w = w; p.flags = flags & (SMD_USE_MIN | SMD_LOSS_L1 | SMD_USE_AUTOMASK);
     const StripPlan ipl = plan(b, 1, h, w, smd::kFwdCols);  // one "scale" only: shorter strips keep the chip full
     p.rh = ipl.rh; p.nsx = ipl.nsx; p.nsy = ipl.nsy;
+    const bool fuse_k0 = sc && !(flags & SMD_LOSS_L1);
     for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
       p.i0 = i0; p.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
       p.first_pass = (i0 == 0); p.last_pass = (i0 + p.ni >= n);
+      p.rowtab = (fuse_k0 && i0 == 0) ? ws.rowtab : nullptr;
+      if (p.rowtab) { p.sc_S = S; for (int s = 0; s < S; ++s) { p.sc_hs[s] = sc->hs[s]; p.sc_ws[s] = sc->ws[s]; } }
       if (int rc = check_launch(smd::launch_recon_prep(p, st), "recon prep")) return rc;
     }
   }
 
   smd::ReconMainArgs a;
   memset(&a, 0, sizeof(a));
+  if (sc && (flags & SMD_LOSS_L1)) {   // the fused K0 exists for the SSIM instantiations: run the K0 kernel for the others
+    if (int rc = check_launch(smd::launch_disp_to_depth_fwd(*sc, b, h, w, min_depth, max_depth, depth_out, nullptr, st), "disp_to_depth_fwd")) return rc;
+    depth = depth_out; sc = nullptr;
+  }
+  if (sc) {
+    a.sc = *sc; a.depth_out = depth_out; a.rowtab = ws.rowtab;
+    a.a_scale = 1.f; a.a_off = 0.f;
+    if (min_depth > 0.f || max_depth > 0.f) {  // to_scaled: i_max = 1/min, i_min = 1/max (0 if unset)
+      const float i_max = 1.f/min_depth, i_min = max_depth > 0.f ? 1.f/max_depth : 0.f;
+      a.a_scale = i_max - i_min; a.a_off = i_min;
+    }
+  }
   a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv;
   a.noise = noise; a.err = err; a.sel = sel; a.partial = ws.loss_partial; a.warp0 = warp0;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
@@ -193,6 +212,7 @@ int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp,
     if (i0 == 0) prof_mark(SMD_PROF_RECON_FWD, st, true);
     if (int rc = check_launch(smd::launch_recon_main(a, st), "image_recon_fwd")) return rc;
     if (a.last_pass) prof_mark(SMD_PROF_RECON_FWD, st, false);
+    if (a.depth_out) { a.depth = a.depth_out; a.depth_out = nullptr; }   // later passes (n > 4) read the depth the first one wrote
   }
   const int count = S*b*pl.nsx*pl.nsy;
   const int rc = check_launch(smd::launch_sum_partials(ws.loss_partial, count, 1.0/((double)S*b*h*w), loss, st), "loss reduction");
@@ -200,12 +220,34 @@ int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp,
   return rc;
 }
 
-int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_packed, const float* T, const float* K,
-                        const float* K_inv, const uint8_t* sel, const float* g_loss,
-                        float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
+int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
+                        const float* K_inv, const float* noise, uint64_t seed, float* supp_packed, float* err, uint8_t* sel, float* loss,
+                        float* warp0, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream) {
+  return recon_fwd_impl(depth, nullptr, nullptr, 0.f, 0.f, tgt, supp, T, K, K_inv, noise, seed, supp_packed, err, sel, loss, warp0, workspace, workspace_bytes,
+                        b, n, S, h, w, flags, stream);
+}
+
+int smd_image_recon_disp_fwd(const float* const* disp, const int* hs, const int* ws, int S, float min_depth, float max_depth,
+                             const float* tgt, const float* supp, const float* T, const float* K, const float* K_inv,
+                             const float* noise, uint64_t seed, float* supp_packed, float* depth_up, float* err, uint8_t* sel, float* loss,
+                             float* warp0, void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream) {
+  if (!disp || !depth_up) return fail(SMD_E_INVALID, "null pointer");
+  if ((min_depth > 0.f || max_depth > 0.f) && !(min_depth > 0.f)) return fail(SMD_E_INVALID, "Min depth must be greater than 0. (%g)", min_depth);
+  if (max_depth > 0.f && max_depth < min_depth) return fail(SMD_E_INVALID, "Max depth must be greater than min. (%g vs. %g)", max_depth, min_depth);
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, disp, nullptr, hs, ws, nullptr, S)) return rc;
+  for (int s = 0; s < S; ++s) if (!disp[s]) return fail(SMD_E_INVALID, "null disparity pointer for scale %d", s);
+  return recon_fwd_impl(nullptr, depth_up, &sc, min_depth, max_depth, tgt, supp, T, K, K_inv, noise, seed, supp_packed, err, sel, loss, warp0,
+                        workspace, workspace_bytes, b, n, S, h, w, flags, stream);
+}
+
+static int recon_bwd_impl(const float* depth, const float* supp_packed, const float* T, const float* K,
+                          const float* K_inv, const uint8_t* sel, const float* g_loss, const float* g_in, float* g_disp0, float a_scale,
+                          float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
+                          int b, int n, int S, int h, int w, int flags, void* stream) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
-  if (!depth || !tgt || !supp_packed || !T || !K || !K_inv || !sel || !g_loss || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (!depth || !supp_packed || !T || !K || !K_inv || !sel || !g_loss || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if ((flags & SMD_NEED_K_GRAD) && (!g_K || !g_Kinv)) return fail(SMD_E_INVALID, "SMD_NEED_K_GRAD requires g_K and g_Kinv");
   if (n >= SMD_SEL_MASKED) return fail(SMD_E_INVALID, "too many supports");
   ReconWs ws = carve_recon(workspace, b, n, S, h, w);
@@ -216,6 +258,7 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
   memset(&a, 0, sizeof(a));
   a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
   a.g_depth = g_depth; a.pose_partial = ws.pose_partial;
+  a.g_in = g_in; a.g_disp0 = g_disp0; a.a_scale = a_scale;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   const StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
@@ -230,6 +273,47 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
                                                         b, n, st), "pose finalize");
   prof_mark(SMD_PROF_RECON_BWD_ALL, st, false);
   return rc;
+}
+
+int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_packed, const float* T, const float* K,
+                        const float* K_inv, const uint8_t* sel, const float* g_loss,
+                        float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
+                        int b, int n, int S, int h, int w, int flags, void* stream) {
+  (void)tgt;   // kept in the signature for ABI stability: the target is read from the packed buffer since ABI 3
+  return recon_bwd_impl(depth, supp_packed, T, K, K_inv, sel, g_loss, nullptr, nullptr, 0.f, g_depth, g_T, g_K, g_Kinv, workspace, workspace_bytes,
+                        b, n, S, h, w, flags, stream);
+}
+
+size_t smd_image_recon_disp_workspace_bytes(const int* hs, const int* ws, int S, int b, int n, int h, int w) {
+  const size_t base = smd_image_recon_workspace_bytes(b, n, S, h, w), k0 = smd_disp_to_depth_workspace_bytes(hs, ws, S, b, h, w);
+  if (!base || !k0) return 0;
+  return align256(base) + align256((size_t)S*b*h*w*sizeof(float)) + k0;
+}
+
+int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_depth, float max_depth, const float* depth_up,
+                             const float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
+                             const float* g_loss, const float* g_depth_up_in, float* const* g_disp, float* g_T, float* g_K, float* g_Kinv,
+                             void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream) {
+  if (!depth_up || !g_disp || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, nullptr, g_disp, hs, ws, nullptr, S)) return rc;
+  for (int s = 0; s < S; ++s) if (!g_disp[s]) return fail(SMD_E_INVALID, "null gradient pointer for scale %d", s);
+  const size_t need = smd_image_recon_disp_workspace_bytes(hs, ws, S, b, n, h, w);
+  if (!need || workspace_bytes < need) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  const size_t base = align256(smd_image_recon_workspace_bytes(b, n, S, h, w));
+  float* g_depth = (float*)((char*)workspace + base);
+  float* k0_tmp = (float*)((char*)workspace + base + align256((size_t)S*b*h*w*sizeof(float)));
+  float a_scale = 1.f;
+  if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
+  // Optional (SMD_BWD_DIRECT0=1): a full-resolution scale 0 gets its disparity gradient straight from the fused backward's last
+  // support pass, and the K0 adjoint skips that scale.  Off by default — measured at cfg 2: the fused kernel pays +7 us (the
+  // last pass can no longer skip dead rows of scale 0) for 2.7 us saved in the element-wise part of the K0 adjoint.
+  const bool direct0 = (hs[0] == h && ws[0] == w) && env_int("SMD_BWD_DIRECT0", 0) != 0;
+  if (int rc = recon_bwd_impl(depth_up, supp_packed, T, K, K_inv, sel, g_loss, g_depth_up_in, direct0 ? g_disp[0] : nullptr, a_scale,
+                              g_depth, g_T, g_K, g_Kinv, workspace, base, b, n, S, h, w, flags, stream)) return rc;
+  if (direct0 && S == 1) return SMD_OK;
+  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth, k0_tmp, direct0, (hipStream_t)stream),
+                      "disp_to_depth_bwd");
 }
 
 // ------------------------------------------------------------------------------------------------

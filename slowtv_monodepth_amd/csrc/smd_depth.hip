@@ -144,7 +144,7 @@ size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, Bwd
 }
 
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
-                                    const float* depth_up, const float* g_depth_up, float* tmp, hipStream_t st) {
+                                    const float* depth_up, const float* g_depth_up, float* tmp, bool skip_identity, hipStream_t st) {
   float a_scale = 1.f;
   if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
   BwdMap m1, m2;
@@ -156,13 +156,13 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
     m1.first_block[s] = n1; m2.first_block[s] = n2;
     if (s < sc.S) {
       const bool ident = sc.hs[s] == h && sc.ws[s] == w;
-      n1 += ident ? ceil_div(h*w, 1024) : ceil_div(h*sc.ws[s], 256);
+      n1 += ident ? (skip_identity ? 0 : ceil_div(h*w, 1024)) : ceil_div(h*sc.ws[s], 256);   // skip: the fused backward already wrote that scale
       n2 += ident ? 0 : ceil_div(sc.hs[s]*sc.ws[s], 256);
       resampled |= !ident;
     }
   }
   m1.first_block[SMD_MAX_SCALES] = n1; m2.first_block[SMD_MAX_SCALES] = n2;
-  hipLaunchKernelGGL(k_disp_to_depth_bwd_h, dim3(n1, b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp);
+  if (n1 > 0) hipLaunchKernelGGL(k_disp_to_depth_bwd_h, dim3(n1, b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp);
   if (resampled) hipLaunchKernelGGL(k_disp_to_depth_bwd_v, dim3(n2, b), dim3(256), 0, st, sc, m2, b, h, w, a_scale, tmp);
   return hipGetLastError();
 }

@@ -58,10 +58,16 @@ struct ReconPrepArgs {     // k_recon_prep: texel repack + target window sums + 
   int flags;
   int rh, nsx, nsy;
   int first_pass, last_pass;
+  uint4* rowtab;           // K0 fused: [S][h+2] vertical up-sampling table for the main kernel (first pass), or null
+  int sc_S, sc_hs[SMD_MAX_SCALES], sc_ws[SMD_MAX_SCALES];
 };
 
 struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over supports + automask, per (strip, sample, scale)
-  const float* depth;      // (S,b,h,w)
+  const float* depth;      // (S,b,h,w), read unless depth_out is set
+  float* depth_out;        // K0 fused: (S,b,h,w) written from `sc` (the low-resolution disparity pyramid), or null
+  ScaleSet sc;             // K0 fused: p[s] (b,1,hs,ws), hs, ws
+  float a_scale, a_off;    // K0 fused: d = a_scale*disp_up + a_off, depth = (d > 0)/max(d, eps)
+  const uint4* rowtab;     // K0 fused: [S][h+2] vertical up-sampling table (written by the prep kernel)
   const float* packed;     // layout above
   const float* T;          // (n,b,4,4)
   const float* K;          // (b,4,4)
@@ -87,6 +93,9 @@ struct ReconBwdArgs {
   const uint8_t* sel;
   const float* g_loss;    // device scalar
   float* g_depth;         // (S,b,h,w)
+  const float* g_in;      // (S,b,h,w) gradient reaching depth from other consumers, added on the last support pass, or null
+  float* g_disp0;         // K0 fused: (b,1,h,w) gradient of the full-resolution disparity scale, written directly (scale 0 then
+  float a_scale;          //   skips g_depth), or null; d depth/d disp = -depth^2*a_scale
   float* pose_partial;    // [n*b][S*nstrips][kPoseSums]
   int b, n, S, h, w;
   int flags;
@@ -133,7 +142,7 @@ hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, flo
 struct BwdMap;
 size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, BwdMap* map);
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
-                                    const float* depth_up, const float* g_depth_up, float* tmp, hipStream_t st);
+                                    const float* depth_up, const float* g_depth_up, float* tmp, bool skip_identity, hipStream_t st);
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st);

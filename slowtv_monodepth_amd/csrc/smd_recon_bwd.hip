@@ -78,6 +78,9 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
   const rsrc_t rs_depth = make_rsrc(a.depth + sb, hw*4);
   const rsrc_t rs_sel = make_rsrc(a.sel + sb, hw);
   const rsrc_t rs_gd = make_rsrc(a.g_depth + sb, hw*4);
+  const rsrc_t rs_gin = make_rsrc(a.g_in ? a.g_in + sb : nullptr, a.g_in ? hw*4 : 0);
+  const bool direct0_scale = (a.g_disp0 != nullptr) && (s == 0);
+  const rsrc_t rs_gd0 = make_rsrc(direct0_scale ? a.g_disp0 + (size_t)bi*hw : nullptr, direct0_scale ? hw*4 : 0);
   const unsigned texel_bytes = (unsigned)(h + 1)*(unsigned)(w + 1)*12u, rowbytes = ((unsigned)w + 1u)*12u;
   const unsigned so_y = (unsigned)(packed_texel_floats(a.b, a.n, h, w)*4) + (unsigned)bi*hw4*3u;
   const unsigned so_ta = (unsigned)((packed_texel_floats(a.b, a.n, h, w) + packed_ypix_floats(a.b, h, w))*4) + (unsigned)bi*hw4*4u;
@@ -221,9 +224,8 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
         // coefficient rows q-1, q, q+1 all skipped and no L1 term anywhere in the wave: the gradient of this row is zero
         const bool dead = SKIP >= 2 ? ((live_hist & 7u) == 0u && __builtin_amdgcn_ballot_w64(gl != 0.f) == 0) : false;
         const unsigned qro = (unsigned)q*w4;
-        if (dead) {
-          if (interior && i == 0) bst(rs_gd, lane4, qro, 0.f);
-        } else {
+        float gD = 0.f;
+        if (!dead) {
           float gpx = 0.f, gpy = 0.f;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
@@ -244,14 +246,20 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
           float gnx = gpx*rz, gny = gpy*rz;
           float gz = (yz >= kZMin) ? -(gpx*nx + gpy*ny)*rz*rz : 0.f;
           if (!interior) { gnx = 0.f; gny = 0.f; gz = 0.f; }
-          float gD = fmaf(gnx, hx, fmaf(gny, hyy, gz*hz));
-          if (interior) {
-            if (i != 0) gD += bld(rs_gd, lane4, qro);
-            bst(rs_gd, lane4, qro, gD);
-          }
+          gD = fmaf(gnx, hx, fmaf(gny, hyy, gz*hz));
           const float dnx = gnx*D2, dny = gny*D2, dz = gz*D2;
           ps[0] += dnx; ps[1] = fmaf(dnx, vf, ps[1]); ps[2] += dny; ps[3] = fmaf(dny, vf, ps[3]); ps[4] += dz; ps[5] = fmaf(dz, vf, ps[5]);
           ps[6] += gnx; ps[7] += gny; ps[8] += gz;
+        }
+        // dL/d depth: accumulated across the support passes through g_depth; the last pass adds what reaches depth from other
+        // consumers and, for the full-resolution disparity scale of the K0-fused path, applies d depth/d disp on the spot.
+        const bool last = (i == a.n - 1);
+        const bool direct0 = last && direct0_scale;
+        if (interior && (!dead || i == 0 || (last && (a.g_in != nullptr || direct0)))) {
+          if (i != 0) gD += bld(rs_gd, lane4, qro);
+          if (last && a.g_in != nullptr) gD += bld(rs_gin, lane4, qro);
+          if (direct0) bst(rs_gd0, lane4, qro, gD*((D2 < 1.f/kEps32) ? -D2*D2 : 0.f)*a.a_scale);
+          else bst(rs_gd, lane4, qro, gD);
         }
       }
 

@@ -28,6 +28,14 @@
 
 namespace smd {
 
+// ATen area_pixel_compute_source_index (align_corners=False) + index / lambda split, as the K0 kernel (smd_depth.hip)
+__device__ __forceinline__ void src_index_f(int dst, float scale, int n_in, int& i0, int& i1, float& l1) {
+  const float src = fmaxf(scale*((float)dst + 0.5f) - 0.5f, 0.f);
+  i0 = min((int)src, n_in - 1);
+  i1 = min(i0 + 1, n_in - 1);
+  l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_recon_prep: per (strip, sample).  Reads the planar target and support frames once and fills the caller-kept `packed`
 // buffer (layout: smd_kernels.h) that the main kernel and the backward read through ONE buffer resource:
@@ -185,6 +193,17 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_prep(const ReconPre
     cx.so_tex[k] = (unsigned)((a.i0 + k)*a.b + bi)*texel_bytes;
   }
 
+  // K0 fused: the vertical half of the bilinear up-sampling is the same for every pixel of an image row, so it is tabulated
+  // once per call ({byte offset of the two low-resolution rows, blend weight} per (scale, row); rows h, h+1 for the prefetch)
+  // and the main kernel reads its row's entry with one scalar load: no vector instruction, no vector register.
+  if (a.rowtab != nullptr && blockIdx.x == 0) {
+    for (int e = threadIdx.x; e < a.sc_S*(a.h + 2); e += 64*kWavesPerBlock) {
+      const int sc_i = e/(a.h + 2), row = e - sc_i*(a.h + 2);
+      int y0, y1; float ly;
+      src_index_f(row, (float)a.sc_hs[sc_i]/(float)a.h, a.sc_hs[sc_i], y0, y1, ly);
+      a.rowtab[e] = uint4{(unsigned)y0*(unsigned)a.sc_ws[sc_i]*4u, (unsigned)y1*(unsigned)a.sc_ws[sc_i]*4u, __builtin_bit_cast(unsigned, ly), 0u};
+    }
+  }
   float XA[N][3], XB[N][3], YA[3], YB[3];
   const int jstart = max(cx.r0 - 1, 0), jlast = min(cx.r1, a.h - 1);
   cx.load_row(jstart);
@@ -255,7 +274,7 @@ struct MainPend {          // gathers in flight for one pair of supports
   float fx[(N > 1) ? 2 : 1], fy[(N > 1) ? 2 : 1];
 };
 
-template <int N, bool SSIM, bool SINGLE, bool AUX>
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP>
 struct MainCtx {
   static constexpr int NG = (N + 1)/2;
   const ReconMainArgs& a;
@@ -275,6 +294,30 @@ struct MainCtx {
   f3 py;                   // target row in flight
   float Dcur, Dnext;       // depth of rows j and j+1
   float vfn;               // (float)(j+1)
+  // DISP (K0 fused): the depth of a row is computed here from the network's low-resolution sigmoid
+  // disparity — bilinear up-sampling (`ops.interpolate_like`, src/tools/ops.py:311-314) + `to_scaled` / `to_inv`
+  // (src/tools/geometry.py:62-90) — and written out once for the backward, instead of being read from a K0 launch's output.
+  rsrc_t rs_disp, rs_dout;
+  unsigned dx0, dx1;       // byte offsets of the two low-resolution columns this lane blends
+  float dlx, a_scale, a_off;
+  const uint4* __restrict__ rowtab;   // this scale's {offset of row y0, offset of row y1, ly, -} per image row (written by the prep kernel)
+  float q00, q01, q10, q11;   // low-resolution taps in flight
+
+  // The table entry of a row is wave-uniform; readfirstlane tells the compiler so (otherwise it wraps every buffer load
+  // that uses the entry as scalar offset into a waterfall loop).
+  __device__ __forceinline__ void load_dtaps(int row) {
+    const uint4 e = rowtab[row];
+    const unsigned o0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.x), o1 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.y);
+    q00 = bld(rs_disp, dx0, o0); q01 = bld(rs_disp, dx1, o0); q10 = bld(rs_disp, dx0, o1); q11 = bld(rs_disp, dx1, o1);
+  }
+  __device__ __forceinline__ float finish_depth(int row) {
+    const float ly = uniform(__builtin_bit_cast(float, rowtab[row].z));
+    const float val = (1.f - ly)*((1.f - dlx)*q00 + dlx*q01) + ly*((1.f - dlx)*q10 + dlx*q11);
+    const float d = fmaf(a_scale, val, a_off);
+    const float dep = (d > 0.f) ? __builtin_amdgcn_rcpf(fmaxf(d, kEps32)) : 0.f;
+    if (row >= r0 && row < r1 && interior) bst(rs_dout, lane4, (unsigned)row*w4, dep);   // each row is interior to one strip
+    return dep;
+  }
 
   // ---- coordinates + the four tap loads of one pair of supports -----------------------------------------
   __device__ __forceinline__ void issue(int g, float D, float vf) {
@@ -307,15 +350,17 @@ struct MainCtx {
   // depth row below the image reads 0 (buffer bounds), and a conditional issue would make every pending register a loop phi
   // with a second copy (36 more VGPRs).
   __device__ __forceinline__ void issue_next_row(int j) {
-    issue(0, Dnext, vfn);
 #if (SMD_ABLATE & 2)
+    issue(0, Dnext, vfn);
     py = f3{vfn*0.001f, 0.5f, vfn*0.002f};
     Dcur = Dnext;
     Dnext = 1.f + vfn*0.01f;
 #else
+    const float Dn = DISP ? finish_depth(j + 1) : Dnext;
+    issue(0, Dn, vfn);
     py = bld3(rs_pk, lane4*3u, so_y + (unsigned)(j + 1)*w4*3u);
-    Dcur = Dnext;
-    Dnext = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
+    Dcur = Dn;
+    if (DISP) load_dtaps(j + 2); else Dnext = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
 #endif
     vfn += 1.f;
   }
@@ -458,7 +503,7 @@ struct MainCtx {
   }
 };
 
-template <int N, bool SSIM, bool SINGLE, bool AUX>
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP>
 __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -467,7 +512,7 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   if (strip >= a.nsx*a.nsy) return;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
 
-  MainCtx<N, SSIM, SINGLE, AUX> cx{a};
+  MainCtx<N, SSIM, SINGLE, AUX, DISP> cx{a};
   cx.bi = bi_; cx.s = s_; cx.h = a.h; cx.w = a.w;
   cx.r0 = syi*a.rh; cx.r1 = min(cx.r0 + a.rh, a.h);
   cx.jlast = min(cx.r1, a.h - 1);
@@ -518,7 +563,17 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, a.h, a.w) + packed_ypix_floats(a.b, a.h, a.w))*4) + (unsigned)bi_*cx.hw4*4u;
   cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, a.h, a.w)*4);
   cx.rs_pk = make_rsrc(a.packed, packed_total_floats(a.b, a.n, a.h, a.w)*4);
-  cx.rs_depth = make_rsrc(a.depth + sb, hw*4);
+  cx.rs_depth = make_rsrc(DISP ? nullptr : a.depth + sb, DISP ? 0 : hw*4);
+  if (DISP) {
+    const int hs = a.sc.hs[s_], ws = a.sc.ws[s_];
+    cx.rs_disp = make_rsrc(a.sc.p[s_] + (size_t)bi_*hs*ws, (size_t)hs*ws*4);
+    cx.rs_dout = make_rsrc(a.depth_out + sb, hw*4);
+    int x0, x1;
+    src_index_f(uc, (float)ws/(float)a.w, ws, x0, x1, cx.dlx);
+    cx.dx0 = (unsigned)x0*4u; cx.dx1 = (unsigned)x1*4u;
+    cx.a_scale = a.a_scale; cx.a_off = a.a_off;
+    cx.rowtab = a.rowtab + (size_t)s_*(a.h + 2);
+  }
   cx.nz_sb = (AUX && a.noise) ? a.noise + sb : nullptr;
   cx.rs_err = make_rsrc(a.err + sb, hw*4);
   cx.rs_sel = make_rsrc(a.sel + sb, hw);
@@ -527,11 +582,12 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   // prologue: row jstart's loads, depth two rows ahead
   const int jstart = max(cx.r0 - 1, 0);
   cx.vfn = (float)jstart;
-  cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)jstart*cx.w4);
+  if (DISP) { cx.load_dtaps(jstart); cx.Dnext = cx.finish_depth(jstart); }
+  else cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)jstart*cx.w4);
   cx.Dcur = cx.Dnext;
   cx.issue(0, cx.Dnext, cx.vfn);
   cx.py = bld3(cx.rs_pk, cx.lane4*3u, cx.so_y + (unsigned)jstart*cx.w4*3u);
-  cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)(jstart + 1)*cx.w4);
+  if (DISP) cx.load_dtaps(jstart + 1); else cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)(jstart + 1)*cx.w4);
   cx.vfn += 1.f;
 
   float XA[N][3], XB[N][3], YA[3], YB[3];
@@ -568,20 +624,25 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
 }
 
 // register budget: 128 VGPRs (4 waves per SIMD) up to two supports, 168 (3 waves) for three and four
-// register budget: up to two supports fit 128 VGPRs (4 waves per SIMD) unaided; three and four are held to 168 (3 waves)
-template <int N, bool SSIM, bool SINGLE, bool AUX>
-__global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 1 : 3)) void k_recon_main(const ReconMainArgs a) { recon_main_body<N, SSIM, SINGLE, AUX>(a); }
+// register budget: up to two supports are held to 128 VGPRs (4 waves per SIMD; the K0-fused instantiation needs 129 unaided), three and four to 168 (3 waves)
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP>
+__global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 4 : 3)) void k_recon_main(const ReconMainArgs a) { recon_main_body<N, SSIM, SINGLE, AUX, DISP>(a); }
 
 hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
   dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b, a.S)), block(64*kWavesPerBlock);
   const bool ssim = !(a.flags & SMD_LOSS_L1);
   const bool single = a.first_pass && a.last_pass;
   const bool aux = a.warp0 != nullptr || a.noise != nullptr;
+  const bool disp = a.depth_out != nullptr;     // K0 fused: only on the first pass over the supports, SSIM instantiations
+  // hot: every support in one launch, no extras; otherwise the general instantiation (carried min / sum, noise tensor, warp output)
 #define SMD_MAIN(N_) do { \
-    if (ssim && single && !aux) hipLaunchKernelGGL((k_recon_main<N_, true, true, false>), grid, block, 0, st, a); \
-    else if (ssim && !aux) hipLaunchKernelGGL((k_recon_main<N_, true, false, false>), grid, block, 0, st, a); \
-    else if (ssim) hipLaunchKernelGGL((k_recon_main<N_, true, false, true>), grid, block, 0, st, a); \
-    else hipLaunchKernelGGL((k_recon_main<N_, false, false, true>), grid, block, 0, st, a); } while (0)
+    if (ssim && single && !aux) { \
+      if (disp) hipLaunchKernelGGL((k_recon_main<N_, true, true, false, true>), grid, block, 0, st, a); \
+      else hipLaunchKernelGGL((k_recon_main<N_, true, true, false, false>), grid, block, 0, st, a); \
+    } else if (ssim) { \
+      if (disp) hipLaunchKernelGGL((k_recon_main<N_, true, false, true, true>), grid, block, 0, st, a); \
+      else hipLaunchKernelGGL((k_recon_main<N_, true, false, true, false>), grid, block, 0, st, a); \
+    } else hipLaunchKernelGGL((k_recon_main<N_, false, false, true, false>), grid, block, 0, st, a); } while (0)
   switch (a.ni) { case 1: SMD_MAIN(1); break; case 2: SMD_MAIN(2); break; case 3: SMD_MAIN(3); break; default: SMD_MAIN(4); break; }
 #undef SMD_MAIN
   return hipGetLastError();

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, call, int_array, ptr_array
 
-__all__ = ['disp_to_depth', 'image_recon_fused', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
+__all__ = ['disp_to_depth', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
            'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'layer_norm_cf', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
@@ -137,6 +137,79 @@ def image_recon_fused(depth, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int,
     was5 = depth.ndim == 5
     d4 = depth.squeeze(2) if was5 else depth
     return _ImageRecon.apply(d4, imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp)
+
+
+class _ImageReconDisp(torch.autograd.Function):
+    """K0 fused into `handlers.image_recon`: from the network's multi-scale sigmoid disparity straight to
+    the loss — `forward_postprocess`' up-sampling + `to_scaled` / `to_inv` (src/core/trainer.py:316-321) happens inside the fused
+    kernel, which also writes `depth_up` for the backward and for `fwd['depth_up']`."""
+
+    @staticmethod
+    def forward(ctx, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp, min_depth, max_depth, *disps):
+        b, _, h, w = tgt.shape
+        n, S = supp.shape[0], len(disps)
+        tgt = _check('imgs', tgt, (b, 3, h, w)); supp = _check('supp_imgs', supp, (n, b, 3, h, w)); T = _check('Ts', T, (n, b, 4, 4))
+        K = _check('Ks', K, (b, 4, 4)); K_inv = _check('K_inv', K_inv, (b, 4, 4))
+        disps = [_check(f'disp[{i}]', d) for i, d in enumerate(disps)]
+        for d in disps:
+            if d.ndim != 4 or d.shape[0] != b or d.shape[1] != 1: raise ValueError(f'disparities must be (b,1,hs,ws), got {tuple(d.shape)}')
+        if noise is not None: noise = _check('noise', noise.reshape(S, b, h, w), (S, b, h, w))
+        hs, ws = [d.shape[2] for d in disps], [d.shape[3] for d in disps]
+        dev = tgt.device
+        depth_up = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32)
+        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32)
+        sel = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.uint8)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        warp0 = torch.empty((n, b, 3, h, w), device=dev, dtype=torch.float32) if want_warp else None
+        nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
+        wsp = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        packed = torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32)
+        call('smd_image_recon_disp_fwd', ptr_array([d.data_ptr() for d in disps]), int_array(hs), int_array(ws), S, float(min_depth or 0), float(max_depth or 0),
+             tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(), noise.data_ptr() if noise is not None else None,
+             int(seed) & (2**64 - 1), packed.data_ptr(), depth_up.data_ptr(), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
+             warp0.data_ptr() if want_warp else None, wsp.data_ptr(), nbytes, b, n, h, w, int(flags), _stream())
+        ctx.save_for_backward(depth_up, packed, T, K, K_inv, sel)
+        # `depth_up` is a differentiable output that usually has no other consumer: without this autograd would hand the backward
+        # a materialised zero tensor for it (one more (S,b,h,w) read, and no dead-row skipping on the last support pass)
+        ctx.set_materialize_grads(False)
+        ctx.meta = (b, n, S, h, w, int(flags), hs, ws, float(min_depth or 0), float(max_depth or 0))
+        ctx.need_k = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        ctx.mark_non_differentiable(err, sel)
+        if want_warp: ctx.mark_non_differentiable(warp0)
+        return loss, err, sel, warp0, depth_up
+
+    @staticmethod
+    def backward(ctx, g_loss, _ge, _gs, _gw, g_depth_up):
+        depth_up, packed, T, K, K_inv, sel = ctx.saved_tensors
+        b, n, S, h, w, flags, hs, ws, mn, mx = ctx.meta
+        dev = depth_up.device
+        g_loss = (g_loss if g_loss is not None else torch.zeros((), device=dev)).to(torch.float32).contiguous()
+        if g_depth_up is not None: g_depth_up = _check('grad(depth_up)', g_depth_up.reshape(S, b, h, w), (S, b, h, w))
+        g_disps = [torch.empty((b, 1, hs[s], ws[s]), device=dev, dtype=torch.float32) for s in range(S)]
+        g_T = torch.empty((n, b, 4, 4), device=dev, dtype=torch.float32)
+        g_K = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
+        g_Ki = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
+        if ctx.need_k: flags |= FLAGS['need_k_grad']
+        hs_a, ws_a = int_array(hs), int_array(ws)
+        nbytes = _lib.lib.smd_image_recon_disp_workspace_bytes(hs_a, ws_a, S, b, n, h, w)
+        wsp = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        call('smd_image_recon_disp_bwd', hs_a, ws_a, S, mn, mx, depth_up.data_ptr(), packed.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
+             sel.data_ptr(), g_loss.data_ptr(), g_depth_up.data_ptr() if g_depth_up is not None else None,
+             ptr_array([g.data_ptr() for g in g_disps]), g_T.data_ptr(), g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
+             wsp.data_ptr(), nbytes, b, n, h, w, flags, _stream())
+        return (None, None, g_T, (g_K if ctx.needs_input_grad[3] else None), (g_Ki if ctx.needs_input_grad[4] else None),
+                None, None, None, None, None, None, *g_disps)
+
+
+def image_recon_fused_disp(disps, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int, min_depth=None, max_depth=None, noise=None, seed: int = 0,
+                           want_warp: bool = False):
+    """disps: sequence of (b,1,hs,ws) sigmoid disparities -> (loss, err, sel, warp0|None, depth_up (S,b,1,h,w)).
+
+    The K0-fused form of `disp_to_depth` + `image_recon_fused`: one prep launch, one fused launch, one reduction."""
+    if min_depth is not None and min_depth <= 0: raise ValueError(f'Min depth must be greater than 0. ({min_depth})')
+    if max_depth and min_depth and max_depth < min_depth: raise ValueError(f'Max depth must be greater than min. ({max_depth} vs. {min_depth})')
+    if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else inv_intrinsics(Ks)
+    return _ImageReconDisp.apply(imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp, min_depth, max_depth, *disps)
 
 
 # ---------------------------------------------------------------------------------------------------

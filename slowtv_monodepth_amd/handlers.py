@@ -10,11 +10,13 @@ reference's structure and run on the un-fused HIP operators (`view_synth`, `phot
 """
 from __future__ import annotations
 
+from collections.abc import Mapping
+
 import torch
 
 from . import functional as F
 
-__all__ = ['image_recon', 'disp_smooth', 'feat_recon', 'autoenc_recon', 'stereo_const', 'depth_regr', 'ScaleDict']
+__all__ = ['image_recon', 'disp_smooth', 'feat_recon', 'autoenc_recon', 'stereo_const', 'depth_regr', 'ScaleDict', 'LazyDepths']
 
 
 class ScaleDict(dict):
@@ -27,6 +29,31 @@ class ScaleDict(dict):
         out = cls({k: stacked[i] for i, k in enumerate(keys)})
         out.stacked = stacked
         return out
+
+
+class LazyDepths(Mapping):
+    """`fwd['depth_up']` = {scale: (b,1,h,w)} that has not been computed yet: it remembers the network's disparities and the
+    to-depth parameters.  The fused `image_recon` handler consumes it WITHOUT a K0 launch (the fused kernel up-samples and
+    converts the rows it is about to warp, and hands back the depth stack it wrote); any other access (`depths[s]`, `.stacked`,
+    iteration over values) materialises it through the K0 kernel, so every consumer of `depth_up` sees the usual tensors."""
+
+    def __init__(self, keys, disps, size, min_depth, max_depth):
+        self.keys_, self.disps, self.size, self.min_depth, self.max_depth = list(keys), list(disps), tuple(size), min_depth, max_depth
+        self._stack = None
+
+    @property
+    def pending(self) -> bool: return self._stack is None
+
+    def adopt(self, stacked: torch.Tensor) -> None: self._stack = stacked
+
+    @property
+    def stacked(self) -> torch.Tensor:
+        if self._stack is None: self._stack, _ = F.disp_to_depth(self.disps, self.size, self.min_depth, self.max_depth)
+        return self._stack
+
+    def __getitem__(self, k): return self.stacked[self.keys_.index(k)]
+    def __iter__(self): return iter(self.keys_)
+    def __len__(self): return len(self.keys_)
 
 
 def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs: torch.Tensor, Ts: torch.Tensor, Ks: torch.Tensor,
@@ -47,11 +74,16 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
         raise ValueError(f'ViewSynth built for {synth.shape}, images are {tuple(imgs.shape[-2:])}')
     if imgs.shape[1] != 3 or crit.loss_name == 'l2':   # features / Euclidean error: un-fused operators
         return _image_recon_generic(crit, depths, imgs, supp_imgs, Ts, Ks, K_inv, noise, want_warp)
-    stacked = getattr(depths, 'stacked', None)
-    if stacked is None: stacked = torch.stack(list(depths.values()))
     flags = F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask)
-    loss, err, sel, warp0 = F.image_recon_fused(stacked, imgs, supp_imgs, Ts, Ks, K_inv, flags=flags, noise=noise, seed=crit.next_seed(),
-                                                want_warp=want_warp)
+    if isinstance(depths, LazyDepths) and depths.pending:   # K0 fused: no up-sampling launch, the kernel writes the depth stack
+        loss, err, sel, warp0, depth_up = F.image_recon_fused_disp(depths.disps, imgs, supp_imgs, Ts, Ks, K_inv, flags=flags, min_depth=depths.min_depth,
+                                                                   max_depth=depths.max_depth, noise=noise, seed=crit.next_seed(), want_warp=want_warp)
+        depths.adopt(depth_up)
+    else:
+        stacked = getattr(depths, 'stacked', None)
+        if stacked is None: stacked = torch.stack(list(depths.values()))
+        loss, err, sel, warp0 = F.image_recon_fused(stacked, imgs, supp_imgs, Ts, Ks, K_inv, flags=flags, noise=noise, seed=crit.next_seed(),
+                                                    want_warp=want_warp)
     ld = {}
     if crit.use_automask: ld['automask'] = sel[0] != 255
     if want_warp: ld['supp_imgs_warp'] = warp0

@@ -25,10 +25,12 @@ class HipLossBackend:
     e.g. the CPU oracle, to exercise the host logic on machines without a GPU; the product never does.)"""
     def postprocess(self, disps: dict, size, min_depth, max_depth, want_disp_up=True):
         from . import functional as F
-        from .handlers import ScaleDict
+        from .handlers import LazyDepths, ScaleDict
         keys = list(disps.keys())
+        if not want_disp_up:   # K0 fused into the reconstruction kernel: nothing is launched here (handlers.LazyDepths)
+            return None, LazyDepths(keys, [disps[k].float() for k in keys], size, min_depth, max_depth)
         depth_up, disp_up = F.disp_to_depth([disps[k].float() for k in keys], size, min_depth, max_depth, want_disp_up=want_disp_up)
-        return (ScaleDict.from_stack(keys, disp_up) if want_disp_up else None), ScaleDict.from_stack(keys, depth_up)
+        return ScaleDict.from_stack(keys, disp_up), ScaleDict.from_stack(keys, depth_up)
 
     def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True, K_inv=None):
         from . import handlers

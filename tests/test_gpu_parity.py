@@ -787,6 +787,69 @@ def test_k0_and_smoothness_at_non_integer_ratios(F, b, h, w, lows, use_edges):
     torch.testing.assert_close(l_g.detach().cpu(), l_c.detach(), rtol=2e-5, atol=1e-7)
 
 
+# ---------------------------------------------------------------------------------------------------
+# K0 fused into the reconstruction kernel: disparity pyramid in, loss + depth stack out
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', TRAIN_CASES)
+def test_k0_fused_path_matches_reference_fixtures(F, golden, name):
+    """`image_recon_fused_disp` on the reference's recorded cases: the depth stack it writes against `out_depth_up_*`, the loss
+    against `out_loss_img_recon`, and the gradients w.r.t. every disparity scale against the reference's own autograd."""
+    g = golden(name)
+    leaves, static = case_inputs(g, device='cuda')
+    scales = static['scales']
+    Ts = g['out_Ts'].cuda().requires_grad_(True)
+    K = (g['out_K'] if g['meta_learn_K'] else g['in_K']).cuda()
+    flags = F.recon_flags(g['meta_loss_name'], bool(g['meta_use_min']), bool(g['meta_use_automask']))
+    l_rec, err, sel, warp0, depth_up = F.image_recon_fused_disp([leaves[f'disp_{s}'] for s in scales], static['imgs'], static['supp_imgs'], Ts, K, flags=flags,
+                                                                min_depth=g['meta_min_depth'] or None, max_depth=g['meta_max_depth'] or None,
+                                                                noise=static['noise'], want_warp=True)
+    for k, s in enumerate(scales):
+        torch.testing.assert_close(depth_up[k].cpu(), g[f'out_depth_up_{s}'], rtol=2e-5, atol=1e-5)
+    torch.testing.assert_close(l_rec.detach().cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(warp0.cpu(), g['out_supp_imgs_warp'], rtol=0, atol=1e-4)
+    loss = l_rec
+    if g['meta_w_smooth'] >= 0:
+        l_sm, _, _ = F.disp_smooth_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'], use_edges=bool(g['meta_use_edges']), want_aux=False)
+        loss = loss + g['meta_w_smooth']*l_sm
+    loss.backward()
+    tol = 1e-2 if g['meta_loss_name'] == 'l1' else 1e-3
+    for s in scales:
+        e = rel_to_max(leaves[f'disp_{s}'].grad.cpu(), g[f'grad_disp_{s}'])
+        assert e < tol, f'{name}: d loss / d disp_{s} off by {e:.3e} (rel. to max) vs the reference autograd'
+
+
+@pytest.mark.parametrize('b,h,w,lows', [(2, 33, 47, [(33, 47), (16, 23), (8, 11)]), (1, 24, 36, [(24, 36), (12, 18), (6, 9), (3, 4)]),
+                                        (1, 96, 128, [(48, 64), (12, 16)]), (2, 21, 30, [(7, 10), (5, 30)])])
+def test_k0_fused_path_at_non_integer_ratios_and_with_a_second_consumer_of_depth(F, b, h, w, lows):
+    """Pyramids that are not exact halvings / have no full-resolution scale, and a second consumer of `depth_up` (as `depth_regr`
+    is in the trainer): fused path == K0 kernel followed by the plain fused path, values and gradients."""
+    gen = torch.Generator(device='cuda').manual_seed(h*w)
+    imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen); supp = torch.rand(2, b, 3, h, w, device='cuda', generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    T0 = torch.eye(4, device='cuda').repeat(2, b, 1, 1); T0[..., :3, 3] = 0.05*torch.randn(2, b, 3, device='cuda', generator=gen)
+    d0 = [0.05 + 0.9*torch.rand(b, 1, hs, ws, device='cuda', generator=gen) for hs, ws in lows]
+    gup = torch.randn(len(lows), b, 1, h, w, device='cuda', generator=gen)
+    noise = torch.randn(len(lows)*b, 1, h, w, device='cuda', generator=gen)
+    flags = F.recon_flags('ssim', True, True)
+
+    def run(fused):
+        d = [v.clone().requires_grad_(True) for v in d0]
+        T = T0.clone().requires_grad_(True)
+        if fused: loss, err, sel, _, dep = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=flags, min_depth=0.1, max_depth=100, noise=noise)
+        else:
+            dep, _ = F.disp_to_depth(d, (h, w), 0.1, 100)
+            loss, err, sel, _ = F.image_recon_fused(dep, imgs, supp, T, K, flags=flags, noise=noise)
+        (loss + 1e-3*(dep*gup).sum()).backward()
+        return loss.detach(), err, sel, dep.detach(), [v.grad for v in d], T.grad
+    la, ea, sa, da, ga, ta = run(True)
+    lb, eb, sb, db, gb, tb = run(False)
+    torch.testing.assert_close(da, db, rtol=1e-6, atol=1e-7)       # v_rcp in the fused kernel vs the K0 kernel's division
+    flips = (sa != sb).float().mean().item()
+    assert flips <= 1e-3 and ((ea - eb).abs() > 1e-4).float().mean().item() <= 1e-3
+    torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-7)
+    for x, y in zip(ga + [ta], gb + [tb]): assert rel_to_max(x, y) < (1e-3 if flips == 0 else 5e-2)
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 1, 1), (2, 5, 6, 20), (1, 4, 33, 65), (3, 8, 48, 160), (2, 6, 40, 70)])
 def test_depthwise_conv7x7_kernel(F, shape):
     import torch.nn.functional as TF
