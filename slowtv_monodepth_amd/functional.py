@@ -10,19 +10,35 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import FLAGS, REGR_FLAGS, call, int_array, ptr_array
+from ._lib import FLAGS, REGR_FLAGS, int_array, ptr_array
+from ._lib import call as _raw_call
 
 __all__ = ['disp_to_depth', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
            'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'layer_norm_cf', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
+_active_device = None   # device of the tensors validated most recently (set by _check); launches go to ITS current stream
+
+
+def call(name: str, *args):
+    """Launch with the operands' device current (the library launches on the calling thread's current HIP device)."""
+    if _active_device is not None and _active_device.index is not None and _active_device.index != torch.cuda.current_device():
+        with torch.cuda.device(_active_device): return _raw_call(name, *args)
+    return _raw_call(name, *args)
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The HIP stream of the operands' device.  (Not simply `torch.cuda.current_stream()`: with tensors on a GPU that is not the
+    process's current device that would be a stream of another device.)"""
+    dev = _active_device if _active_device is not None else torch.cuda.current_device()
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _check(name: str, t: torch.Tensor, shape=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor): raise TypeError(f'{name} must be a Tensor, got {type(t)}')
     if not t.is_cuda: raise RuntimeError(f'{name} must live on the GPU: the view-synthesis hot path has no CPU implementation')
+    global _active_device
+    _active_device = t.device
     if t.dtype != torch.float32: raise TypeError(f'{name} must be float32 (the loss path is fp32 only), got {t.dtype}')
     if shape is not None and tuple(t.shape) != tuple(shape): raise ValueError(f'{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
     return t.contiguous()
@@ -349,6 +365,9 @@ class _Regression(torch.autograd.Function):
         pred = _check('pred', pred); target = _check('target', target, pred.shape)
         if mask is not None:
             if tuple(mask.shape) != tuple(pred.shape): raise ValueError(f'mask: expected shape {tuple(pred.shape)}, got {tuple(mask.shape)}')
+            # The reference multiplies by the mask (`mask*err`, `err.sum()/mask.sum()`, src/losses/regression.py:72-74), so a float mask
+            # there is a per-pixel WEIGHT; the kernel implements the 0/1 case every caller on this path uses (automask, validity).
+            if mask.dtype.is_floating_point: raise TypeError('RegressionLoss: pass a bool (or uint8 0/1) mask; weighting masks are not part of the accelerated path')
             mask = (mask if mask.dtype == torch.bool else mask != 0).contiguous().view(torch.uint8)
         N, dev = pred.numel(), pred.device
         loss = torch.empty((), device=dev, dtype=torch.float32); err = torch.empty_like(pred)

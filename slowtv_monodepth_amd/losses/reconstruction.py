@@ -35,7 +35,11 @@ class ReconstructionLoss(nn.Module):
         return self.noise_seed
 
     def compute_photo(self, pred: torch.Tensor, target: torch.Tensor, mask=None) -> torch.Tensor:
-        """(*n,b,c,h,w) predictions vs (b,c,h,w) target -> reduced error (b,1,h,w) (reconstruction.py:79-96)."""
+        """(*n,b,c,h,w) predictions vs (b,c,h,w) target -> reduced error (b,1,h,w) (reconstruction.py:79-96).
+
+        The per-support errors are differentiable (`functional.photo_error`), the reduced map returned here is not (the
+        reduction kernel's selection is applied without a graph): it serves the comparisons of `handlers.depth_regr`
+        (src/core/handlers.py:236-254), which the reference also evaluates for its value only."""
         from .. import functional as F
         if mask is not None: raise NotImplementedError('weighting masks are outside the accelerated path')
         if pred.ndim == 4: pred = pred[None]

@@ -29,10 +29,18 @@ def install() -> str | None:
     tag = hashlib.sha1(b''.join(f.read_bytes() for f in files)).hexdigest()[:10]   # a new shipped db never meets a stale copy
     dst = Path(tempfile.gettempdir())/f'smd_miopen_db_{os.getuid()}_{tag}'
     try:
-        dst.mkdir(parents=True, exist_ok=True)
+        dst.mkdir(mode=0o700, parents=True, exist_ok=True)
+        st = dst.stat()
+        # the directory name is predictable: refuse one that another user owns or can write to (it could be pre-seeded)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022): return None
         for f in files:
             out = dst/f.name
-            if out.exists(): continue
+            # MIOpen appends its own measurements to the user db, so an existing copy is kept only if it still STARTS with the
+            # shipped content; anything else is replaced
+            if out.exists():
+                shipped = f.read_bytes()
+                with open(out, 'rb') as fh:
+                    if fh.read(len(shipped)) == shipped: continue
             tmp = dst/f'.{f.name}.{os.getpid()}'
             shutil.copyfile(f, tmp)
             os.replace(tmp, out)          # atomic: ranks of one node may race here

@@ -201,6 +201,14 @@ ENCODERS = {
 
 
 def create_encoder(name: str, in_chans: int = 3, pretrained: bool = False) -> nn.Module:
-    """Stand-in for `timm.create_model(name, features_only=True, in_chans=...)`; `pretrained` cannot be honoured offline."""
+    """Stand-in for `timm.create_model(name, features_only=True, in_chans=...)`.
+
+    `pretrained=True` (the reference's default for the depth network) cannot be honoured here — timm and its weight hub are not
+    available — and silently training from scratch would be a different experiment, so it warns.  ImageNet / reference weights
+    can be loaded afterwards from a timm or reference `state_dict` with `networks.checkpoint.load_reference_state_dict`."""
     if name not in ENCODERS: raise KeyError(f'Unknown encoder "{name}". Available: {sorted(ENCODERS)}')
+    if pretrained:
+        import warnings
+        warnings.warn(f'create_encoder({name!r}, pretrained=True): no pretrained weights are available offline, the encoder is randomly initialised; '
+                      'load a timm / reference state_dict with slowtv_monodepth_amd.networks.checkpoint.load_reference_state_dict', UserWarning, stacklevel=2)
     return ENCODERS[name](in_chans)

@@ -4,8 +4,10 @@ Mirrors the flags and cfg handling of the reference's `api/train/train.py:16-33`
 GPUs) with an own loop instead of PyTorch-Lightning: one process per GPU (`torchrun`/`torch.distributed.run` sets
 RANK/LOCAL_RANK/WORLD_SIZE), gradients averaged over RCCL by a few flat-bucket all-reduces (`FlatAllReduce`; stock DDP with
 overlap is selectable), no collective on gradient-accumulation micro-steps (`trainer.accumulate_grad_batches`, train.py:110), AdamW +
-StepLR∘LinearLR.  Data are device-resident synthetic triplets (`synthetic.make_batch`); the dataset section of a
-reference cfg is ignored.
+StepLR∘LinearLR.  Data are device-resident synthetic triplets (`synthetic.make_batch`): datasets are out of scope here
+(SURVEY.md §2), so only `supp_idxs` is read from a cfg's `dataset` section and a cfg that names a real dataset `type` is
+refused unless `--synthetic-data` says that synthetic triplets of its shape are intended.  `last.ckpt` is written in the
+reference's Lightning layout (`state_dict` with the reference's parameter names; `networks/checkpoint.py`).
 """
 from __future__ import annotations
 
@@ -186,6 +188,7 @@ def main(argv=None):
     p = argparse.ArgumentParser(description='Monocular depth trainer (MI355X hot path).')
     p.add_argument('--cfg-files', '-c', type=Path, nargs='*', required=True, help='YAML configs (default, override...).')
     p.add_argument('--ckpt-dir', '-o', default=Path('runs'), type=Path)
+    p.add_argument('--synthetic-data', action='store_true', help='run a cfg that names a real dataset on synthetic triplets of its shape')
     p.add_argument('--name', '-n', required=True, type=str)
     p.add_argument('--version', '-v', default=0, type=int)
     p.add_argument('--seed', '-s', default=42, type=int)
@@ -206,6 +209,10 @@ def main(argv=None):
     if module.auto_scale_lr:
         for g in opt.param_groups: g['lr'] *= world*acc
     b = cfg.get('loader', {}).get('batch_size', 12)
+    named = sorted({d.get('type') for d in (cfg.get('dataset') or {}).values() if isinstance(d, dict) and d.get('type')})
+    if named and not args.synthetic_data:
+        raise SystemExit(f'the cfg names dataset type(s) {named}: this package trains on synthetic triplets only (datasets are out of scope); '
+                         'pass --synthetic-data to run the cfg on synthetic triplets of its shape, or drop the dataset `type`')
     supp_idxs = next((d.get('supp_idxs') for d in (cfg.get('dataset') or {}).values() if isinstance(d, dict) and d.get('supp_idxs')), [-1, 1])
     batch = make_batch(b, args.shape[0], args.shape[1], supp_idxs, seed=args.seed + rank, device=device)
     model = wrap_ddp(StepModule(module), device)
@@ -220,7 +227,8 @@ def main(argv=None):
         if rank == 0:
             dt = time.time() - t0
             print(f'epoch {epoch}: loss {last:.6f}  {args.steps*b*world/dt:.1f} img/s', flush=True)
-            torch.save({'epoch': epoch, 'nets': module.nets.state_dict(), 'opt': opt.state_dict()}, save_dir/'last.ckpt')
+            from .networks.checkpoint import reference_checkpoint
+            torch.save(reference_checkpoint(module, epoch=epoch, global_step=(epoch + 1)*args.steps, optimizer=opt), save_dir/'last.ckpt')
     if world > 1: dist.destroy_process_group()
 
 

@@ -166,7 +166,8 @@ class MonoDepthModule(nn.Module):
         disp_up, fwd['depth_up'] = self.backend.postprocess(fwd['disp'], tuple(x['imgs'].shape[-2:]), self.min_depth, self.max_depth,
                                                             want_disp_up=self.want_aux)
         if disp_up is not None: fwd['disp_up'] = disp_up   # only the image logger reads the un-scaled up-sampled disparity
-        fwd['Ts'] = torch.stack([fwd[f'T_{int(i)}'] for i in x['supp_idxs']])
+        # a stereo support (index 0) brings its known pose with the batch instead of a predicted one (src/core/trainer.py:347)
+        fwd['Ts'] = torch.stack([(y['T_stereo'] if int(i) == 0 else fwd[f'T_{int(i)}']) for i in x['supp_idxs']])
         return fwd
 
     def forward_loss(self, fwd: dict, x: dict, y: dict):
@@ -184,6 +185,21 @@ class MonoDepthModule(nn.Module):
                     from . import handlers
                     l, ld = handlers.depth_regr(crit, self.synth, self.losses['img_recon'].compute_photo, fwd['depth_up'], y['depth_hints'],
                                                 y['imgs'], y['supp_imgs'], fwd['Ts'], fwd.get('K', y['K']))
+                elif k == 'feat_recon':      # feature-metric reconstruction on an autoencoder's features, src/core/trainer.py:405-411
+                    if 'autoenc_feats' not in fwd: raise KeyError('Missing autoencoder features "autoenc_feats" (no `autoencoder` network is configured).')
+                    from . import handlers
+                    l, ld = handlers.feat_recon(crit, self.synth, fwd['depth_up'], fwd.get('mask_up'), fwd['autoenc_feats'], fwd['supp_autoenc_feats'],
+                                                fwd['Ts'], fwd.get('K', y['K']))
+                elif k == 'autoenc_recon':   # src/core/trainer.py:413-418
+                    if 'autoenc_imgs_up' not in fwd: raise KeyError('Missing autoencoder reconstructions "autoenc_imgs_up" (no `autoencoder` network is configured).')
+                    from . import handlers
+                    l, ld = handlers.autoenc_recon(crit, fwd['autoenc_imgs_up'], y['imgs'], fwd['supp_autoenc_imgs_up'], y['supp_imgs'])
+                elif k == 'stereo_const':    # virtual-stereo consistency, src/core/trainer.py:420-428
+                    if 'disp_stereo' not in fwd: raise KeyError('Missing virtual stereo prediction "disp_stereo".')
+                    if 'T_stereo' not in y: raise KeyError('Missing stereo pair "T_stereo".')
+                    from . import handlers
+                    l, ld = handlers.stereo_const(crit, self.synth, fwd['disp_up'], fwd['depth_up'], fwd['disp_stereo_up'], fwd['depth_stereo_up'],
+                                                  y['T_stereo'], fwd.get('K', y['K']))
                 else:
                     raise ValueError(f'Missing loss key: "{k}"')
             loss = loss + self.weights[k]*l

@@ -916,7 +916,10 @@ def test_training_cli_runs_and_the_loss_decreases(tmp_path, capsys):
     out = capsys.readouterr().out
     losses = [float(l.split('loss ')[1].split()[0]) for l in out.splitlines() if l.startswith('epoch')]
     assert len(losses) == 2 and all(l == l for l in losses) and losses[1] < losses[0]
-    assert (tmp_path/'cli'/'000'/'last.ckpt').is_file()
+    ckpt = torch.load(tmp_path/'cli'/'000'/'last.ckpt', map_location='cpu', weights_only=False)
+    # the reference's Lightning layout and parameter names (networks/checkpoint.py)
+    assert 'nets.depth.encoder.layer1.0.conv1.weight' in ckpt['state_dict'] and 'nets.depth.decoders.disp.decoder.0.conv.weight' in ckpt['state_dict']
+    assert ckpt['epoch'] == 1 and 'optimizer_states' in ckpt
 
 
 def test_channel_layer_norm_bf16_io(F):

@@ -236,3 +236,36 @@ def test_miopen_db_is_installed_to_a_private_versioned_copy(tmp_path, monkeypatc
     monkeypatch.setenv('MIOPEN_USER_DB_PATH', '/somewhere/else')
     assert miopen_tuning.install() is None and os.environ['MIOPEN_USER_DB_PATH'] == '/somewhere/else'   # the user's choice wins
     importlib.reload(miopen_tuning)
+
+
+def test_checkpoint_key_bridge_round_trips_and_names_match_timm():
+    """networks/checkpoint.py: our names -> reference/timm names -> our names is the identity for every supported trunk, the
+    timm-side names are the published ones, and a reference-layout checkpoint of the whole trainer loads back bit-exactly."""
+    import torch
+    from slowtv_monodepth_amd.networks import DepthNet, PoseNet, checkpoint as ck
+    for enc in ('resnet18', 'resnet50', 'convnext_tiny'):
+        net = DepthNet(enc_name=enc, pretrained=False)
+        ref = ck.to_reference_state_dict(net)
+        assert {ck.from_reference_key(k, net.out_scales) for k in ref} == set(net.state_dict())
+    r18 = ck.to_reference_state_dict(DepthNet(enc_name='resnet18', pretrained=False))
+    for k in ('encoder.conv1.weight', 'encoder.bn1.running_var', 'encoder.layer1.0.conv1.weight', 'encoder.layer2.0.downsample.0.weight',
+              'encoder.layer4.1.bn2.bias', 'decoders.disp.decoder.0.conv.weight', 'decoders.disp.decoder.9.conv.bias', 'decoders.disp.decoder.13.weight'):
+        assert k in r18, k
+    cnx = ck.to_reference_state_dict(DepthNet(enc_name='convnext_tiny', pretrained=False))
+    for k in ('encoder.stem_0.weight', 'encoder.stem_1.bias', 'encoder.stages_0.blocks.2.conv_dw.weight', 'encoder.stages_1.downsample.1.weight',
+              'encoder.stages_3.blocks.0.mlp.fc2.bias', 'encoder.stages_2.blocks.8.gamma'):
+        assert k in cnx, k
+    trainer = torch.nn.Module()
+    trainer.nets = torch.nn.ModuleDict({'depth': DepthNet(enc_name='resnet18', pretrained=False), 'pose': PoseNet(enc_name='resnet18', learn_K=True)})
+    ckpt = ck.reference_checkpoint(trainer, epoch=3, global_step=99)
+    assert all(k.startswith('nets.') for k in ckpt['state_dict']) and 'nets.depth.encoder.layer1.0.conv1.weight' in ckpt['state_dict']
+    other = torch.nn.Module()
+    other.nets = torch.nn.ModuleDict({'depth': DepthNet(enc_name='resnet18', pretrained=False), 'pose': PoseNet(enc_name='resnet18', learn_K=True)})
+    ck.load_reference_checkpoint(other, ckpt)
+    for (ka, va), (kb, vb) in zip(trainer.state_dict().items(), other.state_dict().items()): assert ka == kb and torch.equal(va, vb)
+
+
+def test_pretrained_request_is_refused_loudly():
+    import pytest, warnings
+    from slowtv_monodepth_amd.networks.encoders import create_encoder
+    with pytest.warns(UserWarning, match='pretrained'): create_encoder('resnet18', pretrained=True)
