@@ -43,12 +43,14 @@ __device__ __forceinline__ void hsum_w3(float a, float b, float c, float wl, flo
 // automask regions (any partly trained network) make 2 the fastest; on noise-like masks the branches cost a few percent.
 template <bool SSIM, int SKIP>
 __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdArgs a) {
+  __shared__ float hist_lds[kWavesPerBlock*3*6*64];   // per wave: 3 row slots x {gx, gy} x 3 channels x 64 lanes
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nstrips = a.nsx*a.nsy;
   int strip, bi, s;
   decode_wave(blockIdx.x, wid, nstrips, a.b, a.S, strip, bi, s);
   if (strip >= nstrips) return;
+  float* const hist = hist_lds + wid*(3*6*64) + lane;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
   const int h = a.h, w = a.w;
   const int r0 = syi*a.rh, r1 = min(r0 + a.rh, h);
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
     // state: rows j-1 (o) and j-2 (q) of the raw values, the sliding sums, the bilinear partials of rows j, j-1, j-2
     float xo[3] = {}, xq[3] = {}, yo[3] = {}, yq[3] = {};
     float Px[3] = {}, Pxx[3] = {}, Pxy[3] = {};
-    float gx0[3] = {}, gx1[3] = {}, gx2[3] = {}, gy0[3] = {}, gy1[3] = {}, gy2[3] = {};   // dx/dpx, dx/dpy (clamp mask, grid scale folded in)
+    float gx0[3] = {}, gy0[3] = {};                   // dx/dpx, dx/dpy of the current row (clamp mask, grid scale folded in)
     float ac1[3][3] = {}, ac0[3][3] = {};             // vertical accumulators of the h-summed coefficient maps {A, B, C}
     float ps[9] = {};                                 // per-lane sums of {dnx, dnx*v, dny, dny*v, dz, dz*v, gnx, gny, gz}
     float D0 = 0.f, D1 = 0.f, D2 = 0.f;               // depth of rows j, j-1, j-2
@@ -125,14 +127,13 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
       py = bld3(rs_pk, lane4*3u, so_y + (unsigned)jr*w4*3u);
     };
 
+    int slot = 0;
     float Da = bld(rs_depth, lane4, (unsigned)jstart*w4);       // depth of the row whose loads are in flight
     issue(jstart, Da);
     float Db = bld(rs_depth, lane4, (unsigned)(jstart + 1)*w4); // ... and of the row after it (a row below the image reads 0)
 
     for (int j = jstart; j <= r1 + 1; ++j) {
       // ---- roll the two-row history (row j-1 -> j-2) before row j overwrites the "current" slots
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { gx2[c] = gx1[c]; gx1[c] = gx0[c]; gy2[c] = gy1[c]; gy1[c] = gy0[c]; }
       D2 = D1; D1 = D0; selq = selp;
       const int p = j - 1, q = j - 2;
       const bool doB = SSIM && p >= pb0 && p <= pb1;
@@ -155,6 +156,10 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
         gy0[c] = ddy*pky;
         yn[c] = py[c];
       }
+      // The partials are needed two row steps later (stage C).  Twelve registers of history per lane would cost the kernel a wave
+      // of occupancy, so they wait in LDS: each lane writes and later reads only its own column slot (no synchronisation).
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { hist[(slot*6 + c)*64] = gx0[c]; hist[(slot*6 + 3 + c)*64] = gy0[c]; }
       D0 = Da;
       // Next row's loads, unconditionally (also after the last row, where nothing consumes them): the tap coordinates are
       // clamped, a depth row below the image reads 0 (buffer bounds), and a conditional issue would turn every register of
@@ -227,16 +232,18 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
         float gD = 0.f;
         if (!dead) {
           float gpx = 0.f, gpy = 0.f;
+          const int rslot = (slot + 1) % 3;               // the slot written two steps ago
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
+            const float gx2c = hist[(rslot*6 + c)*64], gy2c = hist[(rslot*6 + 3 + c)*64];
             const float d = xq[c] - yq[c];
             float gxc = gl*((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
             if (SSIM) {
               const float SA = fmaf(hi_q, hc[c][0], ac1[c][0]), SB = fmaf(hi_q, hc[c][1], ac1[c][1]), SC = fmaf(hi_q, hc[c][2], ac1[c][2]);
               gxc += fmaf(2.f*xq[c], SB, fmaf(yq[c], SC, SA));   // d/dx_q of the x9 sums: 1, 2 x_q, y_q
             }
-            gpx = fmaf(gxc, gx2[c], gpx);
-            gpy = fmaf(gxc, gy2[c], gpy);
+            gpx = fmaf(gxc, gx2c, gpx);
+            gpy = fmaf(gxc, gy2c, gpy);
           }
           // projective chain rule at (q, u): the cheap geometry is recomputed from the depth kept in the ring
           const float vf = (float)q;
@@ -275,6 +282,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_bwd(const ReconBwdA
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) { xq[c] = xo[c]; xo[c] = xn[c]; yq[c] = yo[c]; yo[c] = yn[c]; }
+      slot = (slot == 2) ? 0 : slot + 1;
     }
 
     // per-wave pose partials: d/d(H[0..8], a0, a1, tz); the column factor of H[.,0] is constant per lane
