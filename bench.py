@@ -129,7 +129,7 @@ def measured_hbm_ceilings(lib, device, nbytes=1 << 30, reps=10):
     src = torch.empty(nbytes, device=device, dtype=torch.uint8).fill_(1); dst = torch.empty_like(src)
     st = torch.cuda.current_stream().cuda_stream
     out = [0.0, 0.0]
-    for mode, factor in ((0, 2), (1, 1), (2, 2), (3, 1)):   # modes 2, 3: the deeper-unrolled variant; quote the better one
+    for mode, factor in ((0, 2), (1, 1), (2, 2), (3, 1), (4, 2), (5, 1)):   # 2, 3: deeper unroll; 4, 5: block-contiguous chunks; quote the best
         for _ in range(2): lib.smd_debug_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, mode, st)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -235,10 +235,10 @@ def main():
                        'global_batch': wl['b']*world, 'per_gpu_batch': wl['b'], 'parallelism': f'dp{world}',
                        'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6),
                        'rccl_ranks': rccl_ranks},
-            'roofline': {'kernel': f'smd::k_recon_main<{n}, true, true, false> (fused warp+SSIM+L1+min-reproj+automask forward; name as rocprofv3 prints it)', 'bound': 'hbm',
+            'roofline': {'kernel': f'smd::k_recon_main<{n}, true, true, false, true> (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; name as rocprofv3 prints it)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,
-                         'whole_forward_ms': round(fa_ms, 5), 'whole_forward_launches': 'k_recon_prep + k_recon_main + k_sum_partials',
+                         'whole_forward_ms': round(fa_ms, 5), 'whole_forward_launches': 'k_recon_prep + k_recon_main + k_sum_partials (per step; all 4 scales in each launch)',
                          'whole_forward_frac': round(B_fwd/(fa_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
                          'algorithmic_bytes': B_fwd, 'avg_kernel_ms': round(f_ms, 5), 'launches_timed': len(fwd_ms),
                          'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},

@@ -280,7 +280,8 @@ int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out);
 
 /* Measurement aid: STREAM-style sweep over nbytes (multiple of 16): mode 0 copies src -> dst (read + write), mode 1 only
  * reads src; add 2 (modes 2, 3) for the variant with eight instead of four 16-byte loads in flight per lane and plain instead of
- * non-temporal accesses.  bench.py times all of them and quotes the best as the measured HBM ceiling of the box beside the
+ * non-temporal accesses, add 4 (modes 4, 5) for the variant in which every block walks one contiguous chunk 32 KB at a time
+ * (non-temporal).  bench.py times all of them and quotes the best as the measured HBM ceiling of the box beside the
  * datasheet peak. */
 int smd_debug_stream_copy(const void* src, void* dst, size_t nbytes, int mode, void* stream);
 

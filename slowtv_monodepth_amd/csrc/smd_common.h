@@ -123,6 +123,37 @@ __device__ __forceinline__ void make_cam(Cam& c, const float* __restrict__ T, co
   c.a0 = uniform(c.a0); c.a1 = uniform(c.a1); c.tz = uniform(c.tz);
 }
 
+// The same constants with the pixel -> sampling-grid scale (w/(w-1), h/(h-1): the reference normalises by (w-1) and grid_sample
+// un-normalises with align_corners=False) folded into rows 0/1, so that a source coordinate is fma(nx, 1/z, -0.5).  Only the
+// row-dependent part stays wave-uniform (SGPRs); the column part is folded into three per-lane constants.  Both fused kernels
+// build their coordinates from this one function: the backward re-derives exactly the taps the forward blended.
+struct Cam2 {
+  float H1, H4, H7;        // d(hx, hy, hz)/dv
+  float a0, a1, tz;
+};
+__device__ __forceinline__ void make_cam2(Cam2& c, float& hx0, float& hy0, float& hz0, const float* __restrict__ T,
+                                          const float* __restrict__ K, const float* __restrict__ Ki, float wscale, float hscale, float uf) {
+  float M[9];  // R * Kinv3
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) M[r*3 + q] = T[r*4 + 0]*Ki[0*4 + q] + T[r*4 + 1]*Ki[1*4 + q] + T[r*4 + 2]*Ki[2*4 + q];
+  float H[9];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    H[q] = (K[0]*M[q] + K[1]*M[3 + q] + K[2]*M[6 + q])*wscale;
+    H[3 + q] = (K[4]*M[q] + K[5]*M[3 + q] + K[6]*M[6 + q])*hscale;
+    H[6 + q] = M[6 + q];
+  }
+  c.H1 = uniform(H[1]); c.H4 = uniform(H[4]); c.H7 = uniform(H[7]);
+  c.a0 = uniform((K[0]*T[3] + K[1]*T[7] + K[2]*T[11])*wscale);
+  c.a1 = uniform((K[4]*T[3] + K[5]*T[7] + K[6]*T[11])*hscale);
+  c.tz = uniform(T[11]);
+  hx0 = fmaf(uniform(H[0]), uf, uniform(H[2]));
+  hy0 = fmaf(uniform(H[3]), uf, uniform(H[5]));
+  hz0 = fmaf(uniform(H[6]), uf, uniform(H[8]));
+}
+
 // Bilinear, border-clamped 4-tap gather setup (grid_sample(bilinear, border, align_corners=False)).
 struct Taps {
   int off;        // iy*stride + ix of the north-west tap (ix <= w-2, iy <= h-2 so the 2x2 block is in range)

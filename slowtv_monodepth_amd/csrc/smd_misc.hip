@@ -60,8 +60,28 @@ __global__ __launch_bounds__(256) void k_stream_copy8(const f4* __restrict__ src
   for (; i < n16; i += stride) { const f4 a = src[i]; if (mode == 0) dst[i] = a; else acc += a; }
   if (mode != 0 && (acc[0] + acc[1] + acc[2] + acc[3]) == 12345.678f) dst[blockIdx.x] = acc;   // keeps the loads alive; practically never taken
 }
+// Third variant: each block owns one contiguous chunk and walks it 8 x 4 KB at a time with non-temporal accesses (every
+// wave touches whole DRAM pages; measured best on MI355X: 5.9 TB/s at 1 GiB, scripts/dev/stream_probe.hip).
+__global__ __launch_bounds__(256) void k_stream_chunk8(const f4* __restrict__ src, f4* __restrict__ dst, size_t n16, int mode) {
+  const size_t per_block = (n16 + gridDim.x - 1)/gridDim.x;
+  const size_t lo = (size_t)blockIdx.x*per_block, hi = lo + per_block < n16 ? lo + per_block : n16;
+  size_t i = lo + threadIdx.x;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i + 7*256 < hi; i += 8*256) {
+    f4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(src + i + k*256);
+    if (mode == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], dst + i + k*256);
+    } else acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; i < hi; i += 256) { const f4 a = src[i]; if (mode == 0) dst[i] = a; else acc += a; }
+  if (mode != 0 && (acc[0] + acc[1] + acc[2] + acc[3]) == 12345.678f) dst[blockIdx.x] = acc;
+}
 hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, int mode, hipStream_t st) {
-  if (mode & 2) hipLaunchKernelGGL(k_stream_copy8, dim3(256*16), dim3(256), 0, st, (const f4*)src, (f4*)dst, nbytes/16, mode & 1);
+  if (mode & 4) hipLaunchKernelGGL(k_stream_chunk8, dim3(256*16), dim3(256), 0, st, (const f4*)src, (f4*)dst, nbytes/16, mode & 1);
+  else if (mode & 2) hipLaunchKernelGGL(k_stream_copy8, dim3(256*16), dim3(256), 0, st, (const f4*)src, (f4*)dst, nbytes/16, mode & 1);
   else hipLaunchKernelGGL(k_stream_copy, dim3(256*8), dim3(256), 0, st, (const f4*)src, (f4*)dst, nbytes/16, mode);
   return hipGetLastError();
 }

@@ -263,11 +263,6 @@ hipError_t launch_recon_prep(const ReconPrepArgs& a, hipStream_t st) {
 // no carried min / sum is read or written); AUX (the rarely used extras: caller-supplied tie-break noise, `supp_imgs_warp`
 // output — kept out of the hot instantiation because their wave-uniform addresses would sit in SGPRs for the whole loop).
 // ---------------------------------------------------------------------------------------------
-struct Cam2 {              // wave-uniform part of the folded homography (SGPRs); rows 0/1 carry the grid scale w/(w-1), h/(h-1)
-  float H1, H4, H7;        // d(hx, hy, hz)/dv
-  float a0, a1, tz;
-};
-
 template <int N>
 struct MainPend {          // gathers in flight for one pair of supports
   f3 t[(N > 1) ? 2 : 1][4];
@@ -534,28 +529,8 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int i = a.i0 + k;
-    const float* T = a.T + ((size_t)i*a.b + bi_)*16;
-    const float* K = a.K + (size_t)bi_*16;
-    const float* Ki = a.Kinv + (size_t)bi_*16;
-    float M[9];  // R * Kinv3
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) M[r*3 + q] = T[r*4 + 0]*Ki[0*4 + q] + T[r*4 + 1]*Ki[1*4 + q] + T[r*4 + 2]*Ki[2*4 + q];
-    float H[9];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      H[q] = (K[0]*M[q] + K[1]*M[3 + q] + K[2]*M[6 + q])*a.wscale;
-      H[3 + q] = (K[4]*M[q] + K[5]*M[3 + q] + K[6]*M[6 + q])*a.hscale;
-      H[6 + q] = M[6 + q];
-    }
-    cx.cam[k].H1 = uniform(H[1]); cx.cam[k].H4 = uniform(H[4]); cx.cam[k].H7 = uniform(H[7]);
-    cx.cam[k].a0 = uniform((K[0]*T[3] + K[1]*T[7] + K[2]*T[11])*a.wscale);
-    cx.cam[k].a1 = uniform((K[4]*T[3] + K[5]*T[7] + K[6]*T[11])*a.hscale);
-    cx.cam[k].tz = uniform(T[11]);
-    cx.hx0[k] = fmaf(uniform(H[0]), uf, uniform(H[2]));
-    cx.hy0[k] = fmaf(uniform(H[3]), uf, uniform(H[5]));
-    cx.hz0[k] = fmaf(uniform(H[6]), uf, uniform(H[8]));
+    make_cam2(cx.cam[k], cx.hx0[k], cx.hy0[k], cx.hz0[k], a.T + ((size_t)i*a.b + bi_)*16, a.K + (size_t)bi_*16, a.Kinv + (size_t)bi_*16,
+              a.wscale, a.hscale, uf);
     cx.so_tex[k] = (unsigned)(i*a.b + bi_)*texel_bytes;
   }
   const size_t sb = ((size_t)s_*a.b + bi_)*hw;

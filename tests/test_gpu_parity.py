@@ -172,8 +172,8 @@ def test_baseline_size_matches_oracle(F, name):
     g = torch.Generator().manual_seed(99)
     fs, cs = 0.3*torch.randn(b, 2, generator=g), 0.2*torch.randn(b, 2, generator=g)
 
-    def run(dev, hip, force_sel=None):
-        leaf = lambda v: v.detach().clone().to(dev).requires_grad_(True)
+    def run(dev, hip, force_sel=None, dt=torch.float32):
+        leaf = lambda v: v.detach().clone().to(dev, dt).requires_grad_(True)
         d = {s: leaf(v) for s, v in disps.items()}
         a_, t_, fs_, cs_ = leaf(aa), leaf(t), leaf(fs), leaf(cs)
         imgs, sup = y['imgs'].to(dev), y['supp_imgs'].to(dev)
@@ -187,13 +187,13 @@ def test_baseline_size_matches_oracle(F, name):
             loss = l_rec + 0.001*l_sm
         else:
             Ts = O.T_from_AAt(a_.flatten(0, 1), t_.flatten(0, 1)).unflatten(0, (n, b))
-            K = O.resize_K(O.build_K(fs_, cs_), (h, w)) if learn_k else y['K']
-            loss, out = O.loss_path(d, imgs, sup, Ts, K, noise=noise, aten=True, force_sel=force_sel)
+            K = O.resize_K(O.build_K(fs_, cs_), (h, w)) if learn_k else y['K'].to(dt)
+            loss, out = O.loss_path(d, imgs.to(dt), sup.to(dt), Ts, K, noise=noise.to(dt), aten=True, force_sel=force_sel)
             err, sel, gap = out['full']['err'], out['full']['sel'], out['full'].get('tie_gap')
         loss.backward()
-        grads = {f'disp_{s}': v.grad.cpu() for s, v in d.items()}
-        grads['aa'], grads['t'] = a_.grad.cpu(), t_.grad.cpu()
-        if learn_k: grads['fs'], grads['cs'] = fs_.grad.cpu(), cs_.grad.cpu()
+        grads = {f'disp_{s}': v.grad.cpu().float() for s, v in d.items()}
+        grads['aa'], grads['t'] = a_.grad.cpu().float(), t_.grad.cpu().float()
+        if learn_k: grads['fs'], grads['cs'] = fs_.grad.cpu().float(), cs_.grad.cpu().float()
         return loss.item(), err.detach().cpu().reshape(S, b, h, w), sel.cpu().reshape(S, b, h, w), grads, gap
 
     l_hip, e_hip, s_hip, g_hip, _ = run('cuda', True)
@@ -207,10 +207,14 @@ def test_baseline_size_matches_oracle(F, name):
     bad = ((e_hip - e_ref).abs() > 2e-4).float().mean().item()
     _, _, _, g_ref, gap = run('cpu', False, force_sel=s_hip.reshape(S*b, 1, h, w)) if flips.any() else (None, None, None, g_free, None)
     tie = gap.abs().max().item() if gap is not None else 0.0
+    # fp64 run of the oracle under the same routing: the yardstick for the gradients that are sums over every pixel
+    _, _, _, g_64, _ = run('cpu', False, force_sel=s_hip.reshape(S*b, 1, h, w), dt=torch.float64)
     # The loss has more discontinuities than the arg-min (clamp(0,1) of the SSIM term, sign() of the L1 term, border clamps): a
     # pixel sitting on one of them gets a different one-sided derivative from rounding alone.  Dense gradients are therefore
-    # judged by their bulk (99.9 % quantile of the difference) plus a count of outliers tied to the number of decision flips;
-    # the pose / intrinsics gradients (sums over all pixels) by their relative error.
+    # judged by their bulk (99.9 % quantile of the difference) plus a count of outliers tied to the number of decision flips.
+    # The pose / intrinsics gradients are sums over all pixels in which one such pixel weighs ~1e-3 when there are only two
+    # samples: they are judged by their relative error against the fp32 oracle (5e-3), or — where the fp32 oracle itself is
+    # that far from its own fp64 run — by being no further from the fp64 result than three times the fp32 oracle is.
     n_flips = int(flips.sum())
     report, ok = [], True
     for k in g_ref:
@@ -224,8 +228,10 @@ def test_baseline_size_matches_oracle(F, name):
             ok &= q < 2e-4 and outl <= allow
         else:
             e = (diff.max()/mx).item()
-            report.append(f'{k}={e:.1e}')
-            ok &= e < 5e-3                               # two samples only (cfg 4/5 cases): one outlier pixel weighs 1e-3
+            mx64 = g_64[k].abs().max()
+            e_hip64, e_ref64 = ((g_hip[k] - g_64[k]).abs().max()/mx64).item(), ((g_ref[k] - g_64[k]).abs().max()/mx64).item()
+            report.append(f'{k}={e:.1e} (vs fp64: hip {e_hip64:.1e}, fp32 oracle {e_ref64:.1e})')
+            ok &= e < 5e-3 or e_hip64 <= 3.0*e_ref64
     free = {k: rel_to_max(g_hip[k], g_free[k]) for k in g_free}
     parity_note(f'{name}: loss hip={l_hip:.8f} oracle={l_ref:.8f} (rel {abs(l_hip - l_ref)/abs(l_ref):.2e}); sel flips {n_flips} of {flips.numel()} '
           f'({flips.float().mean().item():.2e}, largest gap between the tied errors {tie:.1e}); |err diff| > 2e-4 on {bad:.2e} of pixels '
