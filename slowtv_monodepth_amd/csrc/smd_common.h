@@ -213,6 +213,10 @@ __device__ __forceinline__ unsigned bld8(rsrc_t r, unsigned voff, unsigned soff)
 __device__ __forceinline__ f4 bld4(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 bld2(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
 // 12-byte load of an RGB texel.  (Never a 16-byte load with an ignored fourth lane: the register allocator treats the
 // never-read .w register of an in-flight load as free, reuses it for address arithmetic and must then wait (s_waitcnt) for
 // that load to land first — which serialises a whole gather batch behind its first load.)

@@ -23,23 +23,30 @@
 
 namespace smd {
 
-// Three independent reflection-weighted horizontal 3-tap sums in one asm block: r = q + wl*left(q) + wr*right(q) as two
-// DPP-sourced v_fmac per value (the shift rides on the FMA's first operand); one hazard nop covers all of them.
+// Three independent reflection-weighted horizontal 3-tap sums in one asm block: r = q + wl*left(q) + wr*right(q) as
+// v_mul_dpp + v_fmac_dpp (the shift rides on the multiply's first operand) + a plain add; pure outputs, so the results land
+// directly in the caller's registers.  One hazard nop covers all of them.
 __device__ __forceinline__ void hsum_w3(float a, float b, float c, float wl, float wr, float& ra, float& rb, float& rc) {
 #ifdef SMD_NO_DPP
   ra = hsum3(a, wl, wr); rb = hsum3(b, wl, wr); rc = hsum3(c, wl, wr);
 #else
-  ra = a; rb = b; rc = c;
+  float ta, tb, tc;
   asm volatile("s_nop 1\n\t"
-               "v_fmac_f32_dpp %0, %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_fmac_f32_dpp %1, %4, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-               "v_fmac_f32_dpp %2, %5, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_mul_f32_dpp %0, %3, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_mul_f32_dpp %1, %4, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "v_mul_f32_dpp %2, %5, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                "v_fmac_f32_dpp %0, %3, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                "v_fmac_f32_dpp %1, %4, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                "v_fmac_f32_dpp %2, %5, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-               : "+&v"(ra), "+&v"(rb), "+&v"(rc)
+               : "=&v"(ta), "=&v"(tb), "=&v"(tc)
                : "v"(a), "v"(b), "v"(c), "v"(wl), "v"(wr));
+  ra = ta + a; rb = tb + b; rc = tc + c;
 #endif
+}
+
+// Select between two wave-uniform floats on the scalar unit (a float ?: would be a v_cndmask per use).
+__device__ __forceinline__ float usel(bool c, float x, float y) {
+  return __builtin_bit_cast(float, c ? __builtin_bit_cast(unsigned, x) : __builtin_bit_cast(unsigned, y));
 }
 
 // SKIP: 0 = every row does the full adjoint; 2 = rows where no pixel of the wave selected the current support skip the SSIM
@@ -55,7 +62,7 @@ template <bool SSIM, int SKIP>
 struct BwdCtx {
   const ReconBwdArgs& a;
   // wave-uniform
-  int h, w, r0, r1, jlast, pb0, pb1, sup;
+  int h, w, r0, r1, pb0, pb1, sup;
   bool use_min, last, direct0, has_gin;
   unsigned w4, rowbytes, so_tex, so_y, so_ta, so_tb;
   float xmax, ymax, wpf;
@@ -65,7 +72,10 @@ struct BwdCtx {
   unsigned lane4, lane1;
   bool interior;
   float wla, wra, hx0, hy0, hz0;
-  float gm_ssim, gm_l1;        // upstream gradient x term weight for the columns of the image, 0 for halo lanes outside it
+  // upstream gradient x term weight for the columns of the image (0 for halo lanes outside it), as the values a pixel gets
+  // when its `sel` equals / differs from `sel_key` (min-reprojection: the support index; mean: the "masked" code)
+  float gs_eq, gs_ne, gl_eq, gl_ne;
+  unsigned sel_key;
   float* hist;                 // this lane's column of the wave's LDS history: 3 row slots x {gx, gy} x 3 channels
   // state
   float X[3][3], Y[3][3];      // [row mod 3][channel]: re-synthesised warped pixel / target pixel
@@ -106,6 +116,8 @@ struct BwdCtx {
 #endif
   }
 
+  __device__ __forceinline__ int reflect_row(int r) const { return (r > h - 1) ? max(2*(h - 1) - r, 0) : r; }
+
   __device__ __forceinline__ void begin(int jstart) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -119,7 +131,7 @@ struct BwdCtx {
     for (int k = 0; k < 9; ++k) ps[k] = 0.f;
     live_hist = 0; Dc = 0.f;
     issue(jstart, bld(rs_depth, lane4, (unsigned)jstart*w4));
-    Dn = bld(rs_depth, lane4, (unsigned)(jstart + 1)*w4);   // a row below the image reads 0 (the bounds check includes soffset)
+    Dn = bld(rs_depth, lane4, (unsigned)reflect_row(jstart + 1)*w4);
   }
 
   // One row step: stage A on row j (slot PH), stage B on centre row p = j-1, stage C on row q = j-2.
@@ -131,7 +143,7 @@ struct BwdCtx {
     const int p = j - 1, q = j - 2;
     const bool doB = SSIM && p >= pb0 && p <= pb1;
     const bool doC = q >= r0 && q < r1;
-    f4 ta = {}; f3 tb = {};
+    f4 ta; f3 tb;                                   // read only where doB holds
 #if (SMD_ABLATE_BWD & 2)
     SEL[SP] = (lane1 + (unsigned)p) & 1u;
     if (doB) { ta = f4{pfx + 1.f, pfy + 1.f, 1.5f, 0.3f}; tb = f3{0.2f, 0.4f, 0.1f}; }
@@ -139,7 +151,8 @@ struct BwdCtx {
     SEL[SP] = bld8(rs_sel, lane1, (unsigned)p*(unsigned)w);   // rows outside the image read 0 and are never used
     if (doB) {
       ta = bld4(rs_pk, lane4*4u, so_ta + (unsigned)p*w4*4u);
-      tb = bld3(rs_pk, lane4*4u, so_tb + (unsigned)p*w4*4u);
+      const f2 tb2 = bld2(rs_pk, lane4*4u, so_tb + (unsigned)p*w4*4u);   // {c1, c2}; the third entry is the forward's static error
+      tb = f3{tb2.x, tb2.y, 0.f};
     }
 #endif
     // ================= stage A: row j — the warped pixel and its bilinear partials from the taps issued one step earlier
@@ -157,24 +170,19 @@ struct BwdCtx {
       hist[(SN*6 + 3 + c)*64] = ddy;                  // dx/dsy
 #endif
     }
-    // Next row's loads, unconditionally (also after the last row, where nothing consumes them): the tap coordinates are
-    // clamped, a depth row below the image reads 0, and a conditional issue would turn every register of the in-flight loads
-    // into a loop phi with a second copy.
-    issue(j + 1, Dn);
+    // Next row's loads, unconditionally (also after the last row, where nothing consumes them): a conditional issue would turn
+    // every register of the in-flight loads into a loop phi with a second copy.  Below the image the next row is the
+    // reflected one (ReflectionPad2d(1): row h is row h-2), re-synthesised like any other row: no special case in vector code.
+    issue(reflect_row(j + 1), Dn);
 #if (SMD_ABLATE_BWD & 2)
     Dn = 1.f + pfx;
 #else
-    Dn = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
+    Dn = bld(rs_depth, lane4, (unsigned)reflect_row(j + 2)*w4);
 #endif
-    if (j > jlast) {
-      // j == h: the row below the image is row h-2 (ReflectionPad2d(1)), still in its slot; beyond that nothing reads it
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { X[SN][c] = X[SQ][c]; Y[SN][c] = Y[SQ][c]; }
-    }
 
     // ================= stage B: centre row p — SSIM partials, h-summed with the adjoint reflection weights
     if (SSIM) {
-      const float m = (p == 0) ? 2.f : 1.f;         // row -1 is row 1
+      const float m = usel(p == 0, 2.f, 1.f);       // row -1 is row 1
       float Vx[3], Vxx[3], Vxy[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -186,8 +194,7 @@ struct BwdCtx {
       bool row_live = false;
       float g2 = 0.f;
       if (doB) {
-        const bool active = use_min ? (SEL[SP] == (unsigned)sup) : (SEL[SP] != (unsigned)SMD_SEL_MASKED);
-        g2 = active ? gm_ssim : 0.f;
+        g2 = (SEL[SP] == sel_key) ? gs_eq : gs_ne;
         // Rows in which no pixel of this wave selected the current support carry no gradient through their windows:
         // skip the SSIM partials (wave-uniform branch; coherent regions of the min-reprojection / automask are common).
         row_live = SKIP >= 1 ? (__builtin_amdgcn_ballot_w64(g2 != 0.f) != 0) : true;
@@ -216,7 +223,10 @@ struct BwdCtx {
           const float dSxy = p9*a1;
           hsum_w3(dSx, dSxx2, dSxy, wla, wra, HC[SP][c][0], HC[SP][c][1], HC[SP][c][2]);
         }
-      } else {
+      } else if (SKIP >= 1) {
+        // (Without row skipping nothing needs clearing: every coefficient row that a stage C reads with a non-zero weight
+        // was computed, the others are stale-but-finite values times a zero weight.)
+        asm volatile("" ::: "memory");               // keep the clears inside the rarely taken branch
 #pragma unroll
         for (int c = 0; c < 3; ++c) { HC[SP][c][0] = 0.f; HC[SP][c][1] = 0.f; HC[SP][c][2] = 0.f; }
       }
@@ -224,10 +234,10 @@ struct BwdCtx {
 
     // ================= stage C: row q — dL/dx -> dL/d(sx, sy) -> depth, pose sums
     if (doC) {
-      float lo_q, hi_q;
-      reflect_weights_adj(q, h, lo_q, hi_q);        // weights of coefficient rows q-1 / q+1 in the gradient of row q
-      const bool active = use_min ? (SEL[SQ] == (unsigned)sup) : (SEL[SQ] != (unsigned)SMD_SEL_MASKED);
-      const float gl = active ? gm_l1 : 0.f;
+      // weights of coefficient rows q-1 / q+1 in the gradient of row q (reflect_weights_adj, on the scalar unit)
+      float lo_q = usel(q == 0, 0.f, usel(q == 1, 2.f, 1.f)), hi_q = usel(q == h - 1, 0.f, usel(q == h - 2, 2.f, 1.f));
+      if (h == 2) { lo_q = usel(q == 1, 2.f, 0.f); hi_q = usel(q == 0, 2.f, 0.f); }
+      const float gl = (SEL[SQ] == sel_key) ? gl_eq : gl_ne;
       // coefficient rows q-1, q, q+1 all skipped and no L1 term anywhere in the wave: the gradient of this row is zero
       const bool dead = SKIP >= 2 ? ((live_hist & 7u) == 0u && __builtin_amdgcn_ballot_w64(gl != 0.f) == 0) : false;
       const unsigned qro = (unsigned)q*w4;
@@ -335,8 +345,10 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   cx.w4 = (unsigned)w*4u;
   float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
   if (!cx.use_min) gscale /= (float)a.n;
-  cx.gm_ssim = col_ok ? gscale*(SSIM ? kWSsim/3.f : 0.f) : 0.f;
-  cx.gm_l1 = col_ok ? gscale*(SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f) : 0.f;
+  const float gm_ssim = col_ok ? gscale*(SSIM ? kWSsim/3.f : 0.f) : 0.f;
+  const float gm_l1 = col_ok ? gscale*(SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f) : 0.f;
+  cx.gs_eq = cx.use_min ? gm_ssim : 0.f; cx.gs_ne = cx.use_min ? 0.f : gm_ssim;
+  cx.gl_eq = cx.use_min ? gm_l1 : 0.f; cx.gl_ne = cx.use_min ? 0.f : gm_l1;
   cx.xmax = (float)(w - 1); cx.ymax = (float)(h - 1); cx.wpf = (float)(w + 1);
 
   const size_t sb = ((size_t)s*a.b + bi)*hw;
@@ -355,7 +367,6 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, h, w)*4);
 
   const int jstart = max(cx.r0 - 2, 0);
-  cx.jlast = min(cx.r1 + 1, h - 1);                       // last real row that is loaded
   cx.pb0 = max(cx.r0 - 1, 0); cx.pb1 = min(cx.r1, h - 1); // centre rows whose coefficients are needed
 
   for (int i = 0; i < a.n; ++i) {
@@ -363,6 +374,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
               a.wscale, a.hscale, uf);
     cx.so_tex = (unsigned)(i*a.b + bi)*texel_bytes;
     cx.sup = i;
+    cx.sel_key = cx.use_min ? (unsigned)i : (unsigned)SMD_SEL_MASKED;
     cx.last = (i == a.n - 1);
     cx.direct0 = cx.last && direct0_scale;
     cx.run(jstart);
