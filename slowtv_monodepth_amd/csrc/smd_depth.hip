@@ -51,9 +51,12 @@ hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, flo
 
 // Adjoint.  depth = 1/d on the pass-through branch, so d depth/d d = -depth^2 (0 where depth is 0 or pinned at 1/eps).
 // A scale whose disparity already has the image size is a pure element-wise product.  For the others the bilinear
-// adjoint A_y^T (G .* f') A_x is evaluated separably and as GATHERS (deterministic, no atomics), both passes coalesced:
-//   pass 1: tmp[v][jx] = sum_u wx(u -> jx) G[v][u] f'(depth[v][u])      thread per (v, jx), walks <= 2f+2 columns
-//   pass 2: out[jy][jx] = a * sum_v wy(v -> jy) tmp[v][jx]               thread per (jy, jx), walks <= 2f+2 rows
+// adjoint A_y^T (G .* f') A_x is evaluated separably and as GATHERS (deterministic, no atomics), ROWS FIRST: the pass over
+// the full-resolution gradient (the only large operand) reads it along image rows, i.e. coalesced, and the strided column
+// gathers of the second pass run on an array that is already f times smaller:
+//   pass 1: tmp[jy][u] = sum_v wy(v -> jy) G[v][u] f'(depth[v][u])      thread per (jy, u), walks <= 2f+2 rows
+//   pass 2: out[jy][jx] = a * sum_u wx(u -> jx) tmp[jy][u]               thread per (jy, jx), walks <= 2f+2 columns
+// (Columns first — the round-1 order — made every wave of pass 1 read 64 columns f apart: 34 us at cfg 2 against 9.)
 // Blocks are mapped to (scale, chunk) through a prefix table so that no block is launched for work that does not exist.
 struct BwdMap { int first_block[SMD_MAX_SCALES + 1]; size_t tmp_off[SMD_MAX_SCALES]; };
 
@@ -71,7 +74,7 @@ __device__ __forceinline__ void footprint(int j, float f, int n_lo, int n_hi, in
   if (j == n_lo - 1) hi = n_hi - 1;
 }
 
-__global__ __launch_bounds__(256) void k_disp_to_depth_bwd_h(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
+__global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
                                                              const float* __restrict__ depth_up, const float* __restrict__ g_depth_up,
                                                              float* __restrict__ tmp) {
   const int s = scale_of_block(map, sc.S, blockIdx.x);
@@ -92,26 +95,26 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_h(const ScaleSet sc, 
     }
     return;
   }
-  const int idx = blk*256 + threadIdx.x;    // (v, jx), jx fastest
-  if (idx >= h*ws) return;
-  const int v = idx/ws, jx = idx - v*ws;
-  const float sx = (float)ws/(float)w;
-  int ulo, uhi;
-  footprint(jx, (float)w/(float)ws, ws, w, ulo, uhi);
-  const float* __restrict__ drow = depth_up + ibase + (size_t)v*w;
-  const float* __restrict__ grow = g_depth_up + ibase + (size_t)v*w;
+  const int idx = blk*256 + threadIdx.x;    // (jy, u), u fastest
+  if (idx >= hs*w) return;
+  const int jy = idx/w, u = idx - jy*w;
+  const float sy = (float)hs/(float)h;
+  int vlo, vhi;
+  footprint(jy, (float)h/(float)hs, hs, h, vlo, vhi);
+  const float* __restrict__ dcol = depth_up + ibase + u;
+  const float* __restrict__ gcol = g_depth_up + ibase + u;
   float acc = 0.f;
-  for (int u = ulo; u <= uhi; ++u) {
-    int x0, x1; float lx;
-    src_index(u, sx, ws, x0, x1, lx);
-    const float wx = ((x0 == jx) ? 1.f - lx : 0.f) + ((x1 == jx) ? lx : 0.f);
-    const float dep = drow[u];
-    acc = fmaf(wx, grow[u]*((dep < dmax) ? -dep*dep : 0.f), acc);
+  for (int v = vlo; v <= vhi; ++v) {
+    int y0, y1; float ly;
+    src_index(v, sy, hs, y0, y1, ly);
+    const float wy = ((y0 == jy) ? 1.f - ly : 0.f) + ((y1 == jy) ? ly : 0.f);
+    const float dep = dcol[(size_t)v*w];
+    acc = fmaf(wy, gcol[(size_t)v*w]*((dep < dmax) ? -dep*dep : 0.f), acc);
   }
-  tmp[map.tmp_off[s] + ((size_t)bi*h + v)*ws + jx] = acc;
+  tmp[map.tmp_off[s] + ((size_t)bi*hs + jy)*w + u] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
+__global__ __launch_bounds__(256) void k_disp_to_depth_bwd_h(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
                                                              const float* __restrict__ tmp) {
   const int s = scale_of_block(map, sc.S, blockIdx.x);
   const int blk = blockIdx.x - map.first_block[s], bi = blockIdx.y;
@@ -120,16 +123,16 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, 
   const int lp = blk*256 + threadIdx.x;
   if (lp >= hs*ws) return;
   const int jy = lp/ws, jx = lp - jy*ws;
-  const float sy = (float)hs/(float)h;
-  int vlo, vhi;
-  footprint(jy, (float)h/(float)hs, hs, h, vlo, vhi);
-  const float* __restrict__ col = tmp + map.tmp_off[s] + (size_t)bi*h*ws + jx;
+  const float sx = (float)ws/(float)w;
+  int ulo, uhi;
+  footprint(jx, (float)w/(float)ws, ws, w, ulo, uhi);
+  const float* __restrict__ row = tmp + map.tmp_off[s] + ((size_t)bi*hs + jy)*w;
   float acc = 0.f;
-  for (int v = vlo; v <= vhi; ++v) {
-    int y0, y1; float ly;
-    src_index(v, sy, hs, y0, y1, ly);
-    const float wy = ((y0 == jy) ? 1.f - ly : 0.f) + ((y1 == jy) ? ly : 0.f);
-    acc = fmaf(wy, col[(size_t)v*ws], acc);
+  for (int u = ulo; u <= uhi; ++u) {
+    int x0, x1; float lx;
+    src_index(u, sx, ws, x0, x1, lx);
+    const float wx = ((x0 == jx) ? 1.f - lx : 0.f) + ((x1 == jx) ? lx : 0.f);
+    acc = fmaf(wx, row[u], acc);
   }
   sc.g[s][(size_t)bi*hs*ws + lp] = acc*a_scale;
 }
@@ -138,7 +141,7 @@ size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, Bwd
   size_t off = 0;
   for (int s = 0; s < sc.S; ++s) {
     if (map) map->tmp_off[s] = off;
-    if (!(sc.hs[s] == h && sc.ws[s] == w)) off += (size_t)b*h*sc.ws[s];
+    if (!(sc.hs[s] == h && sc.ws[s] == w)) off += (size_t)b*sc.hs[s]*w;
   }
   return off;
 }
@@ -156,14 +159,14 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
     m1.first_block[s] = n1; m2.first_block[s] = n2;
     if (s < sc.S) {
       const bool ident = sc.hs[s] == h && sc.ws[s] == w;
-      n1 += ident ? (skip_identity ? 0 : ceil_div(h*w, 1024)) : ceil_div(h*sc.ws[s], 256);   // skip: the fused backward already wrote that scale
+      n1 += ident ? (skip_identity ? 0 : ceil_div(h*w, 1024)) : ceil_div(sc.hs[s]*w, 256);   // skip: the fused backward already wrote that scale
       n2 += ident ? 0 : ceil_div(sc.hs[s]*sc.ws[s], 256);
       resampled |= !ident;
     }
   }
   m1.first_block[SMD_MAX_SCALES] = n1; m2.first_block[SMD_MAX_SCALES] = n2;
-  if (n1 > 0) hipLaunchKernelGGL(k_disp_to_depth_bwd_h, dim3(n1, b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp);
-  if (resampled) hipLaunchKernelGGL(k_disp_to_depth_bwd_v, dim3(n2, b), dim3(256), 0, st, sc, m2, b, h, w, a_scale, tmp);
+  if (n1 > 0) hipLaunchKernelGGL(k_disp_to_depth_bwd_v, dim3(n1, b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp);
+  if (resampled) hipLaunchKernelGGL(k_disp_to_depth_bwd_h, dim3(n2, b), dim3(256), 0, st, sc, m2, b, h, w, a_scale, tmp);
   return hipGetLastError();
 }
 

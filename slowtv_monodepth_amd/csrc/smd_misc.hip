@@ -8,21 +8,30 @@ namespace smd {
 // ---------------------------------------------------------------------------------------------
 // Deterministic second stage of every scalar reduction: one block, fp64 accumulation.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ partial, int count, double scale, float* out) {
-  __shared__ double red[256];
+__global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__ partial, int count, double scale, float* out) {
+  __shared__ double red[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc = 0.0;
-  for (int i = threadIdx.x; i < count; i += 256) acc += (double)partial[i];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int sft = 128; sft > 0; sft >>= 1) {
-    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
-    __syncthreads();
+  int i = threadIdx.x;
+  for (; i + 3*1024 < count; i += 4*1024) {      // four independent loads in flight; the order of the additions is fixed
+    const float a = partial[i], b = partial[i + 1024], c = partial[i + 2048], d = partial[i + 3072];
+    acc += ((double)a + (double)b) + ((double)c + (double)d);
   }
-  if (threadIdx.x == 0) out[0] = (float)(red[0]*scale);
+  for (; i < count; i += 1024) acc += (double)partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    out[0] = (float)(tot*scale);
+  }
 }
 
 hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, partial, count, scale, out);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st, partial, count, scale, out);
   return hipGetLastError();
 }
 

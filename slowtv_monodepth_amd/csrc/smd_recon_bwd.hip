@@ -407,74 +407,88 @@ hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // Epilogue: sum the per-wave partials of dL/d(H, a0, a1, tz) and push them through
 //   H[0:2] = K2 * M,  H[2] = M[2],  M = R * Ki3,  (a0, a1) = K2 * t,  tz = t[2]
-// to dL/dT (n,b,4,4), dL/dK (b,4,4), dL/dKinv (b,4,4).  One block per sample; fp64 accumulation.
+// to dL/dT (n,b,4,4), dL/dK (b,4,4), dL/dKinv (b,4,4).  One block of 16 waves per sample: every wave reduces some of the
+// n*12 sums (fp64, fixed order -> deterministic, four loads in flight), then one thread per support does the 3x3 algebra and
+// thread 0 adds the supports' contributions to dL/dK, dL/dKinv in index order.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pose_finalize(const float* __restrict__ pose_partial, int entries,
-                                                       const float* __restrict__ T, const float* __restrict__ K,
-                                                       const float* __restrict__ Kinv, float* g_T, float* g_K, float* g_Kinv,
-                                                       int b, int n) {
-  __shared__ double tot[kPoseSums];
+__global__ __launch_bounds__(1024) void k_pose_finalize(const float* __restrict__ pose_partial, int entries,
+                                                        const float* __restrict__ T, const float* __restrict__ K,
+                                                        const float* __restrict__ Kinv, float* g_T, float* g_K, float* g_Kinv,
+                                                        int b, int n) {
+  __shared__ double tot[SMD_MAX_SUPPORTS][kPoseSums];
+  __shared__ double gKs[SMD_MAX_SUPPORTS][6], gKis[SMD_MAX_SUPPORTS][9];
   const int bi = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double gK[6] = {0, 0, 0, 0, 0, 0}, gKi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < n; ++i) {
-    const float* pp = pose_partial + ((size_t)i*b + bi)*(size_t)entries*kPoseSums;
-    // each of the four waves reduces three of the twelve sums (fp64, fixed order -> deterministic)
-    for (int k = wv*3; k < wv*3 + 3; ++k) {
-      double acc = 0.0;
-      for (int e = lane; e < entries; e += 64) acc += (double)pp[(size_t)e*kPoseSums + k];
+  for (int pr = wv; pr < n*kPoseSums; pr += 16) {
+    const int i = pr/kPoseSums, k = pr - i*kPoseSums;
+    const float* pp = pose_partial + ((size_t)i*b + bi)*(size_t)entries*kPoseSums + k;
+    double acc = 0.0;
+    int e = lane;
+    for (; e + 192 < entries; e += 256) {
+      const float v0 = pp[(size_t)e*kPoseSums], v1 = pp[(size_t)(e + 64)*kPoseSums], v2 = pp[(size_t)(e + 128)*kPoseSums], v3 = pp[(size_t)(e + 192)*kPoseSums];
+      acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; e < entries; e += 64) acc += (double)pp[(size_t)e*kPoseSums];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (lane == 0) tot[k] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float* Tm = T + ((size_t)i*b + bi)*16;
-      const float* Km = K + (size_t)bi*16;
-      const float* Ki = Kinv + (size_t)bi*16;
-      double R[9], t[3], K2[6], Ki3[9], M[9];
-      for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { R[r*3 + c] = Tm[r*4 + c]; Ki3[r*3 + c] = Ki[r*4 + c]; } t[r] = Tm[r*4 + 3]; }
-      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) K2[r*3 + c] = Km[r*4 + c];
-      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r*3 + c] = R[r*3]*Ki3[c] + R[r*3 + 1]*Ki3[3 + c] + R[r*3 + 2]*Ki3[6 + c];
-      const double* gH = tot;          // 3x3
-      const double ga[2] = {tot[9], tot[10]};
-      const double gtz = tot[11];
-      double gM[9];
-      for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c) gM[m*3 + c] = K2[m]*gH[c] + K2[3 + m]*gH[3 + c];
-      for (int c = 0; c < 3; ++c) gM[6 + c] += gH[6 + c];
-      for (int r = 0; r < 2; ++r) for (int m = 0; m < 3; ++m)
-        gK[r*3 + m] += gH[r*3]*M[m*3] + gH[r*3 + 1]*M[m*3 + 1] + gH[r*3 + 2]*M[m*3 + 2] + ga[r]*t[m];
-      double gt[3];
-      for (int m = 0; m < 3; ++m) gt[m] = K2[m]*ga[0] + K2[3 + m]*ga[1];
-      gt[2] += gtz;
-      float* gTo = g_T + ((size_t)i*b + bi)*16;
-      for (int r = 0; r < 3; ++r) {
-        for (int m = 0; m < 3; ++m)
-          gTo[r*4 + m] = (float)(gM[r*3]*Ki3[m*3] + gM[r*3 + 1]*Ki3[m*3 + 1] + gM[r*3 + 2]*Ki3[m*3 + 2]);
-        gTo[r*4 + 3] = (float)gt[r];
-      }
-      for (int c = 0; c < 4; ++c) gTo[12 + c] = 0.f;
-      for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c)
-        gKi[m*3 + c] += R[m]*gM[c] + R[3 + m]*gM[3 + c] + R[6 + m]*gM[6 + c];
-    }
-    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) tot[i][k] = acc;
   }
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
+    const int i = threadIdx.x;
+    const float* Tm = T + ((size_t)i*b + bi)*16;
+    const float* Km = K + (size_t)bi*16;
+    const float* Ki = Kinv + (size_t)bi*16;
+    double R[9], t[3], K2[6], Ki3[9], M[9];
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { R[r*3 + c] = Tm[r*4 + c]; Ki3[r*3 + c] = Ki[r*4 + c]; } t[r] = Tm[r*4 + 3]; }
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) K2[r*3 + c] = Km[r*4 + c];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r*3 + c] = R[r*3]*Ki3[c] + R[r*3 + 1]*Ki3[3 + c] + R[r*3 + 2]*Ki3[6 + c];
+    const double* gH = tot[i];        // 3x3
+    const double ga[2] = {tot[i][9], tot[i][10]};
+    const double gtz = tot[i][11];
+    double gM[9];
+    for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c) gM[m*3 + c] = K2[m]*gH[c] + K2[3 + m]*gH[3 + c];
+    for (int c = 0; c < 3; ++c) gM[6 + c] += gH[6 + c];
+    for (int r = 0; r < 2; ++r) for (int m = 0; m < 3; ++m)
+      gKs[i][r*3 + m] = gH[r*3]*M[m*3] + gH[r*3 + 1]*M[m*3 + 1] + gH[r*3 + 2]*M[m*3 + 2] + ga[r]*t[m];
+    double gt[3];
+    for (int m = 0; m < 3; ++m) gt[m] = K2[m]*ga[0] + K2[3 + m]*ga[1];
+    gt[2] += gtz;
+    float* gTo = g_T + ((size_t)i*b + bi)*16;
+    for (int r = 0; r < 3; ++r) {
+      for (int m = 0; m < 3; ++m)
+        gTo[r*4 + m] = (float)(gM[r*3]*Ki3[m*3] + gM[r*3 + 1]*Ki3[m*3 + 1] + gM[r*3 + 2]*Ki3[m*3 + 2]);
+      gTo[r*4 + 3] = (float)gt[r];
+    }
+    for (int c = 0; c < 4; ++c) gTo[12 + c] = 0.f;
+    for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c)
+      gKis[i][m*3 + c] = R[m]*gM[c] + R[3 + m]*gM[3 + c] + R[6 + m]*gM[6 + c];
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     if (g_K) {
       float* o = g_K + (size_t)bi*16;
       for (int k = 0; k < 16; ++k) o[k] = 0.f;
-      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) o[r*4 + c] = (float)gK[r*3 + c];
+      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += gKs[i][r*3 + c];
+        o[r*4 + c] = (float)acc;
+      }
     }
     if (g_Kinv) {
       float* o = g_Kinv + (size_t)bi*16;
       for (int k = 0; k < 16; ++k) o[k] = 0.f;
-      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[r*4 + c] = (float)gKi[r*3 + c];
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += gKis[i][r*3 + c];
+        o[r*4 + c] = (float)acc;
+      }
     }
   }
 }
 
 hipError_t launch_pose_finalize(const float* pose_partial, int entries, const float* T, const float* K, const float* Kinv,
                                 float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st) {
-  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(256), 0, st, pose_partial, entries, T, K, Kinv, g_T, g_K, g_Kinv, b, n);
+  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(1024), 0, st, pose_partial, entries, T, K, Kinv, g_T, g_K, g_Kinv, b, n);
   return hipGetLastError();
 }
 
