@@ -48,6 +48,19 @@ StripPlan plan(int b, int S, int h, int w, int cols) {
   return p;
 }
 
+// Tapered partition of the fused kernels (smd_kernels.h: ReconMainArgs::b1): the last `b2` samples of the dispatch order get
+// strips of `rh2` = rh/2 rows.  A launch is two to three "generations" of waves on the 4096 wave slots of the chip and a wave
+// lives 30-40 us, so with equal units the last ones dispatched run almost alone for tens of microseconds (wave traces:
+// scripts/dev/wave_trace.py; time-averaged occupancy 2.96 -> 3.19 waves per SIMD with the taper, forward 93 -> 87-89 us at
+// cfg 2).  Default: a sixth of the batch, when the batch has at least four samples; SMD_*_TAPER_B / _RH override (B = 0: off).
+void taper(int& b1, int& rh2, int& nsy2, int b, int h, const StripPlan& pl, const char* env_b, const char* env_rh) {
+  int b2 = env_int(env_b, -1), r2 = env_int(env_rh, -1);
+  if (b2 < 0) b2 = (b >= 4) ? (b + 3)/6 : 0;
+  if (b2 > b - 1) b2 = b - 1;
+  if (r2 < kMinStripRows) r2 = pl.rh/2 < kMinStripRows ? kMinStripRows : pl.rh/2;
+  b1 = b - b2; rh2 = r2; nsy2 = smd::ceil_div(h, r2);
+}
+
 // ---- optional event-pair recording around the dominant kernels (bench.py roofline measurement) ----
 struct ProfSlot { hipEvent_t* ev = nullptr; int cap = 0, used = 0; };
 ProfSlot g_prof[4];   // SMD_PROF_*: dominant forward kernel, dominant backward kernel, whole forward entry point, whole backward entry point
@@ -206,6 +219,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
+  taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_FWD_TAPER_B", "SMD_FWD_TAPER_RH");
   for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
     a.i0 = i0; a.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
     a.first_pass = (i0 == 0); a.last_pass = (i0 + a.ni >= n);
@@ -214,7 +228,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
     if (a.last_pass) prof_mark(SMD_PROF_RECON_FWD, st, false);
     if (a.depth_out) { a.depth = a.depth_out; a.depth_out = nullptr; }   // later passes (n > 4) read the depth the first one wrote
   }
-  const int count = S*b*pl.nsx*pl.nsy;
+  const int count = S*pl.nsx*(a.b1*pl.nsy + (b - a.b1)*a.nsy2);
   const int rc = check_launch(smd::launch_sum_partials(ws.loss_partial, count, 1.0/((double)S*b*h*w), loss, st), "loss reduction");
   prof_mark(SMD_PROF_RECON_FWD_ALL, st, false);
   return rc;
@@ -263,12 +277,14 @@ static int recon_bwd_impl(const float* depth, const float* supp_packed, const fl
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   const StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
+  taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_BWD_TAPER_B", "SMD_BWD_TAPER_RH");
+  a.pose_stride = S*pl.nsx*(a.nsy2 > pl.nsy ? a.nsy2 : pl.nsy);
   a.skip_level = env_int("SMD_BWD_SKIP", 2);
   prof_mark(SMD_PROF_RECON_BWD_ALL, st, true);
   prof_mark(SMD_PROF_RECON_BWD, st, true);
   if (int rc = check_launch(smd::launch_recon_bwd(a, st), "image_recon_bwd")) return rc;
   prof_mark(SMD_PROF_RECON_BWD, st, false);
-  const int rc = check_launch(smd::launch_pose_finalize(ws.pose_partial, S*pl.nsx*pl.nsy, T, K, K_inv, g_T,
+  const int rc = check_launch(smd::launch_pose_finalize(ws.pose_partial, S*pl.nsx*pl.nsy, S*pl.nsx*a.nsy2, a.b1, a.pose_stride, T, K, K_inv, g_T,
                                                         (flags & SMD_NEED_K_GRAD) ? g_K : nullptr, (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr,
                                                         b, n, st), "pose finalize");
   prof_mark(SMD_PROF_RECON_BWD_ALL, st, false);

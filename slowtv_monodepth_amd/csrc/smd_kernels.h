@@ -82,6 +82,10 @@ struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over suppo
   int flags;
   int rh;                  // rows per strip
   int nsx, nsy;            // strips per image in x / y
+  // Tapered partition: the first b1 samples (in dispatch order) use strips of `rh` rows, the remaining b - b1 samples strips of
+  // `rh2` rows (nsy2 per image), so that the work units dispatched last are short and the launch does not end with a few
+  // long waves running alone (b1 == b: no taper).  Loss partials: [S*b1*nsx*nsy] followed by [S*(b-b1)*nsx*nsy2].
+  int b1, rh2, nsy2;
   float wscale, hscale;    // w/(w-1), h/(h-1)
   float inv_n;
   uint32_t seed_lo, seed_hi;
@@ -96,10 +100,12 @@ struct ReconBwdArgs {
   const float* g_in;      // (S,b,h,w) gradient reaching depth from other consumers, added on the last support pass, or null
   float* g_disp0;         // K0 fused: (b,1,h,w) gradient of the full-resolution disparity scale, written directly (scale 0 then
   float a_scale;          //   skips g_depth), or null; d depth/d disp = -depth^2*a_scale
-  float* pose_partial;    // [n*b][S*nstrips][kPoseSums]
+  float* pose_partial;    // [n*b][pose_stride][kPoseSums], the first S*nstrips entries of a (support, sample) used
   int b, n, S, h, w;
   int flags;
   int rh, nsx, nsy;
+  int b1, rh2, nsy2;      // tapered partition, as in ReconMainArgs
+  int pose_stride;        // entries reserved per (support, sample) in pose_partial: S*nsx*max(nsy, nsy2)
   float wscale, hscale;
   int skip_level;         // 0..2, see k_recon_bwd
 };
@@ -134,8 +140,8 @@ hipError_t launch_recon_prep(const ReconPrepArgs& a, hipStream_t st);
 hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st);
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st);
 hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st);
-hipError_t launch_pose_finalize(const float* pose_partial, int entries, const float* T, const float* K, const float* Kinv,
-                                float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st);
+hipError_t launch_pose_finalize(const float* pose_partial, int entries1, int entries2, int b1, int stride, const float* T, const float* K,
+                                const float* Kinv, float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st);
 
 hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
                                     float* depth_up, float* disp_up, hipStream_t st);
@@ -204,10 +210,11 @@ hipError_t launch_intrinsics_bwd(const float* fs, const float* cs, int b, int h,
 // Rows per strip.  More, shorter waves than fit at once balance better than one resident round (the waves of a round do
 // not finish together), and the forward kernel gains from short strips even though each pays two halo rows.  Measured
 // (scripts/dev/microbench.py, rh sweep 4..64): cfg 2 forward 93 -> 87 us, backward 221 -> 203 us; cfg 4 forward 229 -> 188 us,
-// backward 422 -> 397 us; cfg 5 forward 513 -> 430 us.  Rule: about 8k waves; the forward never longer than 16 rows.
+// backward 422 -> 397 us; cfg 5 forward 513 -> 430 us.  Rule (round 2, with the tapered tail): about 6k waves — cfg 2: 16 rows,
+// backward 127 -> 115 us —; the forward never longer than 16 rows.
 inline int pick_rows_per_strip(int b, int S, int h, int w, int cols, int halo) {
   const int nsx = ceil_div(w, cols);
-  const long target_waves = 8192;
+  const long target_waves = 6144;   // 1.5 x the chip's 4096 wave slots; with the tapered tail (smd_api.hip: taper) fewer, longer waves win
   const int rh_max = (cols == kFwdCols) ? 16 : 64;
   int best = 8;
   for (int rh = rh_max; rh >= 8; rh -= 4) {

@@ -318,17 +318,21 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   __shared__ float hist_lds[kWavesPerBlock*3*6*64];   // per wave: 3 row slots x {gx, gy} x 3 channels x 64 lanes
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nstrips = a.nsx*a.nsy;
+  // segment of the (possibly tapered) partition this block belongs to (smd_kernels.h: ReconMainArgs::b1)
+  const unsigned nblk1 = recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S);
+  const bool tail = blockIdx.x >= nblk1;
+  const int nstrips = a.nsx*(tail ? a.nsy2 : a.nsy), seg_rh = tail ? a.rh2 : a.rh;
   int strip, bi, s;
-  decode_wave(blockIdx.x, wid, nstrips, a.b, a.S, strip, bi, s);
+  decode_wave(tail ? blockIdx.x - nblk1 : blockIdx.x, wid, nstrips, tail ? a.b - a.b1 : a.b1, a.S, strip, bi, s);
   if (strip >= nstrips) return;
+  if (tail) bi += a.b1;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
   const int h = a.h, w = a.w;
 
   BwdCtx<SSIM, SKIP> cx{a};
   cx.hist = hist_lds + wid*(3*6*64) + lane;
   cx.h = h; cx.w = w;
-  cx.r0 = syi*a.rh; cx.r1 = min(cx.r0 + a.rh, h);
+  cx.r0 = syi*seg_rh; cx.r1 = min(cx.r0 + seg_rh, h);
   const int u = sxi*kBwdCols - 2 + lane;
   const bool col_ok = (u >= 0) && (u < w);
   // data column: the lane's own, or the reflected one for the halo lanes outside the image (reflection by data)
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
 
     // per-wave pose partials: d/d(H[0..8], a0, a1, tz) of the UN-scaled homography (rows 0/1 of the folded one carry the grid
     // scale); the column factor of H[.,0] is constant per lane
-    float* pp = a.pose_partial + (((size_t)i*a.b + bi)*((size_t)a.S*nstrips) + (size_t)s*nstrips + strip)*kPoseSums;
+    float* pp = a.pose_partial + (((size_t)i*a.b + bi)*(size_t)a.pose_stride + (size_t)s*nstrips + strip)*kPoseSums;
     const float* ps = cx.ps;
     const float ws = a.wscale, hs = a.hscale;
     const float psum[kPoseSums] = {ps[0]*uf*ws, ps[1]*ws, ps[0]*ws, ps[2]*uf*hs, ps[3]*hs, ps[2]*hs, ps[4]*uf, ps[5], ps[4],
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
 }
 
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
-  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b, a.S)), block(64*kWavesPerBlock);
+  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S) : 0u)), block(64*kWavesPerBlock);
   const bool ssim = !(a.flags & SMD_LOSS_L1);
   if (ssim) {
     if (a.skip_level >= 1) hipLaunchKernelGGL((k_recon_bwd<true, 2>), grid, block, 0, st, a);
@@ -411,16 +415,17 @@ hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
 // n*12 sums (fp64, fixed order -> deterministic, four loads in flight), then one thread per support does the 3x3 algebra and
 // thread 0 adds the supports' contributions to dL/dK, dL/dKinv in index order.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_pose_finalize(const float* __restrict__ pose_partial, int entries,
+__global__ __launch_bounds__(1024) void k_pose_finalize(const float* __restrict__ pose_partial, int entries1, int entries2, int b1, int stride,
                                                         const float* __restrict__ T, const float* __restrict__ K,
                                                         const float* __restrict__ Kinv, float* g_T, float* g_K, float* g_Kinv,
                                                         int b, int n) {
   __shared__ double tot[SMD_MAX_SUPPORTS][kPoseSums];
   __shared__ double gKs[SMD_MAX_SUPPORTS][6], gKis[SMD_MAX_SUPPORTS][9];
   const int bi = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int entries = bi < b1 ? entries1 : entries2;   // tapered partition: the last samples were cut into more strips
   for (int pr = wv; pr < n*kPoseSums; pr += 16) {
     const int i = pr/kPoseSums, k = pr - i*kPoseSums;
-    const float* pp = pose_partial + ((size_t)i*b + bi)*(size_t)entries*kPoseSums + k;
+    const float* pp = pose_partial + ((size_t)i*b + bi)*(size_t)stride*kPoseSums + k;
     double acc = 0.0;
     int e = lane;
     for (; e + 192 < entries; e += 256) {
@@ -486,9 +491,9 @@ __global__ __launch_bounds__(1024) void k_pose_finalize(const float* __restrict_
   }
 }
 
-hipError_t launch_pose_finalize(const float* pose_partial, int entries, const float* T, const float* K, const float* Kinv,
-                                float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st) {
-  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(1024), 0, st, pose_partial, entries, T, K, Kinv, g_T, g_K, g_Kinv, b, n);
+hipError_t launch_pose_finalize(const float* pose_partial, int entries1, int entries2, int b1, int stride, const float* T, const float* K,
+                                const float* Kinv, float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(1024), 0, st, pose_partial, entries1, entries2, b1, stride, T, K, Kinv, g_T, g_K, g_Kinv, b, n);
   return hipGetLastError();
 }
 

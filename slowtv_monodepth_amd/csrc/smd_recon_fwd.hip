@@ -503,13 +503,19 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int strip, bi_, s_;
-  decode_wave(blockIdx.x, wid, a.nsx*a.nsy, a.b, a.S, strip, bi_, s_);
-  if (strip >= a.nsx*a.nsy) return;
+  // segment of the (possibly tapered) partition this block belongs to
+  const unsigned nblk1 = recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S);
+  const bool tail = blockIdx.x >= nblk1;
+  const int nstr = a.nsx*(tail ? a.nsy2 : a.nsy), seg_b = tail ? a.b - a.b1 : a.b1, seg_rh = tail ? a.rh2 : a.rh;
+  decode_wave(tail ? blockIdx.x - nblk1 : blockIdx.x, wid, nstr, seg_b, a.S, strip, bi_, s_);
+  if (strip >= nstr) return;
+  const size_t partial_idx = (tail ? (size_t)a.S*a.b1*(a.nsx*a.nsy) : 0) + ((size_t)s_*seg_b + bi_)*nstr + strip;
+  if (tail) bi_ += a.b1;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
 
   MainCtx<N, SSIM, SINGLE, AUX, DISP> cx{a};
   cx.bi = bi_; cx.s = s_; cx.h = a.h; cx.w = a.w;
-  cx.r0 = syi*a.rh; cx.r1 = min(cx.r0 + a.rh, a.h);
+  cx.r0 = syi*seg_rh; cx.r1 = min(cx.r0 + seg_rh, a.h);
   cx.jlast = min(cx.r1, a.h - 1);
   const int u = sxi*kFwdCols - 1 + lane;
   // The pixel column this lane synthesises: its own, or — for the halo lane just outside the image — the reflected one.
@@ -594,17 +600,39 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
 
   if ((SINGLE || a.last_pass) && a.partial != nullptr) {
     const float tot = wave_sum(cx.lsum);
-    if (lane == 0) a.partial[((size_t)cx.s*a.b + cx.bi)*(a.nsx*a.nsy) + strip] = tot;
+    if (lane == 0) a.partial[partial_idx] = tot;
   }
 }
 
 // register budget: 128 VGPRs (4 waves per SIMD) up to two supports, 168 (3 waves) for three and four
 // register budget: up to two supports are held to 128 VGPRs (4 waves per SIMD; the K0-fused instantiation needs 129 unaided), three and four to 168 (3 waves)
+#ifdef SMD_TRACE_WAVES   // diagnosis builds only (scripts/dev/wave_trace.py): when and where every wave of the last launch ran
+__device__ unsigned long long g_wave_trace[1 << 16][3];
+#endif
 template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP>
-__global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 4 : 3)) void k_recon_main(const ReconMainArgs a) { recon_main_body<N, SSIM, SINGLE, AUX, DISP>(a); }
+__global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 4 : 3)) void k_recon_main(const ReconMainArgs a) {
+#ifdef SMD_TRACE_WAVES
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  recon_main_body<N, SSIM, SINGLE, AUX, DISP>(a);
+#ifdef SMD_TRACE_WAVES
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned widx = blockIdx.x*kWavesPerBlock + (threadIdx.x >> 6);
+    if (widx < (1u << 16)) {
+      g_wave_trace[widx][0] = t0; g_wave_trace[widx][1] = __builtin_amdgcn_s_memrealtime();
+      g_wave_trace[widx][2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    }
+  }
+#endif
+}
+#ifdef SMD_TRACE_WAVES
+extern "C" int smd_debug_wave_trace(unsigned long long* host_out, int max_waves) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_trace), (size_t)max_waves*3*sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
-  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b, a.S)), block(64*kWavesPerBlock);
+  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S) : 0u)), block(64*kWavesPerBlock);
   const bool ssim = !(a.flags & SMD_LOSS_L1);
   const bool single = a.first_pass && a.last_pass;
   const bool aux = a.warp0 != nullptr || a.noise != nullptr;

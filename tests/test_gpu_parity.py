@@ -769,6 +769,36 @@ def test_strip_boundary_shapes_match_oracle(F, b, h, w, n, S, mode):
     assert rel_to_max(T_g.grad.cpu()[..., :3, :], T_c.grad[..., :3, :]) < tol
 
 
+@pytest.mark.parametrize('b,h,w,n,S,b2,rh,rh2', [(3, 37, 70, 2, 2, 1, 12, 5), (5, 50, 130, 3, 1, 2, 16, 4), (4, 24, 61, 1, 3, 3, 8, 6)])
+def test_tapered_partition_gives_the_same_result(F, monkeypatch, b, h, w, n, S, b2, rh, rh2):
+    """The fused kernels cut the last samples of the dispatch order into shorter strips (load balance at the end of a launch).
+    The partition must not change anything: same error map and selection bit for bit, same gradients up to the order of the
+    per-strip partial sums."""
+    gen = torch.Generator().manual_seed(h*w + b)
+    imgs = torch.rand(b, 3, h, w, generator=gen).cuda(); supp = (imgs[None].cpu() + 0.1*torch.randn(n, b, 3, h, w, generator=gen)).clamp(0, 1).cuda()
+    depth = (1 + 10*torch.rand(S, b, 1, h, w, generator=gen)).cuda()
+    aa = 0.02*torch.randn(n*b, 3, generator=gen).cuda(); t = 0.2*torch.randn(n*b, 3, generator=gen).cuda()
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(b, 1, 1).cuda()
+    noise = torch.randn(S*b, 1, h, w, generator=gen).cuda()
+
+    def run(taper):
+        for k in ('SMD_FWD_RH', 'SMD_BWD_RH'): monkeypatch.setenv(k, str(rh))
+        for k in ('SMD_FWD_TAPER_B', 'SMD_BWD_TAPER_B'): monkeypatch.setenv(k, str(b2 if taper else 0))
+        for k in ('SMD_FWD_TAPER_RH', 'SMD_BWD_TAPER_RH'): monkeypatch.setenv(k, str(rh2))
+        d = depth.clone().requires_grad_(True)
+        T = F.pose_matrices(aa, t).unflatten(0, (n, b)).detach().requires_grad_(True)
+        loss, err, sel, _ = F.image_recon_fused(d, imgs, supp, T, K, flags=F.recon_flags('ssim', True, True), noise=noise)
+        loss.backward()
+        return loss.detach(), err, sel, d.grad, T.grad
+
+    l0, e0, s0, gd0, gT0 = run(False)
+    l1, e1, s1, gd1, gT1 = run(True)
+    assert torch.equal(e0, e1) and torch.equal(s0, s1)
+    torch.testing.assert_close(l1, l0, rtol=1e-6, atol=0)
+    assert torch.equal(gd0, gd1)
+    torch.testing.assert_close(gT1, gT0, rtol=1e-4, atol=1e-7*gT0.abs().max().item())
+
+
 @pytest.mark.parametrize('b,h,w,lows', [(2, 33, 47, [(33, 47), (16, 23), (8, 11)]), (1, 8, 12, [(8, 12), (4, 6), (2, 3), (1, 1)]),
                                         (1, 192, 640, [(96, 320), (24, 80)]), (2, 21, 30, [(7, 10), (5, 30)])])
 @pytest.mark.parametrize('use_edges', [True, False])
