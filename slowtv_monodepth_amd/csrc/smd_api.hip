@@ -74,6 +74,14 @@ void prof_mark(int which, hipStream_t st, bool begin) {
 }
 
 
+// The K0-fused instantiations of k_recon_main exist for the SSIM loss and walk the low-resolution rows one at a time, which
+// needs every pyramid level to be no taller than the image (always true for a decoder's outputs).
+bool k0_fusable(const smd::ScaleSet& sc, int h, int flags) {
+  if (flags & SMD_LOSS_L1) return false;
+  for (int s = 0; s < sc.S; ++s) if (sc.hs[s] > h) return false;
+  return true;
+}
+
 struct ReconWs { float* loss_partial; float* pose_partial; uint4* rowtab; size_t bytes; };
 
 ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
@@ -187,7 +195,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
     p.b = b; p.n = n; p.h = h; p.w = w; p.flags = flags & (SMD_USE_MIN | SMD_LOSS_L1 | SMD_USE_AUTOMASK);
     const StripPlan ipl = plan(b, 1, h, w, smd::kFwdCols);  // one "scale" only: shorter strips keep the chip full
     p.rh = ipl.rh; p.nsx = ipl.nsx; p.nsy = ipl.nsy;
-    const bool fuse_k0 = sc && !(flags & SMD_LOSS_L1);
+    const bool fuse_k0 = sc && k0_fusable(*sc, h, flags);
     for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
       p.i0 = i0; p.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
       p.first_pass = (i0 == 0); p.last_pass = (i0 + p.ni >= n);
@@ -199,7 +207,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
 
   smd::ReconMainArgs a;
   memset(&a, 0, sizeof(a));
-  if (sc && (flags & SMD_LOSS_L1)) {   // the fused K0 exists for the SSIM instantiations: run the K0 kernel for the others
+  if (sc && !k0_fusable(*sc, h, flags)) {   // see k0_fusable: run the K0 kernel, then the reconstruction on its output
     if (int rc = check_launch(smd::launch_disp_to_depth_fwd(*sc, b, h, w, min_depth, max_depth, depth_out, nullptr, st), "disp_to_depth_fwd")) return rc;
     depth = depth_out; sc = nullptr;
   }

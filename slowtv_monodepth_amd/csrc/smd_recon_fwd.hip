@@ -296,18 +296,39 @@ struct MainCtx {
   unsigned dx0, dx1;       // byte offsets of the two low-resolution columns this lane blends
   float dlx, a_scale, a_off;
   const uint4* __restrict__ rowtab;   // this scale's {offset of row y0, offset of row y1, ly, -} per image row (written by the prep kernel)
-  float q00, q01, q10, q11;   // low-resolution taps in flight
+  // Horizontally blended disparity of the two low-resolution rows the current image row lies between, the taps of a new lower
+  // row in flight, and which rows those are.  Consecutive image rows share their low-resolution rows (a level f times smaller
+  // advances once every f image rows), so a row step loads two taps when the pair advances and nothing otherwise: 0.94
+  // loads per row on average over a 4-level pyramid instead of 4 (each 4-byte wave load costs the texture unit 16 tag look-ups).
+  float h0, h1, p2, p3;
+  unsigned cur_o0, cur_o1;   // byte offsets of the rows h0 / h1 will belong to once the pending update is applied
+  bool pend;                 // finish_depth must first shift h1 -> h0 and blend the taps in flight into h1
 
+  __device__ __forceinline__ float hblend(float a, float b) const { return (1.f - dlx)*a + dlx*b; }
   // The table entry of a row is wave-uniform; readfirstlane tells the compiler so (otherwise it wraps every buffer load
   // that uses the entry as scalar offset into a waterfall loop).
+  // FIRST: the first row of the strip — both rows, not pipelined.  Afterwards the pair either stays or advances by one row (the
+  // launcher uses this instantiation only for pyramid levels that are not taller than the image).
+  template <bool FIRST>
   __device__ __forceinline__ void load_dtaps(int row) {
     const uint4 e = rowtab[row];
     const unsigned o0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.x), o1 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.y);
-    q00 = bld(rs_disp, dx0, o0); q01 = bld(rs_disp, dx1, o0); q10 = bld(rs_disp, dx0, o1); q11 = bld(rs_disp, dx1, o1);
+    if (FIRST) {
+      const float a0 = bld(rs_disp, dx0, o0), a1 = bld(rs_disp, dx1, o0), b0 = bld(rs_disp, dx0, o1), b1 = bld(rs_disp, dx1, o1);
+      h0 = hblend(a0, a1); h1 = hblend(b0, b1); pend = false;
+    } else {
+      // branch-free (a conditional load splits the loop into regions and costs ~20 registers): when the pair stays, the two
+      // loads are sent out of range — the bounds check drops them before they reach the cache — and their zeros are ignored
+      pend = (o0 != cur_o0) || (o1 != cur_o1);
+      const unsigned so = pend ? o1 : 0xf0000000u;
+      p2 = bld(rs_disp, dx0, so); p3 = bld(rs_disp, dx1, so);
+    }
+    cur_o0 = o0; cur_o1 = o1;
   }
   __device__ __forceinline__ float finish_depth(int row) {
+    { const float hn = hblend(p2, p3); h0 = pend ? h1 : h0; h1 = pend ? hn : h1; }
     const float ly = uniform(__builtin_bit_cast(float, rowtab[row].z));
-    const float val = (1.f - ly)*((1.f - dlx)*q00 + dlx*q01) + ly*((1.f - dlx)*q10 + dlx*q11);
+    const float val = (1.f - ly)*h0 + ly*h1;
     const float d = fmaf(a_scale, val, a_off);
     const float dep = (d > 0.f) ? __builtin_amdgcn_rcpf(fmaxf(d, kEps32)) : 0.f;
     if (row >= r0 && row < r1 && interior) bst(rs_dout, lane4, (unsigned)row*w4, dep);   // each row is interior to one strip
@@ -355,7 +376,7 @@ struct MainCtx {
     issue(0, Dn, vfn);
     py = bld3(rs_pk, lane4*3u, so_y + (unsigned)(j + 1)*w4*3u);
     Dcur = Dn;
-    if (DISP) load_dtaps(j + 2); else Dnext = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
+    if (DISP) load_dtaps<false>(j + 2); else Dnext = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
 #endif
     vfn += 1.f;
   }
@@ -563,12 +584,12 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   // prologue: row jstart's loads, depth two rows ahead
   const int jstart = max(cx.r0 - 1, 0);
   cx.vfn = (float)jstart;
-  if (DISP) { cx.load_dtaps(jstart); cx.Dnext = cx.finish_depth(jstart); }
+  if (DISP) { cx.template load_dtaps<true>(jstart); cx.Dnext = cx.finish_depth(jstart); }
   else cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)jstart*cx.w4);
   cx.Dcur = cx.Dnext;
   cx.issue(0, cx.Dnext, cx.vfn);
   cx.py = bld3(cx.rs_pk, cx.lane4*3u, cx.so_y + (unsigned)jstart*cx.w4*3u);
-  if (DISP) cx.load_dtaps(jstart + 1); else cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)(jstart + 1)*cx.w4);
+  if (DISP) cx.template load_dtaps<false>(jstart + 1); else cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)(jstart + 1)*cx.w4);
   cx.vfn += 1.f;
 
   float XA[N][3], XB[N][3], YA[3], YB[3];
