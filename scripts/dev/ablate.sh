@@ -3,7 +3,7 @@
 # register arithmetic and times each variant.  usage: scripts/dev/ablate.sh [cfg2]     (results are NOT numerically meaningful)
 cfg=${1:-cfg2}
 cd "$GRAFT_REPO_ROOT/slowtv_monodepth_amd/csrc"
-for abl in 0 1 2 3 7; do
+for abl in ${ABLS:-0 1 2 3 7}; do
   rm -f smd_recon_fwd.o
   make -s EXTRA="-DSMD_ABLATE=$abl" >/dev/null 2>&1
   echo -n "SMD_ABLATE=$abl: "

@@ -15,11 +15,12 @@ _, y, _ = make_batch(b, h, w, supp, seed=42, device=dev)
 g = torch.Generator(device=dev).manual_seed(0)
 import torch.nn.functional as Fn
 rough = os.environ.get('MB_ROUGH', '0') == '1'   # 1: per-pixel random disparity (incoherent gathers, worst case)
+noise_amp = float(os.environ.get('MB_NOISE', '0.01'))   # per-pixel uniform noise on top of the smooth field (0: a converged network's output)
 def mk(s):
     hs, ws = h >> s, w >> s
     if rough: return 0.05 + 0.9*torch.rand(b, 1, hs, ws, device=dev, generator=g)
     low = 0.2 + 0.6*torch.rand(b, 1, 4, 10, device=dev, generator=g)   # smooth field, like a network's output
-    return Fn.interpolate(low, size=(hs, ws), mode='bilinear', align_corners=False) + 0.01*torch.rand(b, 1, hs, ws, device=dev, generator=g)
+    return Fn.interpolate(low, size=(hs, ws), mode='bilinear', align_corners=False) + noise_amp*torch.rand(b, 1, hs, ws, device=dev, generator=g)
 disps = [mk(s).requires_grad_(True) for s in range(S)]
 T = torch.eye(4, device=dev).repeat(n, b, 1, 1); T[..., :3, 3] = 0.05*torch.randn(n, b, 3, device=dev, generator=g); T.requires_grad_(True)
 flags = F.recon_flags('ssim', True, True)

@@ -23,7 +23,7 @@
 #include "smd_kernels.h"
 
 #ifndef SMD_ABLATE
-#define SMD_ABLATE 0   // diagnosis builds only (scripts/dev/ablate.sh): bit 0 no tap gathers, bit 1 no row loads, bit 2 no stores
+#define SMD_ABLATE 0   // diagnosis builds only (scripts/dev/ablate.sh): bit 0 no tap gathers, bit 1 no row loads (incl. K0), bit 2 no stores, bit 3 no ta/tb loads, bit 4 no target-row load
 #endif
 
 namespace smd {
@@ -298,8 +298,9 @@ struct MainCtx {
   const uint4* __restrict__ rowtab;   // this scale's {offset of row y0, offset of row y1, ly, -} per image row (written by the prep kernel)
   // Horizontally blended disparity of the two low-resolution rows the current image row lies between, the taps of a new lower
   // row in flight, and which rows those are.  Consecutive image rows share their low-resolution rows (a level f times smaller
-  // advances once every f image rows), so a row step loads two taps when the pair advances and nothing otherwise: 0.94
-  // loads per row on average over a 4-level pyramid instead of 4 (each 4-byte wave load costs the texture unit 16 tag look-ups).
+  // advances once every f image rows), so a row step needs the two taps of a new lower row when the pair advances and nothing
+  // otherwise.  (The texture unit charges every wave load ~16 cycles whatever its width, how many lanes are live or in range —
+  // scripts/dev/ta_probe.hip — so this saves cache traffic and two of four load instructions, not four.)
   float h0, h1, p2, p3;
   unsigned cur_o0, cur_o1;   // byte offsets of the rows h0 / h1 will belong to once the pending update is applied
   bool pend;                 // finish_depth must first shift h1 -> h0 and blend the taps in flight into h1
@@ -374,7 +375,11 @@ struct MainCtx {
 #else
     const float Dn = DISP ? finish_depth(j + 1) : Dnext;
     issue(0, Dn, vfn);
+#if (SMD_ABLATE & 16)
+    py = f3{vfn*0.001f, 0.5f, vfn*0.002f};
+#else
     py = bld3(rs_pk, lane4*3u, so_y + (unsigned)(j + 1)*w4*3u);
+#endif
     Dcur = Dn;
     if (DISP) load_dtaps<false>(j + 2); else Dnext = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
 #endif
@@ -416,7 +421,7 @@ struct MainCtx {
     float nz = 0.f;
     if (EMIT) {   // what the centre row shares across scales and supports: {S_y[3], cy2[3], identity error, -}
       const unsigned to = (unsigned)v*w4*4u;
-#if (SMD_ABLATE & 2)
+#if (SMD_ABLATE & (2 | 8))
       t0 = f4{4.5f + vfn*0.01f, 4.4f, 4.3f, 0.2f}; t1 = f3{0.25f, 0.3f, 0.05f}; (void)to;
 #else
       if (SSIM) t0 = bld4(rs_pk, lane4*4u, so_ta + to);
