@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Vector-instruction statistics of the row loops of the two fused kernels, from the ISA hipcc generates (no GPU needed).
+usage: python scripts/dev/isa_stats.py > profiles/rNN_instruction_counts.txt
+Costs per class are the issue rates measured on gfx950 with >= 2 waves per SIMD (profiles/r02_valu_rate2.txt)."""
+import collections, re, subprocess, sys, tempfile
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[2]
+CSRC = ROOT/'slowtv_monodepth_amd'/'csrc'
+FULL = {'v_fma_f32', 'v_fmac_f32', 'v_add_f32', 'v_sub_f32', 'v_subrev_f32', 'v_mul_f32', 'v_mov_b32', 'v_add_u32', 'v_fmaak_f32', 'v_fmamk_f32',
+        'v_sub_u32', 'v_and_b32', 'v_or_b32', 'v_xor_b32', 'v_cndmask_b32'}
+
+def isa(src):
+    out = Path(tempfile.mkdtemp())/'k.s'
+    subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', f'-I{ROOT}/include', '-S', '--cuda-device-only',
+                    str(CSRC/src), '-o', str(out)], check=True, stderr=subprocess.DEVNULL)
+    return out.read_text().split('\n')
+
+def loop_stats(lines, key, rows_per_iter, what, nested=False):
+    start = [i for i, l in enumerate(lines) if l.startswith(key)][0]
+    end = [i for i, l in enumerate(lines) if i > start and 's_endpgm' in l][0]
+    body = lines[start:end]
+    labels = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r'^(\.LBB\d+_\d+):', l))}
+    loops = []
+    for i, l in enumerate(body):
+        m = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i: loops.append((labels[m.group(1)], i))
+    # the row loop: the largest loop (forward), or the largest loop nested inside another one (backward: inside the loop over supports)
+    loops = sorted(set(loops), key=lambda ab: ab[0] - ab[1])
+    if nested: loops = [ab for ab in loops if any(o[0] <= ab[0] and o[1] >= ab[1] and o != ab and (o[1] - o[0]) > 1.1*(ab[1] - ab[0]) for o in loops)]
+    a, b = loops[0]
+    seg = [l.strip() for l in body[a:b + 1] if l.strip() and not l.strip().startswith(('.', ';'))]
+    c, cost, vmem, lds, salu = collections.Counter(), 0.0, 0, 0, 0
+    for l in seg:
+        op = l.split()[0]
+        if op.startswith(('buffer_', 'global_', 'scratch_')): vmem += 1
+        elif op.startswith('ds_'): lds += 1
+        elif op.startswith('s_'): salu += 1
+        if not op.startswith('v_'): continue
+        base = re.sub(r'_(e32|e64|dpp|sdwa)$', '', op)
+        if 'dpp' in l: k, w = 'DPP', 4.5
+        elif base.startswith(('v_rcp', 'v_sqrt', 'v_rsq', 'v_exp', 'v_log', 'v_cos', 'v_sin')): k, w = 'transcendental', 8.4
+        elif base in FULL or base.startswith('v_cmp'): k, w = 'full rate (fma/add/mul/mov/cndmask/cmp)', 2.65
+        else: k, w = 'half rate (min/max/med3/floor/cvt/bfi/int mul/lane)', 4.4
+        c[k] += 1; cost += w
+    n = sum(c.values())
+    print(f'{what}\n  row loop = {rows_per_iter} row steps per iteration: {n/rows_per_iter:.0f} vector instructions per row step '
+          f'({vmem/rows_per_iter:.1f} vector memory, {lds/rows_per_iter:.1f} LDS, {salu/rows_per_iter:.0f} scalar); estimated issue cycles per row step {cost/rows_per_iter:.0f} '
+          f'(average {cost/n:.2f} per instruction)')
+    for k, v in c.most_common(): print(f'    {v/rows_per_iter:7.1f}  {k}')
+    for l in lines[end:]:
+        pass
+
+def regs(lines, key):
+    i = [k for k, l in enumerate(lines) if '.name:' in l and key in l][0]
+    blk = '\n'.join(lines[i - 30:i + 30])
+    v = re.search(r'\.vgpr_count:\s+(\d+)', '\n'.join(lines[i:i + 30])); s = re.search(r'\.vgpr_spill_count:\s+(\d+)', '\n'.join(lines[i:i + 30]))
+    return f'{v.group(1)} VGPRs, {s.group(1)} spilled'
+
+if __name__ == '__main__':
+    f, bw = isa('smd_recon_fwd.hip'), isa('smd_recon_bwd.hip')
+    print('Instruction statistics of the fused kernels\' row loops (hipcc ROCm 7.2, gfx950), produced by scripts/dev/isa_stats.py\n')
+    for key, what in (('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb1EEE', 'k_recon_main<2, true, true, false, true>  (two supports, K0 fused: the bench\'s forward kernel)'),
+                      ('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb0EEE', 'k_recon_main<2, true, true, false, false> (two supports, depth read from a K0 launch)'),
+                      ('_ZN3smd12k_recon_mainILi4ELb1ELb1ELb0ELb1EEE', 'k_recon_main<4, true, true, false, true>  (four supports, cfg 5)')):
+        loop_stats(f, key, 2, what); print('  ' + regs(f, key) + '\n')
+    for key, what in (('_ZN3smd11k_recon_bwdILb1ELi0EEE', 'k_recon_bwd<true, 0> (per support pass; every row does the full adjoint)'),
+                      ('_ZN3smd11k_recon_bwdILb1ELi2EEE', 'k_recon_bwd<true, 2> (per support pass; dead-row skipping; the static count includes the rarely taken clear paths)')):
+        loop_stats(bw, key, 3, what, nested=True); print('  ' + regs(bw, key) + '\n')
+    print('History (same method): round 1 forward 425 per row for two supports; backward 421 per support row step at the start of round 2 (73 of them v_mov),\n'
+          '328 after the (row mod 3) slot rewrite, 300 / 313 now.')
