@@ -9,15 +9,21 @@
 //     copies swap roles) not a single register move.  Image-border reflection in y is a wave-uniform multiplier on the
 //     new row (top) or one subtraction that recovers row h-2 from P (bottom).
 //   * target-side window sums (sum y, 9*sum y^2 - (sum y)^2 + C2) do not depend on scale or support: k_recon_prep computes them
-//     once per sample, together with the RGBX texel repack (padded by one texel right / below so that the bilinear tap
-//     block needs no clamp) and the identity ("static") error of the automask — one launch instead of round 1's pack +
-//     identity passes.  The main kernel reads them back (six coalesced loads per row, L2 hits for three of four scales).
+//     once per sample, together with the repack of the supports into 12-byte RGB texels (padded by one texel right / below so
+//     that the bilinear tap block needs no clamp) and the identity ("static") error of the automask — one launch instead of
+//     round 1's pack + identity passes.  The main kernel reads them back (three row loads per step: target pixel, {S_y, c_0},
+//     {c_1, c_2, static error}; L2 hits for three of four scales).
 //   * geometry: grid normalisation folded into the homography, per-lane column part hoisted out of the row loop, med3
 //     clamps, one float->int conversion per tap block.
 //   * addressing: every array is a buffer resource; the per-lane column offset is a loop-invariant VGPR and the row / plane
 //     offset a scalar (soffset), so the coalesced loads and stores cost no VALU instruction.
 // Supports are processed in pairs inside one launch (n <= 4 in a single pass, no err/sel read-modify-write); the gathers
 // of the next pair / next row are in flight under the current pair's SSIM math.
+// K0 is inside: the DISP instantiations take the decoder's low-resolution disparities, up-sample the row
+// they are about to warp, convert it to depth and write `depth_up` once.
+// What bounds the kernel: about 340-355 vector instructions and 17-18 vector memory instructions per row step for
+// two supports; the CU's texture unit spends ~16.5 cycles per wave memory instruction whatever its width, which makes the two
+// pipes equally loaded.  The launch shape (strip height, tapered tail) is chosen by smd_api.hip from wave traces.
 // Reference semantics: src/tools/geometry.py:285-391, src/losses/photometric.py:23-88, src/losses/reconstruction.py:43-126.
 #include "smd_common.h"
 #include "smd_kernels.h"
