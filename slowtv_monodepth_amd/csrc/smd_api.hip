@@ -36,8 +36,10 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// Tuning knobs (read per call; unset = built-in heuristics): SMD_BWD_SKIP (0..2, dead-row skipping of the fused backward,
-// default 2), SMD_FWD_RH / SMD_BWD_RH rows per strip (>= 4).
+// Tuning knobs (environment, read per call; unset = built-in heuristics): SMD_BWD_SKIP (0..2, dead-row skipping of the fused
+// backward, default 2), SMD_FWD_RH / SMD_BWD_RH rows per strip (>= 4), SMD_FWD_TAPER_B / SMD_BWD_TAPER_B samples at the end of the
+// dispatch order that get short strips (0: none) and SMD_FWD_TAPER_RH / SMD_BWD_TAPER_RH their height, SMD_FWD_NI supports per
+// forward launch (1..4), SMD_BWD_DIRECT0 (1: the backward writes the gradient of a full-resolution scale 0 itself).
 StripPlan plan(int b, int S, int h, int w, int cols) {
   StripPlan p;
   p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
