@@ -111,13 +111,19 @@ __global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int
     const int n = sc.hs[s]*sc.ws[s];
     const int chunks = smooth_chunks_of(n);
     double e = 0.0, dsum = 0.0;
-    for (int c = lane; c < chunks; c += 64) { e += (double)partial[((size_t)pair*max_chunks + c)*2]; dsum += (double)partial[((size_t)pair*max_chunks + c)*2 + 1]; }
+    const float2* __restrict__ pp = (const float2*)partial + (size_t)pair*max_chunks;
+    int c = lane;
+    for (; c + 192 < chunks; c += 256) {   // four independent loads in flight; the order of the additions is fixed
+      const float2 v0 = pp[c], v1 = pp[c + 64], v2 = pp[c + 128], v3 = pp[c + 192];
+      e += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x); dsum += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; c < chunks; c += 64) { const float2 v = pp[c]; e += (double)v.x; dsum += (double)v.y; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); dsum += __shfl_xor(dsum, off, 64); }
     const float mean = (float)(dsum/n);
     const float E = (float)(e/(double)fmaxf(mean, kEps32));
     if (lane == 0) { stats[(size_t)pair*2] = mean; stats[(size_t)pair*2 + 1] = E; }
-    mine += (double)E/((double)b*n)*exp2(-(double)sc.key[s]);
+    mine += ldexp((double)E/((double)b*n), -sc.key[s]);   // 2^-key exactly, without the double-precision exp2 routine
   }
   if (lane == 0) contrib[wv] = mine;
   __syncthreads();
