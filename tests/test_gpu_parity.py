@@ -737,7 +737,8 @@ def test_decoder_glue_with_bias(F, B, Ca, Cs, h, w):
 # Strip-boundary sweep: a wave covers 62 interior columns forward and 60 backward, strips split the rows; widths and
 # heights around those boundaries (and degenerate 2-3 pixel images) against the oracle with random poses/depths.
 SWEEP = [(1, 2, 2, 1, 1), (2, 3, 5, 2, 1), (1, 5, 59, 1, 2), (1, 7, 60, 2, 1), (1, 4, 61, 2, 2), (2, 6, 62, 3, 1), (1, 9, 63, 2, 1),
-         (1, 5, 64, 1, 1), (1, 6, 65, 2, 2), (1, 3, 120, 2, 1), (1, 4, 121, 3, 1), (1, 5, 124, 2, 1), (1, 33, 125, 2, 2), (1, 70, 30, 4, 1)]
+         (1, 5, 64, 1, 1), (1, 6, 65, 2, 2), (1, 3, 120, 2, 1), (1, 4, 121, 3, 1), (1, 5, 124, 2, 1), (1, 33, 125, 2, 2), (1, 70, 30, 4, 1),
+         (1, 20, 70, 5, 1), (2, 9, 40, 6, 2), (1, 14, 66, 8, 1)]   # more than four supports: passes of four with a carried minimum
 
 
 @pytest.mark.parametrize('b,h,w,n,S', SWEEP)
