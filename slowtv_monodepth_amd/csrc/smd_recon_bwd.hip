@@ -58,6 +58,8 @@ __device__ __forceinline__ float usel(bool c, float x, float y) {
 // parameter, so nothing is ever moved between "current / previous / one before" registers (the rolled version spent 73 of
 // its 421 vector instructions per row on v_mov).  The bilinear partials of a row wait two steps in LDS (own column only, no
 // synchronisation), the depth of the row stage C handles is simply loaded a second time (an L1/L2 hit).
+constexpr int kHist = 7;   // values per lane and row slot of the LDS history: dx/dsx[3], dx/dsy[3], depth
+
 template <bool SSIM, int SKIP>
 struct BwdCtx {
   const ReconBwdArgs& a;
@@ -85,7 +87,7 @@ struct BwdCtx {
   unsigned live_hist;          // bit k: the k-th most recent centre row produced coefficients (wave-uniform)
   f3 t0, t1, t2, t3, py;       // loads in flight for the next row
   float pfx, pfy;
-  float Dn, Dc;                // depth of row j+1 (for the next issue) and of row j-2 (stage C)
+  float Dn;                    // depth of row j+1 (for the next issue); it then waits in LDS for stage C three steps later
 #if (SMD_ABLATE_BWD & 8)
   float GH[3][6];
 #endif
@@ -129,8 +131,10 @@ struct BwdCtx {
     for (int c = 0; c < 3; ++c) { Px[c] = 0.f; Pxx[c] = 0.f; Pxy[c] = 0.f; }
 #pragma unroll
     for (int k = 0; k < 9; ++k) ps[k] = 0.f;
-    live_hist = 0; Dc = 0.f;
-    issue(jstart, bld(rs_depth, lane4, (unsigned)jstart*w4));
+    live_hist = 0;
+    const float Dfirst = bld(rs_depth, lane4, (unsigned)jstart*w4);
+    issue(jstart, Dfirst);
+    hist[(0*kHist + 6)*64] = Dfirst;               // row jstart lives in slot 0 (read by stage C only when the strip starts at row 0)
     Dn = bld(rs_depth, lane4, (unsigned)reflect_row(jstart + 1)*w4);
   }
 
@@ -166,14 +170,15 @@ struct BwdCtx {
 #if (SMD_ABLATE_BWD & 8)
       GH[SN][c] = fmaf(pfy, ds - dn, dn); GH[SN][3 + c] = ddy;
 #else
-      hist[(SN*6 + c)*64] = fmaf(pfy, ds - dn, dn);   // dx/dsx; the border-clamp mask is applied in stage C
-      hist[(SN*6 + 3 + c)*64] = ddy;                  // dx/dsy
+      hist[(SN*kHist + c)*64] = fmaf(pfy, ds - dn, dn);   // dx/dsx; the border-clamp mask is applied in stage C
+      hist[(SN*kHist + 3 + c)*64] = ddy;                  // dx/dsy
 #endif
     }
     // Next row's loads, unconditionally (also after the last row, where nothing consumes them): a conditional issue would turn
     // every register of the in-flight loads into a loop phi with a second copy.  Below the image the next row is the
     // reflected one (ReflectionPad2d(1): row h is row h-2), re-synthesised like any other row: no special case in vector code.
     issue(reflect_row(j + 1), Dn);
+    const float Dkeep = Dn;                          // depth of row j+1: parked in LDS at the end of the step (slot SQ is read first)
 #if (SMD_ABLATE_BWD & 2)
     Dn = 1.f + pfx;
 #else
@@ -241,7 +246,7 @@ struct BwdCtx {
       // coefficient rows q-1, q, q+1 all skipped and no L1 term anywhere in the wave: the gradient of this row is zero
       const bool dead = SKIP >= 2 ? ((live_hist & 7u) == 0u && __builtin_amdgcn_ballot_w64(gl != 0.f) == 0) : false;
       const unsigned qro = (unsigned)q*w4;
-      const float D2 = Dc;
+      const float D2 = hist[(SQ*kHist + 6)*64];
       float gD = 0.f;
       if (!dead) {
         float gpx = 0.f, gpy = 0.f;
@@ -250,7 +255,7 @@ struct BwdCtx {
 #if (SMD_ABLATE_BWD & 8)
           const float gxq = GH[SQ][c], gyq = GH[SQ][3 + c];
 #else
-          const float gxq = hist[(SQ*6 + c)*64], gyq = hist[(SQ*6 + 3 + c)*64];
+          const float gxq = hist[(SQ*kHist + c)*64], gyq = hist[(SQ*kHist + 3 + c)*64];
 #endif
           const float xq = X[SQ][c], yq = Y[SQ][c];
           const float d = xq - yq;
@@ -293,11 +298,7 @@ struct BwdCtx {
         else bst(rs_gd, lane4, qro, gD);
       }
     }
-#if (SMD_ABLATE_BWD & 2)
-    Dc = 1.f + pfy;
-#else
-    Dc = bld(rs_depth, lane4, (unsigned)p*w4);      // row q of the next step
-#endif
+    hist[(SQ*kHist + 6)*64] = Dkeep;               // row j+1's slot: stage C reads it at step j+3 (no second load of the depth)
   }
 
   __device__ __forceinline__ void run(int jstart) {
@@ -315,7 +316,7 @@ struct BwdCtx {
 // 138 -> 127 us at cfg 2 (the gathers' latency is what the extra wave hides).
 template <bool SSIM, int SKIP>
 __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconBwdArgs a) {
-  __shared__ float hist_lds[kWavesPerBlock*3*6*64];   // per wave: 3 row slots x {gx, gy} x 3 channels x 64 lanes
+  __shared__ float hist_lds[kWavesPerBlock*3*kHist*64];   // per wave: 3 row slots x ({gx, gy} x 3 channels + depth) x 64 lanes
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // segment of the (possibly tapered) partition this block belongs to (smd_kernels.h: ReconMainArgs::b1)
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   const int h = a.h, w = a.w;
 
   BwdCtx<SSIM, SKIP> cx{a};
-  cx.hist = hist_lds + wid*(3*6*64) + lane;
+  cx.hist = hist_lds + wid*(3*kHist*64) + lane;
   cx.h = h; cx.w = w;
   cx.r0 = syi*seg_rh; cx.r1 = min(cx.r0 + seg_rh, h);
   const int u = sxi*kBwdCols - 2 + lane;
