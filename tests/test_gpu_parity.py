@@ -108,6 +108,44 @@ def test_fused_path_matches_oracle_and_reference(F, golden, name):
     for k, v in errs.items(): assert v < tol, f'{name}: gradient {k} off by {v:.3e} (rel. to max)\n' + '\n'.join(report)
 
 
+@pytest.mark.parametrize('name', TRAIN_CASES)
+@pytest.mark.parametrize('depth_form', ['dict_of_tensors', 'lazy_from_disparities'])
+def test_handlers_match_reference_fixtures(F, golden, name, depth_form):
+    """The drop-in level itself: `handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks)` and
+    `handlers.disp_smooth(crit, disps, imgs)` (src/core/handlers.py:14-67, 262-281) with the reference's criterion classes'
+    keyword arguments, fed (a) the dict of up-sampled depths the reference trainer holds and (b) the `LazyDepths` the K0-fused
+    trainer holds — loss, `supp_imgs_warp` and `automask` against the values the reference itself produced."""
+    import slowtv_monodepth_amd as amd
+    from slowtv_monodepth_amd.handlers import LazyDepths
+    g = golden(name)
+    dev = 'cuda'
+    leaves, static = case_inputs(g, device=dev, requires_grad=False)
+    scales = static['scales']
+    h, w = static['imgs'].shape[-2:]
+    Ts = g['out_Ts'].to(dev)
+    K = (g['out_K'] if g['meta_learn_K'] else g['in_K']).to(dev)
+    mind, maxd = g['meta_min_depth'] or None, g['meta_max_depth'] or None
+    crit = amd.losses.ReconstructionLoss(loss_name=g['meta_loss_name'], use_min=bool(g['meta_use_min']), use_automask=bool(g['meta_use_automask']))
+    if depth_form == 'dict_of_tensors': depths = {s: g[f'out_depth_up_{s}'].to(dev) for s in scales}
+    else: depths = LazyDepths(scales, [leaves[f'disp_{s}'] for s in scales], (h, w), mind, maxd)
+    synth = amd.geometry.ViewSynth((h, w))
+    loss, ld = amd.handlers.image_recon(crit, synth, depths, None, static['imgs'], static['supp_imgs'], Ts, K, noise=static['noise'])
+    torch.testing.assert_close(loss.cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(ld['supp_imgs_warp'].cpu(), g['out_supp_imgs_warp'], rtol=0, atol=1e-4)
+    if g['meta_use_automask']:
+        flips = (ld['automask'].cpu().reshape(-1) != g['out_automask'].bool().reshape(-1)).float().mean().item()
+        assert flips <= 3e-3, f'automask differs on {flips:.2%} of pixels'
+    if depth_form == 'lazy_from_disparities':      # the depth the fused kernel wrote is what a later consumer of fwd['depth_up'] reads
+        assert not depths.pending
+        for s in scales: torch.testing.assert_close(depths[s].cpu(), g[f'out_depth_up_{s}'], rtol=2e-5, atol=1e-5)
+    if g['meta_w_smooth'] >= 0:
+        reg = amd.regularizers.SmoothReg(use_edges=bool(g['meta_use_edges']))
+        l_sm, ld_sm = amd.handlers.disp_smooth(reg, {s: leaves[f'disp_{s}'] for s in scales}, static['imgs'])
+        torch.testing.assert_close(l_sm.cpu(), g['out_loss_disp_smooth'], rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(ld_sm['disp_grad'].cpu(), g['out_disp_grad'], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(ld_sm['image_grad'].cpu(), g['out_image_grad'], rtol=1e-4, atol=1e-5)
+
+
 def test_in_kernel_noise_is_a_tiebreak_only(F, golden):
     """noise=None uses the counter-based in-kernel Gaussian: loss must agree to ~eps, masks may differ only on ties."""
     g = golden('train_kbr_96x128')
