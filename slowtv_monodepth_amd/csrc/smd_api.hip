@@ -345,7 +345,7 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
 // ------------------------------------------------------------------------------------------------
 static int smooth_chunks(const int* hs, const int* ws, int S) {
   int mx = 1;
-  for (int s = 0; s < S; ++s) mx = smd::smooth_chunks_of(hs[s]*ws[s]) > mx ? smd::smooth_chunks_of(hs[s]*ws[s]) : mx;
+  for (int s = 0; s < S; ++s) mx = smd::smooth_units_of(hs[s], ws[s]) > mx ? smd::smooth_units_of(hs[s], ws[s]) : mx;
   return mx;
 }
 

@@ -24,6 +24,9 @@ constexpr int kSmoothChunk = SMD_SMOOTH_CHUNK;   // pixels per block of the smoo
 // image taps are strided gathers from the full-resolution frame), so they get one pixel per thread and start first.
 __host__ __device__ inline int smooth_chunk_px(int n) { return n > 32768 ? kSmoothChunk : 256; }
 __host__ __device__ inline int smooth_chunks_of(int n) { return (n + smooth_chunk_px(n) - 1)/smooth_chunk_px(n); }
+// The forward sweep streams: a wave owns 63 columns (+ 1 halo lane for the right-hand neighbour) and walks down kSmoothRows rows.
+constexpr int kSmoothCols = 63, kSmoothRows = 8;
+__host__ __device__ inline int smooth_units_of(int hs, int ws) { return ((ws + kSmoothCols - 1)/kSmoothCols)*((hs + kSmoothRows - 1)/kSmoothRows); }
 constexpr int kPoseSums = 12;  // accumulated d/d(H[9], a0, a1, tz) per (support, sample)
 
 struct ScaleSet {  // the multi-scale disparity pyramid, passed by value

@@ -55,46 +55,91 @@ __host__ __device__ inline size_t edge_offset(const ScaleSet& sc, int b, int s) 
   return off;
 }
 
-// Pass 1: per block, partial sums of the UN-normalised edge energy E' = sum w |d_p - d_q| and of d itself.  Because
+// Pass 1: per wave, partial sums of the UN-normalised edge energy E' = sum w |d_p - d_q| and of d itself.  Because
 // dhat = d / m with one m > 0 per image, E = E' / m: the mean is not needed inside the pixel loop, so the reference's
 // mean pass and its stencil pass collapse into one sweep.
+// Streaming form (round 2): a wave owns 63 columns + one halo lane and walks down kSmoothRows rows.  A row costs one disparity
+// load and the (resized) image pixel once — 3 loads at the image's own scale, 6 eight-byte loads at the coarser ones; the
+// right-hand neighbour is the next lane (DPP), the neighbour below is the next row's registers.  The texture unit charges a
+// wave load ~16.5 cycles whatever its width (scripts/dev/ta_probe.hip): the per-pixel form issued 13 / 40 loads per 64 pixels
+// (own scale / coarser scales), this one 4-5 / 8 per 63.
+struct SmoothRow { float d, ic[3]; };
+
 __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
-                                                     float* __restrict__ partial, int max_chunks, float* __restrict__ edge_w) {
-  __shared__ float red[4];
-  const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y, chunk = blockIdx.x;   // coarse scales first
+                                                     float* __restrict__ partial, int max_units, float* __restrict__ edge_w) {
+  const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y;   // coarse scales first
+  const int lane = threadIdx.x & 63, unit = blockIdx.x*4 + (threadIdx.x >> 6);
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
-  const int cpx = smooth_chunk_px(n), ppt = cpx/256;
-  if (chunk*cpx >= n) return;
+  if (unit >= smooth_units_of(hs, ws)) return;
+  const int nsx = (ws + kSmoothCols - 1)/kSmoothCols;
+  const int sxi = unit % nsx, syi = unit/nsx;
+  const int r0 = syi*kSmoothRows, r1 = min(r0 + kSmoothRows, hs);
+  const int u = sxi*kSmoothCols + lane, uc = min(u, ws - 1);        // lanes right of the image repeat its last column: |d - d| = 0
+  const bool live = lane < kSmoothCols && u < ws;
   const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
   const float* __restrict__ im = img + (size_t)bi*3*h*w;
-  const bool edges = flags & SMD_USE_EDGES;
+  const bool edges = flags & SMD_USE_EDGES, ident = (hs == h && ws == w);
   float2* __restrict__ ew = (edges && edge_w) ? (float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
+  // horizontal half of the bilinear resize: constant per lane
+  int x0 = uc, x1 = uc; float lx = 0.f;
+  if (!ident) src_index_s(uc, (float)w/(float)ws, w, x0, x1, lx);
+  const bool pair = (x1 == x0 + 1);                                  // false only where the right tap is clamped onto the left one
+  const size_t hw = (size_t)h*w;
+
+  auto load_row = [&](int v) {
+    SmoothRow r;
+    r.d = d[(size_t)v*ws + uc];
+    r.ic[0] = r.ic[1] = r.ic[2] = 0.f;
+    if (!edges) return r;
+    if (ident) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r.ic[c] = im[(size_t)c*hw + (size_t)v*w + uc];
+    } else {
+      int y0, y1; float ly;
+      src_index_s(v, (float)h/(float)hs, h, y0, y1, ly);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* p0 = im + (size_t)c*hw + (size_t)y0*w + x0;
+        const float* p1 = im + (size_t)c*hw + (size_t)y1*w + x0;
+        // the two columns are adjacent: one 8-byte (4-byte aligned) load per image row; p0[1] / p1[1] stay inside the plane
+        // because x0 + 1 <= w - 1 whenever `pair` holds
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        float p00, p01, p10, p11;
+        if (pair) { const f2u a = *(const f2u*)p0, bb = *(const f2u*)p1; p00 = a.x; p01 = a.y; p10 = bb.x; p11 = bb.y; }
+        else { p00 = p0[0]; p01 = p00; p10 = p1[0]; p11 = p10; }
+        r.ic[c] = (1.f - ly)*((1.f - lx)*p00 + lx*p01) + ly*((1.f - lx)*p10 + lx*p11);
+      }
+    }
+    return r;
+  };
+
+  // every row of the strip (and the one below it) is requested before the first is used: the loop is latency-, not
+  // bandwidth-shaped (8 rows x 4-13 loads per wave), so all of them have to be in flight together
+  SmoothRow rows[kSmoothRows + 1];
+#pragma unroll
+  for (int k = 0; k <= kSmoothRows; ++k) rows[k] = load_row(min(r0 + k, hs - 1));   // the last image row pairs with itself
   float accE = 0.f, accD = 0.f;
-  // Branch-free body: neighbours are addressed with clamped indices (the last column / row then pairs a pixel with itself and
-  // contributes |d - d| = 0), so all loads of the thread's pixels are independent of any comparison and can be in flight together.
-  for (int k = 0; k < ppt; ++k) {
-    const int pix = min(chunk*cpx + k*256 + (int)threadIdx.x, n - 1);
-    const bool live = chunk*cpx + k*256 + (int)threadIdx.x < n;
-    const int v = pix/ws, u = pix - v*ws;
-    const int ur = min(u + 1, ws - 1), vb = min(v + 1, hs - 1);
-    const float dc = d[pix], dr = d[v*ws + ur], db = d[vb*ws + u];
+#pragma unroll
+  for (int k = 0; k < kSmoothRows; ++k) {
+    const int v = r0 + k;
+    const SmoothRow& cur = rows[k];
+    const SmoothRow& nxt = rows[k + 1];
+    const float dr = lane_right(cur.d);
     float wx = 1.f, wy = 1.f;
     if (edges) {
-      float ic[3], ir[3], ib[3];
-      img_at(im, h, w, hs, ws, v, u, ic); img_at(im, h, w, hs, ws, v, ur, ir); img_at(im, h, w, hs, ws, vb, u, ib);
-      wx = __expf(-(fabsf(ic[0] - ir[0]) + fabsf(ic[1] - ir[1]) + fabsf(ic[2] - ir[2]))*(1.f/3.f));
-      wy = __expf(-(fabsf(ic[0] - ib[0]) + fabsf(ic[1] - ib[1]) + fabsf(ic[2] - ib[2]))*(1.f/3.f));
+      const float ir0 = lane_right(cur.ic[0]), ir1 = lane_right(cur.ic[1]), ir2 = lane_right(cur.ic[2]);
+      wx = __expf(-(fabsf(cur.ic[0] - ir0) + fabsf(cur.ic[1] - ir1) + fabsf(cur.ic[2] - ir2))*(1.f/3.f));
+      wy = __expf(-(fabsf(cur.ic[0] - nxt.ic[0]) + fabsf(cur.ic[1] - nxt.ic[1]) + fabsf(cur.ic[2] - nxt.ic[2]))*(1.f/3.f));
     }
-    if (live) {
-      if (ew) ew[pix] = make_float2(wx, wy);       // kept for the adjoint: it then never touches the image
-      accD += dc;
-      accE += fabsf(dc - dr)*wx + fabsf(dc - db)*wy;
+    if (live && v < r1) {
+      if (ew) ew[(size_t)v*ws + u] = make_float2(wx, wy);            // kept for the adjoint: it then never touches the image
+      accD += cur.d;
+      accE += fabsf(cur.d - dr)*wx + fabsf(cur.d - nxt.d)*wy;
     }
   }
-  const float totE = block_sum_256(accE, red);
-  const float totD = block_sum_256(accD, red);
-  if (threadIdx.x == 0) {
-    float* pp = partial + (((size_t)s*b + bi)*max_chunks + chunk)*2;
+  const float totE = wave_sum(accE), totD = wave_sum(accD);
+  if (lane == 0) {
+    float* pp = partial + (((size_t)s*b + bi)*max_units + unit)*2;
     pp[0] = totE; pp[1] = totD;
   }
 }
@@ -109,7 +154,7 @@ __global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int
   for (int pair = wv; pair < sc.S*b; pair += 16) {
     const int s = pair/b;
     const int n = sc.hs[s]*sc.ws[s];
-    const int chunks = smooth_chunks_of(n);
+    const int chunks = smooth_units_of(sc.hs[s], sc.ws[s]);
     double e = 0.0, dsum = 0.0;
     const float2* __restrict__ pp = (const float2*)partial + (size_t)pair*max_chunks;
     int c = lane;
@@ -164,9 +209,9 @@ __global__ __launch_bounds__(256) void k_smooth_aux(const ScaleSet sc, int b, co
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st) {
-  int max_chunks = 1;
-  for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_chunks_of(sc.hs[s]*sc.ws[s]));
-  hipLaunchKernelGGL(k_smooth_main, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks, edge_w);
+  int max_chunks = 1;   // units (waves) of the largest scale; the partial sums of a (scale, sample) are strided by it
+  for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_units_of(sc.hs[s], sc.ws[s]));
+  hipLaunchKernelGGL(k_smooth_main, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks, edge_w);
   hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
   if (disp_grad || image_grad)
     hipLaunchKernelGGL(k_smooth_aux, dim3(min(ceil_div(sc.hs[0]*sc.ws[0], 256), 480), b), dim3(256), 0, st, sc, b, img, h, w, stats, disp_grad, image_grad);
