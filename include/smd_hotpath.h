@@ -108,7 +108,7 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
  * depth and writes `depth_up` (S,b,h,w) once (the backward and `fwd['depth_up']` read it); no K0 launch is needed.
  *   disp[s] (b,1,hs[s],ws[s]) host array of S device pointers;  min_depth / max_depth <= 0 mean "not set" (to_inv).
  * Backward: recomputes nothing of K0 — it reads depth_up, adds `g_depth_up_in` (S,b,h,w; the gradient reaching depth_up from
- * other consumers, or NULL), writes the gradient of a full-resolution scale 0 directly and the coarser scales through the
+ * other consumers, or NULL), applies d depth / d disparity inside the fused backward and sends the result through the
  * bilinear adjoint -> g_disp[s] (b,1,hs,ws), overwritten.  Workspace: smd_image_recon_disp_workspace_bytes(). */
 size_t smd_image_recon_disp_workspace_bytes(const int* hs, const int* ws, int S, int b, int n, int h, int w);
 int smd_image_recon_disp_fwd(const float* const* disp, const int* hs, const int* ws, int S, float min_depth, float max_depth,

@@ -39,7 +39,7 @@ int env_int(const char* name, int dflt) {
 // Tuning knobs (environment, read per call; unset = built-in heuristics): SMD_BWD_SKIP (0..2, dead-row skipping of the fused
 // backward, default 2), SMD_FWD_RH / SMD_BWD_RH rows per strip (>= 4), SMD_FWD_TAPER_B / SMD_BWD_TAPER_B samples at the end of the
 // dispatch order that get short strips (0: none) and SMD_FWD_TAPER_RH / SMD_BWD_TAPER_RH their height, SMD_FWD_NI supports per
-// forward launch (1..4), SMD_BWD_DIRECT0 (1: the backward writes the gradient of a full-resolution scale 0 itself).
+// forward launch (1..4).
 StripPlan plan(int b, int S, int h, int w, int cols) {
   StripPlan p;
   p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
@@ -267,7 +267,7 @@ int smd_image_recon_disp_fwd(const float* const* disp, const int* hs, const int*
 }
 
 static int recon_bwd_impl(const float* depth, const float* supp_packed, const float* T, const float* K,
-                          const float* K_inv, const uint8_t* sel, const float* g_loss, const float* g_in, float* g_disp0, float a_scale,
+                          const float* K_inv, const uint8_t* sel, const float* g_loss, const float* g_in, float k0_scale,
                           float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                           int b, int n, int S, int h, int w, int flags, void* stream) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
@@ -282,7 +282,7 @@ static int recon_bwd_impl(const float* depth, const float* supp_packed, const fl
   memset(&a, 0, sizeof(a));
   a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
   a.g_depth = g_depth; a.pose_partial = ws.pose_partial;
-  a.g_in = g_in; a.g_disp0 = g_disp0; a.a_scale = a_scale;
+  a.g_in = g_in; a.k0_scale = k0_scale;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   const StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
@@ -306,7 +306,7 @@ int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_
                         float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream) {
   (void)tgt;   // kept in the signature for ABI stability: the target is read from the packed buffer since ABI 3
-  return recon_bwd_impl(depth, supp_packed, T, K, K_inv, sel, g_loss, nullptr, nullptr, 0.f, g_depth, g_T, g_K, g_Kinv, workspace, workspace_bytes,
+  return recon_bwd_impl(depth, supp_packed, T, K, K_inv, sel, g_loss, nullptr, 0.f, g_depth, g_T, g_K, g_Kinv, workspace, workspace_bytes,
                         b, n, S, h, w, flags, stream);
 }
 
@@ -331,14 +331,11 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
   float* k0_tmp = (float*)((char*)workspace + base + align256((size_t)S*b*h*w*sizeof(float)));
   float a_scale = 1.f;
   if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
-  // Optional (SMD_BWD_DIRECT0=1): a full-resolution scale 0 gets its disparity gradient straight from the fused backward's last
-  // support pass, and the K0 adjoint skips that scale.  Off by default — measured at cfg 2: the fused kernel pays +7 us (the
-  // last pass can no longer skip dead rows of scale 0) for 2.7 us saved in the element-wise part of the K0 adjoint.
-  const bool direct0 = (hs[0] == h && ws[0] == w) && env_int("SMD_BWD_DIRECT0", 0) != 0;
-  if (int rc = recon_bwd_impl(depth_up, supp_packed, T, K, K_inv, sel, g_loss, g_depth_up_in, direct0 ? g_disp[0] : nullptr, a_scale,
+  // The fused backward applies d depth / d(scaled disparity) itself (it has the depth in a register), so the K0 adjoint is a
+  // pure resampling adjoint of g_depth: it neither reads depth_up again (24 MB at cfg 2) nor multiplies.
+  if (int rc = recon_bwd_impl(depth_up, supp_packed, T, K, K_inv, sel, g_loss, g_depth_up_in, a_scale,
                               g_depth, g_T, g_K, g_Kinv, workspace, base, b, n, S, h, w, flags, stream)) return rc;
-  if (direct0 && S == 1) return SMD_OK;
-  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth, k0_tmp, direct0, (hipStream_t)stream),
+  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth, k0_tmp, true, (hipStream_t)stream),
                       "disp_to_depth_bwd");
 }
 

@@ -77,6 +77,7 @@ __device__ __forceinline__ void footprint(int j, float f, int n_lo, int n_hi, in
 __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
                                                              const float* __restrict__ depth_up, const float* __restrict__ g_depth_up,
                                                              float* __restrict__ tmp) {
+  // depth_up == nullptr: the incoming gradient already carries d depth / d disparity (the fused backward applied it)
   const int s = scale_of_block(map, sc.S, blockIdx.x);
   const int blk = blockIdx.x - map.first_block[s], bi = blockIdx.y;
   const int hs = sc.hs[s], ws = sc.ws[s];
@@ -89,8 +90,8 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, 
     for (int k = 0; k < 4; ++k) {
       const int pix = pix0 + k;
       if (pix < h*w) {
-        const float dep = depth_up[ibase + pix];
-        gout[pix] = g_depth_up[ibase + pix]*((dep < dmax) ? -dep*dep : 0.f)*a_scale;
+        if (depth_up) { const float dep = depth_up[ibase + pix]; gout[pix] = g_depth_up[ibase + pix]*((dep < dmax) ? -dep*dep : 0.f)*a_scale; }
+        else gout[pix] = g_depth_up[ibase + pix];
       }
     }
     return;
@@ -101,15 +102,16 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, 
   const float sy = (float)hs/(float)h;
   int vlo, vhi;
   footprint(jy, (float)h/(float)hs, hs, h, vlo, vhi);
-  const float* __restrict__ dcol = depth_up + ibase + u;
+  const float* __restrict__ dcol = depth_up ? depth_up + ibase + u : nullptr;
   const float* __restrict__ gcol = g_depth_up + ibase + u;
   float acc = 0.f;
   for (int v = vlo; v <= vhi; ++v) {
     int y0, y1; float ly;
     src_index(v, sy, hs, y0, y1, ly);
     const float wy = ((y0 == jy) ? 1.f - ly : 0.f) + ((y1 == jy) ? ly : 0.f);
-    const float dep = dcol[(size_t)v*w];
-    acc = fmaf(wy, gcol[(size_t)v*w]*((dep < dmax) ? -dep*dep : 0.f), acc);
+    float gv = gcol[(size_t)v*w];
+    if (dcol) { const float dep = dcol[(size_t)v*w]; gv *= (dep < dmax) ? -dep*dep : 0.f; }
+    acc = fmaf(wy, gv, acc);
   }
   tmp[map.tmp_off[s] + ((size_t)bi*hs + jy)*w + u] = acc;
 }
@@ -147,9 +149,10 @@ size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, Bwd
 }
 
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
-                                    const float* depth_up, const float* g_depth_up, float* tmp, bool skip_identity, hipStream_t st) {
+                                    const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st) {
   float a_scale = 1.f;
   if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
+  if (premultiplied) { a_scale = 1.f; depth_up = nullptr; }
   BwdMap m1, m2;
   disp_to_depth_bwd_tmp_floats(sc, b, h, w, &m1);
   m2 = m1;
@@ -159,7 +162,7 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
     m1.first_block[s] = n1; m2.first_block[s] = n2;
     if (s < sc.S) {
       const bool ident = sc.hs[s] == h && sc.ws[s] == w;
-      n1 += ident ? (skip_identity ? 0 : ceil_div(h*w, 1024)) : ceil_div(sc.hs[s]*w, 256);   // skip: the fused backward already wrote that scale
+      n1 += ident ? ceil_div(h*w, 1024) : ceil_div(sc.hs[s]*w, 256);
       n2 += ident ? 0 : ceil_div(sc.hs[s]*sc.ws[s], 256);
       resampled |= !ident;
     }

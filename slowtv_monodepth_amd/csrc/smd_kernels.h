@@ -101,8 +101,8 @@ struct ReconBwdArgs {
   const float* g_loss;    // device scalar
   float* g_depth;         // (S,b,h,w)
   const float* g_in;      // (S,b,h,w) gradient reaching depth from other consumers, added on the last support pass, or null
-  float* g_disp0;         // K0 fused: (b,1,h,w) gradient of the full-resolution disparity scale, written directly (scale 0 then
-  float a_scale;          //   skips g_depth), or null; d depth/d disp = -depth^2*a_scale
+  float k0_scale;         // K0 fused: != 0 -> g_depth receives dL/d(up-sampled disparity) = dL/d depth * (-depth^2 * k0_scale) (0 where the
+                          //   depth is pinned), so that the K0 adjoint neither reads the depth again nor multiplies; 0 -> dL/d depth
   float* pose_partial;    // [n*b][pose_stride][kPoseSums], the first S*nstrips entries of a (support, sample) used
   int b, n, S, h, w;
   int flags;
@@ -151,7 +151,7 @@ hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, flo
 struct BwdMap;
 size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, BwdMap* map);
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
-                                    const float* depth_up, const float* g_depth_up, float* tmp, bool skip_identity, hipStream_t st);
+                                    const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st);
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st);

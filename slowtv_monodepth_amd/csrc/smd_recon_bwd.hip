@@ -65,11 +65,11 @@ struct BwdCtx {
   const ReconBwdArgs& a;
   // wave-uniform
   int h, w, r0, r1, pb0, pb1, sup;
-  bool use_min, last, direct0, has_gin;
+  bool use_min, last, has_gin;
   unsigned w4, rowbytes, so_tex, so_y, so_ta, so_tb;
   float xmax, ymax, wpf;
   Cam2 cm;
-  rsrc_t rs_pk, rs_depth, rs_sel, rs_gd, rs_gin, rs_gd0;
+  rsrc_t rs_pk, rs_depth, rs_sel, rs_gd, rs_gin;
   // per-lane constants
   unsigned lane4, lane1;
   bool interior;
@@ -286,16 +286,17 @@ struct BwdCtx {
         ps[6] += gnx; ps[7] += gny; ps[8] += gz;
       }
       // dL/d depth: accumulated across the support passes through g_depth; the last pass adds what reaches depth from other
-      // consumers and, for the full-resolution disparity scale of the K0-fused path, applies d depth/d disp on the spot.
+      // consumers.
 #if (SMD_ABLATE_BWD & 4)
       if (gD == 12345.678f) bst(rs_gd, lane4, qro, gD);
       else
 #endif
-      if (interior && (!dead || sup == 0 || (last && (has_gin || direct0)))) {
-        if (sup != 0) gD += bld(rs_gd, lane4, qro);
+      if (interior && (!dead || sup == 0 || (last && has_gin))) {
         if (last && has_gin) gD += bld(rs_gin, lane4, qro);
-        if (direct0) bst(rs_gd0, lane4, qro, gD*((D2 < 1.f/kEps32) ? -D2*D2 : 0.f)*a.a_scale);
-        else bst(rs_gd, lane4, qro, gD);
+        // K0 fused: d depth / d(up-sampled, scaled disparity) applied here, where the depth is at hand (linear, so per pass)
+        if (a.k0_scale != 0.f) gD *= (D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f;
+        if (sup != 0) gD += bld(rs_gd, lane4, qro);
+        bst(rs_gd, lane4, qro, gD);
       }
     }
     hist[(SQ*kHist + 6)*64] = Dkeep;               // row j+1's slot: stage C reads it at step j+3 (no second load of the depth)
@@ -363,8 +364,6 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   cx.rs_gd = make_rsrc(a.g_depth + sb, hw*4);
   cx.has_gin = a.g_in != nullptr;
   cx.rs_gin = make_rsrc(cx.has_gin ? a.g_in + sb : nullptr, cx.has_gin ? hw*4 : 0);
-  const bool direct0_scale = (a.g_disp0 != nullptr) && (s == 0);
-  cx.rs_gd0 = make_rsrc(direct0_scale ? a.g_disp0 + (size_t)bi*hw : nullptr, direct0_scale ? hw*4 : 0);
   const unsigned texel_bytes = (unsigned)(h + 1)*(unsigned)(w + 1)*12u;
   cx.rowbytes = ((unsigned)w + 1u)*12u;
   cx.so_y = (unsigned)(packed_texel_floats(a.b, a.n, h, w)*4) + (unsigned)bi*hw4*3u;
@@ -381,7 +380,6 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     cx.sup = i;
     cx.sel_key = cx.use_min ? (unsigned)i : (unsigned)SMD_SEL_MASKED;
     cx.last = (i == a.n - 1);
-    cx.direct0 = cx.last && direct0_scale;
     cx.run(jstart);
 
     // per-wave pose partials: d/d(H[0..8], a0, a1, tz) of the UN-scaled homography (rows 0/1 of the folded one carry the grid
