@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, 
   const float* __restrict__ dcol = depth_up ? depth_up + ibase + u : nullptr;
   const float* __restrict__ gcol = g_depth_up + ibase + u;
   float acc = 0.f;
+#pragma unroll 6   // the footprint's loads are independent: keep several in flight (the loop is latency-shaped)
   for (int v = vlo; v <= vhi; ++v) {
     int y0, y1; float ly;
     src_index(v, sy, hs, y0, y1, ly);
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_h(const ScaleSet sc, 
   footprint(jx, (float)w/(float)ws, ws, w, ulo, uhi);
   const float* __restrict__ row = tmp + map.tmp_off[s] + ((size_t)bi*hs + jy)*w;
   float acc = 0.f;
+#pragma unroll 6
   for (int u = ulo; u <= uhi; ++u) {
     int x0, x1; float lx;
     src_index(u, sx, ws, x0, x1, lx);
