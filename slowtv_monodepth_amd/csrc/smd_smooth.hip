@@ -236,18 +236,18 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
   if (edges && edge_w) {   // weights cached by the forward sweep: 4 weight + 5 disparity loads per pixel, no image access, no exp
     const float2* __restrict__ ew = (const float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n;
     auto sg = [](float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); };
+    // Branch-free loads: a neighbour outside the image is addressed as the pixel itself and its term masked afterwards, so every
+    // load of the thread's pixels is unconditional and they are all in flight together (the loop is latency-shaped).
+#pragma unroll 4
     for (int kk = 0; kk < ppt; ++kk) {
-      const int pix = blockIdx.x*cpx + kk*256 + threadIdx.x;
-      if (pix >= n) continue;
+      const int pix = min((int)blockIdx.x*cpx + kk*256 + (int)threadIdx.x, n - 1);
+      const bool live = (int)blockIdx.x*cpx + kk*256 + (int)threadIdx.x < n;
       const int v = pix/ws, u = pix - v*ws;
-      const float dc = d[pix]*inv_m;
-      const float2 wc = ew[pix];
-      float G = 0.f;
-      if (u < ws - 1) G += wc.x*sg(dc - d[pix + 1]*inv_m);
-      if (u > 0) G -= ew[pix - 1].x*sg(d[pix - 1]*inv_m - dc);
-      if (v < hs - 1) G += wc.y*sg(dc - d[pix + ws]*inv_m);
-      if (v > 0) G -= ew[pix - ws].y*sg(d[pix - ws]*inv_m - dc);
-      gd[pix] = gs*(G*inv_m - mean_term);
+      const int pr = v*ws + min(u + 1, ws - 1), pl = v*ws + max(u - 1, 0), pb = min(v + 1, hs - 1)*ws + u, pa = max(v - 1, 0)*ws + u;
+      const float dc = d[pix]*inv_m, dr = d[pr]*inv_m, dl = d[pl]*inv_m, db = d[pb]*inv_m, da = d[pa]*inv_m;
+      const float2 wc = ew[pix], wl = ew[pl], wa = ew[pa];
+      const float G = (u < ws - 1 ? wc.x*sg(dc - dr) : 0.f) - (u > 0 ? wl.x*sg(dl - dc) : 0.f) + (v < hs - 1 ? wc.y*sg(dc - db) : 0.f) - (v > 0 ? wa.y*sg(da - dc) : 0.f);
+      if (live) gd[pix] = gs*(G*inv_m - mean_term);
     }
     return;
   }
