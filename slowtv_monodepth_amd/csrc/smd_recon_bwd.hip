@@ -60,7 +60,7 @@ __device__ __forceinline__ float usel(bool c, float x, float y) {
 // synchronisation), the depth of the row stage C handles is simply loaded a second time (an L1/L2 hit).
 constexpr int kHist = 7;   // values per lane and row slot of the LDS history: dx/dsx[3], dx/dsy[3], depth
 
-template <bool SSIM, int SKIP>
+template <bool SSIM, int SKIP, bool ACC>
 struct BwdCtx {
   const ReconBwdArgs& a;
   // wave-uniform
@@ -79,6 +79,7 @@ struct BwdCtx {
   float gs_eq, gs_ne, gl_eq, gl_ne;
   unsigned sel_key;
   float* hist;                 // this lane's column of the wave's LDS history: 3 row slots x {gx, gy} x 3 channels
+  float* gacc;                 // ACC: this lane's column of the wave's dL/d depth accumulator, one slot per strip row (LDS)
   // state
   float X[3][3], Y[3][3];      // [row mod 3][channel]: re-synthesised warped pixel / target pixel
   float Px[3], Pxx[3], Pxy[3]; // sliding vertical sums: rows j-1 + j-2 once row j is in
@@ -291,7 +292,16 @@ struct BwdCtx {
       if (gD == 12345.678f) bst(rs_gd, lane4, qro, gD);
       else
 #endif
-      if (interior && (!dead || sup == 0 || (last && has_gin))) {
+      if (ACC) {
+        // The sum over the support passes stays in LDS (strips of <= kAccRows rows): no read-modify-write of g_depth, one global
+        // store per pixel by the last pass.  Each lane touches only its own column, so no synchronisation is needed.
+        float* slot = gacc + (q - r0)*64;
+        if (last && has_gin) gD += bld(rs_gin, lane4, qro);
+        if (a.k0_scale != 0.f) gD *= (D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f;
+        if (sup != 0) gD += *slot;
+        if (last) { if (interior) bst(rs_gd, lane4, qro, gD); }
+        else *slot = gD;
+      } else if (interior && (!dead || sup == 0 || (last && has_gin))) {
         if (last && has_gin) gD += bld(rs_gin, lane4, qro);
         // K0 fused: d depth / d(up-sampled, scaled disparity) applied here, where the depth is at hand (linear, so per pass)
         if (a.k0_scale != 0.f) gD *= (D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f;
@@ -315,9 +325,13 @@ struct BwdCtx {
 
 // Four waves per SIMD (<= 128 VGPRs): without the cap the allocator settles at 133 and the kernel loses a wave of occupancy,
 // 138 -> 127 us at cfg 2 (the gathers' latency is what the extra wave hides).
-template <bool SSIM, int SKIP>
+constexpr int kAccRows = 16;   // tallest strip whose dL/d depth rows are accumulated across the support passes in LDS
+
+template <bool SSIM, int SKIP, bool ACC>
 __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconBwdArgs a) {
-  __shared__ float hist_lds[kWavesPerBlock*3*kHist*64];   // per wave: 3 row slots x ({gx, gy} x 3 channels + depth) x 64 lanes
+  // per wave: 3 row slots x ({gx, gy} x 3 channels + depth) x 64 lanes [+ ACC: kAccRows x 64 lanes of dL/d depth]; ONE array (a second
+  // __shared__ object makes the compiler serialise LDS and vector-memory waits)
+  __shared__ float hist_lds[kWavesPerBlock*(3*kHist + (ACC ? kAccRows : 0))*64];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // segment of the (possibly tapered) partition this block belongs to (smd_kernels.h: ReconMainArgs::b1)
@@ -331,8 +345,9 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
   const int h = a.h, w = a.w;
 
-  BwdCtx<SSIM, SKIP> cx{a};
-  cx.hist = hist_lds + wid*(3*kHist*64) + lane;
+  BwdCtx<SSIM, SKIP, ACC> cx{a};
+  cx.hist = hist_lds + wid*((3*kHist + (ACC ? kAccRows : 0))*64) + lane;
+  cx.gacc = cx.hist + 3*kHist*64;
   cx.h = h; cx.w = w;
   cx.r0 = syi*seg_rh; cx.r1 = min(cx.r0 + seg_rh, h);
   const int u = sxi*kBwdCols - 2 + lane;
@@ -400,10 +415,15 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
   dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S) : 0u)), block(64*kWavesPerBlock);
   const bool ssim = !(a.flags & SMD_LOSS_L1);
+  // more than one support and strips short enough: the per-pixel sum over the support passes is kept in LDS
+  const bool acc = a.n >= 2 && a.rh <= kAccRows && (a.b1 == a.b || a.rh2 <= kAccRows);
+#define SMD_BWD(SSIM_, SKIP_) do { \
+    if (acc) hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, true>), grid, block, 0, st, a); \
+    else hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, false>), grid, block, 0, st, a); } while (0)
   if (ssim) {
-    if (a.skip_level >= 1) hipLaunchKernelGGL((k_recon_bwd<true, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_recon_bwd<true, 0>), grid, block, 0, st, a);
-  } else hipLaunchKernelGGL((k_recon_bwd<false, 0>), grid, block, 0, st, a);
+    if (a.skip_level >= 1) SMD_BWD(true, 2); else SMD_BWD(true, 0);
+  } else SMD_BWD(false, 0);
+#undef SMD_BWD
   return hipGetLastError();
 }
 
