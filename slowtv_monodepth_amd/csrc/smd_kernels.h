@@ -218,7 +218,8 @@ hipError_t launch_intrinsics_bwd(const float* fs, const float* cs, int b, int h,
 inline int pick_rows_per_strip(int b, int S, int h, int w, int cols, int halo) {
   const int nsx = ceil_div(w, cols);
   const long target_waves = 6144;   // 1.5 x the chip's 4096 wave slots; with the tapered tail (smd_api.hip: taper) fewer, longer waves win
-  const int rh_max = (cols == kFwdCols) ? 16 : 64;
+  const int rh_max = 16;   // forward: short strips win; backward: <= 16 rows keep the cross-support sum of dL/d depth in LDS (k_recon_bwd, ACC)
+  (void)cols;
   int best = 8;
   for (int rh = rh_max; rh >= 8; rh -= 4) {
     long waves = (long)nsx*ceil_div(h, rh)*b*S;
