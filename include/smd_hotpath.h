@@ -81,7 +81,8 @@ int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int
  *           sample by the forward's prep kernel and kept by the caller for the backward — the supports as padded 12-byte
  *           RGB texels (n,b,h+1,w+1,3), the target as RGB texels (b,h,w,3), and per target pixel the SSIM window sums of the
  *           target and the identity error of the automask (2 x (b,h,w,4))
- *   err     (S,b,h,w) out: per-pixel error after min/mean-reprojection and automasking
+ *   err     (S,b,h,w) out or NULL (allowed when n <= 4): per-pixel error after min/mean-reprojection and automasking; the
+ *           training path does not need it (the loss is reduced in the kernel) and saves its 4 bytes per pixel and scale
  *   sel     (S,b,h,w) out uint8: winning support index, or SMD_SEL_MASKED where the static error won
  *   loss    (1) out: mean of err  (= `loss_img_recon`)
  *   warp0   (n,b,3,h,w) out or NULL: warped supports of scale 0 (`loss_dict['supp_imgs_warp']`)

@@ -24,12 +24,13 @@ def mk(s):
 disps = [mk(s).requires_grad_(True) for s in range(S)]
 T = torch.eye(4, device=dev).repeat(n, b, 1, 1); T[..., :3, 3] = 0.05*torch.randn(n, b, 3, device=dev, generator=g); T.requires_grad_(True)
 flags = F.recon_flags('ssim', True, True)
+want_err = os.environ.get("MB_ERR", "0") == "1"   # 1: also write the per-pixel error map (an optional output)
 fused_k0 = os.environ.get('MB_DISP', '1') == '1'   # 1: K0 fused into the reconstruction kernel (the product path); 0: separate K0 launch
 def step():
-    if fused_k0: loss, err, sel, _, _ = F.image_recon_fused_disp(disps, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, min_depth=0.1, max_depth=100, seed=1)
+    if fused_k0: loss, err, sel, _, _ = F.image_recon_fused_disp(disps, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, min_depth=0.1, max_depth=100, seed=1, want_err=want_err)
     else:
         depth_up, _ = F.disp_to_depth(disps, (h, w), 0.1, 100)
-        loss, err, sel, _ = F.image_recon_fused(depth_up, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, seed=1)
+        loss, err, sel, _ = F.image_recon_fused(depth_up, y["imgs"], y["supp_imgs"], T, y["K"], flags=flags, seed=1, want_err=want_err)
     lsm, _, _ = F.disp_smooth_fused({s: d for s, d in enumerate(disps)}, y['imgs'], use_edges=True, want_aux=False)
     (loss + 0.001*lsm).backward()
     return loss

@@ -179,7 +179,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
                           float* warp0, void* workspace, size_t workspace_bytes,
                           int b, int n, int S, int h, int w, int flags, void* stream) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
-  if ((!depth && !sc) || !tgt || !supp || !T || !K || !K_inv || !supp_packed || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if ((!depth && !sc) || !tgt || !supp || !T || !K || !K_inv || !supp_packed || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (smd_packed_supports_bytes(b, n, h, w) >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "the packed buffer (%zu bytes) must stay below 2^32", smd_packed_supports_bytes(b, n, h, w));
   if ((size_t)n*b*3*h*w*4 >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "n*b*3*h*w*4 must stay below 2^32");
   if ((size_t)(h + 1)*(size_t)(w + 1) >= ((size_t)1 << 24)) return fail(SMD_E_INVALID, "(h+1)*(w+1) must stay below 2^24");
@@ -189,6 +189,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   prof_mark(SMD_PROF_RECON_FWD_ALL, st, true);
   int kMaxPerPass = env_int("SMD_FWD_NI", 4);   // supports held in registers by one launch (1..4)
   if (kMaxPerPass < 1 || kMaxPerPass > 4) kMaxPerPass = 4;
+  if (!err && n > kMaxPerPass) return fail(SMD_E_INVALID, "err may be NULL only when all %d supports fit one pass (%d)", n, kMaxPerPass);
 
   {  // once per sample: texel repack, target window sums, identity error (scale independent)
     smd::ReconPrepArgs p;

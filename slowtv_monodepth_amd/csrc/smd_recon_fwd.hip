@@ -281,7 +281,7 @@ struct MainCtx {
   const ReconMainArgs& a;
   int bi, s, h, w, r0, r1, jlast;
   unsigned lane4;          // byte offset of this lane's (reflected) column inside a row of floats
-  bool interior, use_min, automask, has_noise, want_w0;
+  bool interior, use_min, automask, has_noise, want_w0, has_err;
   unsigned hw4, w4, rowbytes;
   float xmax, ymax, wpf;
   Cam2 cam[N];
@@ -507,7 +507,7 @@ struct MainCtx {
 #if (SMD_ABLATE & 4)
         if (e == 123.456f) bst(rs_err, lane4, cro, e + (float)bsel);
 #else
-        bst(rs_err, lane4, cro, e);
+        if (has_err) bst(rs_err, lane4, cro, e);      // the error map is an optional output (logging / tests): one store less per row
         bst8(rs_sel, lane1, cro1, (unsigned)bsel);
 #endif
         lsum += e;
@@ -588,7 +588,8 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
     cx.rowtab = a.rowtab + (size_t)s_*(a.h + 2);
   }
   cx.nz_sb = (AUX && a.noise) ? a.noise + sb : nullptr;
-  cx.rs_err = make_rsrc(a.err + sb, hw*4);
+  cx.has_err = a.err != nullptr;
+  cx.rs_err = make_rsrc(cx.has_err ? a.err + sb : nullptr, cx.has_err ? hw*4 : 0);
   cx.rs_sel = make_rsrc(a.sel + sb, hw);
   cx.lsum = 0.f;
 

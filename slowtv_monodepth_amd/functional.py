@@ -99,7 +99,7 @@ class _ImageRecon(torch.autograd.Function):
     """Fused `handlers.image_recon` (src/core/handlers.py:14-67)."""
 
     @staticmethod
-    def forward(ctx, depth, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp):
+    def forward(ctx, depth, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp, want_err):
         S, b, h, w = depth.shape  # always 4-D here: `image_recon_fused` squeezes the channel dim as an autograd view
         n = supp.shape[0]
         depth = _check('depth', depth, (S, b, h, w)); tgt = _check('imgs', tgt, (b, 3, h, w))
@@ -107,7 +107,7 @@ class _ImageRecon(torch.autograd.Function):
         K = _check('Ks', K, (b, 4, 4)); K_inv = _check('K_inv', K_inv, (b, 4, 4))
         if noise is not None: noise = _check('noise', noise.reshape(S, b, h, w), (S, b, h, w))
         dev = depth.device
-        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32)
+        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32) if (want_err or n > 4) else None
         sel = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.uint8)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         warp0 = torch.empty((n, b, 3, h, w), device=dev, dtype=torch.float32) if want_warp else None
@@ -116,12 +116,12 @@ class _ImageRecon(torch.autograd.Function):
         # padded RGBX texels of the supports + the target's SSIM window sums; written by the forward, reused by the backward
         supp_pk = torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32)
         call('smd_image_recon_fwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
-             noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), supp_pk.data_ptr(), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
+             noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), supp_pk.data_ptr(), err.data_ptr() if err is not None else None, sel.data_ptr(), loss.data_ptr(),
              warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, int(flags), _stream())
         ctx.save_for_backward(depth, tgt, supp_pk, T, K, K_inv, sel)
         ctx.meta = (b, n, S, h, w, int(flags))
         ctx.need_k = bool(ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
-        ctx.mark_non_differentiable(err, sel)
+        ctx.mark_non_differentiable(*([err, sel] if err is not None else [sel]))
         if want_warp: ctx.mark_non_differentiable(warp0)
         return loss, err, sel, warp0
 
@@ -142,17 +142,20 @@ class _ImageRecon(torch.autograd.Function):
              sel.data_ptr(), g_loss.data_ptr(), g_depth.data_ptr(), g_T.data_ptr(),
              g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
              ws.data_ptr(), nbytes, b, n, S, h, w, flags, _stream())
-        return g_depth, None, None, g_T, (g_K if ctx.needs_input_grad[4] else None), (g_Ki if ctx.needs_input_grad[5] else None), None, None, None, None
+        return g_depth, None, None, g_T, (g_K if ctx.needs_input_grad[4] else None), (g_Ki if ctx.needs_input_grad[5] else None), None, None, None, None, None
 
 
-def image_recon_fused(depth, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int, noise=None, seed: int = 0, want_warp: bool = False):
-    """depth (S,b,1,h,w)|(S,b,h,w); returns (loss, err (S,b,1,h,w), sel uint8 (S,b,1,h,w), warp0 (n,b,3,h,w)|None).
+def image_recon_fused(depth, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int, noise=None, seed: int = 0, want_warp: bool = False,
+                      want_err: bool = True):
+    """depth (S,b,1,h,w)|(S,b,h,w); returns (loss, err (S,b,1,h,w)|None, sel uint8 (S,b,1,h,w), warp0 (n,b,3,h,w)|None).
+
+    `want_err=False` (the handlers' choice: nothing on the training path reads the error map) saves its store in the kernel.
 
     `K_inv=None` inverts `Ks` with torch (differentiable), as `ViewSynth.forward` does (src/tools/geometry.py:383)."""
     if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else inv_intrinsics(Ks)
     was5 = depth.ndim == 5
     d4 = depth.squeeze(2) if was5 else depth
-    return _ImageRecon.apply(d4, imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp)
+    return _ImageRecon.apply(d4, imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp, want_err)
 
 
 class _ImageReconDisp(torch.autograd.Function):
@@ -161,7 +164,7 @@ class _ImageReconDisp(torch.autograd.Function):
     kernel, which also writes `depth_up` for the backward and for `fwd['depth_up']`."""
 
     @staticmethod
-    def forward(ctx, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp, min_depth, max_depth, *disps):
+    def forward(ctx, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp, want_err, min_depth, max_depth, *disps):
         b, _, h, w = tgt.shape
         n, S = supp.shape[0], len(disps)
         tgt = _check('imgs', tgt, (b, 3, h, w)); supp = _check('supp_imgs', supp, (n, b, 3, h, w)); T = _check('Ts', T, (n, b, 4, 4))
@@ -173,7 +176,7 @@ class _ImageReconDisp(torch.autograd.Function):
         hs, ws = [d.shape[2] for d in disps], [d.shape[3] for d in disps]
         dev = tgt.device
         depth_up = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32)
-        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32)
+        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32) if (want_err or n > 4) else None
         sel = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.uint8)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         warp0 = torch.empty((n, b, 3, h, w), device=dev, dtype=torch.float32) if want_warp else None
@@ -182,7 +185,7 @@ class _ImageReconDisp(torch.autograd.Function):
         packed = torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32)
         call('smd_image_recon_disp_fwd', ptr_array([d.data_ptr() for d in disps]), int_array(hs), int_array(ws), S, float(min_depth or 0), float(max_depth or 0),
              tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(), noise.data_ptr() if noise is not None else None,
-             int(seed) & (2**64 - 1), packed.data_ptr(), depth_up.data_ptr(), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
+             int(seed) & (2**64 - 1), packed.data_ptr(), depth_up.data_ptr(), err.data_ptr() if err is not None else None, sel.data_ptr(), loss.data_ptr(),
              warp0.data_ptr() if want_warp else None, wsp.data_ptr(), nbytes, b, n, h, w, int(flags), _stream())
         ctx.save_for_backward(depth_up, packed, T, K, K_inv, sel)
         # `depth_up` is a differentiable output that usually has no other consumer: without this autograd would hand the backward
@@ -190,7 +193,7 @@ class _ImageReconDisp(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.meta = (b, n, S, h, w, int(flags), hs, ws, float(min_depth or 0), float(max_depth or 0))
         ctx.need_k = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
-        ctx.mark_non_differentiable(err, sel)
+        ctx.mark_non_differentiable(*([err, sel] if err is not None else [sel]))
         if want_warp: ctx.mark_non_differentiable(warp0)
         return loss, err, sel, warp0, depth_up
 
@@ -214,18 +217,18 @@ class _ImageReconDisp(torch.autograd.Function):
              ptr_array([g.data_ptr() for g in g_disps]), g_T.data_ptr(), g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
              wsp.data_ptr(), nbytes, b, n, h, w, flags, _stream())
         return (None, None, g_T, (g_K if ctx.needs_input_grad[3] else None), (g_Ki if ctx.needs_input_grad[4] else None),
-                None, None, None, None, None, None, *g_disps)
+                None, None, None, None, None, None, None, *g_disps)
 
 
 def image_recon_fused_disp(disps, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int, min_depth=None, max_depth=None, noise=None, seed: int = 0,
-                           want_warp: bool = False):
-    """disps: sequence of (b,1,hs,ws) sigmoid disparities -> (loss, err, sel, warp0|None, depth_up (S,b,1,h,w)).
+                           want_warp: bool = False, want_err: bool = True):
+    """disps: sequence of (b,1,hs,ws) sigmoid disparities -> (loss, err|None, sel, warp0|None, depth_up (S,b,1,h,w)).
 
     The K0-fused form of `disp_to_depth` + `image_recon_fused`: one prep launch, one fused launch, one reduction."""
     if min_depth is not None and min_depth <= 0: raise ValueError(f'Min depth must be greater than 0. ({min_depth})')
     if max_depth and min_depth and max_depth < min_depth: raise ValueError(f'Max depth must be greater than min. ({max_depth} vs. {min_depth})')
     if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else inv_intrinsics(Ks)
-    return _ImageReconDisp.apply(imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp, min_depth, max_depth, *disps)
+    return _ImageReconDisp.apply(imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp, want_err, min_depth, max_depth, *disps)
 
 
 # ---------------------------------------------------------------------------------------------------

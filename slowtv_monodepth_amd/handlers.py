@@ -77,13 +77,13 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
     flags = F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask)
     if isinstance(depths, LazyDepths) and depths.pending:   # K0 fused: no up-sampling launch, the kernel writes the depth stack
         loss, err, sel, warp0, depth_up = F.image_recon_fused_disp(depths.disps, imgs, supp_imgs, Ts, Ks, K_inv, flags=flags, min_depth=depths.min_depth,
-                                                                   max_depth=depths.max_depth, noise=noise, seed=crit.next_seed(), want_warp=want_warp)
+                                                                   max_depth=depths.max_depth, noise=noise, seed=crit.next_seed(), want_warp=want_warp, want_err=False)
         depths.adopt(depth_up)
     else:
         stacked = getattr(depths, 'stacked', None)
         if stacked is None: stacked = torch.stack(list(depths.values()))
         loss, err, sel, warp0 = F.image_recon_fused(stacked, imgs, supp_imgs, Ts, Ks, K_inv, flags=flags, noise=noise, seed=crit.next_seed(),
-                                                    want_warp=want_warp)
+                                                    want_warp=want_warp, want_err=False)
     ld = {}
     if crit.use_automask: ld['automask'] = sel[0] != 255
     if want_warp: ld['supp_imgs_warp'] = warp0
