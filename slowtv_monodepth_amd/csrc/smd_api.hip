@@ -45,6 +45,7 @@ StripPlan plan(int b, int S, int h, int w, int cols) {
   p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
   const int ov = env_int(cols == smd::kFwdCols ? "SMD_FWD_RH" : "SMD_BWD_RH", 0);
   if (ov >= 1) p.rh = ov < kMinStripRows ? kMinStripRows : ov;
+  if (cols == smd::kFwdCols && p.rh > 60) p.rh = 60;   // the K0-fused forward keeps the strip's rh + 4 row-table entries one per lane
   p.nsx = smd::ceil_div(w, cols);
   p.nsy = smd::ceil_div(h, p.rh);
   return p;

@@ -174,6 +174,18 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_prep(const ReconPre
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nstrips = a.nsx*a.nsy;
   const int nbx = ceil_div(nstrips, kWavesPerBlock);
+  // K0 fused: the vertical half of the bilinear up-sampling is the same for every pixel of an image row, so it is tabulated
+  // once per call ({byte offset of the two low-resolution rows, blend weight} per (scale, row); rows h, h+1 for the prefetch)
+  // and the main kernel fetches its strip's entries once.  (Before the early return of waves without a strip: all 256 threads
+  // of block 0 must take part, or entries beyond 64 x the number of live waves stay unwritten for tiny images.)
+  if (a.rowtab != nullptr && blockIdx.x == 0) {
+    for (int e = threadIdx.x; e < a.sc_S*(a.h + 2); e += 64*kWavesPerBlock) {
+      const int sc_i = e/(a.h + 2), row = e - sc_i*(a.h + 2);
+      int y0, y1; float ly;
+      src_index_f(row, (float)a.sc_hs[sc_i]/(float)a.h, a.sc_hs[sc_i], y0, y1, ly);
+      a.rowtab[e] = uint4{(unsigned)y0*(unsigned)a.sc_ws[sc_i]*4u, (unsigned)y1*(unsigned)a.sc_ws[sc_i]*4u, __builtin_bit_cast(unsigned, ly), 0u};
+    }
+  }
   const int bi = blockIdx.x/nbx, strip = (blockIdx.x - bi*nbx)*kWavesPerBlock + wid;
   if (strip >= nstrips) return;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
@@ -199,17 +211,6 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_prep(const ReconPre
     cx.so_tex[k] = (unsigned)((a.i0 + k)*a.b + bi)*texel_bytes;
   }
 
-  // K0 fused: the vertical half of the bilinear up-sampling is the same for every pixel of an image row, so it is tabulated
-  // once per call ({byte offset of the two low-resolution rows, blend weight} per (scale, row); rows h, h+1 for the prefetch)
-  // and the main kernel reads its row's entry with one scalar load: no vector instruction, no vector register.
-  if (a.rowtab != nullptr && blockIdx.x == 0) {
-    for (int e = threadIdx.x; e < a.sc_S*(a.h + 2); e += 64*kWavesPerBlock) {
-      const int sc_i = e/(a.h + 2), row = e - sc_i*(a.h + 2);
-      int y0, y1; float ly;
-      src_index_f(row, (float)a.sc_hs[sc_i]/(float)a.h, a.sc_hs[sc_i], y0, y1, ly);
-      a.rowtab[e] = uint4{(unsigned)y0*(unsigned)a.sc_ws[sc_i]*4u, (unsigned)y1*(unsigned)a.sc_ws[sc_i]*4u, __builtin_bit_cast(unsigned, ly), 0u};
-    }
-  }
   float XA[N][3], XB[N][3], YA[3], YB[3];
   const int jstart = max(cx.r0 - 1, 0), jlast = min(cx.r1, a.h - 1);
   cx.load_row(jstart);
@@ -301,7 +302,19 @@ struct MainCtx {
   rsrc_t rs_disp, rs_dout;
   unsigned dx0, dx1;       // byte offsets of the two low-resolution columns this lane blends
   float dlx, a_scale, a_off;
-  const uint4* __restrict__ rowtab;   // this scale's {offset of row y0, offset of row y1, ly, -} per image row (written by the prep kernel)
+  // This scale's {offset of row y0, offset of row y1, ly, -} per image row, written by the prep kernel.  The entries of the
+  // strip's rows are fetched ONCE, one per lane (tab_*: lane k holds row tab_base + k), and a row's entry is then picked with
+  // v_readlane: read per row from memory they were two vector loads per step — wave-uniform data, but each costing the texture
+  // unit as much as a 64-lane gather (and the scalar cache is no alternative: it is not invalidated between the prep launch
+  // that rewrites the table and this one).
+  const uint4* __restrict__ rowtab;
+  unsigned tab_x, tab_y, tab_z;
+  int tab_base;
+  __device__ __forceinline__ void tab_entry(int row, unsigned& o0, unsigned& o1, float& ly) const {
+    const int k = row - tab_base;
+    o0 = (unsigned)__builtin_amdgcn_readlane((int)tab_x, k); o1 = (unsigned)__builtin_amdgcn_readlane((int)tab_y, k);
+    ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)tab_z, k));
+  }
   // Horizontally blended disparity of the two low-resolution rows the current image row lies between, the taps of a new lower
   // row in flight, and which rows those are.  Consecutive image rows share their low-resolution rows (a level f times smaller
   // advances once every f image rows), so a row step needs the two taps of a new lower row when the pair advances and nothing
@@ -312,14 +325,12 @@ struct MainCtx {
   bool pend;                 // finish_depth must first shift h1 -> h0 and blend the taps in flight into h1
 
   __device__ __forceinline__ float hblend(float a, float b) const { return (1.f - dlx)*a + dlx*b; }
-  // The table entry of a row is wave-uniform; readfirstlane tells the compiler so (otherwise it wraps every buffer load
-  // that uses the entry as scalar offset into a waterfall loop).
   // FIRST: the first row of the strip — both rows, not pipelined.  Afterwards the pair either stays or advances by one row (the
   // launcher uses this instantiation only for pyramid levels that are not taller than the image).
   template <bool FIRST>
   __device__ __forceinline__ void load_dtaps(int row) {
-    const uint4 e = rowtab[row];
-    const unsigned o0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.x), o1 = (unsigned)__builtin_amdgcn_readfirstlane((int)e.y);
+    unsigned o0, o1; float ly_;
+    tab_entry(row, o0, o1, ly_);
     if (FIRST) {
       const float a0 = bld(rs_disp, dx0, o0), a1 = bld(rs_disp, dx1, o0), b0 = bld(rs_disp, dx0, o1), b1 = bld(rs_disp, dx1, o1);
       h0 = hblend(a0, a1); h1 = hblend(b0, b1); pend = false;
@@ -334,7 +345,8 @@ struct MainCtx {
   }
   __device__ __forceinline__ float finish_depth(int row) {
     { const float hn = hblend(p2, p3); h0 = pend ? h1 : h0; h1 = pend ? hn : h1; }
-    const float ly = uniform(__builtin_bit_cast(float, rowtab[row].z));
+    unsigned o0_, o1_; float ly;
+    tab_entry(row, o0_, o1_, ly);
     const float val = (1.f - ly)*h0 + ly*h1;
     const float d = fmaf(a_scale, val, a_off);
     const float dep = (d > 0.f) ? __builtin_amdgcn_rcpf(fmaxf(d, kEps32)) : 0.f;
@@ -586,6 +598,8 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
     cx.dx0 = (unsigned)x0*4u; cx.dx1 = (unsigned)x1*4u;
     cx.a_scale = a.a_scale; cx.a_off = a.a_off;
     cx.rowtab = a.rowtab + (size_t)s_*(a.h + 2);
+    cx.tab_base = max(cx.r0 - 1, 0);                       // rows tab_base .. r1 + 2 are looked up: at most rh + 4 <= 64 entries
+    { const uint4 e = cx.rowtab[min(cx.tab_base + lane, a.h + 1)]; cx.tab_x = e.x; cx.tab_y = e.y; cx.tab_z = e.z; }
   }
   cx.nz_sb = (AUX && a.noise) ? a.noise + sb : nullptr;
   cx.has_err = a.err != nullptr;
