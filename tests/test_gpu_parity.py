@@ -200,6 +200,29 @@ BASELINE_CASES = {
 }
 
 
+def _judge_gradients(g_hip, g_ref, g_64, n_flips):
+    """Gradient acceptance at BASELINE size (shared by the two baseline-size tests).  Dense gradients: 99.9 % quantile of the
+    difference + an outlier budget tied to the number of decision flips; pose / intrinsics gradients: 5e-3 against the fp32
+    oracle, or no further from the oracle's fp64 run than three times the fp32 oracle is."""
+    report, ok = [], True
+    for k in g_ref:
+        diff, mx = (g_hip[k] - g_ref[k]).abs(), g_ref[k].abs().max()
+        if k.startswith('disp_'):
+            allow = 30*(n_flips + 3)                     # a flip touches its 3x3 window, at most 5x5 low-resolution pixels
+            level = 1.0 - max(1e-3, 2.0*allow/diff.numel())
+            q = torch.quantile(diff.flatten()[:: max(1, diff.numel()//2_000_000)], level).item()/mx.item()
+            outl = int((diff > 1e-3*mx).sum())
+            report.append(f'{k}: q{100*level:.1f}={q:.1e} outliers={outl}')
+            ok &= q < 2e-4 and outl <= allow
+        else:
+            e = (diff.max()/mx).item()
+            mx64 = g_64[k].abs().max()
+            e_hip64, e_ref64 = ((g_hip[k] - g_64[k]).abs().max()/mx64).item(), ((g_ref[k] - g_64[k]).abs().max()/mx64).item()
+            report.append(f'{k}={e:.1e} (vs fp64: hip {e_hip64:.1e}, fp32 oracle {e_ref64:.1e})')
+            ok &= e < 5e-3 or e_hip64 <= 3.0*e_ref64
+    return report, ok
+
+
 @pytest.mark.parametrize('name', list(BASELINE_CASES))
 def test_baseline_size_matches_oracle(F, name):
     """HIP vs oracle at the BASELINE shapes: loss 1e-4 relative (BASELINE.json; asserted at 2e-5), error map, selection flips,
@@ -254,22 +277,7 @@ def test_baseline_size_matches_oracle(F, name):
     # samples: they are judged by their relative error against the fp32 oracle (5e-3), or — where the fp32 oracle itself is
     # that far from its own fp64 run — by being no further from the fp64 result than three times the fp32 oracle is.
     n_flips = int(flips.sum())
-    report, ok = [], True
-    for k in g_ref:
-        diff, mx = (g_hip[k] - g_ref[k]).abs(), g_ref[k].abs().max()
-        if k.startswith('disp_'):
-            allow = 30*(n_flips + 3)                     # a flip touches its 3x3 window, at most 5x5 low-resolution pixels
-            level = 1.0 - max(1e-3, 2.0*allow/diff.numel())
-            q = torch.quantile(diff.flatten()[:: max(1, diff.numel()//2_000_000)], level).item()/mx.item()
-            outl = int((diff > 1e-3*mx).sum())
-            report.append(f'{k}: q{100*level:.1f}={q:.1e} outliers={outl}')
-            ok &= q < 2e-4 and outl <= allow
-        else:
-            e = (diff.max()/mx).item()
-            mx64 = g_64[k].abs().max()
-            e_hip64, e_ref64 = ((g_hip[k] - g_64[k]).abs().max()/mx64).item(), ((g_ref[k] - g_64[k]).abs().max()/mx64).item()
-            report.append(f'{k}={e:.1e} (vs fp64: hip {e_hip64:.1e}, fp32 oracle {e_ref64:.1e})')
-            ok &= e < 5e-3 or e_hip64 <= 3.0*e_ref64
+    report, ok = _judge_gradients(g_hip, g_ref, g_64, n_flips)
     free = {k: rel_to_max(g_hip[k], g_free[k]) for k in g_free}
     parity_note(f'{name}: loss hip={l_hip:.8f} oracle={l_ref:.8f} (rel {abs(l_hip - l_ref)/abs(l_ref):.2e}); sel flips {n_flips} of {flips.numel()} '
           f'({flips.float().mean().item():.2e}, largest gap between the tied errors {tie:.1e}); |err diff| > 2e-4 on {bad:.2e} of pixels '
@@ -278,6 +286,103 @@ def test_baseline_size_matches_oracle(F, name):
     assert abs(l_hip - l_ref) <= 2e-5*abs(l_ref)
     assert bad <= 3e-3 and flips.float().mean().item() <= 1e-4
     assert tie <= 1e-4, 'a selection that differs from the oracle must be a tie within the error-map tolerance (2e-4)'
+    assert ok, f'{name}: gradients differ: ' + ' '.join(report)
+
+
+
+@pytest.mark.parametrize('name', list(BASELINE_CASES))
+def test_baseline_size_timed_path_matches_oracle(F, name, monkeypatch):
+    """The EXACT path `bench.py` times, at the BASELINE shapes, value for value against the oracle: the trainer's call
+    `handlers.image_recon(crit, synth, LazyDepths(...), None, imgs, supp_imgs, Ts, K)` with `want_warp=False` (src/core/trainer.py:316-321,
+    388-392 in the reference) -> `image_recon_fused_disp(noise=None, want_warp=False, want_err=False)` -> the hot instantiation
+    `k_recon_main<n, true, true, false, true>` (K0 fused, in-kernel tie-break noise, no error map) and, through autograd,
+    `smd_image_recon_disp_bwd` (k0_scale != 0, no incoming depth gradient) + the K0 adjoint; `handlers.disp_smooth(want_aux=False)`.
+    Compared with `O.loss_path(noise=zeros)`: loss 2e-5 relative, `sel` equal off the ties (every difference proven a tie by the
+    forced oracle run), the adopted `depth_up`, gradients w.r.t. every disparity scale, `aa`, `t` (`fs`, `cs` at cfg 4) under
+    identical routing.  A second launch of the same build with `want_err=True` checks its error map."""
+    import slowtv_monodepth_amd as amd
+    from slowtv_monodepth_amd import functional as Fm
+    from slowtv_monodepth_amd.handlers import LazyDepths
+    b, h, w, supp, S, learn_k = BASELINE_CASES[name]
+    n = len(supp)
+    y, disps, aa, t, _ = _baseline_inputs(b, h, w, supp, S, seed=7)
+    g = torch.Generator().manual_seed(99)
+    fs, cs = 0.3*torch.randn(b, 2, generator=g), 0.2*torch.randn(b, 2, generator=g)
+    zeros = torch.zeros(S*b, 1, h, w)
+
+    seen = {}
+    real = Fm.image_recon_fused_disp
+
+    def spy(disps_, imgs_, supp_, Ts_, Ks_, K_inv_=None, **kw):
+        out = real(disps_, imgs_, supp_, Ts_, Ks_, K_inv_, **kw)
+        seen.update(kw=kw, err=out[1], sel=out[2], warp0=out[3], depth_up=out[4])
+        return out
+    monkeypatch.setattr(Fm, 'image_recon_fused_disp', spy)
+
+    dev = 'cuda'
+    leaf = lambda v, d=dev, dt=torch.float32: v.detach().clone().to(d, dt).requires_grad_(True)
+    d = {s: leaf(v) for s, v in disps.items()}
+    a_, t_, fs_, cs_ = leaf(aa), leaf(t), leaf(fs), leaf(cs)
+    imgs, sup = y['imgs'].to(dev), y['supp_imgs'].to(dev)
+    Ts = F.pose_matrices(a_.flatten(0, 1), t_.flatten(0, 1)).unflatten(0, (n, b))
+    K, K_inv = F.intrinsics(fs_, cs_, (h, w)) if learn_k else (y['K'].to(dev), None)
+    crit = amd.losses.ReconstructionLoss(loss_name='ssim', use_min=True, use_automask=True)
+    reg = amd.regularizers.SmoothReg(use_edges=True)
+    depths = LazyDepths(list(d.keys()), list(d.values()), (h, w), 0.1, 100)
+    l_rec, ld = amd.handlers.image_recon(crit, amd.geometry.ViewSynth((h, w)), depths, None, imgs, sup, Ts, K, K_inv=K_inv, want_warp=False)
+    l_sm, _ = amd.handlers.disp_smooth(reg, d, imgs, want_aux=False)
+    (l_rec + 0.001*l_sm).backward()
+    torch.cuda.synchronize()
+    # this IS the timed instantiation: no caller noise, no warp output, no error map -> SINGLE && !AUX && DISP (smd_recon_fwd.hip: launch_recon_main)
+    assert seen['kw']['noise'] is None and seen['kw']['want_warp'] is False and seen['kw']['want_err'] is False
+    assert seen['err'] is None and seen['warp0'] is None and not depths.pending
+    l_hip = (l_rec + 0.001*l_sm).item()
+    s_hip = seen['sel'].cpu().reshape(S, b, h, w)
+    g_hip = {f'disp_{s}': v.grad.cpu() for s, v in d.items()}
+    g_hip['aa'], g_hip['t'] = a_.grad.cpu(), t_.grad.cpu()
+    if learn_k: g_hip['fs'], g_hip['cs'] = fs_.grad.cpu(), cs_.grad.cpu()
+    assert torch.equal(ld['automask'].cpu().reshape(b, h, w), s_hip[0] != 255)
+
+    def oracle(force_sel=None, dt=torch.float32):
+        dd = {s: leaf(v, 'cpu', dt) for s, v in disps.items()}
+        ao, to, fo, co = leaf(aa, 'cpu', dt), leaf(t, 'cpu', dt), leaf(fs, 'cpu', dt), leaf(cs, 'cpu', dt)
+        To = O.T_from_AAt(ao.flatten(0, 1), to.flatten(0, 1)).unflatten(0, (n, b))
+        Ko = O.resize_K(O.build_K(fo, co), (h, w)) if learn_k else y['K'].to(dt)
+        loss, out = O.loss_path(dd, y['imgs'].to(dt), y['supp_imgs'].to(dt), To, Ko, noise=zeros.to(dt), aten=True, force_sel=force_sel)
+        loss.backward()
+        grads = {f'disp_{s}': v.grad.float() for s, v in dd.items()}
+        grads['aa'], grads['t'] = ao.grad.float(), to.grad.float()
+        if learn_k: grads['fs'], grads['cs'] = fo.grad.float(), co.grad.float()
+        full = out['full']
+        return (loss.item(), full['err'].detach().reshape(S, b, h, w), full['sel'].reshape(S, b, h, w), grads, full.get('tie_gap'),
+                torch.stack([out['depth_up'][s].detach() for s in dd]).reshape(S, b, h, w))
+
+    l_ref, e_ref, s_ref, g_free, _, dep_ref = oracle()
+    flips = s_hip != s_ref
+    forced = s_hip.reshape(S*b, 1, h, w)
+    _, _, _, g_ref, gap, _ = oracle(force_sel=forced) if flips.any() else (None, None, None, g_free, None, None)
+    tie = gap.abs().max().item() if gap is not None else 0.0
+    _, _, _, g_64, _, _ = oracle(force_sel=forced, dt=torch.float64)
+    n_flips = int(flips.sum())
+    report, ok = _judge_gradients(g_hip, g_ref, g_64, n_flips)
+
+    # the error map of the same build (has_err is a run-time switch of the hot instantiation; same seed -> same decisions)
+    with torch.no_grad():
+        _, err2, sel2, _, _ = real([v.detach() for v in d.values()], imgs, sup, Ts.detach(), K.detach(), K_inv.detach() if K_inv is not None else None,
+                                   flags=F.recon_flags('ssim', True, True), min_depth=0.1, max_depth=100, noise=None, seed=seen['kw']['seed'],
+                                   want_warp=False, want_err=True)
+    e_hip = err2.cpu().reshape(S, b, h, w)
+    bad = ((e_hip - e_ref).abs() > 2e-4).float().mean().item()
+    dep_diff = (seen['depth_up'].detach().cpu().reshape(S, b, h, w) - dep_ref).abs()
+    dep_rel = (dep_diff/dep_ref.abs().clamp(min=1e-6)).max().item()
+    parity_note(f'timed path {name}: loss hip={l_hip:.8f} oracle={l_ref:.8f} (rel {abs(l_hip - l_ref)/abs(l_ref):.2e}); sel differs on {n_flips} of '
+                f'{flips.numel()} ({flips.float().mean().item():.2e}, largest gap between the tied errors {tie:.1e}); |err diff| > 2e-4 on {bad:.2e} of '
+                f'pixels (max {(e_hip - e_ref).abs().max():.2e}); depth_up max rel diff {dep_rel:.1e}\n  gradients, same routing: ' + ' '.join(report))
+    assert torch.equal(sel2.cpu().reshape(S, b, h, w), s_hip), 'want_err must not change the decisions of the same build and seed'
+    assert abs(l_hip - l_ref) <= 2e-5*abs(l_ref)
+    assert bad <= 3e-3 and flips.float().mean().item() <= 1e-4
+    assert tie <= 1e-4, 'a selection that differs from the oracle must be a tie within the error-map tolerance (2e-4)'
+    torch.testing.assert_close(seen['depth_up'].detach().cpu().reshape(S, b, h, w), dep_ref, rtol=2e-5, atol=1e-5)
     assert ok, f'{name}: gradients differ: ' + ' '.join(report)
 
 
