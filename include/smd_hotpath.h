@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 3
+#define SMD_ABI_VERSION 4
 
 #define SMD_OK 0
 #define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
@@ -39,6 +39,7 @@ extern "C" {
 #define SMD_NEED_K_GRAD 0x8    /* backward also emits dL/dK and dL/dK_inv (learned intrinsics) */
 #define SMD_USE_EDGES 0x10     /* SmoothReg(use_edges=True) (smooth.py:91-94) */
 #define SMD_LOSS_L2 0x20       /* DenseL2Error (photometric.py:17-20; loss_name='l2', un-fused operators only) */
+#define SMD_PACKED_READY 0x40  /* smd_image_recon_*_fwd: `supp_packed` was already filled by smd_image_recon_prep() for these frames */
 /* RegressionLoss (src/losses/regression.py:40-75) */
 #define SMD_REGR_L1 0x0
 #define SMD_REGR_LOG_L1 0x1
@@ -80,7 +81,10 @@ int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int
  *   supp_packed out, smd_packed_supports_bytes() bytes (< 4 GB): what every scale and support shares, produced once per
  *           sample by the forward's prep kernel and kept by the caller for the backward — the supports as padded 12-byte
  *           RGB texels (n,b,h+1,w+1,3), the target as RGB texels (b,h,w,3), and per target pixel the SSIM window sums of the
- *           target and the identity error of the automask (2 x (b,h,w,4))
+ *           target and the identity error of the automask (2 x (b,h,w,4)); then a small tail of launch scratch (the K0
+ *           row table and the arrival counters of the in-launch reductions; the backward resets its counters, which is
+ *           why it takes the buffer non-const).  It depends on the frames only: smd_image_recon_prep() can fill it ahead of
+ *           time (e.g. on a side stream while the networks run) and the forward is then called with SMD_PACKED_READY.
  *   err     (S,b,h,w) out or NULL (allowed when n <= 4): per-pixel error after min/mean-reprojection and automasking; the
  *           training path does not need it (the loss is reduced in the kernel) and saves its 4 bytes per pixel and scale
  *   sel     (S,b,h,w) out uint8: winning support index, or SMD_SEL_MASKED where the static error won
@@ -93,11 +97,19 @@ int smd_disp_to_depth_bwd(const int* hs, const int* ws, int S, int b, int h, int
  *           (required iff SMD_NEED_K_GRAD; only the 3x3 / 2x3 blocks the path reads are non-zero). */
 size_t smd_image_recon_workspace_bytes(int b, int n, int S, int h, int w);
 size_t smd_packed_supports_bytes(int b, int n, int h, int w);
+/* The frame-only half of the forward (texel repack, target window sums, identity error; reference: the un-warped `source`
+ * branch of src/losses/reconstruction.py:70-71 and the per-scale re-reads of handlers.py:45-56).  `flags` must carry the same
+ * SMD_USE_MIN / SMD_USE_AUTOMASK / SMD_LOSS_L1 bits as the forward that follows.  hs, ws (S entries) describe the disparity
+ * pyramid of the K0-fused forward (its row table is built here); NULL / S = 0 for the depth-input forward. */
+int smd_image_recon_prep(const float* tgt, const float* supp, float* supp_packed, const int* hs, const int* ws, int S,
+                         int b, int n, int h, int w, int flags, void* stream);
+/* Supports one forward launch holds in registers (4 unless SMD_FWD_NI overrides it): `err` may be NULL only when n <= this. */
+int smd_image_recon_supports_per_pass(void);
 int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
                         const float* K_inv, const float* noise, uint64_t seed, float* supp_packed, float* err, uint8_t* sel, float* loss,
                         float* warp0, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream);
-int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_packed, const float* T, const float* K,
+int smd_image_recon_bwd(const float* depth, const float* tgt, float* supp_packed, const float* T, const float* K,
                         const float* K_inv, const uint8_t* sel, const float* g_loss,
                         float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream);
@@ -117,7 +129,7 @@ int smd_image_recon_disp_fwd(const float* const* disp, const int* hs, const int*
                              const float* noise, uint64_t seed, float* supp_packed, float* depth_up, float* err, uint8_t* sel, float* loss,
                              float* warp0, void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream);
 int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_depth, float max_depth, const float* depth_up,
-                             const float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
+                             float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
                              const float* g_loss, const float* g_depth_up_in, float* const* g_disp, float* g_T, float* g_K, float* g_Kinv,
                              void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream);
 
@@ -270,12 +282,14 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
 /* ------------------------------------------------------------------------------------------------
  * Kernel timing hooks for bench.py: while enabled, every call of the named entry point records a HIP event pair on the
  * caller's stream, either around its DOMINANT kernel (the fused strip kernel k_recon_main / k_recon_bwd) or around ALL
- * of its launches (forward: per-sample prep + main + loss reduction; backward: main + pose finalize).
+ * of its launches (forward: per-sample prep, unless SMD_PACKED_READY, + main; backward: the fused adjoint [+ the K0 adjoint is
+ * outside]; the scalar / pose reductions run inside those launches since ABI 4), or around the prep launches wherever they run.
  * smd_profile_collect() waits for the recorded events and returns their durations in ms.  Not thread-safe; one device. */
 #define SMD_PROF_RECON_FWD 0       /* smd_image_recon_fwd, dominant kernel */
 #define SMD_PROF_RECON_BWD 1       /* smd_image_recon_bwd, dominant kernel */
 #define SMD_PROF_RECON_FWD_ALL 2   /* smd_image_recon_fwd, every launch */
 #define SMD_PROF_RECON_BWD_ALL 3   /* smd_image_recon_bwd, every launch */
+#define SMD_PROF_RECON_PREP 4      /* k_recon_prep launches (inside the forward entry point or smd_image_recon_prep) */
 int smd_profile_enable(int which, int capacity);
 int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out);
 

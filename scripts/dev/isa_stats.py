@@ -63,8 +63,8 @@ if __name__ == '__main__':
                       ('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb0EEE', 'k_recon_main<2, true, true, false, false> (two supports, depth read from a K0 launch)'),
                       ('_ZN3smd12k_recon_mainILi4ELb1ELb1ELb0ELb1EEE', 'k_recon_main<4, true, true, false, true>  (four supports, cfg 5)')):
         loop_stats(f, key, 2, what); print('  ' + regs(f, key) + '\n')
-    for key, what in (('_ZN3smd11k_recon_bwdILb1ELi0ELb1EEE', 'k_recon_bwd<true, 0, true> (per support pass; every row does the full adjoint)'),
-                      ('_ZN3smd11k_recon_bwdILb1ELi2ELb1EEE', 'k_recon_bwd<true, 2, true> (per support pass; dead-row skipping; the static count includes the rarely taken clear paths)')):
+    for key, what in (('_ZN3smd11k_recon_bwdILb1ELi0ELi2EEE', 'k_recon_bwd<true, 0, 2> (per support pass; every row does the full adjoint)'),
+                      ('_ZN3smd11k_recon_bwdILb1ELi2ELi2EEE', 'k_recon_bwd<true, 2, 2> (per support pass; dead-row skipping; the static count includes the rarely taken clear paths)')):
         loop_stats(bw, key, 3, what, nested=True); print('  ' + regs(bw, key) + '\n')
     print('History (same method): round 1 forward 425 per row for two supports; backward 421 per support row step at the start of round 2 (73 of them v_mov),\n'
           '328 after the (row mod 3) slot rewrite, 300 / 313 now.')

@@ -36,7 +36,7 @@ def step():
     return loss
 for _ in range(3): step()
 torch.cuda.synchronize()
-_lib.lib.smd_profile_enable(0, iters); _lib.lib.smd_profile_enable(1, iters)
+for k in range(5): _lib.lib.smd_profile_enable(k, iters)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(iters): l = step()
@@ -45,8 +45,8 @@ def col(which):
     buf = (C.c_float*iters)(); k = C.c_int(0)
     _lib.lib.smd_profile_collect(which, buf, iters, C.byref(k)); v = sorted(buf[i] for i in range(k.value))
     return v[len(v)//2]*1e3, v[0]*1e3
-f, fb = col(0); bw, bb = col(1)
+f, fb = col(0); bw, bb = col(1); fa, _ = col(2); ba, _ = col(3); pr, _ = col(4)
 B = b*h*w*(S*9 + 12*(1 + n))
 tag = ' '.join(f'{k}={v}' for k, v in os.environ.items() if k.startswith('SMD_') or k.startswith('MB_'))
 print(f'{name} [{tag}] fwd med {f:.1f} us (min {fb:.1f}) = {B/f/1e3:.0f} GB/s | bwd med {bw:.1f} us (min {bb:.1f}) = {B/bw/1e3:.0f} GB/s | '
-      f'whole loss path fwd+bwd {e0.elapsed_time(e1)/iters*1e3:.0f} us/iter | loss {l.item():.6f}')
+      f'entry points: fwd {fa:.1f} (of which prep {pr:.1f}) bwd {ba:.1f} us | whole loss path fwd+bwd {e0.elapsed_time(e1)/iters*1e3:.0f} us/iter | loss {l.item():.6f}')

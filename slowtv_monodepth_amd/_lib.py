@@ -17,7 +17,7 @@ __all__ = ['lib', 'call', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_
 _HERE = Path(__file__).resolve().parent
 lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
 
-FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10, 'loss_l2': 0x20}
+FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10, 'loss_l2': 0x20, 'packed_ready': 0x40}
 REGR_FLAGS = {'l1': 0x0, 'log_l1': 0x1, 'berhu': 0x2, 'invert': 0x4}
 SEL_MASKED = 255
 MAX_SCALES = 8
@@ -34,6 +34,8 @@ PROTOTYPES = {
     'smd_disp_to_depth_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'smd_image_recon_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'smd_packed_supports_bytes': (_sz, [_i, _i, _i, _i]),
+    'smd_image_recon_prep': (_i, [_vp]*5 + [_i]*6 + [_vp]),
+    'smd_image_recon_supports_per_pass': (_i, []),
     'smd_image_recon_fwd': (_i, [_vp]*7 + [_u64] + [_vp]*6 + [_sz] + [_i]*6 + [_vp]),
     'smd_image_recon_bwd': (_i, [_vp]*13 + [_sz] + [_i]*6 + [_vp]),
     'smd_image_recon_disp_workspace_bytes': (_sz, [_vp, _vp, _i, _i, _i, _i, _i]),
@@ -95,7 +97,7 @@ def _load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if handle.smd_abi_version() != 3: raise ImportError(f'ABI version mismatch in {lib_path}')
+    if handle.smd_abi_version() != 4: raise ImportError(f'ABI version mismatch in {lib_path}')
     return handle
 
 

@@ -27,6 +27,7 @@ int check_launch(hipError_t e, const char* what) {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct StripPlan { int rh, nsx, nsy; };
+constexpr int kBwdAccRows = 16;    // = smd::kAccRows of smd_recon_bwd.hip
 constexpr int kMinStripRows = 4;   // lower bound of the rows-per-strip override; the workspace is sized for it
 int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil_div(h, kMinStripRows); }
 
@@ -66,7 +67,7 @@ void taper(int& b1, int& rh2, int& nsy2, int b, int h, const StripPlan& pl, cons
 
 // ---- optional event-pair recording around the dominant kernels (bench.py roofline measurement) ----
 struct ProfSlot { hipEvent_t* ev = nullptr; int cap = 0, used = 0; };
-ProfSlot g_prof[4];   // SMD_PROF_*: dominant forward kernel, dominant backward kernel, whole forward entry point, whole backward entry point
+ProfSlot g_prof[5];   // SMD_PROF_*: dominant forward kernel, dominant backward kernel, whole forward entry point, whole backward entry point, prep launches
 
 void prof_mark(int which, hipStream_t st, bool begin) {
   ProfSlot& p = g_prof[which];
@@ -85,7 +86,7 @@ bool k0_fusable(const smd::ScaleSet& sc, int h, int flags) {
   return true;
 }
 
-struct ReconWs { float* loss_partial; float* pose_partial; uint4* rowtab; size_t bytes; };
+struct ReconWs { float* loss_partial; float* pose_partial; size_t bytes; };
 
 ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
   ReconWs r;
@@ -93,10 +94,12 @@ ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
   char* p = (char*)base;
   r.loss_partial = (float*)(p + off); off += align256((size_t)S*b*max_strips(h, w, smd::kFwdCols)*sizeof(float));
   r.pose_partial = (float*)(p + off); off += align256((size_t)n*b*S*max_strips(h, w, smd::kBwdCols)*smd::kPoseSums*sizeof(float));
-  r.rowtab = (uint4*)(p + off); off += align256((size_t)S*(h + 2)*sizeof(uint4));
   r.bytes = off;
   return r;
 }
+
+uint4* packed_rowtab(float* packed, int b, int n, int h, int w) { return (uint4*)(packed + smd::packed_rowtab_offset_floats(b, n, h, w)); }
+unsigned* packed_arrive(float* packed, int b, int n, int h, int w) { return (unsigned*)(packed + smd::packed_arrive_offset_floats(b, n, h, w)); }
 
 int check_dims(int b, int n, int S, int h, int w) {
   if (b < 1 || n < 1 || S < 1 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes b=%d n=%d S=%d h=%d w=%d (need h, w >= 2)", b, n, S, h, w);
@@ -172,6 +175,32 @@ size_t smd_packed_supports_bytes(int b, int n, int h, int w) {
   return smd::packed_total_floats(b, n, h, w)*sizeof(float);
 }
 
+// The input-only half of the forward (k_recon_prep): everything that depends on the frames alone.  `sc` != null and K0 fusable:
+// also the vertical up-sampling table of the pyramid.  Zeroes the arrival counters in the tail of `packed`.
+static int recon_prep_impl(const float* tgt, const float* supp, float* supp_packed, const smd::ScaleSet* sc, int b, int n, int S, int h, int w,
+                           int flags, hipStream_t st) {
+  int kMaxPerPass = env_int("SMD_FWD_NI", 4);   // supports held in registers by one launch (1..4)
+  if (kMaxPerPass < 1 || kMaxPerPass > 4) kMaxPerPass = 4;
+  smd::ReconPrepArgs p;
+  memset(&p, 0, sizeof(p));
+  p.tgt = tgt; p.supp = supp; p.packed = supp_packed;
+  p.b = b; p.n = n; p.h = h; p.w = w; p.flags = flags & (SMD_USE_MIN | SMD_LOSS_L1 | SMD_USE_AUTOMASK);
+  const StripPlan ipl = plan(b, 1, h, w, smd::kFwdCols);  // one "scale" only: shorter strips keep the chip full
+  p.rh = ipl.rh; p.nsx = ipl.nsx; p.nsy = ipl.nsy;
+  const bool fuse_k0 = sc && k0_fusable(*sc, h, flags);
+  prof_mark(SMD_PROF_RECON_PREP, st, true);
+  for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
+    p.i0 = i0; p.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
+    p.first_pass = (i0 == 0); p.last_pass = (i0 + p.ni >= n);
+    p.rowtab = (fuse_k0 && i0 == 0) ? packed_rowtab(supp_packed, b, n, h, w) : nullptr;
+    p.arrive = (i0 == 0) ? packed_arrive(supp_packed, b, n, h, w) : nullptr;
+    if (p.rowtab) { p.sc_S = S; for (int s = 0; s < S; ++s) { p.sc_hs[s] = sc->hs[s]; p.sc_ws[s] = sc->ws[s]; } }
+    if (int rc = check_launch(smd::launch_recon_prep(p, st), "recon prep")) return rc;
+  }
+  prof_mark(SMD_PROF_RECON_PREP, st, false);
+  return SMD_OK;
+}
+
 // Shared body of the two forward entry points.  `sc` != null: K0 fused — the first launch computes the depth from the
 // low-resolution disparity pyramid and writes it to `depth_out`; otherwise the depth is read from `depth`.
 static int recon_fwd_impl(const float* depth, float* depth_out, const smd::ScaleSet* sc, float min_depth, float max_depth,
@@ -192,21 +221,8 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   if (kMaxPerPass < 1 || kMaxPerPass > 4) kMaxPerPass = 4;
   if (!err && n > kMaxPerPass) return fail(SMD_E_INVALID, "err may be NULL only when all %d supports fit one pass (%d)", n, kMaxPerPass);
 
-  {  // once per sample: texel repack, target window sums, identity error (scale independent)
-    smd::ReconPrepArgs p;
-    memset(&p, 0, sizeof(p));
-    p.tgt = tgt; p.supp = supp; p.packed = supp_packed;
-    p.b = b; p.n = n; p.h = h; p.w = w; p.flags = flags & (SMD_USE_MIN | SMD_LOSS_L1 | SMD_USE_AUTOMASK);
-    const StripPlan ipl = plan(b, 1, h, w, smd::kFwdCols);  // one "scale" only: shorter strips keep the chip full
-    p.rh = ipl.rh; p.nsx = ipl.nsx; p.nsy = ipl.nsy;
-    const bool fuse_k0 = sc && k0_fusable(*sc, h, flags);
-    for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
-      p.i0 = i0; p.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
-      p.first_pass = (i0 == 0); p.last_pass = (i0 + p.ni >= n);
-      p.rowtab = (fuse_k0 && i0 == 0) ? ws.rowtab : nullptr;
-      if (p.rowtab) { p.sc_S = S; for (int s = 0; s < S; ++s) { p.sc_hs[s] = sc->hs[s]; p.sc_ws[s] = sc->ws[s]; } }
-      if (int rc = check_launch(smd::launch_recon_prep(p, st), "recon prep")) return rc;
-    }
+  if (!(flags & SMD_PACKED_READY)) {   // once per sample: texel repack, target window sums, identity error (scale independent)
+    if (int rc = recon_prep_impl(tgt, supp, supp_packed, sc, b, n, S, h, w, flags, st)) return rc;
   }
 
   smd::ReconMainArgs a;
@@ -216,7 +232,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
     depth = depth_out; sc = nullptr;
   }
   if (sc) {
-    a.sc = *sc; a.depth_out = depth_out; a.rowtab = ws.rowtab;
+    a.sc = *sc; a.depth_out = depth_out; a.rowtab = packed_rowtab(supp_packed, b, n, h, w);
     a.a_scale = 1.f; a.a_off = 0.f;
     if (min_depth > 0.f || max_depth > 0.f) {  // to_scaled: i_max = 1/min, i_min = 1/max (0 if unset)
       const float i_max = 1.f/min_depth, i_min = max_depth > 0.f ? 1.f/max_depth : 0.f;
@@ -225,6 +241,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   }
   a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv;
   a.noise = noise; a.err = err; a.sel = sel; a.partial = ws.loss_partial; a.warp0 = warp0;
+  a.arrive = packed_arrive(supp_packed, b, n, h, w); a.loss = loss; a.loss_scale = 1.0/((double)S*b*h*w);
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   a.inv_n = (float)(1.0/(double)n);
@@ -232,6 +249,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
   taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_FWD_TAPER_B", "SMD_FWD_TAPER_RH");
+  if (a.rh2 > 60) { a.rh2 = 60; a.nsy2 = smd::ceil_div(h, a.rh2); }   // as plan(): one row-table entry per lane
   for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
     a.i0 = i0; a.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
     a.first_pass = (i0 == 0); a.last_pass = (i0 + a.ni >= n);
@@ -240,10 +258,22 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
     if (a.last_pass) prof_mark(SMD_PROF_RECON_FWD, st, false);
     if (a.depth_out) { a.depth = a.depth_out; a.depth_out = nullptr; }   // later passes (n > 4) read the depth the first one wrote
   }
-  const int count = S*pl.nsx*(a.b1*pl.nsy + (b - a.b1)*a.nsy2);
-  const int rc = check_launch(smd::launch_sum_partials(ws.loss_partial, count, 1.0/((double)S*b*h*w), loss, st), "loss reduction");
-  prof_mark(SMD_PROF_RECON_FWD_ALL, st, false);
-  return rc;
+  prof_mark(SMD_PROF_RECON_FWD_ALL, st, false);   // the loss is reduced inside the last launch (recon_main_reduce)
+  return SMD_OK;
+}
+
+int smd_image_recon_supports_per_pass(void) { const int k = env_int("SMD_FWD_NI", 4); return (k < 1 || k > 4) ? 4 : k; }
+
+int smd_image_recon_prep(const float* tgt, const float* supp, float* supp_packed, const int* hs, const int* ws, int S,
+                         int b, int n, int h, int w, int flags, void* stream) {
+  if (int rc = check_dims(b, n, S > 0 ? S : 1, h, w)) return rc;
+  if (!tgt || !supp || !supp_packed) return fail(SMD_E_INVALID, "null pointer");
+  if (smd_packed_supports_bytes(b, n, h, w) >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "the packed buffer (%zu bytes) must stay below 2^32", smd_packed_supports_bytes(b, n, h, w));
+  if ((size_t)n*b*3*h*w*4 >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "n*b*3*h*w*4 must stay below 2^32");
+  smd::ScaleSet sc;
+  const bool pyramid = hs && ws && S > 0;
+  if (pyramid) { if (int rc = fill_scales(sc, nullptr, nullptr, hs, ws, nullptr, S)) return rc; }
+  return recon_prep_impl(tgt, supp, supp_packed, pyramid ? &sc : nullptr, b, n, S, h, w, flags, (hipStream_t)stream);
 }
 
 int smd_image_recon_fwd(const float* depth, const float* tgt, const float* supp, const float* T, const float* K,
@@ -268,7 +298,7 @@ int smd_image_recon_disp_fwd(const float* const* disp, const int* hs, const int*
                         workspace, workspace_bytes, b, n, S, h, w, flags, stream);
 }
 
-static int recon_bwd_impl(const float* depth, const float* supp_packed, const float* T, const float* K,
+static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T, const float* K,
                           const float* K_inv, const uint8_t* sel, const float* g_loss, const float* g_in, float k0_scale,
                           float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                           int b, int n, int S, int h, int w, int flags, void* stream) {
@@ -285,25 +315,34 @@ static int recon_bwd_impl(const float* depth, const float* supp_packed, const fl
   a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
   a.g_depth = g_depth; a.pose_partial = ws.pose_partial;
   a.g_in = g_in; a.k0_scale = k0_scale;
+  a.arrive = packed_arrive(supp_packed, b, n, h, w) + 1;
+  a.g_T = g_T; a.g_K = (flags & SMD_NEED_K_GRAD) ? g_K : nullptr; a.g_Kinv = (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
-  const StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
+  StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
+  if (n >= 2 && pl.rh > kBwdAccRows) { pl.rh = kBwdAccRows; pl.nsy = smd::ceil_div(h, pl.rh); }   // the supports' shares of dL/d depth are summed from LDS rows
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
   taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_BWD_TAPER_B", "SMD_BWD_TAPER_RH");
+  if (n >= 2 && a.rh2 > kBwdAccRows) { a.rh2 = kBwdAccRows; a.nsy2 = smd::ceil_div(h, a.rh2); }
   a.pose_stride = S*pl.nsx*(a.nsy2 > pl.nsy ? a.nsy2 : pl.nsy);
   a.skip_level = env_int("SMD_BWD_SKIP", 2);
+  // Waves per strip.  min(n, 4) (default): one support per wave — half as long work units (a launch is only ~2 generations of waves,
+  // so its tail is a fraction of a unit) and the waves of a strip share the target-side rows through one L1; 1: a wave takes every
+  // support of its strip in turn.  cfg 2, rocprofv3: 113 vs 115 us on coherent masks, 187 vs 212 us on incoherent inputs, 140 vs
+  // 145 us in the bench (profiles/r03_ab_kernel_times.txt).
+  a.wps = env_int("SMD_BWD_WPS", n < 4 ? n : 4);
+  if (a.wps < 1) a.wps = 1;
+  if (a.wps > 4) a.wps = 4;
+  if (a.wps > n) a.wps = n;
   prof_mark(SMD_PROF_RECON_BWD_ALL, st, true);
   prof_mark(SMD_PROF_RECON_BWD, st, true);
   if (int rc = check_launch(smd::launch_recon_bwd(a, st), "image_recon_bwd")) return rc;
   prof_mark(SMD_PROF_RECON_BWD, st, false);
-  const int rc = check_launch(smd::launch_pose_finalize(ws.pose_partial, S*pl.nsx*pl.nsy, S*pl.nsx*a.nsy2, a.b1, a.pose_stride, T, K, K_inv, g_T,
-                                                        (flags & SMD_NEED_K_GRAD) ? g_K : nullptr, (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr,
-                                                        b, n, st), "pose finalize");
-  prof_mark(SMD_PROF_RECON_BWD_ALL, st, false);
-  return rc;
+  prof_mark(SMD_PROF_RECON_BWD_ALL, st, false);   // g_T / g_K / g_Kinv come out of the same launch (pose_finalize_sample)
+  return SMD_OK;
 }
 
-int smd_image_recon_bwd(const float* depth, const float* tgt, const float* supp_packed, const float* T, const float* K,
+int smd_image_recon_bwd(const float* depth, const float* tgt, float* supp_packed, const float* T, const float* K,
                         const float* K_inv, const uint8_t* sel, const float* g_loss,
                         float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                         int b, int n, int S, int h, int w, int flags, void* stream) {
@@ -319,7 +358,7 @@ size_t smd_image_recon_disp_workspace_bytes(const int* hs, const int* ws, int S,
 }
 
 int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_depth, float max_depth, const float* depth_up,
-                             const float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
+                             float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
                              const float* g_loss, const float* g_depth_up_in, float* const* g_disp, float* g_T, float* g_K, float* g_Kinv,
                              void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream) {
   if (!depth_up || !g_disp || !workspace) return fail(SMD_E_INVALID, "null pointer");
@@ -350,7 +389,7 @@ static int smooth_chunks(const int* hs, const int* ws, int S) {
 
 size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int b) {
   if (!hs || !ws || S < 1 || S > SMD_MAX_SCALES || b < 1) return 0;
-  return align256((size_t)S*b*smooth_chunks(hs, ws, S)*2*sizeof(float));
+  return align256((size_t)S*b*smooth_chunks(hs, ws, S)*2*sizeof(float) + (size_t)S*b*sizeof(double));   // per-unit partials + per-pair loss shares
 }
 
 size_t smd_disp_smooth_edge_weight_bytes(const int* hs, const int* ws, int S, int b) {
@@ -615,7 +654,7 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
 }
 
 int smd_profile_enable(int which, int capacity) {
-  if (which < 0 || which > 3 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
+  if (which < 0 || which > 4 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
   ProfSlot& p = g_prof[which];
   for (int i = 0; i < 2*p.cap; ++i) (void)hipEventDestroy(p.ev[i]);
   delete[] p.ev;
@@ -629,7 +668,7 @@ int smd_profile_enable(int which, int capacity) {
 }
 
 int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out) {
-  if (which < 0 || which > 3 || !ms_out || !n_out) return fail(SMD_E_INVALID, "bad profile arguments");
+  if (which < 0 || which > 4 || !ms_out || !n_out) return fail(SMD_E_INVALID, "bad profile arguments");
   ProfSlot& p = g_prof[which];
   int n = 0;
   for (int i = 0; i < p.used && n < max_out; ++i) {

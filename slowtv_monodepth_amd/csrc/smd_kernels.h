@@ -45,12 +45,19 @@ struct ScaleSet {  // the multi-scale disparity pyramid, passed by value
 //   ypix   (b,h,w,3):       the target as RGB texels (one 12-byte load per lane and row instead of three planar ones);
 //   ta     (b,h,w,4):       {S_y (3 channels), c_0}   with c = 9 S_yy - S_y^2 + 81 C2: what every scale and support shares
 //   tb     (b,h,w,4):       {c_1, c_2, identity error of the automask, 0}              at a target pixel.
+// followed by a small tail that is not image data (packed_tail_*):
+//   rowtab  [SMD_MAX_SCALES][h+2] uint4: vertical half of the K0 up-sampling per (scale, image row), written by the prep kernel
+//   arrive  [1 + b] unsigned:  arrival counters of the in-launch reductions (entry 0: loss of the forward; 1 + bi: pose sums of
+//                              sample bi in the backward).  Zeroed by the prep kernel, reset to zero by the last arriver.
 __host__ __device__ inline size_t packed_texel_floats(int b, int n, int h, int w) { return (size_t)n*b*(size_t)(h + 1)*(size_t)(w + 1)*3; }
 __host__ __device__ inline size_t packed_ypix_floats(int b, int h, int w) { return (size_t)b*(size_t)h*(size_t)w*3; }
 __host__ __device__ inline size_t packed_tpix_floats(int b, int h, int w) { return (size_t)b*(size_t)h*(size_t)w*4; }   // each of ta, tb
-__host__ __device__ inline size_t packed_total_floats(int b, int n, int h, int w) {
+__host__ __device__ inline size_t packed_image_floats(int b, int n, int h, int w) {   // the part the buffer resources of the fused kernels span
   return packed_texel_floats(b, n, h, w) + packed_ypix_floats(b, h, w) + 2*packed_tpix_floats(b, h, w);
 }
+__host__ __device__ inline size_t packed_rowtab_offset_floats(int b, int n, int h, int w) { return (packed_image_floats(b, n, h, w) + 3) & ~(size_t)3; }   // 16-byte aligned
+__host__ __device__ inline size_t packed_arrive_offset_floats(int b, int n, int h, int w) { return packed_rowtab_offset_floats(b, n, h, w) + (size_t)SMD_MAX_SCALES*(size_t)(h + 2)*4; }
+__host__ __device__ inline size_t packed_total_floats(int b, int n, int h, int w) { return packed_arrive_offset_floats(b, n, h, w) + (((size_t)b + 1 + 3) & ~(size_t)3); }
 
 struct ReconPrepArgs {     // k_recon_prep: texel repack + target window sums + identity error, once per sample
   const float* tgt;        // (b,3,h,w)
@@ -62,6 +69,7 @@ struct ReconPrepArgs {     // k_recon_prep: texel repack + target window sums + 
   int rh, nsx, nsy;
   int first_pass, last_pass;
   uint4* rowtab;           // K0 fused: [S][h+2] vertical up-sampling table for the main kernel (first pass), or null
+  unsigned* arrive;        // the arrival counters in the tail of `packed`: zeroed here (first pass)
   int sc_S, sc_hs[SMD_MAX_SCALES], sc_ws[SMD_MAX_SCALES];
 };
 
@@ -78,7 +86,10 @@ struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over suppo
   const float* noise;      // (S,b,h,w) or null
   float* err;              // (S,b,h,w) running / final error
   uint8_t* sel;            // (S,b,h,w) running / final selection
-  float* partial;          // [S*b*nstrips] per-wave loss sums (last pass only)
+  float* partial;          // [grid blocks] DOUBLES: per-block loss sums (last pass only; 8-byte aligned)
+  unsigned* arrive;        // arrival counter of the in-launch loss reduction (zero on entry; the last block resets it)
+  float* loss;             // (1) out: sum of the partials x loss_scale, written by the block that arrives last (last pass only)
+  double loss_scale;       // 1/(S*b*h*w)
   float* warp0;            // (n,b,3,h,w) or null
   int b, n, S, h, w;
   int i0, ni;              // supports [i0, i0+ni) handled by this launch (ni <= 4)
@@ -104,11 +115,15 @@ struct ReconBwdArgs {
   float k0_scale;         // K0 fused: != 0 -> g_depth receives dL/d(up-sampled disparity) = dL/d depth * (-depth^2 * k0_scale) (0 where the
                           //   depth is pinned), so that the K0 adjoint neither reads the depth again nor multiplies; 0 -> dL/d depth
   float* pose_partial;    // [n*b][pose_stride][kPoseSums], the first S*nstrips entries of a (support, sample) used
+  unsigned* arrive;       // [b] arrival counters, one per sample (zero on entry): the block that completes a sample turns its pose sums
+                          //   into g_T / g_K / g_Kinv (the former k_pose_finalize launch) and resets the counter
+  float* g_T; float* g_K; float* g_Kinv;   // (n,b,4,4); (b,4,4) or null
   int b, n, S, h, w;
   int flags;
   int rh, nsx, nsy;
   int b1, rh2, nsy2;      // tapered partition, as in ReconMainArgs
   int pose_stride;        // entries reserved per (support, sample) in pose_partial: S*nsx*max(nsy, nsy2)
+  int wps;                // waves per strip (1 .. min(n, 4)): the supports of a strip are split over this many waves of one block
   float wscale, hscale;
   int skip_level;         // 0..2, see k_recon_bwd
 };
@@ -129,8 +144,8 @@ __device__ __forceinline__ void decode_tile(unsigned p, int nbx, int b, int S, i
 
 // (Tried and dropped: one block = the four scales of ONE strip, so that they also share the CU's vector L1.  L2 requests fell
 // by 20 %, but neighbouring strips then land on different XCDs and HBM reads went back up from 143 to 196 MB; no gain in time.)
-__host__ __device__ inline unsigned recon_grid_blocks(int nstrips, int b, int S) {
-  return (unsigned)ceil_div(nstrips, kWavesPerBlock)*(unsigned)b*(unsigned)S;
+__host__ __device__ inline unsigned recon_grid_blocks(int nstrips, int b, int S, int spb = kWavesPerBlock) {
+  return (unsigned)ceil_div(nstrips, spb)*(unsigned)b*(unsigned)S;
 }
 __device__ __forceinline__ void decode_wave(unsigned p, int wid, int nstrips, int b, int S, int& strip, int& bi, int& s) {
   int xb;
@@ -143,8 +158,9 @@ hipError_t launch_recon_prep(const ReconPrepArgs& a, hipStream_t st);
 hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st);
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st);
 hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st);
-hipError_t launch_pose_finalize(const float* pose_partial, int entries1, int entries2, int b1, int stride, const float* T, const float* K,
-                                const float* Kinv, float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st);
+hipError_t launch_pose_finalize(const float* pose_partial, int entries, int stride, const float* T, const float* K, const float* Kinv,
+                                float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st);
+unsigned* arrive_slots(int count);   // smd_misc.hip: `count` zeroed, self-resetting arrival counters for one launch on the current device (or null)
 
 hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
                                     float* depth_up, float* disp_up, hipStream_t st);

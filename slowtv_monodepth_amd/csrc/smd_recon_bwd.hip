@@ -1,8 +1,12 @@
 // smd_recon_bwd.hip — hand-written adjoint of the fused view-synthesis photometric loss (gfx950), round-2 structure.
 //
 // Same wave-strip streaming as the forward (smd_recon_fwd.hip): 60 interior columns + 2 halo lanes per side, rows
-// r0-2 .. r1+1, one support per pass of the row loop (the state of one support is ~90 registers; two at once would halve the
-// occupancy of a kernel whose gathers need the waves to hide their latency), three stages per row step j:
+// r0-2 .. r1+1, one support per wave (the state of one support is ~90 registers; two at once would halve the occupancy of a
+// kernel whose gathers need the waves to hide their latency).  Round 3: the supports of a strip are handled by DIFFERENT waves
+// of one block, concurrently (n = 2: a block is 2 strips x 2 supports), instead of by one wave in consecutive passes: a work
+// unit is half as long (a launch is only ~2 generations of waves, so its tail is a fraction of a unit), the waves of a strip
+// pull the same target-side rows (`sel`, target pixel, window terms, depth) through one L1, and the per-pixel sum of dL/d depth
+// over the supports is formed once, from LDS, after a block barrier.  Three stages per row step j:
 //   stage A (row j)   : re-synthesise the warped pixel x and its bilinear partials dx/dsx, dx/dsy from the four RGB taps
 //                       whose loads were issued one step earlier; issue the loads of row j+1
 //   stage B (row j-1) : window sums by the forward's sliding scheme (P = r(j-2) + r(j-1); reflection by data in the halo
@@ -11,8 +15,8 @@
 //                       gradient routed by `sel` (min-reprojection / automask); box-summed horizontally with the ADJOINT
 //                       reflection weights (avg_pool2d + reflection_pad2d backward) and accumulated vertically
 //   stage C (row j-2) : dL/dx -> dL/d(sx, sy) (zero where the border clamp is active) -> projective chain rule ->
-//                       dL/d depth (read-modify-written across supports) and nine per-lane sums that become dL/d(H, a);
-//                       a tiny epilogue kernel turns them into dL/dT, dL/dK and dL/dK^-1.
+//                       dL/d depth (this support's share, parked in LDS) and nine per-lane sums that become dL/d(H, a);
+//                       the block that finishes a sample last turns the sums into dL/dT, dL/dK and dL/dK^-1.
 // Nothing of the forward is stored except the packed texels / target sums (which the forward needs itself) and `sel`.
 #include "smd_common.h"
 #include "smd_kernels.h"
@@ -64,8 +68,9 @@ template <bool SSIM, int SKIP, bool ACC>
 struct BwdCtx {
   const ReconBwdArgs& a;
   // wave-uniform
-  int h, w, r0, r1, pb0, pb1, sup;
-  bool use_min, last, has_gin;
+  int h, w, r0, r1, pb0, pb1;
+  bool use_min, add_gin, acc_prev;   // add_gin: this pass adds the gradient that reaches the depth from other consumers; acc_prev: a
+                                     // previous pass of this wave (n > 4) left its share in the LDS rows
   unsigned w4, rowbytes, so_tex, so_y, so_ta, so_tb;
   float xmax, ymax, wpf;
   Cam2 cm;
@@ -79,7 +84,7 @@ struct BwdCtx {
   float gs_eq, gs_ne, gl_eq, gl_ne;
   unsigned sel_key;
   float* hist;                 // this lane's column of the wave's LDS history: 3 row slots x {gx, gy} x 3 channels
-  float* gacc;                 // ACC: this lane's column of the wave's dL/d depth accumulator, one slot per strip row (LDS)
+  float* gacc;                 // ACC: this lane's column of the wave's dL/d depth rows (this wave's supports), one slot per strip row (LDS)
   // state
   float X[3][3], Y[3][3];      // [row mod 3][channel]: re-synthesised warped pixel / target pixel
   float Px[3], Pxx[3], Pxy[3]; // sliding vertical sums: rows j-1 + j-2 once row j is in
@@ -286,28 +291,21 @@ struct BwdCtx {
         ps[0] += dnx; ps[1] = fmaf(dnx, vf, ps[1]); ps[2] += dny; ps[3] = fmaf(dny, vf, ps[3]); ps[4] += dz; ps[5] = fmaf(dz, vf, ps[5]);
         ps[6] += gnx; ps[7] += gny; ps[8] += gz;
       }
-      // dL/d depth: accumulated across the support passes through g_depth; the last pass adds what reaches depth from other
-      // consumers.
+      // dL/d depth of this support.  K0 fused: d depth / d(up-sampled, scaled disparity) is applied here, where the depth is at
+      // hand (linear, so per support); what reaches the depth from other consumers is added once, by the wave of support 0.
+      if (add_gin) gD += bld(rs_gin, lane4, qro);
+      if (a.k0_scale != 0.f) gD *= (D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f;
 #if (SMD_ABLATE_BWD & 4)
       if (gD == 12345.678f) bst(rs_gd, lane4, qro, gD);
       else
 #endif
       if (ACC) {
-        // The sum over the support passes stays in LDS (strips of <= kAccRows rows): no read-modify-write of g_depth, one global
-        // store per pixel by the last pass.  Each lane touches only its own column, so no synchronisation is needed.
+        // The supports of a strip are summed from LDS after the block barrier (k_recon_bwd): each lane parks its own column, one
+        // slot per strip row; no read-modify-write of g_depth, one global store per pixel.
         float* slot = gacc + (q - r0)*64;
-        if (last && has_gin) gD += bld(rs_gin, lane4, qro);
-        if (a.k0_scale != 0.f) gD *= (D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f;
-        if (sup != 0) gD += *slot;
-        if (last) { if (interior) bst(rs_gd, lane4, qro, gD); }
-        else *slot = gD;
-      } else if (interior && (!dead || sup == 0 || (last && has_gin))) {
-        if (last && has_gin) gD += bld(rs_gin, lane4, qro);
-        // K0 fused: d depth / d(up-sampled, scaled disparity) applied here, where the depth is at hand (linear, so per pass)
-        if (a.k0_scale != 0.f) gD *= (D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f;
-        if (sup != 0) gD += bld(rs_gd, lane4, qro);
-        bst(rs_gd, lane4, qro, gD);
-      }
+        if (acc_prev) gD += *slot;
+        *slot = gD;
+      } else if (interior) bst(rs_gd, lane4, qro, gD);   // a single support: the row is final
     }
     hist[(SQ*kHist + 6)*64] = Dkeep;               // row j+1's slot: stage C reads it at step j+3 (no second load of the depth)
   }
@@ -323,161 +321,82 @@ struct BwdCtx {
   }
 };
 
-// Four waves per SIMD (<= 128 VGPRs): without the cap the allocator settles at 133 and the kernel loses a wave of occupancy,
-// 138 -> 127 us at cfg 2 (the gathers' latency is what the extra wave hides).
-constexpr int kAccRows = 16;   // tallest strip whose dL/d depth rows are accumulated across the support passes in LDS
+// ---------------------------------------------------------------------------------------------
+// Epilogue of a sample (the former k_pose_finalize launch), run by ONE wave — the wave that completes the sample LAST: sum the
+// per-wave partials of dL/d(H, a0, a1, tz) and push them through
+//   H[0:2] = K2 * M,  H[2] = M[2],  M = R * Ki3,  (a0, a1) = K2 * t,  tz = t[2]
+// to dL/dT (n,b,4,4), dL/dK (b,4,4), dL/dKinv (b,4,4).  fp64, fixed order -> deterministic whichever wave does it.
+// The partials of a (support, sample) are `entries` x 12 contiguous floats: the wave sweeps them with 16-byte agent-scope loads
+// (lane l owns floats 4l .. 4l+3 of every 256-float chunk).  12 does not divide 256, so the sum a lane's j-th float belongs to
+// rotates with the chunk index: k = (4 (c + l) + j) mod 12 — three accumulator sets (c mod 3), re-labelled after the sweep.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFinScratchDoubles = SMD_MAX_SUPPORTS*15;   // per support: 6 of dL/dK + 9 of dL/dKinv
 
-template <bool SSIM, int SKIP, bool ACC>
-__global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconBwdArgs a) {
-  // per wave: 3 row slots x ({gx, gy} x 3 channels + depth) x 64 lanes [+ ACC: kAccRows x 64 lanes of dL/d depth]; ONE array (a second
-  // __shared__ object makes the compiler serialise LDS and vector-memory waits)
-  __shared__ float hist_lds[kWavesPerBlock*(3*kHist + (ACC ? kAccRows : 0))*64];
+__device__ __forceinline__ f4 ld4_agent(rsrc_t r, unsigned byte_off) {   // 16 bytes another workgroup published in this launch (sc1: agent scope)
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+
+__device__ void pose_finalize_wave(const ReconBwdArgs& a, int bi, int entries, double* scratch) {
   const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // segment of the (possibly tapered) partition this block belongs to (smd_kernels.h: ReconMainArgs::b1)
-  const unsigned nblk1 = recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S);
-  const bool tail = blockIdx.x >= nblk1;
-  const int nstrips = a.nsx*(tail ? a.nsy2 : a.nsy), seg_rh = tail ? a.rh2 : a.rh;
-  int strip, bi, s;
-  decode_wave(tail ? blockIdx.x - nblk1 : blockIdx.x, wid, nstrips, tail ? a.b - a.b1 : a.b1, a.S, strip, bi, s);
-  if (strip >= nstrips) return;
-  if (tail) bi += a.b1;
-  const int sxi = strip % a.nsx, syi = strip/a.nsx;
-  const int h = a.h, w = a.w;
-
-  BwdCtx<SSIM, SKIP, ACC> cx{a};
-  cx.hist = hist_lds + wid*((3*kHist + (ACC ? kAccRows : 0))*64) + lane;
-  cx.gacc = cx.hist + 3*kHist*64;
-  cx.h = h; cx.w = w;
-  cx.r0 = syi*seg_rh; cx.r1 = min(cx.r0 + seg_rh, h);
-  const int u = sxi*kBwdCols - 2 + lane;
-  const bool col_ok = (u >= 0) && (u < w);
-  // data column: the lane's own, or the reflected one for the halo lanes outside the image (reflection by data)
-  const int uc = (u < 0) ? min(-u, w - 1) : ((u >= w) ? max(2*(w - 1) - u, 0) : u);
-  cx.interior = (lane >= 2) && (lane < 2 + kBwdCols) && (u < w);
-  cx.lane4 = (unsigned)uc*4u; cx.lane1 = (unsigned)uc;
-  reflect_weights_adj(min(max(u, 0), w - 1), w, cx.wla, cx.wra);   // how much column u receives from u-1 / u+1
-  if (!col_ok) { cx.wla = 0.f; cx.wra = 0.f; }
-  const float uf = (float)uc;
-
-  cx.use_min = a.flags & SMD_USE_MIN;
-  const size_t hw = (size_t)h*w;
-  const unsigned hw4 = (unsigned)hw*4u;
-  cx.w4 = (unsigned)w*4u;
-  float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
-  if (!cx.use_min) gscale /= (float)a.n;
-  const float gm_ssim = col_ok ? gscale*(SSIM ? kWSsim/3.f : 0.f) : 0.f;
-  const float gm_l1 = col_ok ? gscale*(SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f) : 0.f;
-  cx.gs_eq = cx.use_min ? gm_ssim : 0.f; cx.gs_ne = cx.use_min ? 0.f : gm_ssim;
-  cx.gl_eq = cx.use_min ? gm_l1 : 0.f; cx.gl_ne = cx.use_min ? 0.f : gm_l1;
-  cx.xmax = (float)(w - 1); cx.ymax = (float)(h - 1); cx.wpf = (float)(w + 1);
-
-  const size_t sb = ((size_t)s*a.b + bi)*hw;
-  cx.rs_pk = make_rsrc(a.packed, packed_total_floats(a.b, a.n, h, w)*4);
-  cx.rs_depth = make_rsrc(a.depth + sb, hw*4);
-  cx.rs_sel = make_rsrc(a.sel + sb, hw);
-  cx.rs_gd = make_rsrc(a.g_depth + sb, hw*4);
-  cx.has_gin = a.g_in != nullptr;
-  cx.rs_gin = make_rsrc(cx.has_gin ? a.g_in + sb : nullptr, cx.has_gin ? hw*4 : 0);
-  const unsigned texel_bytes = (unsigned)(h + 1)*(unsigned)(w + 1)*12u;
-  cx.rowbytes = ((unsigned)w + 1u)*12u;
-  cx.so_y = (unsigned)(packed_texel_floats(a.b, a.n, h, w)*4) + (unsigned)bi*hw4*3u;
-  cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, h, w) + packed_ypix_floats(a.b, h, w))*4) + (unsigned)bi*hw4*4u;
-  cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, h, w)*4);
-
-  const int jstart = max(cx.r0 - 2, 0);
-  cx.pb0 = max(cx.r0 - 1, 0); cx.pb1 = min(cx.r1, h - 1); // centre rows whose coefficients are needed
-
-  for (int i = 0; i < a.n; ++i) {
-    make_cam2(cx.cm, cx.hx0, cx.hy0, cx.hz0, a.T + ((size_t)i*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16,
-              a.wscale, a.hscale, uf);
-    cx.so_tex = (unsigned)(i*a.b + bi)*texel_bytes;
-    cx.sup = i;
-    cx.sel_key = cx.use_min ? (unsigned)i : (unsigned)SMD_SEL_MASKED;
-    cx.last = (i == a.n - 1);
-    cx.run(jstart);
-
-    // per-wave pose partials: d/d(H[0..8], a0, a1, tz) of the UN-scaled homography (rows 0/1 of the folded one carry the grid
-    // scale); the column factor of H[.,0] is constant per lane
-    float* pp = a.pose_partial + (((size_t)i*a.b + bi)*(size_t)a.pose_stride + (size_t)s*nstrips + strip)*kPoseSums;
-    const float* ps = cx.ps;
-    const float ws = a.wscale, hs = a.hscale;
-    const float psum[kPoseSums] = {ps[0]*uf*ws, ps[1]*ws, ps[0]*ws, ps[2]*uf*hs, ps[3]*hs, ps[2]*hs, ps[4]*uf, ps[5], ps[4],
-                                   ps[6]*ws, ps[7]*hs, ps[8]};
+  const int n = a.n, b = a.b;
+  const unsigned F4 = (unsigned)entries*kPoseSums*4u;        // bytes per (support, sample); a multiple of 16
+  const int lm = lane % 3;
+  double mytot[kPoseSums];
+#pragma unroll
+  for (int k = 0; k < kPoseSums; ++k) mytot[k] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const float* pp = a.pose_partial + ((size_t)i*b + bi)*(size_t)a.pose_stride*kPoseSums;
+    const rsrc_t rs = make_rsrc(pp, F4);                     // loads beyond the last entry read 0
+    double acc[3][4];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[m][j] = 0.0;
+    // twelve chunks of 1024 bytes per trip, every load issued before the first is used: the sweep is pure latency (this wave
+    // runs alone at the end of a sample), so what counts is the number of round trips — one for up to 256 entries
+    for (unsigned base = 0; base < F4; base += 12u*1024u) {
+      const unsigned o = base + (unsigned)lane*16u;
+      f4 v[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) v[q] = ld4_agent(rs, o + (unsigned)q*1024u);
+#pragma unroll
+      for (int q = 0; q < 12; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[q % 3][j] += (double)v[q][j];
+    }
+    // re-label: sum k lives in set m = (k/4 - lane) mod 3, component k mod 4; then the wave's butterfly (fixed order)
 #pragma unroll
     for (int k = 0; k < kPoseSums; ++k) {
-      const float tot = wave_sum(psum[k]);
-      if (lane == 0) pp[k] = tot;
-    }
-  }
-}
-
-hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
-  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S) : 0u)), block(64*kWavesPerBlock);
-  const bool ssim = !(a.flags & SMD_LOSS_L1);
-  // more than one support and strips short enough: the per-pixel sum over the support passes is kept in LDS
-  const bool acc = a.n >= 2 && a.rh <= kAccRows && (a.b1 == a.b || a.rh2 <= kAccRows);
-#define SMD_BWD(SSIM_, SKIP_) do { \
-    if (acc) hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, true>), grid, block, 0, st, a); \
-    else hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, false>), grid, block, 0, st, a); } while (0)
-  if (ssim) {
-    if (a.skip_level >= 1) SMD_BWD(true, 2); else SMD_BWD(true, 0);
-  } else SMD_BWD(false, 0);
-#undef SMD_BWD
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Epilogue: sum the per-wave partials of dL/d(H, a0, a1, tz) and push them through
-//   H[0:2] = K2 * M,  H[2] = M[2],  M = R * Ki3,  (a0, a1) = K2 * t,  tz = t[2]
-// to dL/dT (n,b,4,4), dL/dK (b,4,4), dL/dKinv (b,4,4).  One block of 16 waves per sample: every wave reduces some of the
-// n*12 sums (fp64, fixed order -> deterministic, four loads in flight), then one thread per support does the 3x3 algebra and
-// thread 0 adds the supports' contributions to dL/dK, dL/dKinv in index order.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_pose_finalize(const float* __restrict__ pose_partial, int entries1, int entries2, int b1, int stride,
-                                                        const float* __restrict__ T, const float* __restrict__ K,
-                                                        const float* __restrict__ Kinv, float* g_T, float* g_K, float* g_Kinv,
-                                                        int b, int n) {
-  __shared__ double tot[SMD_MAX_SUPPORTS][kPoseSums];
-  __shared__ double gKs[SMD_MAX_SUPPORTS][6], gKis[SMD_MAX_SUPPORTS][9];
-  const int bi = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int entries = bi < b1 ? entries1 : entries2;   // tapered partition: the last samples were cut into more strips
-  for (int pr = wv; pr < n*kPoseSums; pr += 16) {
-    const int i = pr/kPoseSums, k = pr - i*kPoseSums;
-    const float* pp = pose_partial + ((size_t)i*b + bi)*(size_t)stride*kPoseSums + k;
-    double acc = 0.0;
-    int e = lane;
-    for (; e + 192 < entries; e += 256) {
-      const float v0 = pp[(size_t)e*kPoseSums], v1 = pp[(size_t)(e + 64)*kPoseSums], v2 = pp[(size_t)(e + 128)*kPoseSums], v3 = pp[(size_t)(e + 192)*kPoseSums];
-      acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-    }
-    for (; e < entries; e += 64) acc += (double)pp[(size_t)e*kPoseSums];
+      const int want = (k/4 + 3 - lm) % 3;
+      double v = (want == 0) ? acc[0][k & 3] : ((want == 1) ? acc[1][k & 3] : acc[2][k & 3]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) tot[i][k] = acc;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == i) mytot[k] = v;
+    }
   }
-  __syncthreads();
-  if ((int)threadIdx.x < n) {
-    const int i = threadIdx.x;
-    const float* Tm = T + ((size_t)i*b + bi)*16;
-    const float* Km = K + (size_t)bi*16;
-    const float* Ki = Kinv + (size_t)bi*16;
-    double R[9], t[3], K2[6], Ki3[9], M[9];
-    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { R[r*3 + c] = Tm[r*4 + c]; Ki3[r*3 + c] = Ki[r*4 + c]; } t[r] = Tm[r*4 + 3]; }
+  double* gKs = scratch;                 // [n][6]
+  double* gKis = scratch + SMD_MAX_SUPPORTS*6;   // [n][9]
+  if (lane < n) {
+    const int i = lane;
+    const float* Tm = a.T + ((size_t)i*b + bi)*16;
+    const float* Km = a.K + (size_t)bi*16;
+    const float* Ki = a.Kinv + (size_t)bi*16;
+    double R[9], tv[3], K2[6], Ki3[9], M[9];
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { R[r*3 + c] = Tm[r*4 + c]; Ki3[r*3 + c] = Ki[r*4 + c]; } tv[r] = Tm[r*4 + 3]; }
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) K2[r*3 + c] = Km[r*4 + c];
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r*3 + c] = R[r*3]*Ki3[c] + R[r*3 + 1]*Ki3[3 + c] + R[r*3 + 2]*Ki3[6 + c];
-    const double* gH = tot[i];        // 3x3
-    const double ga[2] = {tot[i][9], tot[i][10]};
-    const double gtz = tot[i][11];
+    const double* gH = mytot;            // 3x3
+    const double ga[2] = {mytot[9], mytot[10]};
+    const double gtz = mytot[11];
     double gM[9];
     for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c) gM[m*3 + c] = K2[m]*gH[c] + K2[3 + m]*gH[3 + c];
     for (int c = 0; c < 3; ++c) gM[6 + c] += gH[6 + c];
     for (int r = 0; r < 2; ++r) for (int m = 0; m < 3; ++m)
-      gKs[i][r*3 + m] = gH[r*3]*M[m*3] + gH[r*3 + 1]*M[m*3 + 1] + gH[r*3 + 2]*M[m*3 + 2] + ga[r]*t[m];
+      gKs[i*6 + r*3 + m] = gH[r*3]*M[m*3] + gH[r*3 + 1]*M[m*3 + 1] + gH[r*3 + 2]*M[m*3 + 2] + ga[r]*tv[m];
     double gt[3];
     for (int m = 0; m < 3; ++m) gt[m] = K2[m]*ga[0] + K2[3 + m]*ga[1];
     gt[2] += gtz;
-    float* gTo = g_T + ((size_t)i*b + bi)*16;
+    float* gTo = a.g_T + ((size_t)i*b + bi)*16;
     for (int r = 0; r < 3; ++r) {
       for (int m = 0; m < 3; ++m)
         gTo[r*4 + m] = (float)(gM[r*3]*Ki3[m*3] + gM[r*3 + 1]*Ki3[m*3 + 1] + gM[r*3 + 2]*Ki3[m*3 + 2]);
@@ -485,34 +404,225 @@ __global__ __launch_bounds__(1024) void k_pose_finalize(const float* __restrict_
     }
     for (int c = 0; c < 4; ++c) gTo[12 + c] = 0.f;
     for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c)
-      gKis[i][m*3 + c] = R[m]*gM[c] + R[3 + m]*gM[3 + c] + R[6 + m]*gM[6 + c];
+      gKis[i*9 + m*3 + c] = R[m]*gM[c] + R[3 + m]*gM[3 + c] + R[6 + m]*gM[6 + c];
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (g_K) {
-      float* o = g_K + (size_t)bi*16;
-      for (int k = 0; k < 16; ++k) o[k] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the scratch written by lanes < n is read by lane 0 (one wave: program order + this wait)
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    if (a.g_K) {
+      float* o = a.g_K + (size_t)bi*16;
+      for (int q = 0; q < 16; ++q) o[q] = 0.f;
       for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
         double acc = 0.0;
-        for (int i = 0; i < n; ++i) acc += gKs[i][r*3 + c];
+        for (int i = 0; i < n; ++i) acc += gKs[i*6 + r*3 + c];
         o[r*4 + c] = (float)acc;
       }
     }
-    if (g_Kinv) {
-      float* o = g_Kinv + (size_t)bi*16;
-      for (int k = 0; k < 16; ++k) o[k] = 0.f;
+    if (a.g_Kinv) {
+      float* o = a.g_Kinv + (size_t)bi*16;
+      for (int q = 0; q < 16; ++q) o[q] = 0.f;
       for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
         double acc = 0.0;
-        for (int i = 0; i < n; ++i) acc += gKis[i][r*3 + c];
+        for (int i = 0; i < n; ++i) acc += gKis[i*9 + r*3 + c];
         o[r*4 + c] = (float)acc;
       }
     }
   }
 }
 
-hipError_t launch_pose_finalize(const float* pose_partial, int entries1, int entries2, int b1, int stride, const float* T, const float* K,
-                                const float* Kinv, float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st) {
-  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(1024), 0, st, pose_partial, entries1, entries2, b1, stride, T, K, Kinv, g_T, g_K, g_Kinv, b, n);
+// Four waves per SIMD (<= 128 VGPRs): without the cap the allocator settles at 133 and the kernel loses a wave of occupancy,
+// 138 -> 127 us at cfg 2 (the gathers' latency is what the extra wave hides).
+constexpr int kAccRows = 16;   // tallest strip of the multi-support instantiations: its dL/d depth rows wait in LDS for the strip's sum
+
+// NS = waves per strip: wave (strip in block, k) handles supports k, k + NS, ... of its strip (NS = 1: every support, one after
+// the other — balanced waves whatever the selection masks look like; NS = min(n, 4): half / a quarter as long work units).
+// ACC: more than one support — the strip's dL/d depth rows are summed in LDS.
+template <bool SSIM, int SKIP, int NS, bool ACC>
+__global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconBwdArgs a) {
+  static_assert(ACC || NS == 1, "several waves per strip need the LDS sum");
+  constexpr int SPB = (kWavesPerBlock/NS > 0) ? kWavesPerBlock/NS : 1;   // strips per block
+  constexpr int kWaveFloats = (3*kHist + (ACC ? kAccRows : 0))*64;
+  static_assert(kWaveFloats*4 >= kFinScratchDoubles*8, "the epilogue's scratch aliases a wave's LDS rows");
+  // per wave: 3 row slots x ({gx, gy} x 3 channels + depth) x 64 lanes [+ ACC: kAccRows x 64 lanes of dL/d depth]; ONE array (a second
+  // __shared__ object in the row loop makes the compiler serialise LDS and vector-memory waits); the arrival counters of the
+  // epilogue chain sit behind it
+  constexpr int kPoseArea = SMD_MAX_SUPPORTS*kPoseSums;      // per wave: its pose sums, [support][12], zero for the supports it does not handle
+  constexpr int kLdsFloats = SPB*NS*(kWaveFloats + kPoseArea) + 8;
+  __shared__ __attribute__((aligned(16))) float hist_lds[kLdsFloats];
+  float* const pose_lds = hist_lds + SPB*NS*kWaveFloats;
+  unsigned* const cnt = reinterpret_cast<unsigned*>(pose_lds + SPB*NS*kPoseArea);   // [0 .. SPB): waves of a strip done; [4]: waves of the block done
+  for (int e = threadIdx.x; e < SPB*NS*kPoseArea; e += 64*SPB*NS) pose_lds[e] = 0.f;
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0u;
+  __syncthreads();                                           // the only block barrier: at the start, where every wave still is
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sib = wid/NS, kw = wid - sib*NS;               // strip within the block, first support of this wave
+  // segment of the (possibly tapered) partition this block belongs to (smd_kernels.h: ReconMainArgs::b1)
+  const unsigned nblk1 = recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S, SPB);
+  const bool tail = blockIdx.x >= nblk1;
+  const int nstrips = a.nsx*(tail ? a.nsy2 : a.nsy), seg_rh = tail ? a.rh2 : a.rh;
+  const int nbx = ceil_div(nstrips, SPB);
+  int xb, bi, s;
+  decode_tile(tail ? blockIdx.x - nblk1 : blockIdx.x, nbx, tail ? a.b - a.b1 : a.b1, a.S, xb, bi, s);
+  const int strip = xb*SPB + sib;
+  if (tail) bi += a.b1;
+  constexpr int nw = NS;                                   // waves that work on a strip
+  if (strip >= nstrips) return;                // nothing to do (the chain below counts live waves only)
+  const int live_waves = min(SPB, nstrips - xb*SPB)*nw;
+  const int sxi = strip % a.nsx, syi = strip/a.nsx;
+  const int h = a.h, w = a.w;
+  const int r0 = syi*seg_rh, r1 = min(r0 + seg_rh, h);
+  const int u = sxi*kBwdCols - 2 + lane;
+  // data column: the lane's own, or the reflected one for the halo lanes outside the image (reflection by data)
+  const int uc = (u < 0) ? min(-u, w - 1) : ((u >= w) ? max(2*(w - 1) - u, 0) : u);
+  const bool interior = (lane >= 2) && (lane < 2 + kBwdCols) && (u < w);
+  const size_t hw = (size_t)h*w;
+  const size_t sb = ((size_t)s*a.b + bi)*hw;
+  float* const wave_lds = hist_lds + wid*kWaveFloats;
+
+  {
+    BwdCtx<SSIM, SKIP, ACC> cx{a};
+    cx.hist = wave_lds + lane;
+    cx.gacc = cx.hist + 3*kHist*64;
+    cx.h = h; cx.w = w;
+    cx.r0 = r0; cx.r1 = r1;
+    const bool col_ok = (u >= 0) && (u < w);
+    cx.interior = interior;
+    cx.lane4 = (unsigned)uc*4u; cx.lane1 = (unsigned)uc;
+    reflect_weights_adj(min(max(u, 0), w - 1), w, cx.wla, cx.wra);   // how much column u receives from u-1 / u+1
+    if (!col_ok) { cx.wla = 0.f; cx.wra = 0.f; }
+    const float uf = (float)uc;
+
+    cx.use_min = a.flags & SMD_USE_MIN;
+    const unsigned hw4 = (unsigned)hw*4u;
+    cx.w4 = (unsigned)w*4u;
+    float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
+    if (!cx.use_min) gscale /= (float)a.n;
+    const float gm_ssim = col_ok ? gscale*(SSIM ? kWSsim/3.f : 0.f) : 0.f;
+    const float gm_l1 = col_ok ? gscale*(SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f) : 0.f;
+    cx.gs_eq = cx.use_min ? gm_ssim : 0.f; cx.gs_ne = cx.use_min ? 0.f : gm_ssim;
+    cx.gl_eq = cx.use_min ? gm_l1 : 0.f; cx.gl_ne = cx.use_min ? 0.f : gm_l1;
+    cx.xmax = (float)(w - 1); cx.ymax = (float)(h - 1); cx.wpf = (float)(w + 1);
+
+    cx.rs_pk = make_rsrc(a.packed, packed_image_floats(a.b, a.n, h, w)*4);
+    cx.rs_depth = make_rsrc(a.depth + sb, hw*4);
+    cx.rs_sel = make_rsrc(a.sel + sb, hw);
+    cx.rs_gd = make_rsrc(a.g_depth + sb, hw*4);
+    const bool has_gin = a.g_in != nullptr;
+    cx.rs_gin = make_rsrc(has_gin ? a.g_in + sb : nullptr, has_gin ? hw*4 : 0);
+    const unsigned texel_bytes = (unsigned)(h + 1)*(unsigned)(w + 1)*12u;
+    cx.rowbytes = ((unsigned)w + 1u)*12u;
+    cx.so_y = (unsigned)(packed_texel_floats(a.b, a.n, h, w)*4) + (unsigned)bi*hw4*3u;
+    cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, h, w) + packed_ypix_floats(a.b, h, w))*4) + (unsigned)bi*hw4*4u;
+    cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, h, w)*4);
+
+    const int jstart = max(r0 - 2, 0);
+    cx.pb0 = max(r0 - 1, 0); cx.pb1 = min(r1, h - 1); // centre rows whose coefficients are needed
+
+    for (int i = kw; i < a.n; i += NS) {
+      make_cam2(cx.cm, cx.hx0, cx.hy0, cx.hz0, a.T + ((size_t)i*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16,
+                a.wscale, a.hscale, uf);
+      cx.so_tex = (unsigned)(i*a.b + bi)*texel_bytes;
+      cx.sel_key = cx.use_min ? (unsigned)i : (unsigned)SMD_SEL_MASKED;
+      cx.add_gin = has_gin && i == 0;
+      cx.acc_prev = i != kw;
+      cx.run(jstart);
+
+      // per-wave pose sums: d/d(H[0..8], a0, a1, tz) of the UN-scaled homography (rows 0/1 of the folded one carry the grid
+      // scale); the column factor of H[.,0] is constant per lane.  Parked in this wave's row of the block's pose area (LDS).
+      const float* ps = cx.ps;
+      const float ws = a.wscale, hs = a.hscale;
+      const float psum[kPoseSums] = {ps[0]*uf*ws, ps[1]*ws, ps[0]*ws, ps[2]*uf*hs, ps[3]*hs, ps[2]*hs, ps[4]*uf, ps[5], ps[4],
+                                     ps[6]*ws, ps[7]*hs, ps[8]};
+      float mine = 0.f;
+#pragma unroll
+      for (int k = 0; k < kPoseSums; ++k) {
+        const float tot = wave_sum(psum[k]);
+        if (lane == k) mine = tot;
+      }
+      if (lane < kPoseSums) pose_lds[wid*kPoseArea + i*kPoseSums + lane] = mine;
+    }
+  }
+
+  // ---- epilogue chain, no block barrier (every wave of a block would idle through two memory round trips): a wave that is
+  // done bumps LDS counters; the LAST wave of a strip sums the strip's dL/d depth rows, the LAST wave of the block counts the
+  // block's arrival at agent scope, and the wave that completes a sample reduces its pose sums (Guideline 16 of
+  // cdna_hip_programming.md: write-through payload, drained by every storing wave before it is counted; one acquire by the reader).
+  unsigned o_strip = 0, o_block = 0;
+  if (lane == 0) {
+    if (ACC) o_strip = __hip_atomic_fetch_add(cnt + sib, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);   // orders this wave's LDS rows before, the others' after
+    o_block = __hip_atomic_fetch_add(cnt + 4, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  o_strip = (unsigned)__builtin_amdgcn_readfirstlane((int)o_strip); o_block = (unsigned)__builtin_amdgcn_readfirstlane((int)o_block);
+  if (ACC && o_strip == (unsigned)nw - 1u) {
+    // dL/d depth of the strip = sum over its waves' LDS rows in wave order (deterministic whichever wave adds them up)
+    const float* base = hist_lds + (sib*NS)*kWaveFloats + 3*kHist*64 + lane;
+    const rsrc_t rs_gd = make_rsrc(a.g_depth + sb, hw*4);
+#pragma unroll 4
+    for (int r = 0; r < r1 - r0; ++r) {
+      float g = base[r*64];
+#pragma unroll
+      for (int k = 1; k < NS; ++k) g += base[k*kWaveFloats + r*64];
+      if (interior) bst(rs_gd, (unsigned)uc*4u, (unsigned)(r0 + r)*(unsigned)w*4u, g);
+    }
+  }
+  if (o_block != (unsigned)live_waves - 1u) return;
+  // the last wave of the block: the block's pose sums = its waves' sums in wave order (a wave without a strip left its zeros),
+  // published write-through as ONE entry per (support, block)
+  for (int e = lane; e < a.n*kPoseSums; e += 64) {
+    const int i = e/kPoseSums, k = e - i*kPoseSums;
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < SPB*NS; ++wv) v += pose_lds[wv*kPoseArea + e];
+    float* pp = a.pose_partial + (((size_t)i*a.b + bi)*(size_t)a.pose_stride + (size_t)s*nbx + xb)*kPoseSums;
+    __hip_atomic_store((unsigned*)(pp + k), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned last = 0;
+  if (lane == 0) {
+    const unsigned expected = (unsigned)nbx*(unsigned)a.S;
+    last = (__hip_atomic_fetch_add(a.arrive + bi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u) ? 1u : 0u;
+  }
+  if (!__builtin_amdgcn_readfirstlane((int)last)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // scratch: the head of this wave's own history rows (free: its row loop is over, and a strip's sum reads only the dL/d depth rows behind them)
+  pose_finalize_wave(a, bi, a.S*nbx, reinterpret_cast<double*>(wave_lds));
+  if (lane == 0) __hip_atomic_store(a.arrive + bi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call on this buffer
+}
+
+// The same epilogue as a launch of its own, for the un-fused ViewSynth backward (smd_unfused.hip), whose partials come from a
+// one-thread-per-pixel kernel: one wave per sample.
+__global__ __launch_bounds__(64) void k_pose_finalize(const ReconBwdArgs a, int entries) {
+  __shared__ double scratch[kFinScratchDoubles];
+  pose_finalize_wave(a, (int)blockIdx.x, entries, scratch);
+}
+
+hipError_t launch_pose_finalize(const float* pose_partial, int entries, int stride, const float* T, const float* K, const float* Kinv,
+                                float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st) {
+  ReconBwdArgs a = {};
+  a.pose_partial = const_cast<float*>(pose_partial); a.pose_stride = stride; a.T = T; a.K = K; a.Kinv = Kinv;
+  a.g_T = g_T; a.g_K = g_K; a.g_Kinv = g_Kinv; a.b = b; a.n = n;
+  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(64), 0, st, a, entries);
+  return hipGetLastError();
+}
+
+hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
+  const int ns = a.wps, spb = kWavesPerBlock/ns;
+  if (ns < 1 || ns > 4 || ns > a.n) return hipErrorInvalidValue;
+  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S, spb) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S, spb) : 0u)), block(64*ns*spb);
+  const bool ssim = !(a.flags & SMD_LOSS_L1);
+  if (a.n > 1 && (a.rh > kAccRows || (a.b1 < a.b && a.rh2 > kAccRows))) return hipErrorInvalidValue;   // the strip's rows must fit the LDS sum (smd_api.hip clamps)
+#define SMD_BWD_NS(SSIM_, SKIP_) do { \
+    if (a.n == 1) hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 1, false>), grid, block, 0, st, a); \
+    else switch (ns) { \
+    case 1: hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 1, true>), grid, block, 0, st, a); break; \
+    case 2: hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 2, true>), grid, block, 0, st, a); break; \
+    case 3: hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 3, true>), grid, block, 0, st, a); break; \
+    default: hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 4, true>), grid, block, 0, st, a); break; } } while (0)
+  if (ssim) {
+    if (a.skip_level >= 1) SMD_BWD_NS(true, 2); else SMD_BWD_NS(true, 0);
+  } else SMD_BWD_NS(false, 0);
+#undef SMD_BWD_NS
   return hipGetLastError();
 }
 

@@ -178,6 +178,8 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_prep(const ReconPre
   // once per call ({byte offset of the two low-resolution rows, blend weight} per (scale, row); rows h, h+1 for the prefetch)
   // and the main kernel fetches its strip's entries once.  (Before the early return of waves without a strip: all 256 threads
   // of block 0 must take part, or entries beyond 64 x the number of live waves stay unwritten for tiny images.)
+  if (a.arrive != nullptr && blockIdx.x == 0)   // arrival counters of the in-launch reductions of the main kernel / the backward
+    for (int e = threadIdx.x; e < a.b + 1; e += 64*kWavesPerBlock) a.arrive[e] = 0u;
   if (a.rowtab != nullptr && blockIdx.x == 0) {
     for (int e = threadIdx.x; e < a.sc_S*(a.h + 2); e += 64*kWavesPerBlock) {
       const int sc_i = e/(a.h + 2), row = e - sc_i*(a.h + 2);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_prep(const ReconPre
   cx.hw4 = (unsigned)hw*4u; cx.w4 = (unsigned)a.w*4u;
   cx.rs_tgt = make_rsrc(a.tgt + (size_t)bi*3*hw, 3*hw*4);
   cx.rs_sup = make_rsrc(a.supp, (size_t)a.n*a.b*3*hw*4);
-  cx.rs_pk = make_rsrc(a.packed, packed_total_floats(a.b, a.n, a.h, a.w)*4);
+  cx.rs_pk = make_rsrc(a.packed, packed_image_floats(a.b, a.n, a.h, a.w)*4);
   const unsigned texel_bytes = (unsigned)(a.h + 1)*(unsigned)(a.w + 1)*12u;
   cx.so_y = (unsigned)(packed_texel_floats(a.b, a.n, a.h, a.w)*4) + (unsigned)bi*cx.hw4*3u;
   cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, a.h, a.w) + packed_ypix_floats(a.b, a.h, a.w))*4) + (unsigned)bi*cx.hw4*4u;
@@ -543,7 +545,7 @@ struct MainCtx {
 };
 
 template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP>
-__device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
+__device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // -> this lane's share of the loss sum (0 for a wave without a strip)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int strip, bi_, s_;
@@ -552,8 +554,7 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   const bool tail = blockIdx.x >= nblk1;
   const int nstr = a.nsx*(tail ? a.nsy2 : a.nsy), seg_b = tail ? a.b - a.b1 : a.b1, seg_rh = tail ? a.rh2 : a.rh;
   decode_wave(tail ? blockIdx.x - nblk1 : blockIdx.x, wid, nstr, seg_b, a.S, strip, bi_, s_);
-  if (strip >= nstr) return;
-  const size_t partial_idx = (tail ? (size_t)a.S*a.b1*(a.nsx*a.nsy) : 0) + ((size_t)s_*seg_b + bi_)*nstr + strip;
+  if (strip >= nstr) return 0.f;
   if (tail) bi_ += a.b1;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
 
@@ -587,7 +588,7 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
   cx.so_y = (unsigned)(packed_texel_floats(a.b, a.n, a.h, a.w)*4) + (unsigned)bi_*cx.hw4*3u;
   cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, a.h, a.w) + packed_ypix_floats(a.b, a.h, a.w))*4) + (unsigned)bi_*cx.hw4*4u;
   cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, a.h, a.w)*4);
-  cx.rs_pk = make_rsrc(a.packed, packed_total_floats(a.b, a.n, a.h, a.w)*4);
+  cx.rs_pk = make_rsrc(a.packed, packed_image_floats(a.b, a.n, a.h, a.w)*4);
   cx.rs_depth = make_rsrc(DISP ? nullptr : a.depth + sb, DISP ? 0 : hw*4);
   if (DISP) {
     const int hs = a.sc.hs[s_], ws = a.sc.ws[s_];
@@ -645,9 +646,56 @@ __device__ __forceinline__ void recon_main_body(const ReconMainArgs& a) {
     cx.template step<true, true>(a.h, XA, XB, YA, YB);
   }
 
-  if ((SINGLE || a.last_pass) && a.partial != nullptr) {
-    const float tot = wave_sum(cx.lsum);
-    if (lane == 0) a.partial[partial_idx] = tot;
+  return cx.lsum;
+}
+
+// In-launch loss reduction (round 3; the former k_sum_partials launch).  Deterministic: a block's partial is the sum of its
+// waves' sums in wave order, the loss the fp64 sum of the block partials in a fixed order — whichever wave happens to do it.
+// No block barrier at the end of the kernel (every wave of a block would idle through two memory round trips): a wave parks
+// its sum in LDS and bumps an LDS counter; only the wave that arrives LAST in its block goes on — it publishes the block's
+// partial write-through (agent scope), drains, counts the block's arrival at agent scope, and if the block is the last of
+// the launch it acquires and reduces every partial, alone, 64 lanes wide (cdna_hip_programming.md, Guideline 16).
+struct MainTail { double wsum[kWavesPerBlock]; unsigned arrived; };
+
+__device__ __forceinline__ void recon_main_reduce(const ReconMainArgs& a, MainTail& tl, float lane_sum) {
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float tot = wave_sum(lane_sum);
+  unsigned old = 0;
+  if (lane == 0) {
+    tl.wsum[wid] = (double)tot;
+    old = __hip_atomic_fetch_add(&tl.arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);   // orders the LDS store before, the LDS loads after
+  }
+  old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+  if (old != (unsigned)kWavesPerBlock - 1u) return;        // not the last wave of the block
+  unsigned last = 0;
+  if (lane == 0) {
+    double bsum = 0.0;
+#pragma unroll
+    for (int k = 0; k < kWavesPerBlock; ++k) bsum += tl.wsum[k];
+    __hip_atomic_store((unsigned long long*)a.partial + blockIdx.x, __builtin_bit_cast(unsigned long long, bsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = (__hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
+  }
+  if (!__builtin_amdgcn_readfirstlane((int)last)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // The sweep is pure latency (this wave runs alone at the very end of the launch): 16-byte agent-scope loads, sixteen of them
+  // per lane issued before the first is used — one round trip per 2048 partials.  Beyond the last partial the buffer reads 0.
+  const unsigned bytes = gridDim.x*8u;
+  const rsrc_t rs = make_rsrc(a.partial, bytes);
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  double acc = 0.0;
+  for (unsigned base = 0; base < bytes; base += 16u*1024u) {
+    d2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)q*1024u + (unsigned)lane*16u, 0, 16));   // aux 16 = sc1: agent scope
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) acc += ((v[q].x + v[q].y) + (v[q + 1].x + v[q + 1].y)) + ((v[q + 2].x + v[q + 2].y) + (v[q + 3].x + v[q + 3].y));   // fixed order
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) {
+    a.loss[0] = (float)(acc*a.loss_scale);
+    __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this buffer
   }
 }
 
@@ -661,7 +709,13 @@ __global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 4 : 3)) void k_recon_m
 #ifdef SMD_TRACE_WAVES
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  recon_main_body<N, SSIM, SINGLE, AUX, DISP>(a);
+  __shared__ MainTail tail;
+  const bool reduce = (SINGLE || a.last_pass) && a.partial != nullptr;
+  if (reduce) {                       // the only block barrier, at the start, where every wave still is
+    if (threadIdx.x == 0) tail.arrived = 0u;
+    __syncthreads();
+  }
+  const float lane_sum = recon_main_body<N, SSIM, SINGLE, AUX, DISP>(a);
 #ifdef SMD_TRACE_WAVES
   if ((threadIdx.x & 63) == 0) {
     const unsigned widx = blockIdx.x*kWavesPerBlock + (threadIdx.x >> 6);
@@ -671,6 +725,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 4 : 3)) void k_recon_m
     }
   }
 #endif
+  if (reduce) recon_main_reduce(a, tail, lane_sum);
 }
 #ifdef SMD_TRACE_WAVES
 extern "C" int smd_debug_wave_trace(unsigned long long* host_out, int max_waves) {

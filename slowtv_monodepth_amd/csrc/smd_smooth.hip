@@ -65,12 +65,27 @@ __host__ __device__ inline size_t edge_offset(const ScaleSet& sc, int b, int s) 
 // (own scale / coarser scales), this one 4-5 / 8 per 63.
 struct SmoothRow { float d, ic[3]; };
 
+// `arrive` != null: the second stage runs inside this launch (round 3; the former k_smooth_finalize launch) as a chain of wave-level
+// hand-offs without a block barrier (cdna_hip_programming.md, Guideline 16): a wave publishes its partial write-through and
+// drains; the LAST wave of a block counts the block's arrival for its (scale, sample) pair; the wave that completes a pair
+// reduces it to (mean, E) -> stats and publishes the pair's share of the loss; the wave that completes the last pair adds
+// the shares up in a fixed order.  fp64, deterministic whichever waves end up doing it.
+//   arrive[0 .. S*b): arrival counters of the pairs, arrive[S*b]: pairs done (zero on entry, reset by their last arrivers)
+//   contrib: [S*b] doubles behind the partials in the workspace
 __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
-                                                     float* __restrict__ partial, int max_units, float* __restrict__ edge_w) {
+                                                     float* partial, int max_units, float* __restrict__ edge_w, float* stats, float* loss,
+                                                     unsigned* arrive, double* contrib) {
   const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y;   // coarse scales first
   const int lane = threadIdx.x & 63, unit = blockIdx.x*4 + (threadIdx.x >> 6);
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
-  if (unit >= smooth_units_of(hs, ws)) return;
+  const int units = smooth_units_of(hs, ws);
+  __shared__ unsigned waves_done;
+  if (arrive != nullptr) {            // the only block barrier: at the start, where every wave still is
+    if (threadIdx.x == 0) waves_done = 0u;
+    __syncthreads();
+  }
+  if (unit >= units) return;
+  {
   const int nsx = (ws + kSmoothCols - 1)/kSmoothCols;
   const int sxi = unit % nsx, syi = unit/nsx;
   const int r0 = syi*kSmoothRows, r1 = min(r0 + kSmoothRows, hs);
@@ -138,14 +153,64 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
     }
   }
   const float totE = wave_sum(accE), totD = wave_sum(accD);
+  if (lane == 0) {   // published write-through (agent scope): the block that arrives last reads every partial in this launch
+    unsigned long long* pp = (unsigned long long*)partial + ((size_t)s*b + bi)*max_units + unit;
+    __hip_atomic_store(pp, ((unsigned long long)__builtin_bit_cast(unsigned, totD) << 32) | __builtin_bit_cast(unsigned, totE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  }
+  if (arrive == nullptr) return;      // two-launch form: k_smooth_finalize follows
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int pair = s*b + bi, npairs = sc.S*b;
+  const unsigned live = (unsigned)min(4, units - (int)blockIdx.x*4);
+  unsigned flag = 0;
   if (lane == 0) {
-    float* pp = partial + (((size_t)s*b + bi)*max_units + unit)*2;
-    pp[0] = totE; pp[1] = totD;
+    if (__hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == live - 1u)
+      flag = (__hip_atomic_fetch_add(arrive + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ceil_div(units, 4) - 1u) ? 1u : 0u;
+  }
+  if (!__builtin_amdgcn_readfirstlane((int)flag)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  {  // this wave completed the pair: (mean, E) and the pair's share of the loss
+    double e = 0.0, dsum = 0.0;
+    const unsigned long long* pp = (const unsigned long long*)partial + (size_t)pair*max_units;
+    auto ldp = [&](int c, double& ee, double& dd) {
+      const unsigned long long v = __hip_atomic_load(pp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ee += (double)__builtin_bit_cast(float, (unsigned)v); dd += (double)__builtin_bit_cast(float, (unsigned)(v >> 32));
+    };
+    int c = lane;
+    for (; c + 192 < units; c += 256) {   // four independent loads in flight; the order of the additions is fixed
+      double e0 = 0, d0 = 0, e1 = 0, d1 = 0, e2 = 0, d2 = 0, e3 = 0, d3 = 0;
+      ldp(c, e0, d0); ldp(c + 64, e1, d1); ldp(c + 128, e2, d2); ldp(c + 192, e3, d3);
+      e += (e0 + e1) + (e2 + e3); dsum += (d0 + d1) + (d2 + d3);
+    }
+    for (; c < units; c += 64) ldp(c, e, dsum);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); dsum += __shfl_xor(dsum, off, 64); }
+    const float mean = (float)(dsum/n);
+    const float E = (float)(e/(double)fmaxf(mean, kEps32));
+    flag = 0;
+    if (lane == 0) {
+      stats[(size_t)pair*2] = mean; stats[(size_t)pair*2 + 1] = E;
+      const double share = ldexp((double)E/((double)b*n), -sc.key[s]);   // 2^-key exactly, without the double-precision exp2 routine
+      __hip_atomic_store((unsigned long long*)contrib + pair, __builtin_bit_cast(unsigned long long, share), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(arrive + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the slot is free again
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      flag = (__hip_atomic_fetch_add(arrive + npairs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)npairs - 1u) ? 1u : 0u;
+    }
+  }
+  if (!__builtin_amdgcn_readfirstlane((int)flag)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  double total = 0.0;
+  for (int q = lane; q < npairs; q += 64) total += __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)contrib + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+  if (lane == 0) {
+    loss[0] = (float)(total/sc.S);
+    __hip_atomic_store(arrive + npairs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-// Pass 2: per image mean m and E = E'/max(m, eps) -> stats; loss = mean_s( 2^-key_s * sum_b E / (b*hs*ws) ).
-// One wave per (scale, sample) pair, 16 waves per block, one block.
+// Second stage as a launch of its own (used when the pyramid has more (scale, sample) pairs than arrival slots): per image mean m
+// and E = E'/max(m, eps) -> stats; loss = mean_s( 2^-key_s * sum_b E / (b*hs*ws) ).  One wave per pair, 16 waves, one block.
 __global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int b, const float* __restrict__ partial, int max_chunks,
                                                           float* __restrict__ stats, float* __restrict__ loss) {
   __shared__ double contrib[16];
@@ -211,8 +276,12 @@ hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st) {
   int max_chunks = 1;   // units (waves) of the largest scale; the partial sums of a (scale, sample) are strided by it
   for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_units_of(sc.hs[s], sc.ws[s]));
-  hipLaunchKernelGGL(k_smooth_main, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks, edge_w);
-  hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
+  // in-launch second stage when the pairs fit the arrival-slot pool; `contrib` sits behind the partials in the workspace
+  unsigned* arrive = arrive_slots(sc.S*b + 1);
+  double* contrib = (double*)(ws_sums + (size_t)sc.S*b*max_chunks*2);
+  hipLaunchKernelGGL(k_smooth_main, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks, edge_w,
+                     stats, loss, arrive, contrib);
+  if (!arrive) hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
   if (disp_grad || image_grad)
     hipLaunchKernelGGL(k_smooth_aux, dim3(min(ceil_div(sc.hs[0]*sc.ws[0], 256), 480), b), dim3(256), 0, st, sc, b, img, h, w, stats, disp_grad, image_grad);
   return hipGetLastError();

@@ -126,7 +126,7 @@ hipError_t launch_view_synth_bwd(const float* input, const float* depth, const f
                      ws, C, h, w, wscale, hscale);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return launch_pose_finalize(ws, nblk, nblk, B, nblk, T, K, Kinv, g_T, g_K, g_Kinv, B, 1, st);
+  return launch_pose_finalize(ws, nblk, nblk, T, K, Kinv, g_T, g_K, g_Kinv, B, 1, st);
 }
 
 // ---------------------------------------------------------------------------------------------

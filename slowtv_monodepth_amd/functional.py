@@ -7,38 +7,50 @@ CPU tensors are rejected.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, int_array, ptr_array
 from ._lib import call as _raw_call
 
-__all__ = ['disp_to_depth', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
+__all__ = ['disp_to_depth', 'image_recon_prep', 'PreparedFrames', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
            'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'layer_norm_cf', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
-_active_device = None   # device of the tensors validated most recently (set by _check); launches go to ITS current stream
+# Device of the operands of the operator this THREAD is executing: launches go to ITS current stream.  Thread-local, and set at
+# the top of every forward (by `_check`) AND every backward (by `_on`): autograd runs the backward of each device on its own
+# thread and has already made that device current there, so a process-wide "last validated device" would send the backward of
+# one GPU's graph to another GPU's stream as soon as two devices are used in one process.
+_tls = threading.local()
+
+
+def _on(t: torch.Tensor) -> torch.device:
+    """Declare `t`'s device the device of the operator being executed on this thread (call first in every backward)."""
+    _tls.device = t.device
+    return t.device
 
 
 def call(name: str, *args):
     """Launch with the operands' device current (the library launches on the calling thread's current HIP device)."""
-    if _active_device is not None and _active_device.index is not None and _active_device.index != torch.cuda.current_device():
-        with torch.cuda.device(_active_device): return _raw_call(name, *args)
+    dev = getattr(_tls, 'device', None)
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev): return _raw_call(name, *args)
     return _raw_call(name, *args)
 
 
 def _stream() -> int:
     """The HIP stream of the operands' device.  (Not simply `torch.cuda.current_stream()`: with tensors on a GPU that is not the
     process's current device that would be a stream of another device.)"""
-    dev = _active_device if _active_device is not None else torch.cuda.current_device()
-    return torch.cuda.current_stream(dev).cuda_stream
+    dev = getattr(_tls, 'device', None)
+    return torch.cuda.current_stream(dev if dev is not None else torch.cuda.current_device()).cuda_stream
 
 
 def _check(name: str, t: torch.Tensor, shape=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor): raise TypeError(f'{name} must be a Tensor, got {type(t)}')
     if not t.is_cuda: raise RuntimeError(f'{name} must live on the GPU: the view-synthesis hot path has no CPU implementation')
-    global _active_device
-    _active_device = t.device
+    _tls.device = t.device
     if t.dtype != torch.float32: raise TypeError(f'{name} must be float32 (the loss path is fp32 only), got {t.dtype}')
     if shape is not None and tuple(t.shape) != tuple(shape): raise ValueError(f'{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
     return t.contiguous()
@@ -76,6 +88,7 @@ class _DispToDepth(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_depth_up, _g_disp_up):
         (depth_up,) = ctx.saved_tensors
+        _on(depth_up)
         hs, ws, S, b, h, w, mn, mx = ctx.meta
         g_depth_up = _check('grad(depth_up)', g_depth_up)
         g_disps = [torch.empty((b, 1, hs[s], ws[s]), device=depth_up.device, dtype=torch.float32) for s in range(S)]
@@ -95,29 +108,92 @@ def disp_to_depth(disps, size, min_depth=None, max_depth=None, want_disp_up=Fals
 
 
 # ---------------------------------------------------------------------------------------------------
+class PreparedFrames:
+    """What the reconstruction forward needs from the FRAMES alone (`smd_image_recon_prep`): the packed texel / target-window
+    buffer, the HIP event after which it is complete, and what it was built for.  It does not depend on any network output, so
+    the training step fills it on a side stream while the networks run (`MonoDepthModule.step`)."""
+    def __init__(self, packed, event, key):
+        self.packed, self.event, self.key = packed, event, key
+
+    def matches(self, imgs, supp_imgs, flags, hs, ws) -> bool:
+        k = (imgs.data_ptr(), supp_imgs.data_ptr(), tuple(imgs.shape), tuple(supp_imgs.shape), int(flags) & _PREP_FLAGS,
+             tuple(hs) if hs is not None else None, tuple(ws) if ws is not None else None)
+        return k == self.key
+
+
+_PREP_FLAGS = FLAGS['use_min'] | FLAGS['use_automask'] | FLAGS['loss_l1']
+
+
+def image_recon_prep(imgs, supp_imgs, *, flags: int, pyramid=None, stream=None) -> PreparedFrames:
+    """Fill the frame-only buffer of the fused reconstruction for (imgs (b,3,h,w), supp_imgs (n,b,3,h,w)).
+
+    :param flags: `recon_flags(...)` of the criterion that will consume it (the identity error of the automask is part of it).
+    :param pyramid: [(hs, ws), ...] of the disparity pyramid when the K0-fused forward follows (its row table is built here).
+    :param stream: `torch.cuda.Stream` to run on (default: the current one).  The returned object carries the completion event;
+        the forward that consumes it waits for that event on ITS stream."""
+    b, _, h, w = imgs.shape
+    n = supp_imgs.shape[0]
+    imgs_c = _check('imgs', imgs, (b, 3, h, w)); supp_c = _check('supp_imgs', supp_imgs, (n, b, 3, h, w))
+    dev = imgs.device
+    cur = torch.cuda.current_stream(dev)
+    st = stream if stream is not None else cur
+    hs = [int(p[0]) for p in pyramid] if pyramid else None
+    ws = [int(p[1]) for p in pyramid] if pyramid else None
+    if st is not cur: st.wait_stream(cur)          # the frames were produced on the caller's stream
+    with torch.cuda.stream(st):
+        packed = torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32)
+        call('smd_image_recon_prep', imgs_c.data_ptr(), supp_c.data_ptr(), packed.data_ptr(), int_array(hs) if hs else None, int_array(ws) if ws else None,
+             len(hs) if hs else 0, b, n, h, w, int(flags) & _PREP_FLAGS, st.cuda_stream)
+        event = torch.cuda.Event()
+        event.record(st)
+    if st is not cur:
+        for t in (imgs_c, supp_c): t.record_stream(st)
+        packed.record_stream(cur)
+    key = (imgs.data_ptr(), supp_imgs.data_ptr(), tuple(imgs.shape), tuple(supp_imgs.shape), int(flags) & _PREP_FLAGS,
+           tuple(hs) if hs else None, tuple(ws) if ws else None)
+    return PreparedFrames(packed, event, key)
+
+
+def _packed_for(prepared, imgs, supp, flags, hs, ws, b, n, h, w, dev):
+    """-> (packed buffer, flags): the prepared one (after waiting for it on the current stream) or a fresh one for an inline prep."""
+    if prepared is not None:
+        if not prepared.matches(imgs, supp, flags, hs, ws):
+            raise ValueError('PreparedFrames were built for other frames, flags or another disparity pyramid')
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(prepared.event)
+        prepared.packed.record_stream(cur)      # allocated on the stream that filled it, used (and later freed) on this one
+        return prepared.packed, int(flags) | FLAGS['packed_ready']
+    return torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32), int(flags)
+
+
+def _need_err(want_err: bool, n: int) -> bool:
+    return bool(want_err) or n > _lib.lib.smd_image_recon_supports_per_pass()
+
+
 class _ImageRecon(torch.autograd.Function):
     """Fused `handlers.image_recon` (src/core/handlers.py:14-67)."""
 
     @staticmethod
-    def forward(ctx, depth, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp, want_err):
+    def forward(ctx, depth, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp, want_err, prepared):
         S, b, h, w = depth.shape  # always 4-D here: `image_recon_fused` squeezes the channel dim as an autograd view
         n = supp.shape[0]
+        tgt_in, supp_in = tgt, supp
         depth = _check('depth', depth, (S, b, h, w)); tgt = _check('imgs', tgt, (b, 3, h, w))
         supp = _check('supp_imgs', supp, (n, b, 3, h, w)); T = _check('Ts', T, (n, b, 4, 4))
         K = _check('Ks', K, (b, 4, 4)); K_inv = _check('K_inv', K_inv, (b, 4, 4))
         if noise is not None: noise = _check('noise', noise.reshape(S, b, h, w), (S, b, h, w))
         dev = depth.device
-        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32) if (want_err or n > 4) else None
+        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32) if _need_err(want_err, n) else None
         sel = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.uint8)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         warp0 = torch.empty((n, b, 3, h, w), device=dev, dtype=torch.float32) if want_warp else None
         nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        # padded RGBX texels of the supports + the target's SSIM window sums; written by the forward, reused by the backward
-        supp_pk = torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32)
+        # padded RGB texels of the supports + the target's SSIM window sums; written by the prep launch, reused by the backward
+        supp_pk, cflags = _packed_for(prepared, tgt_in, supp_in, flags, None, None, b, n, h, w, dev)
         call('smd_image_recon_fwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), supp_pk.data_ptr(), err.data_ptr() if err is not None else None, sel.data_ptr(), loss.data_ptr(),
-             warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, int(flags), _stream())
+             warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, cflags, _stream())
         ctx.save_for_backward(depth, tgt, supp_pk, T, K, K_inv, sel)
         ctx.meta = (b, n, S, h, w, int(flags))
         ctx.need_k = bool(ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
@@ -129,7 +205,7 @@ class _ImageRecon(torch.autograd.Function):
     def backward(ctx, g_loss, *_):
         depth, tgt, supp_pk, T, K, K_inv, sel = ctx.saved_tensors
         b, n, S, h, w, flags = ctx.meta
-        dev = depth.device
+        dev = _on(depth)
         g_loss = g_loss.to(torch.float32).contiguous()
         g_depth = torch.empty((S, b, h, w), device=dev, dtype=torch.float32)
         g_T = torch.empty((n, b, 4, 4), device=dev, dtype=torch.float32)
@@ -142,20 +218,21 @@ class _ImageRecon(torch.autograd.Function):
              sel.data_ptr(), g_loss.data_ptr(), g_depth.data_ptr(), g_T.data_ptr(),
              g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
              ws.data_ptr(), nbytes, b, n, S, h, w, flags, _stream())
-        return g_depth, None, None, g_T, (g_K if ctx.needs_input_grad[4] else None), (g_Ki if ctx.needs_input_grad[5] else None), None, None, None, None, None
+        return g_depth, None, None, g_T, (g_K if ctx.needs_input_grad[4] else None), (g_Ki if ctx.needs_input_grad[5] else None), None, None, None, None, None, None
 
 
 def image_recon_fused(depth, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int, noise=None, seed: int = 0, want_warp: bool = False,
-                      want_err: bool = True):
+                      want_err: bool = True, prepared: PreparedFrames | None = None):
     """depth (S,b,1,h,w)|(S,b,h,w); returns (loss, err (S,b,1,h,w)|None, sel uint8 (S,b,1,h,w), warp0 (n,b,3,h,w)|None).
 
     `want_err=False` (the handlers' choice: nothing on the training path reads the error map) saves its store in the kernel.
 
-    `K_inv=None` inverts `Ks` with torch (differentiable), as `ViewSynth.forward` does (src/tools/geometry.py:383)."""
+    `K_inv=None` inverts `Ks` with torch (differentiable), as `ViewSynth.forward` does (src/tools/geometry.py:383).
+    `prepared`: the frame-only buffer from `image_recon_prep(imgs, supp_imgs, flags=flags)` (built without `pyramid`)."""
     if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else inv_intrinsics(Ks)
     was5 = depth.ndim == 5
     d4 = depth.squeeze(2) if was5 else depth
-    return _ImageRecon.apply(d4, imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp, want_err)
+    return _ImageRecon.apply(d4, imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp, want_err, prepared)
 
 
 class _ImageReconDisp(torch.autograd.Function):
@@ -164,9 +241,10 @@ class _ImageReconDisp(torch.autograd.Function):
     kernel, which also writes `depth_up` for the backward and for `fwd['depth_up']`."""
 
     @staticmethod
-    def forward(ctx, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp, want_err, min_depth, max_depth, *disps):
+    def forward(ctx, tgt, supp, T, K, K_inv, noise, seed, flags, want_warp, want_err, min_depth, max_depth, prepared, *disps):
         b, _, h, w = tgt.shape
         n, S = supp.shape[0], len(disps)
+        tgt_in, supp_in = tgt, supp
         tgt = _check('imgs', tgt, (b, 3, h, w)); supp = _check('supp_imgs', supp, (n, b, 3, h, w)); T = _check('Ts', T, (n, b, 4, 4))
         K = _check('Ks', K, (b, 4, 4)); K_inv = _check('K_inv', K_inv, (b, 4, 4))
         disps = [_check(f'disp[{i}]', d) for i, d in enumerate(disps)]
@@ -176,17 +254,17 @@ class _ImageReconDisp(torch.autograd.Function):
         hs, ws = [d.shape[2] for d in disps], [d.shape[3] for d in disps]
         dev = tgt.device
         depth_up = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32)
-        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32) if (want_err or n > 4) else None
+        err = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32) if _need_err(want_err, n) else None
         sel = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.uint8)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         warp0 = torch.empty((n, b, 3, h, w), device=dev, dtype=torch.float32) if want_warp else None
         nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
         wsp = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        packed = torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32)
+        packed, cflags = _packed_for(prepared, tgt_in, supp_in, flags, hs, ws, b, n, h, w, dev)
         call('smd_image_recon_disp_fwd', ptr_array([d.data_ptr() for d in disps]), int_array(hs), int_array(ws), S, float(min_depth or 0), float(max_depth or 0),
              tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(), noise.data_ptr() if noise is not None else None,
              int(seed) & (2**64 - 1), packed.data_ptr(), depth_up.data_ptr(), err.data_ptr() if err is not None else None, sel.data_ptr(), loss.data_ptr(),
-             warp0.data_ptr() if want_warp else None, wsp.data_ptr(), nbytes, b, n, h, w, int(flags), _stream())
+             warp0.data_ptr() if want_warp else None, wsp.data_ptr(), nbytes, b, n, h, w, cflags, _stream())
         ctx.save_for_backward(depth_up, packed, T, K, K_inv, sel)
         # `depth_up` is a differentiable output that usually has no other consumer: without this autograd would hand the backward
         # a materialised zero tensor for it (one more (S,b,h,w) read, and no dead-row skipping on the last support pass)
@@ -201,7 +279,7 @@ class _ImageReconDisp(torch.autograd.Function):
     def backward(ctx, g_loss, _ge, _gs, _gw, g_depth_up):
         depth_up, packed, T, K, K_inv, sel = ctx.saved_tensors
         b, n, S, h, w, flags, hs, ws, mn, mx = ctx.meta
-        dev = depth_up.device
+        dev = _on(depth_up)
         g_loss = (g_loss if g_loss is not None else torch.zeros((), device=dev)).to(torch.float32).contiguous()
         if g_depth_up is not None: g_depth_up = _check('grad(depth_up)', g_depth_up.reshape(S, b, h, w), (S, b, h, w))
         g_disps = [torch.empty((b, 1, hs[s], ws[s]), device=dev, dtype=torch.float32) for s in range(S)]
@@ -217,18 +295,19 @@ class _ImageReconDisp(torch.autograd.Function):
              ptr_array([g.data_ptr() for g in g_disps]), g_T.data_ptr(), g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
              wsp.data_ptr(), nbytes, b, n, h, w, flags, _stream())
         return (None, None, g_T, (g_K if ctx.needs_input_grad[3] else None), (g_Ki if ctx.needs_input_grad[4] else None),
-                None, None, None, None, None, None, None, *g_disps)
+                None, None, None, None, None, None, None, None, *g_disps)
 
 
 def image_recon_fused_disp(disps, imgs, supp_imgs, Ts, Ks, K_inv=None, *, flags: int, min_depth=None, max_depth=None, noise=None, seed: int = 0,
-                           want_warp: bool = False, want_err: bool = True):
+                           want_warp: bool = False, want_err: bool = True, prepared: PreparedFrames | None = None):
     """disps: sequence of (b,1,hs,ws) sigmoid disparities -> (loss, err|None, sel, warp0|None, depth_up (S,b,1,h,w)).
 
-    The K0-fused form of `disp_to_depth` + `image_recon_fused`: one prep launch, one fused launch, one reduction."""
+    The K0-fused form of `disp_to_depth` + `image_recon_fused`: one prep launch (or none with `prepared` =
+    `image_recon_prep(imgs, supp_imgs, flags=flags, pyramid=[d.shape[-2:] for d in disps])`) and one fused launch that also reduces the loss."""
     if min_depth is not None and min_depth <= 0: raise ValueError(f'Min depth must be greater than 0. ({min_depth})')
     if max_depth and min_depth and max_depth < min_depth: raise ValueError(f'Max depth must be greater than min. ({max_depth} vs. {min_depth})')
     if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else inv_intrinsics(Ks)
-    return _ImageReconDisp.apply(imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp, want_err, min_depth, max_depth, *disps)
+    return _ImageReconDisp.apply(imgs, supp_imgs, Ts, Ks, K_inv, noise, seed, flags, want_warp, want_err, min_depth, max_depth, prepared, *disps)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -266,6 +345,7 @@ class _DispSmooth(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *_):
         img, stats, ew, *disps = ctx.saved_tensors
+        _on(img)
         hs, ws, keys, S, b, h, w, flags = ctx.meta
         g_loss = g_loss.to(torch.float32).contiguous()
         g_disps = [torch.empty_like(d) for d in disps]
@@ -306,7 +386,7 @@ class _ViewSynth(torch.autograd.Function):
     def backward(ctx, g_warp, g_dwarp, _g_valid):
         inp, depth, T, K, K_inv = ctx.saved_tensors
         B, Cc, h, w = inp.shape
-        dev = inp.device
+        dev = _on(inp)
         g_warp = _check('grad(warp)', g_warp if g_warp is not None else torch.zeros_like(inp))
         g_dwarp = _check('grad(depth_warp)', g_dwarp) if g_dwarp is not None else None
         need_in, need_k = ctx.needs_input_grad[0], (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
@@ -344,6 +424,7 @@ class _PhotoError(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_err):
         pred, target = ctx.saved_tensors
+        _on(pred)
         N, c, h, w = pred.shape
         g_err = _check('grad(err)', g_err)
         g_pred = torch.empty_like(pred)
@@ -386,6 +467,7 @@ class _Regression(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_err):
         pred, target, mask, stats = ctx.saved_tensors
+        _on(pred)
         N = pred.numel()
         g_pred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
         g_target = torch.empty_like(target) if ctx.needs_input_grad[1] else None
@@ -427,6 +509,7 @@ class _ReconReduce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *_):
         (sel,) = ctx.saved_tensors
+        _on(sel)
         n, B, h, w, flags = ctx.meta
         g = torch.empty((n, B, h, w), device=sel.device, dtype=torch.float32)
         call('smd_recon_reduce_bwd', sel.data_ptr(), g_loss.to(torch.float32).contiguous().data_ptr(), g.data_ptr(), n, B, h, w, flags, _stream())
@@ -474,6 +557,7 @@ class _EluPad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         x, bias = ctx.saved_tensors
+        _on(x)
         B, C, h, w = x.shape
         g_x = torch.empty_like(x)
         g_b = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[1]) else None
@@ -512,6 +596,7 @@ class _EluUpCatPad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         a, bias = ctx.saved_tensors
+        _on(a)
         B, Ca, h, w = a.shape
         Cs = ctx.Cs
         g_b = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[1]) else None
@@ -556,6 +641,7 @@ class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         x, y, weight, save = ctx.saved_tensors
+        _on(x)
         N, C, H, W = x.shape
         g_y = g_y.contiguous()
         g_x = torch.empty_like(x)
@@ -591,6 +677,7 @@ class _MaxPool3x3s2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         (idx,) = ctx.saved_tensors
+        _on(idx)
         N, C, H, W = ctx.shape
         g_x = torch.empty((N, C, H, W), device=idx.device, dtype=torch.float32)
         call('smd_maxpool3x3s2_bwd', g_y.contiguous().data_ptr(), idx.data_ptr(), g_x.data_ptr(), N, C, H, W, _stream())
@@ -620,6 +707,7 @@ class _DwConv7x7(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         x, weight = ctx.saved_tensors
+        _on(x)
         N, C, H, W = x.shape
         g_y = g_y.contiguous()
         g_x = g_w = g_b = None
@@ -660,6 +748,7 @@ class _LayerNormCF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         x, weight, stats = ctx.saved_tensors
+        _on(x)
         N, C, H, W = x.shape
         if g_y.dtype not in (torch.float32, torch.bfloat16): g_y = g_y.float()
         g_y = g_y.contiguous()
@@ -698,6 +787,7 @@ class _PoseMatrices(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_T):
         aa, t, invert = ctx.saved_tensors
+        _on(aa)
         g_T = g_T.contiguous()
         g_aa, g_t = torch.empty_like(aa), torch.empty_like(t)
         call('smd_pose_bwd', aa.data_ptr(), t.data_ptr(), invert.data_ptr() if invert is not None else None, aa.shape[0], g_T.data_ptr(),
@@ -726,6 +816,7 @@ class _Intrinsics(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_K, g_Kinv):
         fs, cs = ctx.saved_tensors
+        _on(fs)
         h, w = ctx.size
         g_fs, g_cs = torch.empty_like(fs), torch.empty_like(cs)
         call('smd_intrinsics_bwd', fs.data_ptr(), cs.data_ptr(), fs.shape[0], h, w, g_K.contiguous().data_ptr(), g_Kinv.contiguous().data_ptr(),

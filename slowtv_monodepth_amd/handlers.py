@@ -57,7 +57,7 @@ class LazyDepths(Mapping):
 
 
 def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs: torch.Tensor, Ts: torch.Tensor, Ks: torch.Tensor,
-                *, K_inv: torch.Tensor | None = None, noise: torch.Tensor | None = None, want_warp: bool = True):
+                *, K_inv: torch.Tensor | None = None, noise: torch.Tensor | None = None, want_warp: bool = True, prepared=None):
     """Reconstruction loss over all scales and supports (src/core/handlers.py:14-67).
 
     :param crit: `ReconstructionLoss` (its loss_name / use_min / use_automask select the kernel flags).
@@ -67,6 +67,8 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
     :param imgs: (b,3,h,w) target; supp_imgs: (n,b,3,h,w); Ts: (n,b,4,4); Ks: (b,4,4).
     :param K_inv: optional (b,4,4) inverse intrinsics when the caller already has them (`functional.intrinsics`).
     :param noise: optional (S*b,1,h,w) replacement for the reference's `randn_like` tie-break draw (reconstruction.py:72).
+    :param prepared: optional `functional.PreparedFrames` for (imgs, supp_imgs): the frame-only half of the forward, launched ahead
+        of time (the trainer does it on a side stream under the networks); ignored if it was built for something else.
     :return: (loss, {'supp_imgs_warp': (n,b,3,h,w) of scale 0 [, 'automask': (b,1,h,w) bool of scale 0]})
     """
     if masks is not None: raise NotImplementedError('predictive masks are outside the accelerated path')
@@ -76,14 +78,17 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
         return _image_recon_generic(crit, depths, imgs, supp_imgs, Ts, Ks, K_inv, noise, want_warp)
     flags = F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask)
     if isinstance(depths, LazyDepths) and depths.pending:   # K0 fused: no up-sampling launch, the kernel writes the depth stack
+        if prepared is not None and not prepared.matches(imgs, supp_imgs, flags, [d.shape[-2] for d in depths.disps], [d.shape[-1] for d in depths.disps]): prepared = None
         loss, err, sel, warp0, depth_up = F.image_recon_fused_disp(depths.disps, imgs, supp_imgs, Ts, Ks, K_inv, flags=flags, min_depth=depths.min_depth,
-                                                                   max_depth=depths.max_depth, noise=noise, seed=crit.next_seed(), want_warp=want_warp, want_err=False)
+                                                                   max_depth=depths.max_depth, noise=noise, seed=crit.next_seed(), want_warp=want_warp, want_err=False,
+                                                                   prepared=prepared)
         depths.adopt(depth_up)
     else:
         stacked = getattr(depths, 'stacked', None)
         if stacked is None: stacked = torch.stack(list(depths.values()))
+        if prepared is not None and not prepared.matches(imgs, supp_imgs, flags, None, None): prepared = None
         loss, err, sel, warp0 = F.image_recon_fused(stacked, imgs, supp_imgs, Ts, Ks, K_inv, flags=flags, noise=noise, seed=crit.next_seed(),
-                                                    want_warp=want_warp, want_err=False)
+                                                    want_warp=want_warp, want_err=False, prepared=prepared)
     ld = {}
     if crit.use_automask: ld['automask'] = sel[0] != 255
     if want_warp: ld['supp_imgs_warp'] = warp0

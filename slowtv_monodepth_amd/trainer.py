@@ -32,9 +32,17 @@ class HipLossBackend:
         depth_up, disp_up = F.disp_to_depth([disps[k].float() for k in keys], size, min_depth, max_depth, want_disp_up=want_disp_up)
         return ScaleDict.from_stack(keys, disp_up), ScaleDict.from_stack(keys, depth_up)
 
-    def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True, K_inv=None):
+    def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True, K_inv=None, prepared=None):
         from . import handlers
-        return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), K_inv=K_inv, want_warp=want_warp)
+        return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), K_inv=K_inv, want_warp=want_warp, prepared=prepared)
+
+    def prepare_frames(self, crit, imgs, supp_imgs, pyramid, stream):
+        """The frame-only half of the reconstruction forward (texel repack, target window sums, identity error of the automask:
+        everything `handlers.image_recon` needs that no network output enters), enqueued on `stream` so that it runs under the
+        networks instead of after them.  None when the fused operator will not be used for these tensors."""
+        from . import functional as F
+        if not imgs.is_cuda or imgs.shape[1] != 3 or crit.loss_name == 'l2' or imgs.dtype != torch.float32: return None
+        return F.image_recon_prep(imgs, supp_imgs, flags=F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask), pyramid=pyramid, stream=stream)
 
     def pose_matrices(self, aa, t, invert):
         """(N,3),(N,3) + python bool list -> (N,4,4); one launch for Rodrigues + the backward-in-time inverses."""
@@ -103,6 +111,15 @@ class MonoDepthModule(nn.Module):
         self.want_aux = bool(tcfg.get('log_images', False))  # supp_imgs_warp etc. are only for the image logger
         self.overlap_nets = bool(tcfg.get('overlap_nets', True))   # pose network on a second HIP stream, concurrent with the depth network
         self._side_streams = {}
+        self._prep_streams = {}
+        self._prepared = None
+        import os
+        # frame-only half of the reconstruction loss ahead of the networks: 'own' = on its own side stream at the start of the step,
+        # 'pose' = on the pose network's side stream behind that network, False = inline, inside the loss (after the networks)
+        self.prep_ahead = tcfg.get('prep_ahead', os.environ.get('SMD_PREP_AHEAD', 'pose'))
+        if self.prep_ahead in ('0', 'false', 'False', 0): self.prep_ahead = False
+        if self.prep_ahead in ('1', 'true', 'True', 1, True): self.prep_ahead = 'pose'   # measured at cfg 2: 'pose' 16.91-16.96 ms per step = inline (16.89-16.95); 'own' 17.13-17.23 (a third stream beside the two networks)
+        if self.prep_ahead == 'pose' and not self.overlap_nets: self.prep_ahead = 'own'
         self.timer = EventTimer(enabled=bool(tcfg.get('profile_phases', False)))
         if self.channels_last: self.nets.to(memory_format=torch.channels_last)
 
@@ -134,6 +151,8 @@ class MonoDepthModule(nn.Module):
             elif key == 'pose':
                 with (torch.cuda.stream(side) if side is not None else nullcontext()):
                     produced = self._forward_pose(net, x, idxs_all)
+                    if self.prep_ahead == 'pose' and side is not None and getattr(self, '_y', None) is not None:
+                        self._prepared = self._prepare_frames(self._y, stream=side)
                 if side is not None:
                     for v in produced.values(): v.record_stream(main)
                 fwd.update(produced)
@@ -176,8 +195,9 @@ class MonoDepthModule(nn.Module):
         for k, crit in self.losses.items():
             with self.timer(f'Loss-{k}'):
                 if k == 'img_recon':
+                    kw = {'prepared': self._prepared} if self._prepared is not None else {}
                     l, ld = self.backend.image_recon(crit, self.synth, fwd['depth_up'], fwd.get('mask_up'), y['imgs'], y['supp_imgs'],
-                                                     fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux, K_inv=fwd.get('K_inv'))
+                                                     fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux, K_inv=fwd.get('K_inv'), **kw)
                 elif k == 'disp_smooth':
                     l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'], want_aux=self.want_aux)
                 elif k == 'depth_regr':   # proxy-depth (Depth Hints) regression, src/core/trainer.py:425-433
@@ -211,11 +231,26 @@ class MonoDepthModule(nn.Module):
         """One forward pass + losses (src/core/trainer.py:115-190) -> (loss, loss_dict, fwd)."""
         x, y, m = batch
         self.synth = ViewSynth(x['imgs'].shape[-2:])
+        self._prepared = self._prepare_frames(y) if self.prep_ahead == 'own' else None
+        self._y = y
         with self.timer('Total'):
             with self.timer('Forward'): fwd = self.forward(x)
             with self.timer('Post-Process'): fwd = self.forward_postprocess(fwd, x, y)
             with self.timer('Loss'): loss, loss_dict = self.forward_loss(fwd, x, y)
         return loss, loss_dict, fwd
+
+    def _prepare_frames(self, y: dict, stream=None):
+        """Launch the frame-only half of `img_recon` before the networks (it needs `y['imgs']`, `y['supp_imgs']` only).  With the
+        decoder's pyramid (scale s = image size >> s) the K0 row table is built there too; if the networks then emit other sizes
+        the handler falls back to an inline prep."""
+        crit = self.losses['img_recon'] if 'img_recon' in self.losses else None
+        fn = getattr(self.backend, 'prepare_frames', None)
+        if not (self.prep_ahead and crit is not None and fn is not None and y['imgs'].is_cuda): return None
+        dev = y['imgs'].device
+        st = stream if stream is not None else self._prep_streams.setdefault(dev.index, torch.cuda.Stream(device=dev))
+        h, w = y['imgs'].shape[-2:]
+        pyramid = None if self.want_aux else [(max(h >> s, 1), max(w >> s, 1)) for s in self.scales]   # want_aux: depth comes from the K0 launch
+        return fn(crit, y['imgs'], y['supp_imgs'], pyramid, st)
 
     # ------------------------------------------------------------------------------------------------
     def configure_optimizers(self):

@@ -77,7 +77,7 @@ out['signature_problems'] = problems
 
 # ---- dispatch: the reference's own forward_loss, unbound, with the losses built by the reference's parser from a reference cfg
 calls = []
-def fake_recon(stacked, imgs, supp, Ts, Ks, K_inv=None, *, flags, noise=None, seed=0, want_warp=False, want_err=True):
+def fake_recon(stacked, imgs, supp, Ts, Ks, K_inv=None, *, flags, noise=None, seed=0, want_warp=False, want_err=True, prepared=None):
     calls.append(('image_recon_fused', tuple(stacked.shape), flags))
     S, b = stacked.shape[:2]; h, w = imgs.shape[-2:]
     return stacked.mean(), torch.zeros(S, b, 1, h, w), torch.zeros(S, b, 1, h, w, dtype=torch.uint8), torch.zeros_like(supp)
