@@ -39,6 +39,9 @@ extern "C" {
 #define SMD_NEED_K_GRAD 0x8    /* backward also emits dL/dK and dL/dK_inv (learned intrinsics) */
 #define SMD_USE_EDGES 0x10     /* SmoothReg(use_edges=True) (smooth.py:91-94) */
 #define SMD_LOSS_L2 0x20       /* DenseL2Error (photometric.py:17-20; loss_name='l2', un-fused operators only) */
+#define SMD_MASK_EXPLAINABILITY 0x80   /* smd_recon_reduce_*: ReconstructionLoss(mask_name='explainability'): err * mask (reconstruction.py:55) */
+#define SMD_MASK_UNCERTAINTY 0x100     /* smd_recon_reduce_*: mask_name='uncertainty': err * exp(-mask) + mask (reconstruction.py:56) */
+#define SMD_USE_LAPLACIAN 0x200        /* smd_disp_smooth_*: SmoothReg(use_laplacian=True): second-order differences (smooth.py:33-48) */
 #define SMD_PACKED_READY 0x40  /* smd_image_recon_*_fwd: `supp_packed` was already filled by smd_image_recon_prep() for these frames */
 /* RegressionLoss (src/losses/regression.py:40-75) */
 #define SMD_REGR_L1 0x0
@@ -136,7 +139,8 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
 /* ------------------------------------------------------------------------------------------------
  * Edge-aware disparity smoothness over all scales.  Replaces `handlers.disp_smooth(crit, disps, imgs)`
  * (src/core/handlers.py:262-281) = per scale SmoothReg.forward (src/regularizers/smooth.py:71-97) on the
- * bilinearly resized image, then mean_s(loss_s / 2^s).  use_laplacian/use_blur are not part of this path.
+ * bilinearly resized image, then mean_s(loss_s / 2^s).  SMD_USE_LAPLACIAN selects the second-order form (smooth.py:33-48);
+ * use_blur (a kornia Gaussian, absent from the build image) is not part of this path.
  *   disp[s] (b,1,hs,ws)   img (b,3,h,w)   scale_keys[s]: the dictionary key of scale s (loss_s is divided by 2^key;
  *   NULL -> key = s)
  *   loss (1) out;  stats (S,b,2) out: per (scale, sample) {mean disparity, un-normalised edge sum E} kept for backward
@@ -168,13 +172,14 @@ int smd_view_synth_bwd(const float* input, const float* depth, const float* T, c
                        float* g_input, float* g_depth, float* g_T, float* g_K, float* g_Kinv,
                        void* workspace, size_t workspace_bytes, int B, int C, int h, int w, void* stream);
 
-/* smd_photo_error_*: `PhotoError(0.85)(pred, target)`, `DenseL1Error` with SMD_LOSS_L1, `DenseL2Error` with SMD_LOSS_L2
+/* smd_photo_error_*: `PhotoError(weight_ssim)(pred, target)`, `DenseL1Error` with SMD_LOSS_L1, `DenseL2Error` with SMD_LOSS_L2
  * (src/losses/photometric.py:11-20, 54-88) for any channel count C (images: 3; `feat_recon` features: 64..256).
+ * weight_ssim in [0, 1] (photometric.py:65-73; `ReconstructionLoss` builds 0.85; 0 = L1 only, 1 = SSIM only); ignored by L1 / L2.
  * pred, target (N,C,h,w) -> err (N,1,h,w).  Backward: g_err (N,1,h,w) -> g_pred (N,C,h,w). */
 size_t smd_photo_error_workspace_bytes(int N, int C, int h, int w);
-int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, void* stream);
+int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, float weight_ssim, void* stream);
 int smd_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred,
-                        void* workspace, size_t workspace_bytes, int N, int C, int h, int w, int flags, void* stream);
+                        void* workspace, size_t workspace_bytes, int N, int C, int h, int w, int flags, float weight_ssim, void* stream);
 
 /* smd_regression_*: `RegressionLoss.forward(pred, target, mask)` (src/losses/regression.py:69-75) used by the
  * `stereo_const` and `depth_regr` handlers (src/core/handlers.py:152-259).  pred, target: N floats; mask: N uint8 or
@@ -187,15 +192,18 @@ int smd_regression_bwd(const float* pred, const float* target, const uint8_t* ma
                        const float* g_loss, float* g_pred, float* g_target, void* workspace, size_t workspace_bytes, void* stream);
 
 /* smd_recon_reduce_*: the reduction half of `ReconstructionLoss.forward` on per-support error maps
- * (reconstruction.py:43-44, 59-77, 125).  err_warp (n,B,h,w); err_static (n,B,h,w) (required with SMD_USE_AUTOMASK);
- * noise (B,h,w) or NULL (in-kernel tie-break noise keyed by `seed`).
- * -> err (B,h,w), sel (B,h,w) uint8, loss (1).  Backward -> g_err_warp (n,B,h,w). */
+ * (reconstruction.py:43-57, 59-77, 125).  err_warp (n,B,h,w); err_static (n,B,h,w) (required with SMD_USE_AUTOMASK);
+ * mask (B,n,h,w) or NULL: the predictive weighting mask of `apply_mask` (reconstruction.py:46-57), reference layout, applied to the
+ * warped AND the static errors before the reductions, with SMD_MASK_EXPLAINABILITY (err * mask) or SMD_MASK_UNCERTAINTY
+ * (err * exp(-mask) + mask); noise (B,h,w) or NULL (in-kernel tie-break noise keyed by `seed`).
+ * -> err (B,h,w), sel (B,h,w) uint8, loss (1).  Backward -> g_err_warp (n,B,h,w) and, with a mask, g_mask (B,n,h,w)
+ * (then err_warp / err_static / mask are read again; all three may be NULL without a mask). */
 size_t smd_recon_reduce_workspace_bytes(int B, int h, int w);
-int smd_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed,
+int smd_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* mask, const float* noise, uint64_t seed,
                          float* err, uint8_t* sel, float* loss, void* workspace, size_t workspace_bytes,
                          int n, int B, int h, int w, int flags, void* stream);
-int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp,
-                         int n, int B, int h, int w, int flags, void* stream);
+int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, const float* err_warp, const float* err_static,
+                         const float* mask, float* g_mask, int n, int B, int h, int w, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Monodepth decoder glue: everything between two 3x3 convolutions of

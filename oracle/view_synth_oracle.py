@@ -196,12 +196,14 @@ def ssim_error(pred, target, aten=False):
     return ((1 - num/den)/2).clamp(min=0, max=1)
 
 
-def photo_error(pred, target, loss_name='ssim', aten=False):
-    """(N,3,h,w) x2 -> (N,1,h,w).  'ssim': PhotoError(0.85) (photometric.py:75-88); 'l1': DenseL1Error (:11-14);
-    'l2': DenseL2Error (:17-20).  Selection table at src/losses/reconstruction.py:37-41."""
+def photo_error(pred, target, loss_name='ssim', aten=False, weight_ssim=W_SSIM):
+    """(N,3,h,w) x2 -> (N,1,h,w).  'ssim': PhotoError(weight_ssim) (photometric.py:65-88: each term is skipped when its weight
+    is 0); 'l1': DenseL1Error (:11-14); 'l2': DenseL2Error (:17-20).  Selection table at src/losses/reconstruction.py:37-41."""
     if loss_name == 'ssim':
-        return W_SSIM*ssim_error(pred, target, aten).mean(dim=1, keepdim=True) + \
-               (1 - W_SSIM)*(pred - target).abs().mean(dim=1, keepdim=True)
+        out = pred.new_zeros((pred.shape[0], 1, *pred.shape[-2:]))
+        if weight_ssim > 0: out = out + weight_ssim*ssim_error(pred, target, aten).mean(dim=1, keepdim=True)
+        if 1 - weight_ssim > 0: out = out + (1 - weight_ssim)*(pred - target).abs().mean(dim=1, keepdim=True)
+        return out
     if loss_name == 'l1': return (pred - target).abs().mean(dim=1, keepdim=True)
     if loss_name == 'l2': return (pred - target).pow(2).sum(dim=1, keepdim=True).clamp(min=EPS32).sqrt()
     raise KeyError(loss_name)
@@ -210,20 +212,29 @@ def photo_error(pred, target, loss_name='ssim', aten=False):
 # ---------------------------------------------------------------------------------------------------
 # a10: reconstruction loss (min / mean reprojection, automask)
 # ---------------------------------------------------------------------------------------------------
-def compute_photo(pred, target, loss_name='ssim', use_min=False, aten=False):
-    """`ReconstructionLoss.compute_photo` (src/losses/reconstruction.py:79-96) without the optional weighting mask.
+def apply_mask(err, mask, mask_name):
+    """`ReconstructionLoss.apply_mask` (src/losses/reconstruction.py:46-57): err (B,n,h,w), mask (B,n|1,h,w)."""
+    if mask_name and mask is None: raise ValueError("Must provide a 'mask' when masking...")
+    if mask_name == 'explainability': return err*mask
+    if mask_name == 'uncertainty': return err*(-mask).exp() + mask
+    return err
+
+
+def compute_photo(pred, target, loss_name='ssim', use_min=False, aten=False, mask=None, mask_name=None):
+    """`ReconstructionLoss.compute_photo` (src/losses/reconstruction.py:79-96).
     pred (n,B,3,h,w) or (B,3,h,w); target (B,3,h,w) -> reduced error (B,1,h,w) and per-support errors (B,n,h,w)."""
     if pred.ndim == 4: pred = pred[None]
     n, B = pred.shape[:2]
     tgt = target[None].expand_as(pred)
     err = photo_error(pred.flatten(0, 1), tgt.flatten(0, 1), loss_name, aten)             # (n*B,1,h,w)
     err = err.squeeze(1).unflatten(0, (n, B)).permute(1, 0, 2, 3)                          # (B,n,h,w)
+    err = apply_mask(err, mask, mask_name)                                                 # :94
     red = err.min(dim=1, keepdim=True)[0] if use_min else err.mean(dim=1, keepdim=True)    # :43-44
     return red, err
 
 
 def recon_loss(pred, target, source=None, loss_name='ssim', use_min=False, use_automask=False, noise=None, aten=False,
-               force_sel=None):
+               force_sel=None, mask=None, mask_name=None):
     """`ReconstructionLoss.forward` (src/losses/reconstruction.py:98-126).
     `noise` replaces the `torch.randn_like` draw of :72 (must be (B,1,h,w)); pass None to draw it here.
     Returns loss, dict(automask, err (after automask), err_warp, sel) — sel: index of the winning support, or
@@ -231,7 +242,7 @@ def recon_loss(pred, target, source=None, loss_name='ssim', use_min=False, use_a
     `force_sel` (B,1,h,w uint8; test aid, not part of the reference): take the min-reprojection / automask decisions from this
     map instead of the arg-min.  The parity tests use it to compare GRADIENTS under identical routing when a handful of
     near-ties (errors equal to ~1e-7) are decided differently by fp32 rounding; out['tie_gap'] reports how close they were."""
-    err_warp, per = compute_photo(pred, target, loss_name, use_min, aten)
+    err_warp, per = compute_photo(pred, target, loss_name, use_min, aten, mask, mask_name)
     sel = per.argmin(dim=1, keepdim=True) if use_min else torch.zeros_like(err_warp, dtype=torch.long)
     out = {}
     if force_sel is not None and use_min:
@@ -245,7 +256,7 @@ def recon_loss(pred, target, source=None, loss_name='ssim', use_min=False, use_a
     err = err_warp
     if use_automask:
         if source is None: raise ValueError("Must provide the original 'source' images when automasking...")
-        err_static, _ = compute_photo(source, target, loss_name, use_min, aten)              # :71
+        err_static, _ = compute_photo(source, target, loss_name, use_min, aten, mask, mask_name)   # :70 (the mask weights the identity error too)
         if noise is None: noise = torch.randn_like(err_static)
         err_static = err_static + EPS32*noise                                                # :72
         err, idx = torch.min(torch.cat((err_warp, err_static), dim=1), dim=1, keepdim=True)  # :74-75
@@ -272,12 +283,19 @@ def _abs_fwd_diff(x):
     return dx, dy
 
 
-def smooth_reg(disp, img, use_edges=False):
-    """`SmoothReg.forward` with use_laplacian=False, use_blur=False (src/regularizers/smooth.py:71-97)."""
+def _laplacian(x):
+    """`compute_laplacian(x)[:2]` (src/regularizers/smooth.py:33-48, use_blur=False): (|d/dx |dx||, |d/dy |dy||)."""
+    dx, dy = _abs_fwd_diff(x)
+    return _abs_fwd_diff(dx)[0], _abs_fwd_diff(dy)[1]
+
+
+def smooth_reg(disp, img, use_edges=False, use_laplacian=False):
+    """`SmoothReg.forward` with use_blur=False (src/regularizers/smooth.py:71-97); `use_laplacian`: second-order differences."""
+    fn = _laplacian if use_laplacian else _abs_fwd_diff
     d = disp/disp.mean(dim=(2, 3), keepdim=True).clamp(min=EPS32)        # ops.mean_normalize, src/tools/ops.py:279-286
-    ddx, ddy = _abs_fwd_diff(d)
+    ddx, ddy = fn(d)
     disp_grad = (ddx.pow(2) + ddy.pow(2)).clamp(min=EPS32).sqrt()        # :86
-    idx_, idy_ = _abs_fwd_diff(img)
+    idx_, idy_ = fn(img)
     idx_, idy_ = idx_.mean(dim=1, keepdim=True), idy_.mean(dim=1, keepdim=True)
     img_grad = (idx_.pow(2) + idy_.pow(2)).clamp(min=EPS32).sqrt()       # :89
     if use_edges: ddx, ddy = ddx*(-idx_).exp(), ddy*(-idy_).exp()        # :91-94

@@ -17,7 +17,8 @@ __all__ = ['lib', 'call', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_
 _HERE = Path(__file__).resolve().parent
 lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
 
-FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10, 'loss_l2': 0x20, 'packed_ready': 0x40}
+FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10, 'loss_l2': 0x20, 'packed_ready': 0x40,
+         'mask_explainability': 0x80, 'mask_uncertainty': 0x100, 'use_laplacian': 0x200}
 REGR_FLAGS = {'l1': 0x0, 'log_l1': 0x1, 'berhu': 0x2, 'invert': 0x4}
 SEL_MASKED = 255
 MAX_SCALES = 8
@@ -49,14 +50,14 @@ PROTOTYPES = {
     'smd_view_synth_fwd': (_i, [_vp]*8 + [_i]*4 + [_vp]),
     'smd_view_synth_bwd': (_i, [_vp]*13 + [_sz] + [_i]*4 + [_vp]),
     'smd_photo_error_workspace_bytes': (_sz, [_i, _i, _i, _i]),
-    'smd_photo_error_fwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
-    'smd_photo_error_bwd': (_i, [_vp]*5 + [_sz] + [_i]*5 + [_vp]),
+    'smd_photo_error_fwd': (_i, [_vp]*3 + [_i]*5 + [_f, _vp]),
+    'smd_photo_error_bwd': (_i, [_vp]*5 + [_sz] + [_i]*5 + [_f, _vp]),
     'smd_regression_workspace_bytes': (_sz, [_sz]),
     'smd_regression_fwd': (_i, [_vp]*3 + [_sz, _i] + [_vp]*4 + [_sz, _vp]),
     'smd_regression_bwd': (_i, [_vp]*3 + [_sz, _i] + [_vp]*5 + [_sz, _vp]),
     'smd_recon_reduce_workspace_bytes': (_sz, [_i, _i, _i]),
-    'smd_recon_reduce_fwd': (_i, [_vp]*3 + [_u64] + [_vp]*4 + [_sz] + [_i]*5 + [_vp]),
-    'smd_recon_reduce_bwd': (_i, [_vp]*3 + [_i]*5 + [_vp]),
+    'smd_recon_reduce_fwd': (_i, [_vp]*4 + [_u64] + [_vp]*4 + [_sz] + [_i]*5 + [_vp]),
+    'smd_recon_reduce_bwd': (_i, [_vp]*7 + [_i]*5 + [_vp]),
     'smd_decoder_glue_workspace_bytes': (_sz, [_i]*4),
     'smd_elu_pad_fwd': (_i, [_vp]*3 + [_i]*6 + [_vp]),
     'smd_elu_pad_bwd': (_i, [_vp]*6 + [_sz] + [_i]*6 + [_vp]),

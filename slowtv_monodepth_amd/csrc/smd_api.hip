@@ -383,7 +383,10 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
 // ------------------------------------------------------------------------------------------------
 static int smooth_chunks(const int* hs, const int* ws, int S) {
   int mx = 1;
-  for (int s = 0; s < S; ++s) mx = smd::smooth_units_of(hs[s], ws[s]) > mx ? smd::smooth_units_of(hs[s], ws[s]) : mx;
+  for (int s = 0; s < S; ++s) {   // units of the streaming sweep, or blocks of 256 pixels of the second-order (laplacian) sweep
+    const int u = smd::smooth_units_of(hs[s], ws[s]), p = smd::ceil_div(hs[s]*ws[s], 256);
+    mx = (u > p ? u : p) > mx ? (u > p ? u : p) : mx;
+  }
   return mx;
 }
 
@@ -421,6 +424,7 @@ int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, 
   smd::ScaleSet sc;
   if (int rc = fill_scales(sc, disp, g_disp, hs, ws, scale_keys, S)) return rc;
   for (int s = 0; s < S; ++s) if (!disp[s] || !g_disp[s]) return fail(SMD_E_INVALID, "null pointer for scale %d", s);
+  if ((flags & SMD_USE_LAPLACIAN) && (flags & SMD_USE_EDGES) && !edge_weights) return fail(SMD_E_INVALID, "the second-order adjoint needs the edge weights the forward cached");
   return check_launch(smd::launch_smooth_bwd(sc, b, img, h, w, flags, stats, g_loss, edge_weights, (hipStream_t)stream), "disp_smooth_bwd");
 }
 
@@ -453,18 +457,20 @@ size_t smd_photo_error_workspace_bytes(int N, int C, int h, int w) {
   return align256((size_t)N*3*C*h*w*sizeof(float));
 }
 
-int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, void* stream) {
+int smd_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, float weight_ssim, void* stream) {
   if (!pred || !target || !err) return fail(SMD_E_INVALID, "null pointer");
   if (N < 1 || N > 65535 || C < 1 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d h=%d w=%d", N, C, h, w);
-  return check_launch(smd::launch_photo_error_fwd(pred, target, err, N, C, h, w, flags, (hipStream_t)stream), "photo_error_fwd");
+  if (!(weight_ssim >= 0.f && weight_ssim <= 1.f)) return fail(SMD_E_INVALID, "Invalid SSIM weight. (%g vs. [0, 1])", weight_ssim);
+  return check_launch(smd::launch_photo_error_fwd(pred, target, err, N, C, h, w, flags, weight_ssim, (hipStream_t)stream), "photo_error_fwd");
 }
 
 int smd_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred, void* workspace, size_t workspace_bytes,
-                        int N, int C, int h, int w, int flags, void* stream) {
+                        int N, int C, int h, int w, int flags, float weight_ssim, void* stream) {
   if (!pred || !target || !g_err || !g_pred || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (N < 1 || N > 65535 || C < 1 || h < 2 || w < 2) return fail(SMD_E_INVALID, "invalid sizes N=%d C=%d h=%d w=%d", N, C, h, w);
   if (workspace_bytes < smd_photo_error_workspace_bytes(N, C, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
-  return check_launch(smd::launch_photo_error_bwd(pred, target, g_err, g_pred, (float*)workspace, N, C, h, w, flags, (hipStream_t)stream), "photo_error_bwd");
+  if (!(weight_ssim >= 0.f && weight_ssim <= 1.f)) return fail(SMD_E_INVALID, "Invalid SSIM weight. (%g vs. [0, 1])", weight_ssim);
+  return check_launch(smd::launch_photo_error_bwd(pred, target, g_err, g_pred, (float*)workspace, N, C, h, w, flags, weight_ssim, (hipStream_t)stream), "photo_error_bwd");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -496,20 +502,23 @@ size_t smd_recon_reduce_workspace_bytes(int B, int h, int w) {
   return align256((size_t)smd::ceil_div(B*h*w, 256)*sizeof(float));
 }
 
-int smd_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed, float* err, uint8_t* sel,
+int smd_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* mask, const float* noise, uint64_t seed, float* err, uint8_t* sel,
                          float* loss, void* workspace, size_t workspace_bytes, int n, int B, int h, int w, int flags, void* stream) {
   if (!err_warp || !err || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if ((flags & (SMD_MASK_EXPLAINABILITY | SMD_MASK_UNCERTAINTY)) && !mask) return fail(SMD_E_INVALID, "Must provide a 'mask' when masking...");
   if ((flags & SMD_USE_AUTOMASK) && !err_static) return fail(SMD_E_INVALID, "Must provide the original 'source' images when automasking...");
   if (n < 1 || n >= SMD_SEL_MASKED || B < 1 || h < 1 || w < 1) return fail(SMD_E_INVALID, "invalid sizes");
   if (workspace_bytes < smd_recon_reduce_workspace_bytes(B, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
-  return check_launch(smd::launch_recon_reduce_fwd(err_warp, err_static, noise, seed, err, sel, loss, (float*)workspace, n, B, h, w, flags,
+  return check_launch(smd::launch_recon_reduce_fwd(err_warp, err_static, mask, noise, seed, err, sel, loss, (float*)workspace, n, B, h, w, flags,
                                                    (hipStream_t)stream), "recon_reduce_fwd");
 }
 
-int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w, int flags, void* stream) {
+int smd_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, const float* err_warp, const float* err_static,
+                         const float* mask, float* g_mask, int n, int B, int h, int w, int flags, void* stream) {
   if (!sel || !g_loss || !g_err_warp) return fail(SMD_E_INVALID, "null pointer");
   if (n < 1 || B < 1 || h < 1 || w < 1) return fail(SMD_E_INVALID, "invalid sizes");
-  return check_launch(smd::launch_recon_reduce_bwd(sel, g_loss, g_err_warp, n, B, h, w, flags, (hipStream_t)stream), "recon_reduce_bwd");
+  if (mask && (!g_mask || !err_warp || ((flags & SMD_USE_AUTOMASK) && !err_static))) return fail(SMD_E_INVALID, "a masked reduction needs err_warp, err_static (with automask) and g_mask");
+  return check_launch(smd::launch_recon_reduce_bwd(sel, g_loss, g_err_warp, err_warp, err_static, mask, g_mask, n, B, h, w, flags, (hipStream_t)stream), "recon_reduce_bwd");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -313,6 +313,16 @@ __device__ __forceinline__ void ssim_err_grad(float mx, float exx, float exy, fl
   d_exy = pass*(2.f*a1)*rden;        // dval/dexy = 2 a1 / den
 }
 
+// Reader side of the in-launch hand-offs (the wave that arrived last reads what the others published).  Every such read in this
+// library is an agent-scope load (sc1: `__hip_atomic_load(.., AGENT)` or a buffer load with aux = 16), which is coherent at agent
+// scope by itself — the two-granule form R2 of cdna_hip_programming.md Guideline 16 — so no acquire fence (`buffer_inv sc1`,
+// ~1.7 us on the critical path of a launch's last wave) is needed; it would be before PLAIN loads.  -DSMD_TAIL_FENCE restores it.
+#ifdef SMD_TAIL_FENCE
+#define SMD_TAIL_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define SMD_TAIL_ACQUIRE() ((void)0)
+#endif
+
 // Counter-based Gaussian for the automask tie-break when the caller supplies no noise tensor.
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;

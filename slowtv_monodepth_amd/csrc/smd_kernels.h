@@ -179,14 +179,14 @@ hipError_t launch_view_synth_fwd(const float* input, const float* depth, const f
 hipError_t launch_view_synth_bwd(const float* input, const float* depth, const float* T, const float* K, const float* Kinv,
                                  const float* g_warp, const float* g_depth_warp, float* g_input, float* g_depth,
                                  float* g_T, float* g_K, float* g_Kinv, float* ws, int B, int C, int h, int w, hipStream_t st);
-hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, hipStream_t st);
+hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, float w_ssim, hipStream_t st);
 hipError_t launch_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred, float* ws,
-                                  int N, int C, int h, int w, int flags, hipStream_t st);
-hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed,
+                                  int N, int C, int h, int w, int flags, float w_ssim, hipStream_t st);
+hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* mask, const float* noise, uint64_t seed,
                                    float* err, uint8_t* sel, float* loss, float* ws, int n, int B, int h, int w, int flags,
                                    hipStream_t st);
-hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w,
-                                   int flags, hipStream_t st);
+hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, const float* err_warp, const float* err_static,
+                                   const float* mask, float* g_mask, int n, int B, int h, int w, int flags, hipStream_t st);
 hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
 hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, int mode, hipStream_t st);
 size_t decoder_bias_partials(int B, int C, int h, int w);

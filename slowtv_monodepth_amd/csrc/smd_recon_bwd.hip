@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     last = (__hip_atomic_fetch_add(a.arrive + bi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u) ? 1u : 0u;
   }
   if (!__builtin_amdgcn_readfirstlane((int)last)) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  SMD_TAIL_ACQUIRE();
   // scratch: the head of this wave's own history rows (free: its row loop is over, and a strip's sum reads only the dL/d depth rows behind them)
   pose_finalize_wave(a, bi, a.S*nbx, reinterpret_cast<double*>(wave_lds));
   if (lane == 0) __hip_atomic_store(a.arrive + bi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call on this buffer

@@ -677,7 +677,7 @@ __device__ __forceinline__ void recon_main_reduce(const ReconMainArgs& a, MainTa
     last = (__hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
   }
   if (!__builtin_amdgcn_readfirstlane((int)last)) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  SMD_TAIL_ACQUIRE();
   // The sweep is pure latency (this wave runs alone at the very end of the launch): 16-byte agent-scope loads, sixteen of them
   // per lane issued before the first is used — one round trip per 2048 partials.  Beyond the last partial the buffer reads 0.
   const unsigned bytes = gridDim.x*8u;

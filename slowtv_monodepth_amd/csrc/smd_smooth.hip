@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
       flag = (__hip_atomic_fetch_add(arrive + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ceil_div(units, 4) - 1u) ? 1u : 0u;
   }
   if (!__builtin_amdgcn_readfirstlane((int)flag)) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  SMD_TAIL_ACQUIRE();
   {  // this wave completed the pair: (mean, E) and the pair's share of the loss
     double e = 0.0, dsum = 0.0;
     const unsigned long long* pp = (const unsigned long long*)partial + (size_t)pair*max_units;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
     }
   }
   if (!__builtin_amdgcn_readfirstlane((int)flag)) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  SMD_TAIL_ACQUIRE();
   double total = 0.0;
   for (int q = lane; q < npairs; q += 64) total += __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)contrib + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
@@ -212,14 +212,14 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
 // Second stage as a launch of its own (used when the pyramid has more (scale, sample) pairs than arrival slots): per image mean m
 // and E = E'/max(m, eps) -> stats; loss = mean_s( 2^-key_s * sum_b E / (b*hs*ws) ).  One wave per pair, 16 waves, one block.
 __global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int b, const float* __restrict__ partial, int max_chunks,
-                                                          float* __restrict__ stats, float* __restrict__ loss) {
+                                                          float* __restrict__ stats, float* __restrict__ loss, int per_pixel_units) {
   __shared__ double contrib[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double mine = 0.0;
   for (int pair = wv; pair < sc.S*b; pair += 16) {
     const int s = pair/b;
     const int n = sc.hs[s]*sc.ws[s];
-    const int chunks = smooth_units_of(sc.hs[s], sc.ws[s]);
+    const int chunks = per_pixel_units ? ceil_div(n, 256) : smooth_units_of(sc.hs[s], sc.ws[s]);
     double e = 0.0, dsum = 0.0;
     const float2* __restrict__ pp = (const float2*)partial + (size_t)pair*max_chunks;
     int c = lane;
@@ -241,6 +241,133 @@ __global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int
     double total = 0.0;
     for (int k = 0; k < 16; ++k) total += contrib[k];
     loss[0] = (float)(total/sc.S);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// SmoothReg(use_laplacian=True) (src/regularizers/smooth.py:33-48): second-order differences
+//   a[u] = |x[u] - x[u+1]| (0 in the last column),  xx[u] = |a[u] - a[u+1]| (0 in the last column),  likewise in y.
+// Still 1-homogeneous in the disparity, so the mean-normalisation algebra of the first-order form carries over unchanged
+// (E = E'/m; the adjoint needs only (mean, E) and signs).  No BASELINE configuration enables it: one thread per pixel, the
+// two-launch second stage; the edge weights exp(-image xx), exp(-image yy) are always cached for the adjoint.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lap1(float x0, float x1, float x2, int i, int n) {   // xx at position i of a line of n values x0 = x[i], x1 = x[i+1], x2 = x[i+2]
+  if (i >= n - 1) return 0.f;
+  const float a0 = fabsf(x0 - x1), a1 = (i + 1 < n - 1) ? fabsf(x1 - x2) : 0.f;
+  return fabsf(a0 - a1);
+}
+
+__global__ __launch_bounds__(256) void k_smooth_lap_main(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
+                                                         float* __restrict__ partial, int max_units, float* __restrict__ edge_w) {
+  __shared__ float red[4];
+  const int s = blockIdx.z, bi = blockIdx.y;
+  const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
+  const int pix = blockIdx.x*256 + threadIdx.x;
+  if ((int)blockIdx.x*256 >= n) return;
+  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
+  const float* __restrict__ im = img + (size_t)bi*3*h*w;
+  const bool edges = flags & SMD_USE_EDGES;
+  float2* __restrict__ ew = (edges && edge_w) ? (float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
+  float e = 0.f, dsum = 0.f;
+  if (pix < n) {
+    const int v = pix/ws, u = pix - v*ws;
+    auto D = [&](int vv, int uu) { return d[(size_t)min(vv, hs - 1)*ws + min(uu, ws - 1)]; };
+    const float dc = D(v, u);
+    const float dxx = lap1(dc, D(v, u + 1), D(v, u + 2), u, ws), dyy = lap1(dc, D(v + 1, u), D(v + 2, u), v, hs);
+    float wx = 1.f, wy = 1.f;
+    if (edges) {
+      float c0[3], r1[3], r2[3], b1[3], b2[3];
+      img_at(im, h, w, hs, ws, v, u, c0);
+      img_at(im, h, w, hs, ws, v, min(u + 1, ws - 1), r1); img_at(im, h, w, hs, ws, v, min(u + 2, ws - 1), r2);
+      img_at(im, h, w, hs, ws, min(v + 1, hs - 1), u, b1); img_at(im, h, w, hs, ws, min(v + 2, hs - 1), u, b2);
+      float ix = 0.f, iy = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { ix += lap1(c0[c], r1[c], r2[c], u, ws); iy += lap1(c0[c], b1[c], b2[c], v, hs); }
+      wx = __expf(-ix*(1.f/3.f)); wy = __expf(-iy*(1.f/3.f));
+      if (ew) ew[pix] = make_float2(wx, wy);
+    }
+    e = dxx*wx + dyy*wy; dsum = dc;
+  }
+  const float totE = block_sum_256(e, red), totD = block_sum_256(dsum, red);
+  if (threadIdx.x == 0) {
+    float* pp = partial + (((size_t)s*b + bi)*max_units + blockIdx.x)*2;
+    pp[0] = totE; pp[1] = totD;
+  }
+}
+
+// dE'/dd at pixel i of a line (un-normalised disparities x[-2..2] around it, weights wgt[-2..0] of the three terms that contain it)
+__device__ __forceinline__ float lap1_grad(const float x[5], const float wgt[3], int i, int n) {
+  auto sg = [](float t) { return (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f); };
+  float G = 0.f;
+#pragma unroll
+  for (int t = -2; t <= 0; ++t) {                 // term at position p = i + t: | a[p] - a[p+1] |, a[k] = |x[k] - x[k+1]| (0 for k >= n-1)
+    const int p = i + t;
+    if (p < 0 || p >= n - 1) continue;
+    const float xa = x[t + 2], xb = x[t + 3], xc = (t + 4 <= 4) ? x[t + 4] : 0.f;       // x[p], x[p+1], x[p+2]
+    const float a0 = fabsf(xa - xb), a1 = (p + 1 < n - 1) ? fabsf(xb - xc) : 0.f;
+    // d a0 / d x[i]: i == p -> sg(xa - xb), i == p+1 -> -sg(xa - xb);  d a1 / d x[i]: i == p+1 -> sg(xb - xc), i == p+2 -> -sg(xb - xc)
+    float da0 = 0.f, da1 = 0.f;
+    if (t == 0) da0 = sg(xa - xb);
+    else if (t == -1) { da0 = -sg(xa - xb); if (p + 1 < n - 1) da1 = sg(xb - xc); }
+    else if (p + 1 < n - 1) da1 = -sg(xb - xc);
+    G = fmaf(wgt[t + 2]*sg(a0 - a1), da0 - da1, G);
+  }
+  return G;
+}
+
+__global__ __launch_bounds__(256) void k_smooth_lap_bwd(const ScaleSet sc, int b, int flags, const float* __restrict__ stats, const float* __restrict__ g_loss,
+                                                        const float* __restrict__ edge_w) {
+  const int s = blockIdx.z, bi = blockIdx.y;
+  const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
+  const int pix = blockIdx.x*256 + threadIdx.x;
+  if (pix >= n) return;
+  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
+  float* __restrict__ gd = sc.g[s] + (size_t)bi*n;
+  const float mean = stats[((size_t)s*b + bi)*2], E = stats[((size_t)s*b + bi)*2 + 1];
+  const float m = fmaxf(mean, kEps32), inv_m = 1.f/m;
+  const float gs = g_loss[0]*exp2f(-(float)sc.key[s])/((float)sc.S*(float)b*(float)n);
+  const float mean_term = (mean >= kEps32) ? E*inv_m/(float)n : 0.f;
+  const float2* __restrict__ ew = ((flags & SMD_USE_EDGES) && edge_w) ? (const float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
+  const int v = pix/ws, u = pix - v*ws;
+  float xh[5], xv[5], wh[3], wv[3];
+#pragma unroll
+  for (int t = -2; t <= 2; ++t) {
+    xh[t + 2] = d[(size_t)v*ws + min(max(u + t, 0), ws - 1)];
+    xv[t + 2] = d[(size_t)min(max(v + t, 0), hs - 1)*ws + u];
+  }
+#pragma unroll
+  for (int t = -2; t <= 0; ++t) {
+    wh[t + 2] = ew ? ew[(size_t)v*ws + max(u + t, 0)].x : 1.f;
+    wv[t + 2] = ew ? ew[(size_t)max(v + t, 0)*ws + u].y : 1.f;
+  }
+  const float G = lap1_grad(xh, wh, u, ws) + lap1_grad(xv, wv, v, hs);
+  gd[pix] = gs*(G*inv_m - mean_term);
+}
+
+// aux maps of the first scale for the second-order form (smooth.py:86, 89 on the laplacian's (xx, yy))
+__global__ __launch_bounds__(256) void k_smooth_lap_aux(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w,
+                                                        const float* __restrict__ stats, float* __restrict__ disp_grad, float* __restrict__ image_grad) {
+  const int bi = blockIdx.y;
+  const int hs = sc.hs[0], ws = sc.ws[0], n = hs*ws;
+  const float* __restrict__ d = sc.p[0] + (size_t)bi*n;
+  const float* __restrict__ im = img + (size_t)bi*3*h*w;
+  const float inv_m = 1.f/fmaxf(stats[(size_t)bi*2], kEps32);
+  for (int pix = blockIdx.x*256 + threadIdx.x; pix < n; pix += gridDim.x*256) {
+    const int v = pix/ws, u = pix - v*ws;
+    auto D = [&](int vv, int uu) { return d[(size_t)min(vv, hs - 1)*ws + min(uu, ws - 1)]*inv_m; };
+    const float dc = D(v, u);
+    const float gx = lap1(dc, D(v, u + 1), D(v, u + 2), u, ws), gy = lap1(dc, D(v + 1, u), D(v + 2, u), v, hs);
+    float c0[3], r1[3], r2[3], b1[3], b2[3];
+    img_at(im, h, w, hs, ws, v, u, c0);
+    img_at(im, h, w, hs, ws, v, min(u + 1, ws - 1), r1); img_at(im, h, w, hs, ws, v, min(u + 2, ws - 1), r2);
+    img_at(im, h, w, hs, ws, min(v + 1, hs - 1), u, b1); img_at(im, h, w, hs, ws, min(v + 2, hs - 1), u, b2);
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ax += lap1(c0[c], r1[c], r2[c], u, ws); ay += lap1(c0[c], b1[c], b2[c], v, hs); }
+    ax *= (1.f/3.f); ay *= (1.f/3.f);
+    if (disp_grad) disp_grad[(size_t)bi*n + pix] = sqrtf(fmaxf(gx*gx + gy*gy, kEps32));
+    if (image_grad) image_grad[(size_t)bi*n + pix] = sqrtf(fmaxf(ax*ax + ay*ay, kEps32));
   }
 }
 
@@ -276,12 +403,22 @@ hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st) {
   int max_chunks = 1;   // units (waves) of the largest scale; the partial sums of a (scale, sample) are strided by it
   for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_units_of(sc.hs[s], sc.ws[s]));
+  if (flags & SMD_USE_LAPLACIAN) {   // second-order form: one thread per pixel, two-launch second stage
+    int mu = 1;
+    for (int s = 0; s < sc.S; ++s) mu = max(mu, ceil_div(sc.hs[s]*sc.ws[s], 256));
+    // (the C ABI sizes the workspace for these units too: smd_disp_smooth_workspace_bytes)
+    hipLaunchKernelGGL(k_smooth_lap_main, dim3(mu, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, mu, edge_w);
+    hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, mu, stats, loss, 1);
+    if (disp_grad || image_grad)
+      hipLaunchKernelGGL(k_smooth_lap_aux, dim3(min(ceil_div(sc.hs[0]*sc.ws[0], 256), 480), b), dim3(256), 0, st, sc, b, img, h, w, stats, disp_grad, image_grad);
+    return hipGetLastError();
+  }
   // in-launch second stage when the pairs fit the arrival-slot pool; `contrib` sits behind the partials in the workspace
   unsigned* arrive = arrive_slots(sc.S*b + 1);
   double* contrib = (double*)(ws_sums + (size_t)sc.S*b*max_chunks*2);
   hipLaunchKernelGGL(k_smooth_main, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks, edge_w,
                      stats, loss, arrive, contrib);
-  if (!arrive) hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss);
+  if (!arrive) hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss, 0);
   if (disp_grad || image_grad)
     hipLaunchKernelGGL(k_smooth_aux, dim3(min(ceil_div(sc.hs[0]*sc.ws[0], 256), 480), b), dim3(256), 0, st, sc, b, img, h, w, stats, disp_grad, image_grad);
   return hipGetLastError();
@@ -358,6 +495,12 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
 
 hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
                              const float* g_loss, const float* edge_w, hipStream_t st) {
+  if (flags & SMD_USE_LAPLACIAN) {
+    int mu = 1;
+    for (int s = 0; s < sc.S; ++s) mu = max(mu, ceil_div(sc.hs[s]*sc.ws[s], 256));
+    hipLaunchKernelGGL(k_smooth_lap_bwd, dim3(mu, b, sc.S), dim3(256), 0, st, sc, b, flags, stats, g_loss, edge_w);
+    return hipGetLastError();
+  }
   int max_chunks = 1;
   for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_chunks_of(sc.hs[s]*sc.ws[s]));
   hipLaunchKernelGGL(k_smooth_bwd, dim3(max_chunks, b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, stats, g_loss, edge_w);

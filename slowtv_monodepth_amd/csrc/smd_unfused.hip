@@ -153,7 +153,7 @@ __device__ __forceinline__ void window_sums(const float* __restrict__ x, const f
 }
 
 __global__ __launch_bounds__(kUfBlock) void k_photo_error_fwd(const float* __restrict__ pred, const float* __restrict__ target,
-                                                              float* __restrict__ err, int C, int h, int w, int mode) {
+                                                              float* __restrict__ err, int C, int h, int w, int mode, float w_ssim) {
   const int ni = blockIdx.y;
   const int pix = blockIdx.x*kUfBlock + threadIdx.x;
   if (pix >= h*w) return;
@@ -175,26 +175,29 @@ __global__ __launch_bounds__(kUfBlock) void k_photo_error_fwd(const float* __res
     }
   }
   const float rc = 1.f/(float)C;
-  err[(size_t)ni*hw + pix] = mode == kPhotoL2 ? sqrtf(fmaxf(e2, kEps32)) : (mode == kPhotoL1 ? el*rc : fmaf(kWSsim*rc, es, ((1.f - kWSsim)*rc)*el));
+  // PhotoError(weight_ssim) (src/losses/photometric.py:85-86): weight_ssim * mean_c SSIM + (1 - weight_ssim) * mean_c |.|
+  err[(size_t)ni*hw + pix] = mode == kPhotoL2 ? sqrtf(fmaxf(e2, kEps32)) : (mode == kPhotoL1 ? el*rc : fmaf(w_ssim*rc, es, ((1.f - w_ssim)*rc)*el));
 }
 
 static inline int photo_mode(int flags) { return (flags & SMD_LOSS_L2) ? kPhotoL2 : ((flags & SMD_LOSS_L1) ? kPhotoL1 : kPhotoSsim); }
 
-hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, hipStream_t st) {
-  hipLaunchKernelGGL(k_photo_error_fwd, dim3(ceil_div(h*w, kUfBlock), N), dim3(kUfBlock), 0, st, pred, target, err, C, h, w, photo_mode(flags));
+hipError_t launch_photo_error_fwd(const float* pred, const float* target, float* err, int N, int C, int h, int w, int flags, float w_ssim, hipStream_t st) {
+  int mode = photo_mode(flags);
+  if (mode == kPhotoSsim && w_ssim == 0.f) mode = kPhotoL1;      // PhotoError(0): the SSIM term is not evaluated (photometric.py:72)
+  hipLaunchKernelGGL(k_photo_error_fwd, dim3(ceil_div(h*w, kUfBlock), N), dim3(kUfBlock), 0, st, pred, target, err, C, h, w, mode, w_ssim);
   return hipGetLastError();
 }
 
 // Backward, pass 1: per pixel p the three SSIM partials (w.r.t. the x9 sums) times the upstream gradient -> coef (N,9,h,w).
 __global__ __launch_bounds__(kUfBlock) void k_photo_coef(const float* __restrict__ pred, const float* __restrict__ target,
-                                                         const float* __restrict__ g_err, float* __restrict__ coef, int C, int h, int w) {
+                                                         const float* __restrict__ g_err, float* __restrict__ coef, int C, int h, int w, float w_ssim) {
   const int ni = blockIdx.y;
   const int pix = blockIdx.x*kUfBlock + threadIdx.x;
   if (pix >= h*w) return;
   const int v = pix/w, u = pix - v*w;
   const size_t hw = (size_t)h*w;
   constexpr float c1 = 81.f*kC1, c2 = 81.f*kC2;
-  const float g = g_err[(size_t)ni*hw + pix]*(kWSsim/(float)C);
+  const float g = g_err[(size_t)ni*hw + pix]*(w_ssim/(float)C);
   for (int c = 0; c < C; ++c) {
     const float* x = pred + ((size_t)ni*C + c)*hw; const float* y = target + ((size_t)ni*C + c)*hw;
     float sx, sxx, sxy, sy, syy;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(kUfBlock) void k_photo_coef(const float* __restrict
 // Backward, pass 2: adjoint of (reflection pad + 3x3 sum) applied to the coefficient maps, plus the L1 term.
 __global__ __launch_bounds__(kUfBlock) void k_photo_error_bwd(const float* __restrict__ pred, const float* __restrict__ target,
                                                               const float* __restrict__ g_err, const float* __restrict__ coef,
-                                                              float* __restrict__ g_pred, int C, int h, int w, int mode) {
+                                                              float* __restrict__ g_pred, int C, int h, int w, int mode, float w_ssim) {
   const int ni = blockIdx.y;
   const int pix = blockIdx.x*kUfBlock + threadIdx.x;
   if (pix >= h*w) return;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kUfBlock) void k_photo_error_bwd(const float* __res
     for (int c = 0; c < C; ++c) g_pred[((size_t)ni*C + c)*hw + pix] = k*(pred[((size_t)ni*C + c)*hw + pix] - target[((size_t)ni*C + c)*hw + pix]);
     return;
   }
-  const float gl = ge*(mode == kPhotoL1 ? 1.f : (1.f - kWSsim))/(float)C;
+  const float gl = ge*(mode == kPhotoL1 ? 1.f : (1.f - w_ssim))/(float)C;
   float wv[3], wu[3];
   reflect_weights_adj(v, h, wv[0], wv[2]); wv[1] = 1.f;
   reflect_weights_adj(u, w, wu[0], wu[2]); wu[1] = 1.f;
@@ -259,33 +262,40 @@ __global__ __launch_bounds__(kUfBlock) void k_photo_error_bwd(const float* __res
 }
 
 hipError_t launch_photo_error_bwd(const float* pred, const float* target, const float* g_err, float* g_pred, float* ws,
-                                  int N, int C, int h, int w, int flags, hipStream_t st) {
-  const int mode = photo_mode(flags);
+                                  int N, int C, int h, int w, int flags, float w_ssim, hipStream_t st) {
+  int mode = photo_mode(flags);
+  if (mode == kPhotoSsim && w_ssim == 0.f) mode = kPhotoL1;
   dim3 grid(ceil_div(h*w, kUfBlock), N);
-  if (mode == kPhotoSsim) hipLaunchKernelGGL(k_photo_coef, grid, dim3(kUfBlock), 0, st, pred, target, g_err, ws, C, h, w);
-  hipLaunchKernelGGL(k_photo_error_bwd, grid, dim3(kUfBlock), 0, st, pred, target, g_err, ws, g_pred, C, h, w, mode);
+  if (mode == kPhotoSsim) hipLaunchKernelGGL(k_photo_coef, grid, dim3(kUfBlock), 0, st, pred, target, g_err, ws, C, h, w, w_ssim);
+  hipLaunchKernelGGL(k_photo_error_bwd, grid, dim3(kUfBlock), 0, st, pred, target, g_err, ws, g_pred, C, h, w, mode, w_ssim);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // Reduction half of ReconstructionLoss.forward (src/losses/reconstruction.py:43-44, 59-77, 125)
 // ---------------------------------------------------------------------------------------------
+// Predictive weighting masks of `ReconstructionLoss.apply_mask` (src/losses/reconstruction.py:46-57): mask (B,n,h,w) in the
+// reference's layout, one channel per support.  mode 1 'explainability': err * mask; mode 2 'uncertainty': err * exp(-mask) + mask.
+__device__ __forceinline__ float masked_err(float e, float m, int mode) { return mode == 1 ? e*m : (mode == 2 ? fmaf(e, __expf(-m), m) : e); }
+
 __global__ __launch_bounds__(kUfBlock) void k_recon_reduce_fwd(const float* __restrict__ err_warp, const float* __restrict__ err_static,
                                                                const float* __restrict__ noise, uint32_t seed_lo, uint32_t seed_hi,
                                                                float* __restrict__ err, uint8_t* __restrict__ sel, float* __restrict__ partial,
-                                                               int n, unsigned total, int use_min) {
+                                                               int n, unsigned total, int use_min, const float* __restrict__ mask, int mask_mode, unsigned hw) {
   __shared__ float red[kUfBlock/64];
   const unsigned idx = blockIdx.x*kUfBlock + threadIdx.x;
   float e = 0.f;
   if (idx < total) {
-    float best = err_warp[idx], acc = best;
+    const unsigned bi = idx/hw, pix = idx - bi*hw;
+    auto mk = [&](int i) { return mask_mode ? mask[((size_t)bi*n + i)*hw + pix] : 0.f; };
+    float best = masked_err(err_warp[idx], mk(0), mask_mode), acc = best;
     int bsel = 0;
-    for (int i = 1; i < n; ++i) { const float v = err_warp[(size_t)i*total + idx]; acc += v; if (v < best) { best = v; bsel = i; } }
+    for (int i = 1; i < n; ++i) { const float v = masked_err(err_warp[(size_t)i*total + idx], mk(i), mask_mode); acc += v; if (v < best) { best = v; bsel = i; } }
     e = use_min ? best : acc/(float)n;
     if (!use_min) bsel = 0;
     if (err_static) {
-      float sb = err_static[idx], sa = sb;
-      for (int i = 1; i < n; ++i) { const float v = err_static[(size_t)i*total + idx]; sa += v; sb = fminf(sb, v); }
+      float sb = masked_err(err_static[idx], mk(0), mask_mode), sa = sb;
+      for (int i = 1; i < n; ++i) { const float v = masked_err(err_static[(size_t)i*total + idx], mk(i), mask_mode); sa += v; sb = fminf(sb, v); }
       float est = use_min ? sb : sa/(float)n;
       est = fmaf(kEps32, noise ? noise[idx] : gauss_noise(seed_lo, seed_hi, idx), est);
       if (est < e) { e = est; bsel = SMD_SEL_MASKED; }
@@ -298,36 +308,62 @@ __global__ __launch_bounds__(kUfBlock) void k_recon_reduce_fwd(const float* __re
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* noise, uint64_t seed,
+static inline int mask_mode_of(int flags, const float* mask) { return !mask ? 0 : ((flags & SMD_MASK_UNCERTAINTY) ? 2 : ((flags & SMD_MASK_EXPLAINABILITY) ? 1 : 0)); }
+
+hipError_t launch_recon_reduce_fwd(const float* err_warp, const float* err_static, const float* mask, const float* noise, uint64_t seed,
                                    float* err, uint8_t* sel, float* loss, float* ws, int n, int B, int h, int w, int flags, hipStream_t st) {
   const unsigned total = (unsigned)B*h*w;
   const int nblk = ceil_div((int)total, kUfBlock);
   hipLaunchKernelGGL(k_recon_reduce_fwd, dim3(nblk), dim3(kUfBlock), 0, st, err_warp, (flags & SMD_USE_AUTOMASK) ? err_static : nullptr, noise,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), err, sel, ws, n, total, (flags & SMD_USE_MIN) ? 1 : 0);
+                     (uint32_t)seed, (uint32_t)(seed >> 32), err, sel, ws, n, total, (flags & SMD_USE_MIN) ? 1 : 0, mask, mask_mode_of(flags, mask), (unsigned)(h*w));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_sum_partials(ws, nblk, 1.0/(double)total, loss, st);
 }
 
+// Backward.  Without a mask: the upstream gradient routed by `sel`.  With a mask the error that reached the loss was
+// f(err, m) = err*m | err*exp(-m) + m, so the routed gradient is scaled by df/derr and the mask receives df/dm — also where the
+// STATIC error won (sel == masked): the identity error carries no gradient to the images but it does to the mask
+// (reconstruction.py:70-71 evaluates `compute_photo(source, target, mask=mask)`); its winning support is re-derived here.
 __global__ __launch_bounds__(kUfBlock) void k_recon_reduce_bwd(const uint8_t* __restrict__ sel, const float* __restrict__ g_loss,
-                                                               float* __restrict__ g_err_warp, int n, unsigned total, int use_min) {
+                                                               float* __restrict__ g_err_warp, int n, unsigned total, int use_min,
+                                                               const float* __restrict__ err_warp, const float* __restrict__ err_static,
+                                                               const float* __restrict__ mask, float* __restrict__ g_mask, int mask_mode, unsigned hw) {
   const unsigned idx = blockIdx.x*kUfBlock + threadIdx.x;
   if (idx >= total) return;
   const float g = g_loss[0]/(float)total;
   const uint8_t s = sel[idx];
+  const unsigned bi = idx/hw, pix = idx - bi*hw;
+  int jstat = -1;                       // static winner (min-reprojection over the masked identity errors), when the automask removed the pixel
+  if (mask_mode && s == (uint8_t)SMD_SEL_MASKED && use_min && err_static) {
+    float sb = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float v = masked_err(err_static[(size_t)i*total + idx], mask[((size_t)bi*n + i)*hw + pix], mask_mode);
+      if (i == 0 || v < sb) { sb = v; jstat = i; }
+    }
+  }
   for (int i = 0; i < n; ++i) {
     float v = 0.f;
     if (use_min) v = (s == (uint8_t)i) ? g : 0.f;
     else v = (s != (uint8_t)SMD_SEL_MASKED) ? g/(float)n : 0.f;
+    if (mask_mode) {
+      const size_t mi = ((size_t)bi*n + i)*hw + pix;
+      const float m = mask[mi];
+      float gs = 0.f;                   // gradient reaching the masked STATIC error of support i
+      if (s == (uint8_t)SMD_SEL_MASKED && err_static) gs = use_min ? (i == jstat ? g : 0.f) : g/(float)n;
+      const float ew = err_warp[(size_t)i*total + idx], es = err_static ? err_static[(size_t)i*total + idx] : 0.f;
+      if (mask_mode == 1) { g_mask[mi] = v*ew + gs*es; v *= m; }
+      else { const float em = __expf(-m); g_mask[mi] = v*fmaf(-ew, em, 1.f) + gs*fmaf(-es, em, 1.f); v *= em; }
+    }
     g_err_warp[(size_t)i*total + idx] = v;
   }
 }
 
-hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, int n, int B, int h, int w,
-                                   int flags, hipStream_t st) {
+hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, float* g_err_warp, const float* err_warp, const float* err_static,
+                                   const float* mask, float* g_mask, int n, int B, int h, int w, int flags, hipStream_t st) {
   const unsigned total = (unsigned)B*h*w;
   hipLaunchKernelGGL(k_recon_reduce_bwd, dim3(ceil_div((int)total, kUfBlock)), dim3(kUfBlock), 0, st, sel, g_loss, g_err_warp, n, total,
-                     (flags & SMD_USE_MIN) ? 1 : 0);
+                     (flags & SMD_USE_MIN) ? 1 : 0, err_warp, (flags & SMD_USE_AUTOMASK) ? err_static : nullptr, mask, g_mask, mask_mode_of(flags, mask), (unsigned)(h*w));
   return hipGetLastError();
 }
 

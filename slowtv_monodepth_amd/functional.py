@@ -355,10 +355,11 @@ class _DispSmooth(torch.autograd.Function):
         return (None, None, None, None, *g_disps)
 
 
-def disp_smooth_fused(disps: dict, imgs, *, use_edges: bool = False, want_aux: bool = True):
-    """disps {key: (b,1,hs,ws)} -> (loss, disp_grad|None, image_grad|None); aux maps are those of key 0."""
+def disp_smooth_fused(disps: dict, imgs, *, use_edges: bool = False, want_aux: bool = True, use_laplacian: bool = False):
+    """disps {key: (b,1,hs,ws)} -> (loss, disp_grad|None, image_grad|None); aux maps are those of key 0.
+    `use_laplacian`: second-order differences, `SmoothReg(use_laplacian=True)` (src/regularizers/smooth.py:33-48)."""
     keys = [int(k) for k in disps.keys()]
-    flags = FLAGS['use_edges'] if use_edges else 0
+    flags = (FLAGS['use_edges'] if use_edges else 0) | (FLAGS['use_laplacian'] if use_laplacian else 0)
     return _DispSmooth.apply(imgs, flags, keys, want_aux, *disps.values())
 
 
@@ -412,13 +413,13 @@ def view_synth(inp, depth, T, K, K_inv=None):
 
 class _PhotoError(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, flags):
+    def forward(ctx, pred, target, flags, weight_ssim):
         if pred.ndim != 4: raise ValueError(f'photometric error expects (N,C,h,w) tensors, got {tuple(pred.shape)}')
         N, c, h, w = pred.shape
         pred = _check('pred', pred, (N, c, h, w)); target = _check('target', target, (N, c, h, w))
         err = torch.empty((N, 1, h, w), device=pred.device, dtype=torch.float32)
-        call('smd_photo_error_fwd', pred.data_ptr(), target.data_ptr(), err.data_ptr(), N, c, h, w, int(flags), _stream())
-        ctx.save_for_backward(pred, target); ctx.flags = int(flags)
+        call('smd_photo_error_fwd', pred.data_ptr(), target.data_ptr(), err.data_ptr(), N, c, h, w, int(flags), float(weight_ssim), _stream())
+        ctx.save_for_backward(pred, target); ctx.flags, ctx.weight_ssim = int(flags), float(weight_ssim)
         return err
 
     @staticmethod
@@ -431,14 +432,16 @@ class _PhotoError(torch.autograd.Function):
         nbytes = _lib.lib.smd_photo_error_workspace_bytes(N, c, h, w)
         ws = torch.empty(nbytes, device=pred.device, dtype=torch.uint8)
         call('smd_photo_error_bwd', pred.data_ptr(), target.data_ptr(), g_err.data_ptr(), g_pred.data_ptr(), ws.data_ptr(), nbytes, N, c, h, w,
-             ctx.flags, _stream())
-        return g_pred, None, None
+             ctx.flags, ctx.weight_ssim, _stream())
+        return g_pred, None, None, None
 
 
-def photo_error(pred, target, loss_name: str = 'ssim'):
-    """(N,C,h,w) x2 -> (N,1,h,w): 0.85 SSIM + 0.15 L1 ('ssim'), channel-mean |.| ('l1') or Euclidean distance ('l2')."""
+def photo_error(pred, target, loss_name: str = 'ssim', weight_ssim: float = 0.85):
+    """(N,C,h,w) x2 -> (N,1,h,w): weight_ssim * SSIM + (1 - weight_ssim) * L1 ('ssim'; `PhotoError(weight_ssim)`,
+    src/losses/photometric.py:65-88), channel-mean |.| ('l1') or Euclidean distance ('l2')."""
     if loss_name not in ('ssim', 'l1', 'l2'): raise KeyError(loss_name)
-    return _PhotoError.apply(pred, target, {'ssim': 0, 'l1': FLAGS['loss_l1'], 'l2': FLAGS['loss_l2']}[loss_name])
+    if not (0 <= weight_ssim <= 1): raise ValueError(f'Invalid SSIM weight. ({weight_ssim} vs. [0, 1])')
+    return _PhotoError.apply(pred, target, {'ssim': 0, 'l1': FLAGS['loss_l1'], 'l2': FLAGS['loss_l2']}[loss_name], weight_ssim)
 
 
 class _Regression(torch.autograd.Function):
@@ -488,10 +491,11 @@ def regression_loss(pred, target, mask=None, *, loss_name: str = 'berhu', invert
 
 class _ReconReduce(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, err_warp, err_static, noise, seed, flags):
+    def forward(ctx, err_warp, err_static, mask, noise, seed, flags):
         n, B, h, w = err_warp.shape
         err_warp = _check('err_warp', err_warp, (n, B, h, w))
         if err_static is not None: err_static = _check('err_static', err_static, (n, B, h, w))
+        if mask is not None: mask = _check('mask', mask, (B, n, h, w))
         if noise is not None: noise = _check('noise', noise.reshape(B, h, w), (B, h, w))
         dev = err_warp.device
         err = torch.empty((B, h, w), device=dev, dtype=torch.float32)
@@ -500,26 +504,39 @@ class _ReconReduce(torch.autograd.Function):
         nbytes = _lib.lib.smd_recon_reduce_workspace_bytes(B, h, w)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         call('smd_recon_reduce_fwd', err_warp.data_ptr(), err_static.data_ptr() if err_static is not None else None,
-             noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), err.data_ptr(), sel.data_ptr(), loss.data_ptr(),
-             ws.data_ptr(), nbytes, n, B, h, w, int(flags), _stream())
-        ctx.save_for_backward(sel); ctx.meta = (n, B, h, w, int(flags))
+             mask.data_ptr() if mask is not None else None, noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1),
+             err.data_ptr(), sel.data_ptr(), loss.data_ptr(), ws.data_ptr(), nbytes, n, B, h, w, int(flags), _stream())
+        if mask is not None: ctx.save_for_backward(sel, err_warp, err_static, mask)   # the masked forms' derivatives need the errors and the mask
+        else: ctx.save_for_backward(sel, None, None, None)
+        ctx.meta = (n, B, h, w, int(flags))
         ctx.mark_non_differentiable(err, sel)
         return loss, err, sel
 
     @staticmethod
     def backward(ctx, g_loss, *_):
-        (sel,) = ctx.saved_tensors
+        sel, err_warp, err_static, mask = ctx.saved_tensors
         _on(sel)
         n, B, h, w, flags = ctx.meta
         g = torch.empty((n, B, h, w), device=sel.device, dtype=torch.float32)
-        call('smd_recon_reduce_bwd', sel.data_ptr(), g_loss.to(torch.float32).contiguous().data_ptr(), g.data_ptr(), n, B, h, w, flags, _stream())
-        return g, None, None, None, None
+        g_mask = torch.empty_like(mask) if mask is not None else None
+        call('smd_recon_reduce_bwd', sel.data_ptr(), g_loss.to(torch.float32).contiguous().data_ptr(), g.data_ptr(),
+             err_warp.data_ptr() if err_warp is not None else None, err_static.data_ptr() if err_static is not None else None,
+             mask.data_ptr() if mask is not None else None, g_mask.data_ptr() if g_mask is not None else None, n, B, h, w, flags, _stream())
+        return g, None, g_mask, None, None, None
 
 
-def recon_reduce(err_warp, err_static=None, *, use_min: bool = False, noise=None, seed: int = 0):
-    """Per-support error maps (n,B,h,w) [+ static ones] -> (loss, err (B,h,w), sel uint8 (B,h,w); 255 = auto-masked)."""
+def recon_reduce(err_warp, err_static=None, *, use_min: bool = False, noise=None, seed: int = 0, mask=None, mask_name: str | None = None):
+    """Per-support error maps (n,B,h,w) [+ static ones] -> (loss, err (B,h,w), sel uint8 (B,h,w); 255 = auto-masked).
+
+    `mask` (B,n,h,w) with `mask_name` 'explainability' | 'uncertainty': the predictive weighting of `ReconstructionLoss.apply_mask`
+    (src/losses/reconstruction.py:46-57), applied to the warped and the static errors before the reductions; differentiable."""
+    if mask_name not in {'explainability', 'uncertainty', None}: raise ValueError(f'Invalid mask type: {mask_name}')
+    if mask_name and mask is None: raise ValueError("Must provide a 'mask' when masking...")
     flags = (FLAGS['use_min'] if use_min else 0) | (FLAGS['use_automask'] if err_static is not None else 0)
-    return _ReconReduce.apply(err_warp, err_static, noise, seed, flags)
+    if mask_name:
+        flags |= FLAGS['mask_' + mask_name]
+        if mask.shape[1] == 1 and err_warp.shape[0] > 1: mask = mask.expand(-1, err_warp.shape[0], -1, -1)   # one mask for every support (broadcast in the reference)
+    return _ReconReduce.apply(err_warp, err_static, mask if mask_name else None, noise, seed, flags)
 
 
 # ---------------------------------------------------------------------------------------------------

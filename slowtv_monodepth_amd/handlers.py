@@ -63,7 +63,8 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
     :param crit: `ReconstructionLoss` (its loss_name / use_min / use_automask select the kernel flags).
     :param synth: `ViewSynth` for the image size (kept for signature parity; the fused kernel does its own projection).
     :param depths: {s: (b,1,h,w)} up-sampled depth per scale (a `ScaleDict` avoids one copy).
-    :param masks: must be None (predictive masks are outside the accelerated path).
+    :param masks: None, or {s: (b,n,h,w)} up-sampled predictive weighting masks for a criterion built with `mask_name` — then the
+        un-fused operators run (warp, per-support errors, masked reduction), as the reference does (src/core/handlers.py:47, 62).
     :param imgs: (b,3,h,w) target; supp_imgs: (n,b,3,h,w); Ts: (n,b,4,4); Ks: (b,4,4).
     :param K_inv: optional (b,4,4) inverse intrinsics when the caller already has them (`functional.intrinsics`).
     :param noise: optional (S*b,1,h,w) replacement for the reference's `randn_like` tie-break draw (reconstruction.py:72).
@@ -71,11 +72,10 @@ def image_recon(crit, synth, depths: dict, masks, imgs: torch.Tensor, supp_imgs:
         of time (the trainer does it on a side stream under the networks); ignored if it was built for something else.
     :return: (loss, {'supp_imgs_warp': (n,b,3,h,w) of scale 0 [, 'automask': (b,1,h,w) bool of scale 0]})
     """
-    if masks is not None: raise NotImplementedError('predictive masks are outside the accelerated path')
     if synth is not None and tuple(synth.shape) != tuple(imgs.shape[-2:]):
         raise ValueError(f'ViewSynth built for {synth.shape}, images are {tuple(imgs.shape[-2:])}')
-    if imgs.shape[1] != 3 or crit.loss_name == 'l2':   # features / Euclidean error: un-fused operators
-        return _image_recon_generic(crit, depths, imgs, supp_imgs, Ts, Ks, K_inv, noise, want_warp)
+    if imgs.shape[1] != 3 or crit.loss_name == 'l2' or masks is not None or getattr(crit, 'mask_name', None):   # features / Euclidean error / predictive masks: un-fused operators
+        return _image_recon_generic(crit, depths, imgs, supp_imgs, Ts, Ks, K_inv, noise, want_warp, masks)
     flags = F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask)
     if isinstance(depths, LazyDepths) and depths.pending:   # K0 fused: no up-sampling launch, the kernel writes the depth stack
         if prepared is not None and not prepared.matches(imgs, supp_imgs, flags, [d.shape[-2] for d in depths.disps], [d.shape[-1] for d in depths.disps]): prepared = None
@@ -107,11 +107,12 @@ def _expand_views(depths: dict, imgs, supp_imgs, Ts, Ks, K_inv):
     return n, S, b, dep, tgt, src, T, K, Ki
 
 
-def _image_recon_generic(crit, depths, imgs, supp_imgs, Ts, Ks, K_inv, noise, want_warp):
+def _image_recon_generic(crit, depths, imgs, supp_imgs, Ts, Ks, K_inv, noise, want_warp, masks=None):
     if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else F.inv_intrinsics(Ks)
     n, S, b, dep, tgt, src, T, K, Ki = _expand_views(depths, imgs, supp_imgs, Ts, Ks, K_inv)
     warp = F.view_synth(src.flatten(0, 1), dep[None].expand(n, *dep.shape).flatten(0, 1), T, K, Ki)[0].unflatten(0, (n, S*b))
-    loss, ld = crit(warp, tgt, source=src, noise=noise)
+    mask = torch.stack(list(masks.values())).flatten(0, 1) if masks is not None else None    # (S*b,n,h,w), handlers.py:47
+    loss, ld = crit(warp, tgt, source=src, mask=mask, noise=noise)
     out = {}
     if crit.use_automask: out['automask'] = ld['automask'].unflatten(0, (S, b))[0]
     if want_warp: out['supp_imgs_warp'] = warp.unflatten(1, (S, b))[:, 0]
@@ -125,7 +126,6 @@ def feat_recon(crit, synth, depths: dict, masks, feats, supp_feats, Ts: torch.Te
         entry `[-4]` is used, as in the reference); supp_feats: (n,b,c,hf,wf) or the matching list.
     :return: (loss, {'supp_feats_warp': (n,b,c,h,w)})
     """
-    if masks is not None: raise NotImplementedError('predictive masks are outside the accelerated path')
     if isinstance(feats, (list, tuple)): feats, supp_feats = feats[-4], supp_feats[-4]
     size = tuple(depths[0].shape[-2:])
     with torch.no_grad():   # features are detached and resized to the depth map (handlers.py:102-110)
@@ -133,7 +133,7 @@ def feat_recon(crit, synth, depths: dict, masks, feats, supp_feats, Ts: torch.Te
         feats = torch.nn.functional.interpolate(feats.detach().float(), size=size, mode='bilinear', align_corners=False)
         supp_feats = torch.nn.functional.interpolate(supp_feats.detach().float().flatten(0, 1), size=size, mode='bilinear',
                                                      align_corners=False).unflatten(0, (n, -1))
-    loss, ld = image_recon(crit, synth, {0: depths[0]}, None, feats, supp_feats, Ts, Ks, noise=noise, want_warp=True)
+    loss, ld = image_recon(crit, synth, {0: depths[0]}, ({0: masks[0]} if masks is not None else None), feats, supp_feats, Ts, Ks, noise=noise, want_warp=True)
     return loss, {'supp_feats_warp': ld['supp_imgs_warp']}
 
 
@@ -197,5 +197,5 @@ def disp_smooth(crit, disps: dict, imgs: torch.Tensor, *, want_aux: bool = True)
     :param want_aux: also produce the two logging maps (one extra small launch); the training loop turns this off.
     :return: (loss, {'disp_grad', 'image_grad'} of scale 0)
     """
-    loss, dg, ig = F.disp_smooth_fused(disps, imgs, use_edges=crit.use_edges, want_aux=want_aux)
+    loss, dg, ig = F.disp_smooth_fused(disps, imgs, use_edges=crit.use_edges, want_aux=want_aux, use_laplacian=getattr(crit, 'use_laplacian', False))
     return loss, ({'disp_grad': dg, 'image_grad': ig} if want_aux and dg is not None else {})

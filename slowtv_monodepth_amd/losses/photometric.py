@@ -22,16 +22,14 @@ class DenseL2Error(nn.Module):
 
 
 class PhotoError(nn.Module):
-    """0.85 * SSIM error (3x3 mean filter, reflection padding) + 0.15 * L1 (src/losses/photometric.py:54-88).
-
-    Only the reference's operating point `weight_ssim=0.85` (the one `ReconstructionLoss` builds,
-    src/losses/reconstruction.py:38) is compiled into the kernels."""
+    """weight_ssim * SSIM error (3x3 mean filter, reflection padding) + (1 - weight_ssim) * L1 (src/losses/photometric.py:54-88);
+    `weight_ssim=0` drops the SSIM term, `weight_ssim=1` the L1 term.  (The FUSED reconstruction kernels are built for the 0.85
+    that `ReconstructionLoss` constructs, src/losses/reconstruction.py:38; this class runs on the un-fused operator.)"""
     def __init__(self, weight_ssim: float = 0.85):
         super().__init__()
         if not (0 <= weight_ssim <= 1): raise ValueError(f'Invalid SSIM weight. ({weight_ssim} vs. [0, 1])')
-        if abs(weight_ssim - 0.85) > 1e-12: raise NotImplementedError('the HIP photometric kernels are built for weight_ssim=0.85')
         self.weight_ssim, self.weight_l1 = weight_ssim, 1 - weight_ssim
 
     def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         from .. import functional as F
-        return F.photo_error(pred, target, loss_name='ssim')
+        return F.photo_error(pred, target, loss_name='ssim', weight_ssim=self.weight_ssim)

@@ -356,6 +356,56 @@ def run_handler_cases(R):
                                           **{f'in_disp_{s}': v for s, v in disps.items()}, **{f'grad_disp_{s}': v.grad for s, v in disps.items()}))
 
 
+
+def run_option_cases(R):
+    """Reference options the accelerated path gained in round 3: `PhotoError(weight_ssim != 0.85)`
+    (src/losses/photometric.py:65-88), `ReconstructionLoss(mask_name='explainability' | 'uncertainty')` with a predictive
+    mask (src/losses/reconstruction.py:46-57, :70-71) and `SmoothReg(use_laplacian=True)` (src/regularizers/smooth.py:33-48)."""
+    g = torch.Generator().manual_seed(2468)
+    for tag, wgt in (('w0', 0.0), ('w03', 0.3), ('w1', 1.0)):
+        pred = torch.rand(3, 3, 15, 21, generator=g).requires_grad_(True)
+        tgt = (pred.detach() + 0.2*torch.randn(3, 3, 15, 21, generator=g)).clamp(0, 1)
+        tgt[0, :, :5] = pred.detach()[0, :, :5]
+        err = R.PhotoError(weight_ssim=wgt)(pred, tgt)
+        ge = torch.randn(err.shape, generator=g)
+        (err*ge).sum().backward()
+        save(f'op_photo_{tag}', dict(in_pred=pred, in_target=tgt, in_ge=ge, meta_weight_ssim=wgt, out_err=err, grad_pred=pred.grad))
+
+    n, b, h, w = 3, 2, 14, 18
+    for mask_name, use_min, use_automask, ch in (('explainability', True, True, n), ('uncertainty', True, True, n), ('uncertainty', False, False, n),
+                                                 ('explainability', False, True, 1)):
+        tgt = texture(g, b, h, w)
+        src = torch.stack([texture(g, b, h, w, shift=(1.5*(i + 1), -0.7*(i + 1))) for i in range(n)])
+        pred = (src + 0.05*torch.randn(n, b, 3, h, w, generator=g)).clamp(0, 1).requires_grad_(True)
+        if mask_name == 'explainability': mask = torch.rand(b, ch, h, w, generator=g)            # sigmoid-like weights
+        else: mask = 0.3*torch.randn(b, ch, h, w, generator=g)                                    # log-variance-like
+        mask.requires_grad_(True)
+        crit = R.ReconstructionLoss(loss_name='ssim', use_min=use_min, use_automask=use_automask, mask_name=mask_name)
+        noise_log = []
+        orig = torch.randn_like
+
+        def rec(tensor, *a, **k):
+            out = orig(tensor, *a, **k); noise_log.append(out.clone()); return out
+        torch.manual_seed(99)
+        torch.randn_like = rec
+        try: loss, ld = crit(pred, tgt, source=src, mask=mask)
+        finally: torch.randn_like = orig
+        loss.backward()
+        rec_ = dict(in_pred=pred, in_target=tgt, in_source=src, in_mask=mask, meta_mask_name=mask_name, meta_use_min=int(use_min),
+                    meta_use_automask=int(use_automask), out_loss=loss, grad_pred=pred.grad, grad_mask=mask.grad)
+        if noise_log: rec_['in_noise'] = noise_log[0]
+        if 'automask' in ld: rec_['out_automask'] = ld['automask']
+        save(f'op_recon_mask_{mask_name[:5]}_min{int(use_min)}_auto{int(use_automask)}_c{ch}', rec_)
+
+    for use_edges in (True, False):
+        disp = (0.05 + 0.9*torch.rand(3, 1, 12, 20, generator=g)).requires_grad_(True)
+        img = texture(g, 3, 12, 20)
+        l, ld = R.SmoothReg(use_edges=use_edges, use_laplacian=True)(disp, img)
+        l.backward()
+        save(f'op_smooth_lap_edges{int(use_edges)}', dict(in_disp=disp, in_img=img, out_loss=l, out_disp_grad=ld['disp_grad'],
+                                                           out_image_grad=ld['image_grad'], grad_disp=disp.grad))
+
+
 def save(name, rec):
     arrs = {}
     for k, v in rec.items():
@@ -369,6 +419,9 @@ def main():
     R = import_reference()
     if '--handlers-only' in sys.argv:   # regenerate just the §8f rank-3 fixtures
         run_handler_cases(R)
+        return
+    if '--options-only' in sys.argv:    # regenerate just the round-3 option fixtures
+        run_option_cases(R)
         return
     kbr = dict(loss_kw=dict(loss_name='ssim', use_min=True, use_automask=True), smooth_kw=dict(use_edges=True),
                min_depth=0.1, max_depth=100)
@@ -395,6 +448,7 @@ def main():
                      pose_scale=0.15, **kbr)
     run_op_cases(R)
     run_handler_cases(R)
+    run_option_cases(R)
 
 
 if __name__ == '__main__':

@@ -615,6 +615,124 @@ def test_generic_channel_photo_errors(F, golden, name, loss_name):
     assert rel_to_max(pred.grad.cpu(), g['grad_pred']) < 2e-4
 
 
+@pytest.mark.parametrize('name', ['op_photo_w0', 'op_photo_w03', 'op_photo_w1'])
+def test_photo_error_weight_ssim(F, golden, name):
+    """`PhotoError(weight_ssim)` away from 0.85 (src/losses/photometric.py:65-88): values and gradient against the reference's."""
+    import slowtv_monodepth_amd as amd
+    g = golden(name)
+    pred = g['in_pred'].cuda().requires_grad_(True)
+    err = amd.losses.PhotoError(weight_ssim=float(g['meta_weight_ssim']))(pred, g['in_target'].cuda())
+    (err*g['in_ge'].cuda()).sum().backward()
+    torch.testing.assert_close(err.detach().cpu(), g['out_err'], rtol=1e-5, atol=2e-5)
+    assert rel_to_max(pred.grad.cpu(), g['grad_pred']) < 1e-3
+    with pytest.raises(ValueError): amd.losses.PhotoError(weight_ssim=1.5)
+
+
+@pytest.mark.parametrize('name', ['op_recon_mask_expla_min1_auto1_c3', 'op_recon_mask_uncer_min1_auto1_c3', 'op_recon_mask_uncer_min0_auto0_c3',
+                                  'op_recon_mask_expla_min0_auto1_c1'])
+def test_masked_reconstruction_loss(F, golden, name):
+    """`ReconstructionLoss(mask_name='explainability'|'uncertainty')` with a predictive mask (src/losses/reconstruction.py:46-57,
+    70-71): loss, automask and the gradients w.r.t. the warped images AND the mask against the reference's autograd."""
+    import slowtv_monodepth_amd as amd
+    g = golden(name)
+    crit = amd.losses.ReconstructionLoss(loss_name='ssim', use_min=bool(g['meta_use_min']), use_automask=bool(g['meta_use_automask']), mask_name=g['meta_mask_name'])
+    pred, mask = g['in_pred'].cuda().requires_grad_(True), g['in_mask'].cuda().requires_grad_(True)
+    noise = g['in_noise'].cuda() if 'in_noise' in g else None
+    loss, ld = crit(pred, g['in_target'].cuda(), source=g['in_source'].cuda(), mask=mask, noise=noise)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+    # The routing decisions (winning support / automask) against the oracle's on the same inputs: a pixel whose two candidates tie
+    # to ~1e-6 may be decided differently and then moves a whole G = 1/N of gradient from one mask channel to another, so the
+    # gradients are compared where the decisions agree (the 3x3 neighbourhood of a flip is excluded for the image gradient) and
+    # the flips are counted.
+    n, b = g['in_pred'].shape[:2]
+    with torch.no_grad():
+        tg = g['in_target'].cuda()[None].expand(n, *g['in_target'].shape).flatten(0, 1)
+        ew = F.photo_error(pred.detach().flatten(0, 1), tg).view(n, b, *pred.shape[-2:])
+        es = F.photo_error(g['in_source'].cuda().flatten(0, 1), tg).view(n, b, *pred.shape[-2:]) if g['meta_use_automask'] else None
+        _, _, sel = F.recon_reduce(ew, es, use_min=bool(g['meta_use_min']), noise=noise, mask=mask.detach(), mask_name=g['meta_mask_name'])
+        _, out = O.recon_loss(g['in_pred'], g['in_target'], source=g['in_source'], use_min=bool(g['meta_use_min']), use_automask=bool(g['meta_use_automask']),
+                              noise=g.get('in_noise'), mask=g['in_mask'], mask_name=g['meta_mask_name'])
+    agree = sel.cpu() == out['sel'].reshape(sel.shape)                                       # (b,h,w)
+    if g['meta_use_automask'] and g['meta_use_min']:   # where the identity error won, the mask's gradient goes to the static winner: a decision too
+        mk = lambda e, m: O.apply_mask(e.permute(1, 0, 2, 3), m, g['meta_mask_name'])          # (n,b,h,w) errors -> masked (b,n,h,w)
+        es_ref = O.compute_photo(g['in_source'], g['in_target'], 'ssim', True)[1]             # (b,n,h,w) un-masked per-support identity errors
+        j_hip = mk(es.cpu(), mask.detach().cpu().expand(b, n, -1, -1)).argmin(1)
+        j_ref = O.apply_mask(es_ref, g['in_mask'].expand(b, n, -1, -1), g['meta_mask_name']).argmin(1)
+        agree &= (sel.cpu() != 255) | (j_hip == j_ref)
+    flips = int((~agree).sum())
+    assert flips <= 2, f'{flips} routing decisions differ from the oracle'
+    near = torch.nn.functional.max_pool2d((~agree).float()[:, None], 3, 1, 1)[:, 0] > 0    # pixels whose SSIM window contains a flip
+    keep_m = agree[:, None].expand_as(g['grad_mask']); keep_p = (~near)[None, :, None].expand_as(g['grad_pred'])
+    parity_note(f'{name}: loss hip={loss.item():.8f} ref={g["out_loss"].item():.8f}; routing flips {flips} of {agree.numel()}')
+    assert ((pred.grad.cpu() - g['grad_pred']).abs()*keep_p).max() < 1e-3*g['grad_pred'].abs().max()
+    assert ((mask.grad.cpu() - g['grad_mask']).abs()*keep_m).max() < 1e-3*g['grad_mask'].abs().max()
+    with pytest.raises(ValueError): crit(pred, g['in_target'].cuda(), source=g['in_source'].cuda())   # "Must provide a 'mask' when masking..."
+
+
+def test_image_recon_handler_with_predictive_masks_matches_oracle(F):
+    """`handlers.image_recon(crit, synth, depths, masks, ...)` with masks {s: (b,n,h,w)} (src/core/handlers.py:47, 62) on the un-fused
+    operators against the oracle's restatement of the same call."""
+    import slowtv_monodepth_amd as amd
+    from slowtv_monodepth_amd.synthetic import make_batch
+    b, h, w, n, S = 2, 24, 40, 2, 2
+    _, y, _ = make_batch(b, h, w, (-1, 1), seed=5)
+    g = torch.Generator().manual_seed(3)
+    depths = {s: 0.5 + 5*torch.rand(b, 1, h, w, generator=g) for s in range(S)}
+    masks = {s: 0.2*torch.randn(b, n, h, w, generator=g) for s in range(S)}
+    Ts = torch.eye(4).repeat(n, b, 1, 1); Ts[..., :3, 3] = 0.05*torch.randn(n, b, 3, generator=g)
+    noise = torch.randn(S*b, 1, h, w, generator=g)
+    leaf = lambda t, dev: t.clone().to(dev).requires_grad_(True)
+
+    def run(dev):
+        d = {s: leaf(v, dev) for s, v in depths.items()}; m = {s: leaf(v, dev) for s, v in masks.items()}
+        imgs, sup, K, T = y['imgs'].to(dev), y['supp_imgs'].to(dev), y['K'].to(dev), Ts.to(dev)
+        if dev == 'cuda':
+            crit = amd.losses.ReconstructionLoss('ssim', use_min=True, use_automask=True, mask_name='uncertainty')
+            loss, _ = amd.handlers.image_recon(crit, amd.geometry.ViewSynth((h, w)), d, m, imgs, sup, T, K, noise=noise.to(dev))
+        else:
+            dep = torch.stack(list(d.values())).flatten(0, 1)
+            src = sup[:, None].expand(n, S, *sup.shape[1:]).flatten(1, 2)
+            tgt = imgs[None].expand(S, *imgs.shape).flatten(0, 1)
+            warp = O.view_synth(src.flatten(0, 1), dep[None].expand(n, *dep.shape).flatten(0, 1), T[:, None].expand(n, S, b, 4, 4).flatten(0, 2),
+                                K[None, None].expand(n, S, b, 4, 4).flatten(0, 2))[0].unflatten(0, (n, S*b))
+            loss, _ = O.recon_loss(warp, tgt, source=src, use_min=True, use_automask=True, noise=noise,
+                                   mask=torch.stack(list(m.values())).flatten(0, 1), mask_name='uncertainty')
+        loss.backward()
+        return loss.item(), [v.grad.cpu() for v in d.values()] + [v.grad.cpu() for v in m.values()]
+    l_hip, g_hip = run('cuda'); l_ref, g_ref = run('cpu')
+    assert abs(l_hip - l_ref) <= 2e-5*abs(l_ref)
+    for a, r in zip(g_hip, g_ref): assert rel_to_max(a, r) < 1e-3
+
+
+@pytest.mark.parametrize('use_edges', [True, False])
+def test_laplacian_smoothness(F, golden, use_edges):
+    """`SmoothReg(use_laplacian=True)` (src/regularizers/smooth.py:33-48): loss, aux maps, gradient against the reference's; and the
+    multi-scale handler at non-integer ratios against the oracle."""
+    import slowtv_monodepth_amd as amd
+    g = golden(f'op_smooth_lap_edges{int(use_edges)}')
+    disp = g['in_disp'].cuda().requires_grad_(True)
+    reg = amd.regularizers.SmoothReg(use_edges=use_edges, use_laplacian=True)
+    loss, ld = reg(disp, g['in_img'].cuda())
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(ld['disp_grad'].cpu(), g['out_disp_grad'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ld['image_grad'].cpu(), g['out_image_grad'], rtol=1e-4, atol=1e-5)
+    assert rel_to_max(disp.grad.cpu(), g['grad_disp']) < 1e-3
+    gen = torch.Generator().manual_seed(8)
+    img = torch.rand(2, 3, 33, 47, generator=gen)
+    lows = [(33, 47), (16, 23), (5, 7), (2, 3)]
+    d_c = {s: (0.05 + 0.9*torch.rand(2, 1, *hw, generator=gen)).requires_grad_(True) for s, hw in enumerate(lows)}
+    d_g = {s: v.detach().clone().cuda().requires_grad_(True) for s, v in d_c.items()}
+    l_ref = torch.stack([O.smooth_reg(d, O.resize_bilinear(img, d.shape[-2:]), use_edges, use_laplacian=True)[0]/2**s for s, d in d_c.items()]).mean()
+    l_ref.backward()
+    l_hip, _ = amd.handlers.disp_smooth(reg, d_g, img.cuda(), want_aux=False)
+    l_hip.backward()
+    assert abs(l_hip.item() - l_ref.item()) <= 2e-5*abs(l_ref.item())
+    for s in d_c: assert rel_to_max(d_g[s].grad.cpu(), d_c[s].grad) < 1e-3
+    with pytest.raises(NotImplementedError): amd.regularizers.SmoothReg(use_blur=True)
+
+
 @pytest.mark.parametrize('name', [f'op_regr_{l}{i}{m}' for l in ('l1', 'log_l1', 'berhu') for i in ('', '_inv') for m in ('', '_mask')])
 def test_regression_loss_matches_reference(F, golden, name):
     import slowtv_monodepth_amd as amd

@@ -98,8 +98,9 @@ def test_parsers_build_losses_nets_optimizer():
     assert losses['img_recon'].use_min and losses['img_recon'].use_automask and losses['disp_smooth'].use_edges
     with pytest.raises(KeyError): parsers.get_loss({'nope': {}})
     with pytest.raises(ValueError): ReconstructionLoss(mask_name='bogus')
-    with pytest.raises(NotImplementedError): ReconstructionLoss(mask_name='explainability')
-    with pytest.raises(NotImplementedError): SmoothReg(use_laplacian=True)
+    assert ReconstructionLoss(mask_name='explainability').mask_name == 'explainability'   # predictive masks run on the un-fused operators
+    assert SmoothReg(use_laplacian=True).use_laplacian
+    with pytest.raises(NotImplementedError): SmoothReg(use_blur=True)                      # kornia's Gaussian cannot be pinned here
     with pytest.raises(ValueError, match="original 'source'"):
         ReconstructionLoss(use_automask=True)(torch.rand(2, 1, 3, 4, 4), torch.rand(1, 3, 4, 4))
 

@@ -206,3 +206,46 @@ def test_depth_regr_handler(golden, tag):
     torch.testing.assert_close(l, g['out_loss'], rtol=2e-3 if flips else 1e-5, atol=1e-7)
     l.backward()
     for s in (0, 1): assert rel_to_max(disps[s].grad, g[f'grad_disp_{s}']) < (2e-2 if flips else 1e-4), s
+
+
+# ------------------------------------------------------------------------------------------------- round-3 options
+MASK_CASES = ['op_recon_mask_expla_min1_auto1_c3', 'op_recon_mask_uncer_min1_auto1_c3', 'op_recon_mask_uncer_min0_auto0_c3',
+              'op_recon_mask_expla_min0_auto1_c1']
+
+
+@pytest.mark.parametrize('name', ['op_photo_w0', 'op_photo_w03', 'op_photo_w1'])
+def test_photo_error_weight_ssim_matches_reference(golden, name):
+    """`PhotoError(weight_ssim)` (src/losses/photometric.py:65-88) away from the 0.85 `ReconstructionLoss` builds."""
+    g = golden(name)
+    pred = g['in_pred'].clone().requires_grad_(True)
+    err = O.photo_error(pred, g['in_target'], 'ssim', weight_ssim=float(g['meta_weight_ssim']))
+    (err*g['in_ge']).sum().backward()
+    torch.testing.assert_close(err.detach(), g['out_err'], rtol=1e-5, atol=2e-6)
+    assert rel_to_max(pred.grad, g['grad_pred']) < 2e-4
+
+
+@pytest.mark.parametrize('name', MASK_CASES)
+def test_masked_reconstruction_loss_matches_reference(golden, name):
+    """`ReconstructionLoss(mask_name=...)(pred, target, source, mask)` (src/losses/reconstruction.py:46-57, 70-71, 98-126)."""
+    g = golden(name)
+    pred, mask = g['in_pred'].clone().requires_grad_(True), g['in_mask'].clone().requires_grad_(True)
+    loss, out = O.recon_loss(pred, g['in_target'], source=g['in_source'], loss_name='ssim', use_min=bool(g['meta_use_min']),
+                             use_automask=bool(g['meta_use_automask']), noise=g.get('in_noise'), mask=mask, mask_name=g['meta_mask_name'])
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), g['out_loss'], rtol=2e-6, atol=1e-7)
+    if 'out_automask' in g: assert (out['automask'] != g['out_automask']).float().mean().item() <= 2e-3
+    assert rel_to_max(pred.grad, g['grad_pred']) < 2e-4
+    assert rel_to_max(mask.grad, g['grad_mask']) < 2e-4
+
+
+@pytest.mark.parametrize('use_edges', [True, False])
+def test_laplacian_smoothness_matches_reference(golden, use_edges):
+    """`SmoothReg(use_laplacian=True)` (src/regularizers/smooth.py:33-48, 71-97)."""
+    g = golden(f'op_smooth_lap_edges{int(use_edges)}')
+    disp = g['in_disp'].clone().requires_grad_(True)
+    loss, ld = O.smooth_reg(disp, g['in_img'], use_edges=use_edges, use_laplacian=True)
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), g['out_loss'], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(ld['disp_grad'].detach(), g['out_disp_grad'], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ld['image_grad'], g['out_image_grad'], rtol=1e-5, atol=1e-6)
+    assert rel_to_max(disp.grad, g['grad_disp']) < 2e-4
