@@ -127,11 +127,19 @@ def to_reference_state_dict(module: nn.Module) -> dict:
     return {to_reference_key(k, out_sc, _is_convnext(module, k)): v for k, v in module.state_dict().items()}
 
 
-def reference_checkpoint(trainer: nn.Module, epoch: int = 0, global_step: int = 0, optimizer=None) -> dict:
-    """A checkpoint dict with the layout `MonoDepthModule.load_from_checkpoint` / Lightning's resume expect: `state_dict` keyed as
-    the reference's LightningModule (`nets.<key>.…`, `weights.<loss>`) plus the bookkeeping fields Lightning reads."""
+def reference_checkpoint(trainer: nn.Module, epoch: int = 0, global_step: int = 0, optimizer=None, scheduler=None,
+                         lightning_version: str = '2.0.1') -> dict:
+    """A checkpoint dict in the layout of the reference's Lightning checkpoints: `state_dict` keyed as its LightningModule
+    (`nets.<key>.…`, `weights.<loss>`) — what `MonoDepthModule.load_from_checkpoint` and every `state_dict` consumer read — plus
+    the bookkeeping Lightning's restore path indexes: `epoch`, `global_step`, `optimizer_states`, `lr_schedulers`
+    (`restore_lr_schedulers` reads `ckpt['lr_schedulers']`), `loops` and `callbacks` (empty: this package's loop has no Lightning
+    loop / callback state to hand over, so a Lightning `fit(ckpt_path=...)` restarts its progress counters from `epoch` /
+    `global_step`).  `lightning_version` defaults to the reference's pin (docker/environment.yml).  The optimizer state is
+    `torch.optim` state as is: it round-trips through this package's `--resume`; loading it into the reference additionally
+    needs its `get_opt` to create the parameter groups in the same order (timm's `create_optimizer_v2` there, not checked here)."""
     ckpt = {'state_dict': to_reference_state_dict(trainer), 'epoch': int(epoch), 'global_step': int(global_step),
-            'pytorch-lightning_version': '2.0.1', 'hyper_parameters': {'cfg': getattr(trainer, 'cfg', None)}}
+            'pytorch-lightning_version': str(lightning_version), 'hyper_parameters': {'cfg': getattr(trainer, 'cfg', None)},
+            'lr_schedulers': [scheduler.state_dict()] if scheduler is not None else [], 'loops': {}, 'callbacks': {}}
     if optimizer is not None: ckpt['optimizer_states'] = [optimizer.state_dict()]
     return ckpt
 

@@ -184,6 +184,26 @@ def train_steps(model: nn.Module, opt: torch.optim.Optimizer, batch_fn, steps: i
     return losses
 
 
+def dataset_types(cfg: dict) -> list:
+    """Dataset types a cfg names.  The reference keys the `dataset` section BY TYPE — `dataset: {kitti_lmdb: {split: ...}}`,
+    `parsers.get_ds` iterates `for t, kw in cfg.items()` (src/tools/parsers.py:109-135) — so every key with a (possibly empty)
+    mapping as value is a type; an explicit `type:` field inside an entry is honoured as well."""
+    out = set()
+    for k, d in (cfg.get('dataset') or {}).items():
+        if d is None: continue                      # `key: null` removes an inherited dataset in the reference's cfgs
+        if isinstance(d, dict):
+            out.add(str(d['type']) if d.get('type') else str(k))
+    return sorted(out)
+
+
+def dataset_supp_idxs(cfg: dict) -> list:
+    for d in (cfg.get('dataset') or {}).values():
+        if isinstance(d, dict):
+            for v in (d, *(x for x in d.values() if isinstance(x, dict))):     # entry-level or per-mode (`train:` / `val:`) override
+                if v.get('supp_idxs'): return list(v['supp_idxs'])
+    return [-1, 1]
+
+
 def main(argv=None):
     p = argparse.ArgumentParser(description='Monocular depth trainer (MI355X hot path).')
     p.add_argument('--cfg-files', '-c', type=Path, nargs='*', required=True, help='YAML configs (default, override...).')
@@ -195,6 +215,8 @@ def main(argv=None):
     p.add_argument('--gpus', '-g', default=1, type=int, help='informational: launch with torch.distributed.run --nproc-per-node N')
     p.add_argument('--steps', default=100, type=int, help='optimizer micro-steps per epoch on synthetic data')
     p.add_argument('--shape', default=[192, 640], type=int, nargs=2)
+    p.add_argument('--resume', type=Path, default=None, help='checkpoint to continue from (this package\'s last.ckpt or a reference checkpoint): weights, '
+                                                               'optimizer and scheduler state, epoch counter')
     args = p.parse_args(argv)
 
     cfg = io.load_merge_yaml(*args.cfg_files)
@@ -209,16 +231,25 @@ def main(argv=None):
     if module.auto_scale_lr:
         for g in opt.param_groups: g['lr'] *= world*acc
     b = cfg.get('loader', {}).get('batch_size', 12)
-    named = sorted({d.get('type') for d in (cfg.get('dataset') or {}).values() if isinstance(d, dict) and d.get('type')})
+    named = dataset_types(cfg)
     if named and not args.synthetic_data:
         raise SystemExit(f'the cfg names dataset type(s) {named}: this package trains on synthetic triplets only (datasets are out of scope); '
                          'pass --synthetic-data to run the cfg on synthetic triplets of its shape, or drop the dataset `type`')
-    supp_idxs = next((d.get('supp_idxs') for d in (cfg.get('dataset') or {}).values() if isinstance(d, dict) and d.get('supp_idxs')), [-1, 1])
+    supp_idxs = dataset_supp_idxs(cfg)
     batch = make_batch(b, args.shape[0], args.shape[1], supp_idxs, seed=args.seed + rank, device=device)
     model = wrap_ddp(StepModule(module), device)
     save_dir = args.ckpt_dir/args.name/f'{args.version:03}'
     if rank == 0: save_dir.mkdir(parents=True, exist_ok=True)
-    for epoch in range(tcfg.get('max_epochs', 1)):
+    first_epoch = 0
+    if args.resume is not None:
+        from .networks.checkpoint import load_reference_checkpoint
+        ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)
+        load_reference_checkpoint(module, ckpt)
+        if ckpt.get('optimizer_states'): opt.load_state_dict(ckpt['optimizer_states'][0])
+        if sched is not None and ckpt.get('lr_schedulers'): sched.load_state_dict(ckpt['lr_schedulers'][0])
+        first_epoch = int(ckpt.get('epoch', -1)) + 1
+        if rank == 0: print(f'resumed from {args.resume}: epoch {first_epoch}, global step {ckpt.get("global_step", 0)}', flush=True)
+    for epoch in range(first_epoch, tcfg.get('max_epochs', 1)):
         t0 = time.time()
         losses = train_steps(model, opt, lambda it: batch, args.steps, accumulate=acc, clip=tcfg.get('gradient_clip_val'),
                              detect_anomaly=bool(tcfg.get('detect_anomaly', False)))
@@ -228,7 +259,7 @@ def main(argv=None):
             dt = time.time() - t0
             print(f'epoch {epoch}: loss {last:.6f}  {args.steps*b*world/dt:.1f} img/s', flush=True)
             from .networks.checkpoint import reference_checkpoint
-            torch.save(reference_checkpoint(module, epoch=epoch, global_step=(epoch + 1)*args.steps, optimizer=opt), save_dir/'last.ckpt')
+            torch.save(reference_checkpoint(module, epoch=epoch, global_step=(epoch + 1)*args.steps, optimizer=opt, scheduler=sched), save_dir/'last.ckpt')
     if world > 1: dist.destroy_process_group()
 
 

@@ -98,6 +98,15 @@ class MonoDepthModule(nn.Module):
         self.nets = parsers.get_net(cfg['net'])
         self.losses, self.weights = parsers.get_loss(copy.deepcopy(cfg['loss']))
         self.backend = loss_backend or HipLossBackend()
+        # Losses whose inputs only networks outside this package produce (the autoencoder network and the
+        # virtual-stereo decoder head are out of scope; their handlers and criteria exist and are parity-tested on their own):
+        # refuse at construction instead of failing with a KeyError in the middle of the first step.
+        needs = {'feat_recon': ('autoencoder', 'an `autoencoder` network (fwd["autoenc_feats"])'),
+                 'autoenc_recon': ('autoencoder', 'an `autoencoder` network (fwd["autoenc_imgs_up"])'),
+                 'stereo_const': (None, 'a depth network with `use_virtual_stereo` (fwd["disp_stereo"], its up-sampled forms and y["T_stereo"])')}
+        for k, (net_key, what) in needs.items():
+            if k in self.losses and (net_key is None or net_key not in self.nets):
+                raise NotImplementedError(f'loss "{k}" needs {what}, which this package does not build; the handler `handlers.{k}` can be called directly')
         self.synth = None
         self.scales = self.nets['depth'].out_scales
         self.n_scales = len(self.scales)

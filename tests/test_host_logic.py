@@ -271,3 +271,52 @@ def test_pretrained_request_is_refused_loudly():
     import pytest, warnings
     from slowtv_monodepth_amd.networks.encoders import create_encoder
     with pytest.warns(UserWarning, match='pretrained'): create_encoder('resnet18', pretrained=True)
+
+
+# ------------------------------------------------------------------------------------------------- train.py guards
+def test_cfg_in_the_reference_dataset_layout_is_refused_without_synthetic_data(tmp_path):
+    """The reference keys `dataset` BY TYPE (cfg/default.yaml:86-111, parsers.get_ds iterates `for t, kw in cfg.items()`): such a
+    cfg names real datasets and must not silently train on synthetic triplets."""
+    from slowtv_monodepth_amd import train as T
+    cfg = {'dataset': {'kitti_lmdb': {'split': 'eigen_benchmark', 'supp_idxs': [-1, 1], 'train': {'mode': 'train', 'shape': [376, 1242]}},
+                       'mannequin_lmdb': {'datum': 'image support K', 'supp_idxs': [-2, 1]}, 'slow_tv_lmdb': None}}
+    assert T.dataset_types(cfg) == ['kitti_lmdb', 'mannequin_lmdb']           # `key: null` drops an inherited dataset
+    assert T.dataset_types({'dataset': {'main': {'type': 'kitti_lmdb'}}}) == ['kitti_lmdb'] and T.dataset_types({}) == []
+    assert T.dataset_supp_idxs(cfg) == [-1, 1] and T.dataset_supp_idxs({}) == [-1, 1]
+    import yaml
+    full = {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False, 'dec_name': 'monodepth', 'out_scales': [0, 1, 2, 3]},
+                    'pose': {'enc_name': 'resnet18', 'pretrained': False}},
+            'loss': {'img_recon': {'weight': 1, 'loss_name': 'ssim', 'use_min': True, 'use_automask': True}},
+            'optimizer': {'type': 'adamw', 'lr': 1e-4}, 'loader': {'batch_size': 1}, **cfg}
+    f = tmp_path/'cfg.yaml'; f.write_text(yaml.safe_dump(full))
+    with pytest.raises(SystemExit) as e: T.main(['-c', str(f), '-n', 'x', '-o', str(tmp_path), '--steps', '1', '--shape', '32', '64'])
+    assert 'kitti_lmdb' in str(e.value) and '--synthetic-data' in str(e.value)
+
+
+def test_losses_without_a_producing_network_are_refused_at_construction():
+    cfg = {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False, 'dec_name': 'monodepth', 'out_scales': [0]},
+                   'pose': {'enc_name': 'resnet18', 'pretrained': False}},
+           'loss': {'img_recon': {'weight': 1}, 'stereo_const': {'weight': 1}}}
+    with pytest.raises(NotImplementedError, match='stereo_const'): MonoDepthModule(cfg, loss_backend=OracleBackend())
+    cfg['loss'] = {'img_recon': {'weight': 1}, 'feat_recon': {'weight': 1, 'loss_name': 'l2'}}
+    with pytest.raises(NotImplementedError, match='autoencoder'): MonoDepthModule(cfg, loss_backend=OracleBackend())
+
+
+def test_checkpoint_has_the_fields_lightning_restores_and_resume_round_trips(tmp_path):
+    from slowtv_monodepth_amd.networks.checkpoint import load_reference_checkpoint, reference_checkpoint
+    cfg = {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False, 'dec_name': 'monodepth', 'out_scales': [0, 1]},
+                   'pose': {'enc_name': 'resnet18', 'pretrained': False}},
+           'loss': {'img_recon': {'weight': 1}}, 'optimizer': {'type': 'adamw', 'lr': 1e-3},
+           'scheduler': {'steplr': {'step_size': 1, 'gamma': 0.5}}}
+    torch.manual_seed(0)
+    m = MonoDepthModule(cfg, loss_backend=OracleBackend())
+    conf = m.configure_optimizers(); opt, sched = conf['optimizer'], conf['lr_scheduler']
+    sched.step()
+    ck = reference_checkpoint(m, epoch=3, global_step=77, optimizer=opt, scheduler=sched)
+    for k in ('state_dict', 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers', 'loops', 'callbacks', 'pytorch-lightning_version'): assert k in ck
+    assert ck['lr_schedulers'][0] == sched.state_dict() and ck['epoch'] == 3
+    torch.save(ck, tmp_path/'last.ckpt')
+    torch.manual_seed(1)
+    m2 = MonoDepthModule(cfg, loss_backend=OracleBackend())
+    load_reference_checkpoint(m2, str(tmp_path/'last.ckpt'))
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()): assert k1 == k2 and torch.equal(v1, v2)
