@@ -195,6 +195,7 @@ def main():
     for which in range(5): _lib.lib.smd_profile_enable(which, args.steps)
     t0 = time.perf_counter()
     losses = train_steps(model, opt, batch_fn, args.steps)
+    host_enqueue = time.perf_counter() - t0      # nothing in the loop synchronises: this is the Python / ATen front end's time to ENQUEUE the steps
     fence()
     elapsed = time.perf_counter() - t0
     if dist.is_initialized():
@@ -235,7 +236,8 @@ def main():
                                    f'img_recon(ssim,min,automask)+disp_smooth(edges), AdamW, random init',
                        'global_batch': wl['b']*world, 'per_gpu_batch': wl['b'], 'parallelism': f'dp{world}',
                        'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6),
-                       'rccl_ranks': rccl_ranks},
+                       'rccl_ranks': rccl_ranks, 'dp_impl': (os.environ.get('SMD_DP_IMPL', 'flat') if rccl_ranks > 1 or os.environ.get('SMD_FORCE_DDP') == '1' else None),
+                       'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3)},
             'roofline': {'kernel': f'smd::k_recon_main<{n}, true, true, false, true> (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; name as rocprofv3 prints it)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,
