@@ -288,6 +288,18 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
                        float* g_fs, float* g_cs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * GPU-side aspect-ratio augmentation.  Replaces `crop_aug` + `resize_aug` of
+ * src/core/aspect_ratio.py:67-151 for the image tensors of a batch and `centre_crop_K` + `resize_K`
+ * (src/tools/geometry.py:233-263) for its intrinsics, in one launch: every plane of every segment (a tensor viewed as
+ * (planes[k], H, W): x.imgs, y.imgs, x.supp_imgs, y.supp_imgs, depth ...) is centre-cropped to (crop_h, crop_w) — the integer
+ * window of kornia's `center_crop`, start = int(H/2 - crop_h/2) — and the crop resized to (out_h, out_w) with
+ * `F.interpolate(mode='bilinear', align_corners=False)` semantics; dst[k] is (planes[k], out_h, out_w).  crop == input size:
+ * resize only; out == crop size: crop only.  K_in / K_out (nK,4,4) or both NULL.  The shapes are sampled on the host
+ * (`slowtv_monodepth_amd.aspect_ratio`, same random streams as the reference). */
+int smd_crop_resize(const float* const* src, float* const* dst, const int* planes, int nseg, int H, int W, int crop_h, int crop_w,
+                    int out_h, int out_w, const float* K_in, float* K_out, int nK, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel timing hooks for bench.py: while enabled, every call of the named entry point records a HIP event pair on the
  * caller's stream, either around its DOMINANT kernel (the fused strip kernel k_recon_main / k_recon_bwd) or around ALL
  * of its launches (forward: per-sample prep, unless SMD_PACKED_READY, + main; backward: the fused adjoint [+ the K0 adjoint is

@@ -33,6 +33,10 @@ class OracleBackend:
         if not want_warp: ld.pop('supp_imgs_warp', None)
         return loss, ld
 
+    def crop_resize(self, tensors, crop_shape, out_shape, K):
+        from . import aspect_ratio_oracle as A
+        return A.crop_resize(tensors, crop_shape, out_shape, K)
+
     def disp_smooth(self, crit, disps, imgs, want_aux=True):
         loss, ld = O.disp_smooth({k: d.float() for k, d in disps.items()}, imgs, crit.use_edges, aten=self.aten)
         return loss, (ld if want_aux else {})

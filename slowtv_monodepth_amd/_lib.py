@@ -78,6 +78,7 @@ PROTOTYPES = {
     'smd_pose_bwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'smd_intrinsics_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'smd_intrinsics_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'smd_crop_resize': (_i, [_vp, _vp, _vp] + [_i]*7 + [_vp, _vp, _i, _vp]),
     'smd_profile_enable': (_i, [_i, _i]),
     'smd_profile_collect': (_i, [_i, _vp, _i, _vp]),
     'smd_debug_stream_copy': (_i, [_vp, _vp, _sz, _i, _vp]),

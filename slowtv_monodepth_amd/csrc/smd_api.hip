@@ -662,6 +662,31 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
   return check_launch(smd::launch_intrinsics_bwd(fs, cs, b, h, w, g_K, g_Kinv, g_fs, g_cs, (hipStream_t)stream), "intrinsics_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Aspect-ratio augmentation
+int smd_crop_resize(const float* const* src, float* const* dst, const int* planes, int nseg, int H, int W, int crop_h, int crop_w,
+                    int out_h, int out_w, const float* K_in, float* K_out, int nK, void* stream) {
+  if (!src || !dst || !planes) return fail(SMD_E_INVALID, "null pointer");
+  if (nseg < 1 || nseg > smd::SMD_MAX_AR_SEGMENTS) return fail(SMD_E_INVALID, "nseg=%d outside [1, %d]", nseg, smd::SMD_MAX_AR_SEGMENTS);
+  if (H < 1 || W < 1 || crop_h < 1 || crop_w < 1 || crop_h > H || crop_w > W || out_h < 1 || out_w < 1)
+    return fail(SMD_E_INVALID, "invalid sizes: input %dx%d, crop %dx%d, output %dx%d", H, W, crop_h, crop_w, out_h, out_w);
+  if ((K_in != nullptr) != (K_out != nullptr) || (K_in && nK < 1)) return fail(SMD_E_INVALID, "K_in / K_out / nK must be given together");
+  smd::CropResizeArgs a;
+  memset(&a, 0, sizeof(a));
+  long long total = 0;
+  for (int k = 0; k < nseg; ++k) {
+    if (!src[k] || !dst[k] || planes[k] < 1) return fail(SMD_E_INVALID, "segment %d: null pointer or no planes", k);
+    a.src[k] = src[k]; a.dst[k] = dst[k]; a.planes[k] = planes[k]; a.first_plane[k] = (int)total;
+    total += planes[k];
+  }
+  if (total + 1 > 65535) return fail(SMD_E_INVALID, "too many image planes for one launch (%lld)", total);
+  a.nseg = nseg; a.H = H; a.W = W; a.ch = crop_h; a.cw = crop_w; a.oh = out_h; a.ow = out_w;
+  // kornia.geometry.transform.center_crop: start = int(src/2 - dst/2) (truncation), an integer window
+  a.y0 = (int)((double)H/2.0 - (double)crop_h/2.0); a.x0 = (int)((double)W/2.0 - (double)crop_w/2.0);
+  a.K_in = K_in; a.K_out = K_out; a.nK = nK;
+  return check_launch(smd::launch_crop_resize(a, (hipStream_t)stream), "crop_resize");
+}
+
 int smd_profile_enable(int which, int capacity) {
   if (which < 0 || which > 4 || capacity < 0) return fail(SMD_E_INVALID, "bad profile slot");
   ProfSlot& p = g_prof[which];

@@ -130,6 +130,18 @@ struct ReconBwdArgs {
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1)/b; }
 
+constexpr int SMD_MAX_AR_SEGMENTS = 8;
+struct CropResizeArgs {    // k_crop_resize: centre crop + bilinear resize of up to 8 tensors of (planes, H, W) + the intrinsics
+  const float* src[SMD_MAX_AR_SEGMENTS]; float* dst[SMD_MAX_AR_SEGMENTS];
+  int planes[SMD_MAX_AR_SEGMENTS], first_plane[SMD_MAX_AR_SEGMENTS];
+  int nseg;
+  int H, W;                // input size
+  int y0, x0, ch, cw;      // crop window
+  int oh, ow;              // output size
+  const float* K_in; float* K_out; int nK;
+};
+hipError_t launch_crop_resize(const CropResizeArgs& a, hipStream_t st);
+
 // XCD-aware block -> (strip block, sample, scale) mapping for the two fused kernels (1-D grid of nbx*b*S blocks).
 // MI355X dispatches workgroup p to XCD p % 8, each XCD with its own 4 MB L2.  The S scales of one image region gather from
 // the same support texels, so they are placed on ONE XCD in consecutive dispatch slots: the texels are fetched from HBM once

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, int_array, ptr_array
 from ._lib import call as _raw_call
 
-__all__ = ['disp_to_depth', 'image_recon_prep', 'PreparedFrames', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
+__all__ = ['crop_resize', 'disp_to_depth', 'image_recon_prep', 'PreparedFrames', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
            'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'layer_norm_cf', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
@@ -853,6 +853,30 @@ def inv_intrinsics(K):
     K_inv = torch.empty_like(K)
     call('smd_intrinsics_fwd', None, None, K.data_ptr(), K.shape[0], 1, 1, None, K_inv.data_ptr(), _stream())
     return K_inv
+
+
+def crop_resize(tensors, crop_shape, out_shape, K=None):
+    """Centre crop + bilinear resize of every tensor in `tensors` ((..., H, W) float32, same H, W) and of the intrinsics `K`
+    (..., 4, 4), in one launch: `crop_aug` + `resize_aug` of src/core/aspect_ratio.py:67-151 without materialising the crop.
+    -> ([(..., oh, ow) ...], K' or None).  Not differentiable (the reference runs it under `no_grad`, on the data)."""
+    if not 1 <= len(tensors) <= 8: raise ValueError('1 to 8 tensors per call')
+    H, W = tensors[0].shape[-2:]
+    ch, cw = (int(v) for v in crop_shape); oh, ow = (int(v) for v in out_shape)
+    ts = []
+    for i, t in enumerate(tensors):
+        t = _check(f'tensors[{i}]', t.detach())
+        if tuple(t.shape[-2:]) != (H, W): raise ValueError(f'tensors[{i}]: expected (..., {H}, {W}), got {tuple(t.shape)}')
+        ts.append(t)
+    outs = [torch.empty((*t.shape[:-2], oh, ow), device=t.device, dtype=torch.float32) for t in ts]
+    Kc = Ko = None
+    if K is not None:
+        Kc = _check('K', K.detach())
+        if tuple(Kc.shape[-2:]) != (4, 4): raise ValueError(f'K must be (..., 4, 4), got {tuple(K.shape)}')
+        Ko = torch.empty_like(Kc)
+    call('smd_crop_resize', ptr_array([t.data_ptr() for t in ts]), ptr_array([o.data_ptr() for o in outs]),
+         int_array([t.numel()//(H*W) for t in ts]), len(ts), H, W, ch, cw, oh, ow, Kc.data_ptr() if Kc is not None else None,
+         Ko.data_ptr() if Ko is not None else None, Kc.numel()//16 if Kc is not None else 0, _stream())
+    return outs, Ko
 
 
 def lane_shift_selftest(device='cuda'):

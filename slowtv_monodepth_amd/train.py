@@ -254,7 +254,8 @@ def main(argv=None):
         if rank == 0: print(f'resumed from {args.resume}: epoch {first_epoch}, global step {ckpt.get("global_step", 0)}', flush=True)
     for epoch in range(first_epoch, tcfg.get('max_epochs', 1)):
         t0 = time.time()
-        losses = train_steps(model, opt, lambda it: batch, args.steps, accumulate=acc, clip=tcfg.get('gradient_clip_val'),
+        # (shallow copies: the aspect-ratio augmentation replaces entries of the batch dicts in place, as in the reference)
+        losses = train_steps(model, opt, lambda it: tuple(dict(d) for d in batch), args.steps, accumulate=acc, clip=tcfg.get('gradient_clip_val'),
                              detect_anomaly=bool(tcfg.get('detect_anomaly', False)))
         if sched is not None: sched.step()
         last = losses[-1].item()

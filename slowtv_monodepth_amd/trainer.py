@@ -113,7 +113,9 @@ class MonoDepthModule(nn.Module):
         self.min_depth, self.max_depth = tcfg.get('min_depth', None), tcfg.get('max_depth', None)
         self.always_fwd_pose = tcfg.get('always_fwd_pose', True)
         self.auto_scale_lr = tcfg.get('auto_scale_lr', False)
-        if tcfg.get('aspect_ratio_aug_prob', 0.0): pass  # GPU-side aspect-ratio augmentation is a "next" row
+        # GPU-side aspect-ratio augmentation of the training batches (src/core/trainer.py:54-60, 106): off at probability 0
+        self.ar_kwargs = dict(p=tcfg.get('aspect_ratio_aug_prob', 0.0), crop_min=tcfg.get('aspect_ratio_min', 0.5),
+                              crop_max=tcfg.get('aspect_ratio_max', 1), ref_shape=tcfg.get('aspect_ratio_ref_shape', None))
         prec = str(tcfg.get('precision', 32))
         self.amp_dtype = {'32': None, '32-true': None, 'bf16': torch.bfloat16, 'bf16-mixed': torch.bfloat16}.get(prec, None)
         self.channels_last = bool(tcfg.get('channels_last', False))
@@ -238,6 +240,9 @@ class MonoDepthModule(nn.Module):
 
     def step(self, batch, mode: str = 'train'):
         """One forward pass + losses (src/core/trainer.py:115-190) -> (loss, loss_dict, fwd)."""
+        if mode == 'train' and (self.ar_kwargs['p'] > 0 or self.ar_kwargs['ref_shape']):   # `training_step`: `batch = self.ar_aug(batch)` (trainer.py:106)
+            from .aspect_ratio import aspect_ratio_aug
+            batch = aspect_ratio_aug(batch, **self.ar_kwargs, resample=getattr(self.backend, 'crop_resize', None))
         x, y, m = batch
         self.synth = ViewSynth(x['imgs'].shape[-2:])
         self._prepared = self._prepare_frames(y) if self.prep_ahead == 'own' else None

@@ -406,6 +406,43 @@ def run_option_cases(R):
                                                            out_image_grad=ld['image_grad'], grad_disp=disp.grad))
 
 
+
+def run_aspect_cases(R):
+    """GPU-side aspect-ratio augmentation: everything of `src/core/aspect_ratio.py` that runs without
+    kornia — the crop / resize shape sampling under seeded generators, `resize_aug` on a whole batch (images, depth, K), the
+    not-applied branch of `aspect_ratio_aug` with a `ref_shape`, and `centre_crop_K`.  (`KT.center_crop` itself cannot be run
+    here: kornia is absent; that half of the oracle is restated from kornia's published algorithm, "parity unpinned".)"""
+    import random
+    import importlib
+    AR = importlib.import_module('src.core.aspect_ratio')
+    geo = importlib.import_module('src.tools.geometry')
+    rows = []
+    for seed, shape, lo, hi in ((0, (376, 1242), 0.5, 1.0), (1, (376, 1242), 0.5, 1.0), (2, (720, 1280), 0.5, 1.0), (3, (192, 640), 0.6, 0.9),
+                                (4, (384, 640), 0.5, 1.0), (5, (376, 1242), 0.3, 0.7), (6, (720, 1280), 0.5, 1.0), (7, (96, 128), 0.5, 1.0)):
+        random.seed(seed); torch.manual_seed(seed)
+        crop, r = AR.sample_crop(shape, lo, hi)
+        res = AR.sample_resize(crop, (192, 640), eps=0.8)
+        res1 = AR.sample_resize(shape, (192, 640), eps=1)
+        rows.append([seed, shape[0], shape[1], lo, hi, crop[0], crop[1], r, res[0], res[1], res1[0], res1[1]])
+    g = torch.Generator().manual_seed(77)
+    b, n, h, w = 2, 1, 24, 40
+    mk = lambda *s: torch.rand(*s, generator=g)
+    x = {'imgs': mk(b, 3, h, w), 'supp_imgs': mk(n, b, 3, h, w)}
+    y = {'imgs': mk(b, 3, h, w), 'supp_imgs': mk(n, b, 3, h, w), 'depth': 1 + 9*mk(b, 1, h, w),
+         'K': torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(b, 1, 1)}
+    rec = {f'in_x_{k}': v.clone() for k, v in x.items()}
+    rec.update({f'in_y_{k}': v.clone() for k, v in y.items()})
+    xo, yo, mo = AR.resize_aug(({k: v.clone() for k, v in x.items()}, {k: v.clone() for k, v in y.items()}, {}), ref_shape=(32, 96), eps=0.8)
+    rec.update({f'out_x_{k}': v for k, v in xo.items()}); rec.update({f'out_y_{k}': v for k, v in yo.items()})
+    rec['meta_res_shape'] = np.array(xo['imgs'].shape[-2:]); rec['meta_augs'] = str(mo['augs'])
+    random.seed(11)
+    xo2, yo2, mo2 = AR.aspect_ratio_aug(({k: v.clone() for k, v in x.items()}, {k: v.clone() for k, v in y.items()}, {}), p=0.0, ref_shape=(32, 64))
+    rec.update({f'out2_x_{k}': v for k, v in xo2.items()}); rec.update({f'out2_y_{k}': v for k, v in yo2.items()})
+    rec['out_centre_crop_K'] = geo.centre_crop_K(y['K'], (17, 30), (h, w))
+    rec['sampling'] = np.array(rows, dtype=np.float64)
+    save('ar_reference', rec)
+
+
 def save(name, rec):
     arrs = {}
     for k, v in rec.items():
@@ -422,6 +459,9 @@ def main():
         return
     if '--options-only' in sys.argv:    # regenerate just the round-3 option fixtures
         run_option_cases(R)
+        return
+    if '--aspect-only' in sys.argv:
+        run_aspect_cases(R)
         return
     kbr = dict(loss_kw=dict(loss_name='ssim', use_min=True, use_automask=True), smooth_kw=dict(use_edges=True),
                min_depth=0.1, max_depth=100)
@@ -449,6 +489,7 @@ def main():
     run_op_cases(R)
     run_handler_cases(R)
     run_option_cases(R)
+    run_aspect_cases(R)
 
 
 if __name__ == '__main__':

@@ -1253,3 +1253,62 @@ def test_decoder_glue_bf16_io(F):
         res.append([t.detach().float() for t in (o1, o2, aa.grad, ss.grad, bb.grad)])
     for nm, x, e in zip(('up_cat_pad', 'elu_pad', 'g_a', 'g_skip', 'g_bias'), res[1], res[0]):
         assert rel_to_max(x, e) < 3e-2, f'{nm}: {rel_to_max(x, e):.3e}'
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU-side aspect-ratio augmentation
+# ---------------------------------------------------------------------------------------------------
+def test_crop_resize_kernel_matches_reference_resize_and_oracle(F, golden):
+    """`smd_crop_resize` (one launch for every image tensor of the batch + K): (1) the resize half against the REFERENCE's
+    `resize_aug` output (pinned fixture), (2) crop + resize at odd / even window offsets against the oracle (crop = kornia's
+    published integer window, parity unpinned), (3) crop only and identity."""
+    from oracle import aspect_ratio_oracle as A
+    g = golden('ar_reference')
+    x = {k[5:]: v for k, v in g.items() if k.startswith('in_x_')}; y = {k[5:]: v for k, v in g.items() if k.startswith('in_y_')}
+    sh = tuple(x['imgs'].shape[-2:]); res = tuple(int(v) for v in g['meta_res_shape'])
+    keys = [('x', 'imgs'), ('y', 'imgs'), ('x', 'supp_imgs'), ('y', 'supp_imgs'), ('y', 'depth')]
+    tens = [{'x': x, 'y': y}[d][k].cuda() for d, k in keys]
+    outs, K = F.crop_resize(tens, sh, res, y['K'].cuda())
+    for (d, k), o in zip(keys, outs): torch.testing.assert_close(o.cpu(), g[f'out_{d}_{k}'], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(K.cpu(), g['out_y_K'], rtol=1e-6, atol=1e-6)
+    gen = torch.Generator().manual_seed(3)
+    big = [torch.rand(2, 3, 37, 61, generator=gen), torch.rand(3, 2, 3, 37, 61, generator=gen), torch.rand(2, 1, 37, 61, generator=gen)]
+    Kc = torch.rand(2, 4, 4, generator=gen)
+    for crop, out in (((20, 33), (32, 64)), ((21, 32), (32, 32)), ((37, 61), (64, 96)), ((19, 40), (19, 40)), ((37, 61), (37, 61)), ((2, 3), (32, 32))):
+        o_hip, K_hip = F.crop_resize([t.cuda() for t in big], crop, out, Kc.cuda())
+        o_ref, K_ref = A.crop_resize(big, crop, out, Kc)
+        for a, r in zip(o_hip, o_ref): torch.testing.assert_close(a.cpu(), r, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(K_hip.cpu(), K_ref, rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError): F.crop_resize([big[0].cuda()], (40, 10), (32, 32))          # crop larger than the image
+
+
+def test_aspect_ratio_aug_on_a_training_batch(F):
+    """The whole entry point on the HIP operator against the same call on the oracle's operator (same seeds -> same sampled shapes),
+    then one training step of the trainer with `aspect_ratio_aug_prob = 1` on the augmented shapes."""
+    import random
+    from oracle import aspect_ratio_oracle as A
+    from slowtv_monodepth_amd import aspect_ratio as AR
+    from slowtv_monodepth_amd.synthetic import make_batch
+    from slowtv_monodepth_amd.trainer import MonoDepthModule
+    xb, yb, mb = make_batch(2, 96, 320, (-1, 1), seed=3)
+    clone = lambda d, dev: {k: (v.clone().to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+    random.seed(5); torch.manual_seed(5)
+    xh, yh, mh = AR.aspect_ratio_aug((clone(xb, 'cuda'), clone(yb, 'cuda'), {}), p=1.0, ref_shape=(96, 320))
+    random.seed(5); torch.manual_seed(5)
+    xo, yo, mo = AR.aspect_ratio_aug((clone(xb, 'cpu'), clone(yb, 'cpu'), {}), p=1.0, ref_shape=(96, 320), resample=A.crop_resize)
+    assert mh['augs'] == mo['augs'] and xh['imgs'].shape == xo['imgs'].shape and xh['imgs'].shape[-1] % 32 == 0
+    for k in ('imgs', 'supp_imgs'):
+        torch.testing.assert_close(xh[k].cpu(), xo[k], rtol=1e-5, atol=1e-5); torch.testing.assert_close(yh[k].cpu(), yo[k], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(yh['K'].cpu(), yo['K'], rtol=1e-6, atol=1e-6)
+    cfg = {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False, 'dec_name': 'monodepth', 'out_scales': [0, 1, 2, 3]},
+                   'pose': {'enc_name': 'resnet18', 'pretrained': False}},
+           'loss': {'img_recon': {'weight': 1, 'loss_name': 'ssim', 'use_min': True, 'use_automask': True}, 'disp_smooth': {'weight': 0.001, 'use_edges': True}},
+           'trainer': {'min_depth': 0.1, 'max_depth': 100, 'aspect_ratio_aug_prob': 1.0, 'aspect_ratio_ref_shape': [128, 192]}}
+    torch.manual_seed(0)
+    m = MonoDepthModule(cfg).cuda()
+    random.seed(5); torch.manual_seed(5)                  # samples a 16/9 crop (81, 145) of a (128, 192) frame -> resized to (96, 192)
+    xs, ys, _ = make_batch(2, 128, 192, (-1, 1), seed=3)
+    batch = (clone(xs, 'cuda'), clone(ys, 'cuda'), {})
+    loss, ld, fwd = m.step(batch, mode='train')
+    loss.backward()
+    assert torch.isfinite(loss).item() and len(batch[2]['augs']) == 2 and tuple(batch[0]['imgs'].shape[-2:]) == (96, 192)

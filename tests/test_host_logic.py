@@ -320,3 +320,24 @@ def test_checkpoint_has_the_fields_lightning_restores_and_resume_round_trips(tmp
     m2 = MonoDepthModule(cfg, loss_backend=OracleBackend())
     load_reference_checkpoint(m2, str(tmp_path/'last.ckpt'))
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()): assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_trainer_applies_the_aspect_ratio_augmentation_in_training_mode_only():
+    """src/core/trainer.py:54-60, 106: `training_step` augments the batch, `validation_step` does not (host logic, CPU operator)."""
+    import random
+    cfg = {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False, 'dec_name': 'monodepth', 'out_scales': [0, 1]},
+                   'pose': {'enc_name': 'resnet18', 'pretrained': False}},
+           'loss': {'img_recon': {'weight': 1, 'use_min': True, 'use_automask': True}},
+           'trainer': {'min_depth': 0.1, 'max_depth': 100, 'aspect_ratio_aug_prob': 1.0, 'aspect_ratio_ref_shape': [128, 192]}}
+    torch.manual_seed(0)
+    m = MonoDepthModule(cfg, loss_backend=OracleBackend())
+    random.seed(5); torch.manual_seed(5)                  # samples a 16/9 crop (81, 145) -> resized to (96, 192)
+    batch = make_batch(1, 128, 192, (-1, 1), seed=1)
+    loss, _, fwd = m.step(batch, mode='train')
+    assert torch.isfinite(loss) and len(batch[2]['augs']) == 2
+    h, w = batch[0]['imgs'].shape[-2:]
+    assert (h, w) == (96, 192) and h*w <= 0.8*128*192
+    assert batch[1]['supp_imgs'].shape[-2:] == (h, w) and fwd['depth_up'][0].shape[-2:] == (h, w)
+    batch2 = make_batch(1, 128, 192, (-1, 1), seed=1)
+    m.step(batch2, mode='val')
+    assert tuple(batch2[0]['imgs'].shape[-2:]) == (128, 192) and 'augs' not in batch2[2]

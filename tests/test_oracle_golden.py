@@ -249,3 +249,37 @@ def test_laplacian_smoothness_matches_reference(golden, use_edges):
     torch.testing.assert_close(ld['disp_grad'].detach(), g['out_disp_grad'], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(ld['image_grad'], g['out_image_grad'], rtol=1e-5, atol=1e-6)
     assert rel_to_max(disp.grad, g['grad_disp']) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------------- aspect-ratio augmentation (§8f rank 4)
+def test_aspect_ratio_sampling_and_resize_match_reference(golden):
+    """Everything of src/core/aspect_ratio.py that runs without kornia, against the reference's own outputs: the seeded crop / resize
+    shape sampling of this package's mirror, the oracle's resize of a whole batch (images, depth, K) and the not-applied branch
+    with a `ref_shape`.  (The crop itself: kornia's `center_crop`, restated — "parity unpinned", oracle/aspect_ratio_oracle.py.)"""
+    import random
+    from oracle import aspect_ratio_oracle as A
+    from slowtv_monodepth_amd import aspect_ratio as AR
+    g = golden('ar_reference')
+    for row in g['sampling'].tolist():
+        seed, H, W, lo, hi, ch, cw, r, rh, rw, r1h, r1w = row
+        random.seed(int(seed)); torch.manual_seed(int(seed))
+        crop, ratio = AR.sample_crop((int(H), int(W)), lo, hi)
+        assert crop == (int(ch), int(cw)) and abs(ratio - r) < 1e-12, (row, crop, ratio)
+        assert AR.sample_resize(crop, (192, 640), eps=0.8) == [int(rh), int(rw)]
+        assert AR.sample_resize((int(H), int(W)), (192, 640), eps=1) == [int(r1h), int(r1w)]
+    x = {k[5:]: v for k, v in g.items() if k.startswith('in_x_')}; y = {k[5:]: v for k, v in g.items() if k.startswith('in_y_')}
+    sh = tuple(x['imgs'].shape[-2:])
+    res = tuple(int(v) for v in g['meta_res_shape'])
+    keys = [('x', 'imgs'), ('y', 'imgs'), ('x', 'supp_imgs'), ('y', 'supp_imgs'), ('y', 'depth')]
+    outs, K = A.crop_resize([{'x': x, 'y': y}[d][k] for d, k in keys], sh, res, y['K'])        # crop == input: the resize half alone
+    for (d, k), o in zip(keys, outs): torch.testing.assert_close(o, g[f'out_{d}_{k}'], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(K, g['out_y_K'], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(A.centre_crop_K(y['K'], (17, 30), sh), g['out_centre_crop_K'], rtol=1e-6, atol=1e-6)
+    # the whole entry point on the not-applied branch (p = 0, ref_shape given), with the oracle as the operator
+    random.seed(11)
+    xb, yb, mb = AR.aspect_ratio_aug(({k: v.clone() for k, v in x.items()}, {k: v.clone() for k, v in y.items()}, {}), p=0.0, ref_shape=(32, 64),
+                                     resample=A.crop_resize)
+    for k in ('imgs', 'supp_imgs'):
+        torch.testing.assert_close(xb[k], g[f'out2_x_{k}'], rtol=1e-6, atol=1e-6); torch.testing.assert_close(yb[k], g[f'out2_y_{k}'], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(yb['K'], g['out2_y_K'], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(yb['depth'], g['out2_y_depth'], rtol=1e-6, atol=1e-6)
