@@ -301,7 +301,7 @@ int smd_image_recon_disp_fwd(const float* const* disp, const int* hs, const int*
 static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T, const float* K,
                           const float* K_inv, const uint8_t* sel, const float* g_loss, const float* g_in, float k0_scale,
                           float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
-                          int b, int n, int S, int h, int w, int flags, void* stream) {
+                          int b, int n, int S, int h, int w, int flags, void* stream, smd::PoseFinJob* guest = nullptr) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
   if (!depth || !supp_packed || !T || !K || !K_inv || !sel || !g_loss || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if ((flags & SMD_NEED_K_GRAD) && (!g_K || !g_Kinv)) return fail(SMD_E_INVALID, "SMD_NEED_K_GRAD requires g_K and g_Kinv");
@@ -334,6 +334,12 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   if (a.wps < 1) a.wps = 1;
   if (a.wps > 4) a.wps = 4;
   if (a.wps > n) a.wps = n;
+  if (guest) {   // the caller's next launch finalises the pose sums: no in-launch hand-off (the kernel skips it when `arrive` is null)
+    a.arrive = nullptr;
+    const int spb = smd::kWavesPerBlock/a.wps;
+    guest->a = a; guest->b1 = a.b1;
+    guest->entries1 = S*smd::ceil_div(pl.nsx*pl.nsy, spb); guest->entries2 = S*smd::ceil_div(pl.nsx*a.nsy2, spb);
+  }
   prof_mark(SMD_PROF_RECON_BWD_ALL, st, true);
   prof_mark(SMD_PROF_RECON_BWD, st, true);
   if (int rc = check_launch(smd::launch_recon_bwd(a, st), "image_recon_bwd")) return rc;
@@ -374,10 +380,13 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
   if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
   // The fused backward applies d depth / d(scaled disparity) itself (it has the depth in a register), so the K0 adjoint is a
   // pure resampling adjoint of g_depth: it neither reads depth_up again (24 MB at cfg 2) nor multiplies.
+  smd::PoseFinJob guest;
+  memset(&guest, 0, sizeof(guest));
+  const bool ride = env_int("SMD_BWD_GUEST_FINALIZE", 1) != 0;   // 0: the in-launch hand-off of smd_image_recon_bwd instead
   if (int rc = recon_bwd_impl(depth_up, supp_packed, T, K, K_inv, sel, g_loss, g_depth_up_in, a_scale,
-                              g_depth, g_T, g_K, g_Kinv, workspace, base, b, n, S, h, w, flags, stream)) return rc;
-  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth, k0_tmp, true, (hipStream_t)stream),
-                      "disp_to_depth_bwd");
+                              g_depth, g_T, g_K, g_Kinv, workspace, base, b, n, S, h, w, flags, stream, ride ? &guest : nullptr)) return rc;
+  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth, k0_tmp, true, (hipStream_t)stream,
+                                                    ride ? &guest : nullptr), "disp_to_depth_bwd");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -4,8 +4,10 @@
 // src/core/trainer.py:320) and `to_scaled` / `to_inv` (src/tools/geometry.py:62-90, applied at trainer.py:321).
 // One launch handles every scale and writes the scale-major (S,b,h,w) stack the fused kernels read, so the
 // `torch.stack` of src/core/handlers.py:48 never materialises.
+#include <string.h>
 #include "smd_common.h"
 #include "smd_kernels.h"
+#include "smd_pose_fin.h"
 
 namespace smd {
 
@@ -76,10 +78,24 @@ __device__ __forceinline__ void footprint(int j, float f, int n_lo, int n_hi, in
 
 __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
                                                              const float* __restrict__ depth_up, const float* __restrict__ g_depth_up,
-                                                             float* __restrict__ tmp) {
+                                                             float* __restrict__ tmp, const PoseFinJob job) {
+  // Guest work (training path): the launch that precedes this one — the fused reconstruction backward — leaves per-block pose
+  // sums; one extra block per sample (its first wave) turns them into dL/dT, dL/dK, dL/dK^-1 here, beside the resampling
+  // blocks, so that neither a launch of its own nor an in-launch hand-off at the tail of the big kernel is needed.
+  // (The guest blocks come FIRST in dispatch order: their single wave is a chain of latencies, ~8 us, that should start with the
+  // launch and hide under the resampling blocks rather than trail them.)
+  const int guest = job.a.pose_partial != nullptr ? 1 : 0;
+  if (guest && blockIdx.x == 0) {
+    // two of the block's waves take the supports in turn (their round trips run side by side); static LDS counts against every
+    // block of this launch, so no more than that
+    __shared__ double scratch[fin_scratch_doubles(2)];
+    pose_finalize<true>(job.a, (int)blockIdx.y, (int)blockIdx.y < job.b1 ? job.entries1 : job.entries2, scratch, (int)(threadIdx.x >> 6), 2);
+    return;
+  }
   // depth_up == nullptr: the incoming gradient already carries d depth / d disparity (the fused backward applied it)
-  const int s = scale_of_block(map, sc.S, blockIdx.x);
-  const int blk = blockIdx.x - map.first_block[s], bi = blockIdx.y;
+  const int bx = (int)blockIdx.x - guest;
+  const int s = scale_of_block(map, sc.S, bx);
+  const int blk = bx - map.first_block[s], bi = blockIdx.y;
   const int hs = sc.hs[s], ws = sc.ws[s];
   const size_t ibase = ((size_t)s*b + bi)*h*w;
   const float dmax = 1.f/kEps32;
@@ -151,7 +167,8 @@ size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, Bwd
 }
 
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
-                                    const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st) {
+                                    const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st,
+                                    const PoseFinJob* job) {
   float a_scale = 1.f;
   if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
   if (premultiplied) { a_scale = 1.f; depth_up = nullptr; }
@@ -170,7 +187,11 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
     }
   }
   m1.first_block[SMD_MAX_SCALES] = n1; m2.first_block[SMD_MAX_SCALES] = n2;
-  if (n1 > 0) hipLaunchKernelGGL(k_disp_to_depth_bwd_v, dim3(n1, b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp);
+  PoseFinJob none;
+  memset(&none, 0, sizeof(none));
+  if (n1 > 0) hipLaunchKernelGGL(k_disp_to_depth_bwd_v, dim3(n1 + (job ? 1 : 0), b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp,
+                                 job ? *job : none);
+  else if (job) return hipErrorInvalidValue;
   if (resampled) hipLaunchKernelGGL(k_disp_to_depth_bwd_h, dim3(n2, b), dim3(256), 0, st, sc, m2, b, h, w, a_scale, tmp);
   return hipGetLastError();
 }

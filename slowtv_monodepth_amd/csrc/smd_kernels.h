@@ -178,8 +178,10 @@ hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, flo
                                     float* depth_up, float* disp_up, hipStream_t st);
 struct BwdMap;
 size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, BwdMap* map);
+struct PoseFinJob { ReconBwdArgs a; int entries1, entries2, b1; };   // the per-sample epilogue of the fused backward as guest work of the K0 adjoint
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
-                                    const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st);
+                                    const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st,
+                                    const PoseFinJob* job = nullptr);
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st);

@@ -20,6 +20,7 @@
 // Nothing of the forward is stored except the packed texels / target sums (which the forward needs itself) and `sel`.
 #include "smd_common.h"
 #include "smd_kernels.h"
+#include "smd_pose_fin.h"
 
 #ifndef SMD_ABLATE_BWD
 #define SMD_ABLATE_BWD 0   // diagnosis builds only (scripts/dev/ablate_bwd.sh): bit 0 no tap gathers, bit 1 no row loads, bit 2 no g_depth traffic, bit 3 no LDS
@@ -321,115 +322,6 @@ struct BwdCtx {
   }
 };
 
-// ---------------------------------------------------------------------------------------------
-// Epilogue of a sample (the former k_pose_finalize launch), run by ONE wave — the wave that completes the sample LAST: sum the
-// per-wave partials of dL/d(H, a0, a1, tz) and push them through
-//   H[0:2] = K2 * M,  H[2] = M[2],  M = R * Ki3,  (a0, a1) = K2 * t,  tz = t[2]
-// to dL/dT (n,b,4,4), dL/dK (b,4,4), dL/dKinv (b,4,4).  fp64, fixed order -> deterministic whichever wave does it.
-// The partials of a (support, sample) are `entries` x 12 contiguous floats: the wave sweeps them with 16-byte agent-scope loads
-// (lane l owns floats 4l .. 4l+3 of every 256-float chunk).  12 does not divide 256, so the sum a lane's j-th float belongs to
-// rotates with the chunk index: k = (4 (c + l) + j) mod 12 — three accumulator sets (c mod 3), re-labelled after the sweep.
-// ---------------------------------------------------------------------------------------------
-constexpr int kFinScratchDoubles = SMD_MAX_SUPPORTS*15;   // per support: 6 of dL/dK + 9 of dL/dKinv
-
-__device__ __forceinline__ f4 ld4_agent(rsrc_t r, unsigned byte_off) {   // 16 bytes another workgroup published in this launch (sc1: agent scope)
-  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
-}
-
-__device__ void pose_finalize_wave(const ReconBwdArgs& a, int bi, int entries, double* scratch) {
-  const int lane = threadIdx.x & 63;
-  const int n = a.n, b = a.b;
-  const unsigned F4 = (unsigned)entries*kPoseSums*4u;        // bytes per (support, sample); a multiple of 16
-  const int lm = lane % 3;
-  double mytot[kPoseSums];
-#pragma unroll
-  for (int k = 0; k < kPoseSums; ++k) mytot[k] = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const float* pp = a.pose_partial + ((size_t)i*b + bi)*(size_t)a.pose_stride*kPoseSums;
-    const rsrc_t rs = make_rsrc(pp, F4);                     // loads beyond the last entry read 0
-    double acc[3][4];
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[m][j] = 0.0;
-    // twelve chunks of 1024 bytes per trip, every load issued before the first is used: the sweep is pure latency (this wave
-    // runs alone at the end of a sample), so what counts is the number of round trips — one for up to 256 entries
-    for (unsigned base = 0; base < F4; base += 12u*1024u) {
-      const unsigned o = base + (unsigned)lane*16u;
-      f4 v[12];
-#pragma unroll
-      for (int q = 0; q < 12; ++q) v[q] = ld4_agent(rs, o + (unsigned)q*1024u);
-#pragma unroll
-      for (int q = 0; q < 12; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[q % 3][j] += (double)v[q][j];
-    }
-    // re-label: sum k lives in set m = (k/4 - lane) mod 3, component k mod 4; then the wave's butterfly (fixed order)
-#pragma unroll
-    for (int k = 0; k < kPoseSums; ++k) {
-      const int want = (k/4 + 3 - lm) % 3;
-      double v = (want == 0) ? acc[0][k & 3] : ((want == 1) ? acc[1][k & 3] : acc[2][k & 3]);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == i) mytot[k] = v;
-    }
-  }
-  double* gKs = scratch;                 // [n][6]
-  double* gKis = scratch + SMD_MAX_SUPPORTS*6;   // [n][9]
-  if (lane < n) {
-    const int i = lane;
-    const float* Tm = a.T + ((size_t)i*b + bi)*16;
-    const float* Km = a.K + (size_t)bi*16;
-    const float* Ki = a.Kinv + (size_t)bi*16;
-    double R[9], tv[3], K2[6], Ki3[9], M[9];
-    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) { R[r*3 + c] = Tm[r*4 + c]; Ki3[r*3 + c] = Ki[r*4 + c]; } tv[r] = Tm[r*4 + 3]; }
-    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) K2[r*3 + c] = Km[r*4 + c];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r*3 + c] = R[r*3]*Ki3[c] + R[r*3 + 1]*Ki3[3 + c] + R[r*3 + 2]*Ki3[6 + c];
-    const double* gH = mytot;            // 3x3
-    const double ga[2] = {mytot[9], mytot[10]};
-    const double gtz = mytot[11];
-    double gM[9];
-    for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c) gM[m*3 + c] = K2[m]*gH[c] + K2[3 + m]*gH[3 + c];
-    for (int c = 0; c < 3; ++c) gM[6 + c] += gH[6 + c];
-    for (int r = 0; r < 2; ++r) for (int m = 0; m < 3; ++m)
-      gKs[i*6 + r*3 + m] = gH[r*3]*M[m*3] + gH[r*3 + 1]*M[m*3 + 1] + gH[r*3 + 2]*M[m*3 + 2] + ga[r]*tv[m];
-    double gt[3];
-    for (int m = 0; m < 3; ++m) gt[m] = K2[m]*ga[0] + K2[3 + m]*ga[1];
-    gt[2] += gtz;
-    float* gTo = a.g_T + ((size_t)i*b + bi)*16;
-    for (int r = 0; r < 3; ++r) {
-      for (int m = 0; m < 3; ++m)
-        gTo[r*4 + m] = (float)(gM[r*3]*Ki3[m*3] + gM[r*3 + 1]*Ki3[m*3 + 1] + gM[r*3 + 2]*Ki3[m*3 + 2]);
-      gTo[r*4 + 3] = (float)gt[r];
-    }
-    for (int c = 0; c < 4; ++c) gTo[12 + c] = 0.f;
-    for (int m = 0; m < 3; ++m) for (int c = 0; c < 3; ++c)
-      gKis[i*9 + m*3 + c] = R[m]*gM[c] + R[3 + m]*gM[3 + c] + R[6 + m]*gM[6 + c];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the scratch written by lanes < n is read by lane 0 (one wave: program order + this wait)
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {
-    if (a.g_K) {
-      float* o = a.g_K + (size_t)bi*16;
-      for (int q = 0; q < 16; ++q) o[q] = 0.f;
-      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
-        double acc = 0.0;
-        for (int i = 0; i < n; ++i) acc += gKs[i*6 + r*3 + c];
-        o[r*4 + c] = (float)acc;
-      }
-    }
-    if (a.g_Kinv) {
-      float* o = a.g_Kinv + (size_t)bi*16;
-      for (int q = 0; q < 16; ++q) o[q] = 0.f;
-      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
-        double acc = 0.0;
-        for (int i = 0; i < n; ++i) acc += gKis[i*9 + r*3 + c];
-        o[r*4 + c] = (float)acc;
-      }
-    }
-  }
-}
-
 // Four waves per SIMD (<= 128 VGPRs): without the cap the allocator settles at 133 and the kernel loses a wave of occupancy,
 // 138 -> 127 us at cfg 2 (the gathers' latency is what the extra wave hides).
 constexpr int kAccRows = 16;   // tallest strip of the multi-support instantiations: its dL/d depth rows wait in LDS for the strip's sum
@@ -441,7 +333,8 @@ template <bool SSIM, int SKIP, int NS, bool ACC>
 __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconBwdArgs a) {
   static_assert(ACC || NS == 1, "several waves per strip need the LDS sum");
   constexpr int SPB = (kWavesPerBlock/NS > 0) ? kWavesPerBlock/NS : 1;   // strips per block
-  constexpr int kWaveFloats = (3*kHist + (ACC ? kAccRows : 0))*64;
+  // (a wave's region is at least the epilogue's scratch, which aliases it: single-support strips have no dL/d depth rows)
+  constexpr int kWaveFloats = ((3*kHist + (ACC ? kAccRows : 0))*64 >= 2*kFinScratchDoubles) ? (3*kHist + (ACC ? kAccRows : 0))*64 : 2*kFinScratchDoubles;
   static_assert(kWaveFloats*4 >= kFinScratchDoubles*8, "the epilogue's scratch aliases a wave's LDS rows");
   // per wave: 3 row slots x ({gx, gy} x 3 channels + depth) x 64 lanes [+ ACC: kAccRows x 64 lanes of dL/d depth]; ONE array (a second
   // __shared__ object in the row loop makes the compiler serialise LDS and vector-memory waits); the arrival counters of the
@@ -577,6 +470,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     float* pp = a.pose_partial + (((size_t)i*a.b + bi)*(size_t)a.pose_stride + (size_t)s*nbx + xb)*kPoseSums;
     __hip_atomic_store((unsigned*)(pp + k), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (a.arrive == nullptr) return;   // the sample's epilogue rides in the launch that follows (K0 adjoint: smd_depth.hip), no hand-off needed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   unsigned last = 0;
   if (lane == 0) {
@@ -591,10 +485,10 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
 }
 
 // The same epilogue as a launch of its own, for the un-fused ViewSynth backward (smd_unfused.hip), whose partials come from a
-// one-thread-per-pixel kernel: one wave per sample.
-__global__ __launch_bounds__(64) void k_pose_finalize(const ReconBwdArgs a, int entries) {
-  __shared__ double scratch[kFinScratchDoubles];
-  pose_finalize_wave(a, (int)blockIdx.x, entries, scratch);
+// one-thread-per-pixel kernel: one block of four waves per sample.
+__global__ __launch_bounds__(256) void k_pose_finalize(const ReconBwdArgs a, int entries) {
+  __shared__ double scratch[fin_scratch_doubles(4)];
+  pose_finalize<true>(a, (int)blockIdx.x, entries, scratch, (int)(threadIdx.x >> 6), 4);
 }
 
 hipError_t launch_pose_finalize(const float* pose_partial, int entries, int stride, const float* T, const float* K, const float* Kinv,
@@ -602,7 +496,7 @@ hipError_t launch_pose_finalize(const float* pose_partial, int entries, int stri
   ReconBwdArgs a = {};
   a.pose_partial = const_cast<float*>(pose_partial); a.pose_stride = stride; a.T = T; a.K = K; a.Kinv = Kinv;
   a.g_T = g_T; a.g_K = g_K; a.g_Kinv = g_Kinv; a.b = b; a.n = n;
-  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(64), 0, st, a, entries);
+  hipLaunchKernelGGL(k_pose_finalize, dim3(b), dim3(256), 0, st, a, entries);
   return hipGetLastError();
 }
 
