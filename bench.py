@@ -218,7 +218,7 @@ def main():
         copy_gbps, read_gbps = measured_hbm_ceilings(_lib.lib, device)
         # HBM traffic cannot be measured inside this run (it needs rocprofv3 --pmc passes, which serialise the kernels): it is
         # read from the committed summary of such passes over THIS command (scripts/pmc_traffic.sh -> profiles/traffic.json).
-        traffic, traffic_source = None, None
+        traffic, traffic_source, tj = None, None, {}
         tf = ROOT/'profiles'/'traffic.json'
         if tf.is_file():
             try:
@@ -242,16 +242,17 @@ def main():
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,
                          'whole_forward_ms': round(fa_ms, 5), 'whole_forward_launches': 'the forward entry point on the critical path: k_recon_main (all 4 scales; the loss is reduced inside it by the last block)',
-                         'prep_ms': round(p_ms, 5), 'prep_launch': 'k_recon_prep (frame-only: texel repack, target window sums, identity error), enqueued on a side stream at the start of the step, under the networks',
+                         'prep_ms': round(p_ms, 5), 'prep_launch': 'k_recon_prep (frame-only: texel repack, target window sums, identity error), enqueued on the pose network\'s side stream behind that network, i.e. under the depth network (trainer.prep_ahead)',
                          'whole_forward_frac': round(B_fwd/(fa_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
                          'forward_incl_prep_frac': round(B_fwd/((fa_ms + p_ms)*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
                          'algorithmic_bytes': B_fwd, 'avg_kernel_ms': round(f_ms, 5), 'launches_timed': len(fwd_ms),
                          'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
-            'roofline_bwd': {'kernel': f'smd::k_recon_bwd<true, 2, {min(n, 4)}> (fused adjoint, one wave per (strip, support), pose sums finalised in-launch; name as rocprofv3 prints it)', 'bound': 'hbm',
+            'roofline_bwd': {'kernel': f'smd::k_recon_bwd<true, 2, {min(n, 4)}, true> (fused adjoint, one wave per (strip, support); the pose / intrinsics epilogue rides in the K0-adjoint launch that follows; name as rocprofv3 prints it)', 'bound': 'hbm',
                              'achieved': round(B_bwd/(b_ms*1e-3)/1e9, 1) if b_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                              'frac': round(B_bwd/(b_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if b_ms else None,
                              'algorithmic_bytes': B_bwd, 'avg_kernel_ms': round(b_ms, 5), 'launches_timed': len(bwd_ms),
-                             'whole_backward_ms': round(ba_ms, 5), 'whole_backward_launches': 'k_recon_bwd (the pose / intrinsics gradients are finalised by the last block of each sample)'},
+                             'traffic': (tj.get(args.workload, {}).get('recon_bwd_bytes') if tf.is_file() else None),
+                             'whole_backward_ms': round(ba_ms, 5), 'whole_backward_launches': 'k_recon_bwd alone (events around smd_image_recon_bwd\'s launches; the K0 adjoint, which also carries the pose epilogue, follows outside this pair)'},
         }
         note(f'timed region done: {out["value"]} img/s')
         if world == 1 and not args.no_cpu_baseline:

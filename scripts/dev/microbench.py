@@ -26,8 +26,14 @@ T = torch.eye(4, device=dev).repeat(n, b, 1, 1); T[..., :3, 3] = 0.05*torch.rand
 flags = F.recon_flags('ssim', True, True)
 want_err = os.environ.get("MB_ERR", "0") == "1"   # 1: also write the per-pixel error map (an optional output)
 fused_k0 = os.environ.get('MB_DISP', '1') == '1'   # 1: K0 fused into the reconstruction kernel (the product path); 0: separate K0 launch
+prep_mode = os.environ.get('MB_PREP', 'inline')   # inline | ahead (prepared frames, consumed right away) | cold (prepared, then 1 GiB of unrelated traffic before the forward)
+flush_src = torch.empty(1 << 28, device=dev) if prep_mode == 'cold' else None
 def step():
-    if fused_k0: loss, err, sel, _, _ = F.image_recon_fused_disp(disps, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, min_depth=0.1, max_depth=100, seed=1, want_err=want_err)
+    prepared = None
+    if prep_mode != 'inline':
+        prepared = F.image_recon_prep(y['imgs'], y['supp_imgs'], flags=flags, pyramid=[d.shape[-2:] for d in disps] if fused_k0 else None)
+        if flush_src is not None: flush_src.add_(1.0)     # reads + writes 1 GiB: evicts L2 and the 256 MB Infinity Cache
+    if fused_k0: loss, err, sel, _, _ = F.image_recon_fused_disp(disps, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, min_depth=0.1, max_depth=100, seed=1, want_err=want_err, prepared=prepared)
     else:
         depth_up, _ = F.disp_to_depth(disps, (h, w), 0.1, 100)
         loss, err, sel, _ = F.image_recon_fused(depth_up, y["imgs"], y["supp_imgs"], T, y["K"], flags=flags, seed=1, want_err=want_err)
