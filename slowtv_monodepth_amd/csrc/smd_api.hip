@@ -46,7 +46,7 @@ StripPlan plan(int b, int S, int h, int w, int cols) {
   p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
   const int ov = env_int(cols == smd::kFwdCols ? "SMD_FWD_RH" : "SMD_BWD_RH", 0);
   if (ov >= 1) p.rh = ov < kMinStripRows ? kMinStripRows : ov;
-  if (cols == smd::kFwdCols && p.rh > 60) p.rh = 60;   // the K0-fused forward keeps the strip's rh + 4 row-table entries one per lane
+  if (cols == smd::kFwdCols && p.rh > 58) p.rh = 58;   // the K0-fused forward keeps the strip's rh + 3 + look-ahead row-table entries one per lane
   p.nsx = smd::ceil_div(w, cols);
   p.nsy = smd::ceil_div(h, p.rh);
   return p;
@@ -249,7 +249,8 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
   taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_FWD_TAPER_B", "SMD_FWD_TAPER_RH");
-  if (a.rh2 > 60) { a.rh2 = 60; a.nsy2 = smd::ceil_div(h, a.rh2); }   // as plan(): one row-table entry per lane
+  if (a.rh2 > 58) { a.rh2 = 58; a.nsy2 = smd::ceil_div(h, a.rh2); }   // as plan(): one row-table entry per lane
+  a.lookahead = env_int("SMD_FWD_AHEAD", 1) == 2 ? 2 : 1;
   for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
     a.i0 = i0; a.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
     a.first_pass = (i0 == 0); a.last_pass = (i0 + a.ni >= n);

@@ -46,7 +46,7 @@ struct ScaleSet {  // the multi-scale disparity pyramid, passed by value
 //   ta     (b,h,w,4):       {S_y (3 channels), c_0}   with c = 9 S_yy - S_y^2 + 81 C2: what every scale and support shares
 //   tb     (b,h,w,4):       {c_1, c_2, identity error of the automask, 0}              at a target pixel.
 // followed by a small tail that is not image data (packed_tail_*):
-//   rowtab  [SMD_MAX_SCALES][h+2] uint4: vertical half of the K0 up-sampling per (scale, image row), written by the prep kernel
+//   rowtab  [SMD_MAX_SCALES][h+4] uint4: vertical half of the K0 up-sampling per (scale, image row), written by the prep kernel
 //   arrive  [1 + b] unsigned:  arrival counters of the in-launch reductions (entry 0: loss of the forward; 1 + bi: pose sums of
 //                              sample bi in the backward).  Zeroed by the prep kernel, reset to zero by the last arriver.
 __host__ __device__ inline size_t packed_texel_floats(int b, int n, int h, int w) { return (size_t)n*b*(size_t)(h + 1)*(size_t)(w + 1)*3; }
@@ -56,7 +56,7 @@ __host__ __device__ inline size_t packed_image_floats(int b, int n, int h, int w
   return packed_texel_floats(b, n, h, w) + packed_ypix_floats(b, h, w) + 2*packed_tpix_floats(b, h, w);
 }
 __host__ __device__ inline size_t packed_rowtab_offset_floats(int b, int n, int h, int w) { return (packed_image_floats(b, n, h, w) + 3) & ~(size_t)3; }   // 16-byte aligned
-__host__ __device__ inline size_t packed_arrive_offset_floats(int b, int n, int h, int w) { return packed_rowtab_offset_floats(b, n, h, w) + (size_t)SMD_MAX_SCALES*(size_t)(h + 2)*4; }
+__host__ __device__ inline size_t packed_arrive_offset_floats(int b, int n, int h, int w) { return packed_rowtab_offset_floats(b, n, h, w) + (size_t)SMD_MAX_SCALES*(size_t)(h + 4)*4; }
 __host__ __device__ inline size_t packed_total_floats(int b, int n, int h, int w) { return packed_arrive_offset_floats(b, n, h, w) + (((size_t)b + 1 + 3) & ~(size_t)3); }
 
 struct ReconPrepArgs {     // k_recon_prep: texel repack + target window sums + identity error, once per sample
@@ -68,7 +68,7 @@ struct ReconPrepArgs {     // k_recon_prep: texel repack + target window sums + 
   int flags;
   int rh, nsx, nsy;
   int first_pass, last_pass;
-  uint4* rowtab;           // K0 fused: [S][h+2] vertical up-sampling table for the main kernel (first pass), or null
+  uint4* rowtab;           // K0 fused: [S][h+4] vertical up-sampling table for the main kernel (first pass), or null
   unsigned* arrive;        // the arrival counters in the tail of `packed`: zeroed here (first pass)
   int sc_S, sc_hs[SMD_MAX_SCALES], sc_ws[SMD_MAX_SCALES];
 };
@@ -78,7 +78,7 @@ struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over suppo
   float* depth_out;        // K0 fused: (S,b,h,w) written from `sc` (the low-resolution disparity pyramid), or null
   ScaleSet sc;             // K0 fused: p[s] (b,1,hs,ws), hs, ws
   float a_scale, a_off;    // K0 fused: d = a_scale*disp_up + a_off, depth = (d > 0)/max(d, eps)
-  const uint4* rowtab;     // K0 fused: [S][h+2] vertical up-sampling table (written by the prep kernel)
+  const uint4* rowtab;     // K0 fused: [S][h+4] vertical up-sampling table (written by the prep kernel)
   const float* packed;     // layout above
   const float* T;          // (n,b,4,4)
   const float* K;          // (b,4,4)
@@ -104,6 +104,7 @@ struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over suppo
   float inv_n;
   uint32_t seed_lo, seed_hi;
   int first_pass, last_pass;
+  int lookahead;           // 1 or 2 row steps between a tap gather and its first use (2: the hot K0-fused instantiation with N <= 2 only)
 };
 
 struct ReconBwdArgs {

@@ -181,8 +181,8 @@ __global__ __launch_bounds__(64*kWavesPerBlock) void k_recon_prep(const ReconPre
   if (a.arrive != nullptr && blockIdx.x == 0)   // arrival counters of the in-launch reductions of the main kernel / the backward
     for (int e = threadIdx.x; e < a.b + 1; e += 64*kWavesPerBlock) a.arrive[e] = 0u;
   if (a.rowtab != nullptr && blockIdx.x == 0) {
-    for (int e = threadIdx.x; e < a.sc_S*(a.h + 2); e += 64*kWavesPerBlock) {
-      const int sc_i = e/(a.h + 2), row = e - sc_i*(a.h + 2);
+    for (int e = threadIdx.x; e < a.sc_S*(a.h + 4); e += 64*kWavesPerBlock) {
+      const int sc_i = e/(a.h + 4), row = e - sc_i*(a.h + 4);
       int y0, y1; float ly;
       src_index_f(row, (float)a.sc_hs[sc_i]/(float)a.h, a.sc_hs[sc_i], y0, y1, ly);
       a.rowtab[e] = uint4{(unsigned)y0*(unsigned)a.sc_ws[sc_i]*4u, (unsigned)y1*(unsigned)a.sc_ws[sc_i]*4u, __builtin_bit_cast(unsigned, ly), 0u};
@@ -278,8 +278,13 @@ struct MainPend {          // gathers in flight for one pair of supports
   float fx[(N > 1) ? 2 : 1], fy[(N > 1) ? 2 : 1];
 };
 
-template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP>
+// LA: look-ahead of the tap gathers in row steps.  1: the taps of row j+1 are requested while row j is scored.  2 (N <= 2 only): the
+// taps of row j+2 — two sets of pending registers, each tied to the row buffer (XA / XB) its row will be blended into, so the
+// unrolled loop still never moves a register; 28 more VGPRs (3 waves per SIMD instead of 4) for twice the distance between a
+// gather and its first use.
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA>
 struct MainCtx {
+  static_assert(LA == 1 || (LA == 2 && N <= 2), "two rows of look-ahead only with a single pair of supports");
   static constexpr int NG = (N + 1)/2;
   const ReconMainArgs& a;
   int bi, s, h, w, r0, r1, jlast;
@@ -294,10 +299,10 @@ struct MainCtx {
   rsrc_t rs_pk, rs_depth, rs_err, rs_sel;
   float lsum;
   float Px[N][3], Pxx[N][3], Pxy[N][3];
-  MainPend<N> P;
+  MainPend<N> P[LA];
   f3 py;                   // target row in flight
   float Dcur, Dnext;       // depth of rows j and j+1
-  float vfn;               // (float)(j+1)
+  float vfn;               // (float)(j + LA): the row whose taps the next issue requests
   // DISP (K0 fused): the depth of a row is computed here from the network's low-resolution sigmoid
   // disparity — bilinear up-sampling (`ops.interpolate_like`, src/tools/ops.py:311-314) + `to_scaled` / `to_inv`
   // (src/tools/geometry.py:62-90) — and written out once for the backward, instead of being read from a K0 launch's output.
@@ -357,7 +362,9 @@ struct MainCtx {
   }
 
   // ---- coordinates + the four tap loads of one pair of supports -----------------------------------------
+  template <int PS>
   __device__ __forceinline__ void issue(int g, float D, float vf) {
+    MainPend<N>& P = this->P[PS];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int k = 2*g + kk;
@@ -386,27 +393,30 @@ struct MainCtx {
   // unconditionally — also after the last row of the strip, where nothing consumes them: the tap coordinates are clamped, a
   // depth row below the image reads 0 (buffer bounds), and a conditional issue would make every pending register a loop phi
   // with a second copy (36 more VGPRs).
+  template <int PS>
   __device__ __forceinline__ void issue_next_row(int j) {
 #if (SMD_ABLATE & 2)
-    issue(0, Dnext, vfn);
+    issue<PS>(0, Dnext, vfn);
     py = f3{vfn*0.001f, 0.5f, vfn*0.002f};
     Dcur = Dnext;
     Dnext = 1.f + vfn*0.01f;
 #else
-    const float Dn = DISP ? finish_depth(j + 1) : Dnext;
-    issue(0, Dn, vfn);
+    const float Dn = DISP ? finish_depth(j + LA) : Dnext;
+    issue<PS>(0, Dn, vfn);
 #if (SMD_ABLATE & 16)
     py = f3{vfn*0.001f, 0.5f, vfn*0.002f};
 #else
     py = bld3(rs_pk, lane4*3u, so_y + (unsigned)(j + 1)*w4*3u);
 #endif
     Dcur = Dn;
-    if (DISP) load_dtaps<false>(j + 2); else Dnext = bld(rs_depth, lane4, (unsigned)(j + 2)*w4);
+    if (DISP) load_dtaps<false>(j + LA + 1); else Dnext = bld(rs_depth, lane4, (unsigned)(j + LA + 1)*w4);
 #endif
     vfn += 1.f;
   }
 
+  template <int PS>
   __device__ __forceinline__ void finish(int g, float (&Xn)[N][3], int j) {
+    const MainPend<N>& P = this->P[PS];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int k = 2*g + kk;
@@ -432,7 +442,8 @@ struct MainCtx {
 
   // One row step: row j is the NEW row, centre row v = j-1.  EMIT = false only updates the sliding sums.
   // VIRT (j == h): the new row is the reflected row h-2: the target row is read again, the warped row is P - x(h-1).
-  template <bool EMIT, bool VIRT>
+  // PS: the pending set tied to Xn (LA = 2: 0 for XA, 1 for XB; LA = 1: always 0)
+  template <bool EMIT, bool VIRT, int PS>
   __device__ __forceinline__ void step(int j, float (&Xo)[N][3], float (&Xn)[N][3], float (&Yo)[3], float (&Yn)[3]) {
     const int v = j - 1;
     constexpr float c1 = 81.f*kC1;
@@ -456,7 +467,7 @@ struct MainCtx {
     int bsel = a.i0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (!VIRT) finish(g, Xn, j);
+      if (!VIRT) finish<PS>(g, Xn, j);
       else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) { const int k = 2*g + kk; if (k < N) {
@@ -466,8 +477,8 @@ struct MainCtx {
       __builtin_amdgcn_sched_barrier(0);
       // keep the memory pipe busy: next pair of this row, or the first pair of the next row
       if (!VIRT) {
-        if (g + 1 < NG) issue(g + 1, Dcur, vfn - 1.f);
-        else issue_next_row(j);
+        if (g + 1 < NG) issue<PS>(g + 1, Dcur, vfn - 1.f);
+        else issue_next_row<PS>(j);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -529,22 +540,43 @@ struct MainCtx {
     }
   }
 
+  template <int PS>
   __device__ __forceinline__ void init(float (&X)[N][3], float (&Y)[3], int j) {   // P = r(jstart) alone
     Y[0] = py.x; Y[1] = py.y; Y[2] = py.z;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      finish(g, X, j);
-      if (g + 1 < NG) issue(g + 1, Dcur, vfn - 1.f);
-      else issue_next_row(j);
+      finish<PS>(g, X, j);
+      if (g + 1 < NG) issue<PS>(g + 1, Dcur, vfn - 1.f);
+      else issue_next_row<PS>(j);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) { const int k = 2*g + kk; if (k < N) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { Px[k][c] = X[k][c]; Pxx[k][c] = X[k][c]*X[k][c]; Pxy[k][c] = X[k][c]*Y[c]; } } }
     }
   }
+  // Everything in flight before the first row is blended: the taps of row jstart into set PSF (the set of the buffer `init` fills),
+  // with LA = 2 also those of row jstart + 1 into the other set, the target row jstart, the depth pipeline LA rows ahead.
+  template <int PSF>
+  __device__ __forceinline__ void prologue(int jstart) {
+    vfn = (float)jstart;
+    if (DISP) { load_dtaps<true>(jstart); Dnext = finish_depth(jstart); }
+    else Dnext = bld(rs_depth, lane4, (unsigned)jstart*w4);
+    Dcur = Dnext;
+    issue<PSF>(0, Dnext, vfn);
+    py = bld3(rs_pk, lane4*3u, so_y + (unsigned)jstart*w4*3u);
+    vfn += 1.f;
+    if (LA == 2) {
+      float D1;
+      if (DISP) { load_dtaps<false>(jstart + 1); D1 = finish_depth(jstart + 1); }
+      else D1 = bld(rs_depth, lane4, (unsigned)(jstart + 1)*w4);
+      issue<(LA == 2) ? 1 - PSF : 0>(0, D1, vfn);
+      vfn += 1.f;
+    }
+    if (DISP) load_dtaps<false>(jstart + LA); else Dnext = bld(rs_depth, lane4, (unsigned)(jstart + LA)*w4);
+  }
 };
 
-template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP>
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA>
 __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // -> this lane's share of the loss sum (0 for a wave without a strip)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -558,7 +590,7 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
   if (tail) bi_ += a.b1;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
 
-  MainCtx<N, SSIM, SINGLE, AUX, DISP> cx{a};
+  MainCtx<N, SSIM, SINGLE, AUX, DISP, LA> cx{a};
   cx.bi = bi_; cx.s = s_; cx.h = a.h; cx.w = a.w;
   cx.r0 = syi*seg_rh; cx.r1 = min(cx.r0 + seg_rh, a.h);
   cx.jlast = min(cx.r1, a.h - 1);
@@ -598,9 +630,9 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
     src_index_f(uc, (float)ws/(float)a.w, ws, x0, x1, cx.dlx);
     cx.dx0 = (unsigned)x0*4u; cx.dx1 = (unsigned)x1*4u;
     cx.a_scale = a.a_scale; cx.a_off = a.a_off;
-    cx.rowtab = a.rowtab + (size_t)s_*(a.h + 2);
-    cx.tab_base = max(cx.r0 - 1, 0);                       // rows tab_base .. r1 + 2 are looked up: at most rh + 4 <= 64 entries
-    { const uint4 e = cx.rowtab[min(cx.tab_base + lane, a.h + 1)]; cx.tab_x = e.x; cx.tab_y = e.y; cx.tab_z = e.z; }
+    cx.rowtab = a.rowtab + (size_t)s_*(a.h + 4);
+    cx.tab_base = max(cx.r0 - 1, 0);                       // rows tab_base .. r1 + LA + 1 are looked up: at most rh + LA + 3 <= 64 entries
+    { const uint4 e = cx.rowtab[min(cx.tab_base + lane, a.h + 3)]; cx.tab_x = e.x; cx.tab_y = e.y; cx.tab_z = e.z; }
   }
   cx.nz_sb = (AUX && a.noise) ? a.noise + sb : nullptr;
   cx.has_err = a.err != nullptr;
@@ -608,31 +640,25 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
   cx.rs_sel = make_rsrc(a.sel + sb, hw);
   cx.lsum = 0.f;
 
-  // prologue: row jstart's loads, depth two rows ahead
+  // The pending set of a row is tied to the buffer the row is blended into: XA <-> set 0, XB <-> set (LA == 2 ? 1 : 0).
+  constexpr int SA = 0, SB = (LA == 2) ? 1 : 0;
   const int jstart = max(cx.r0 - 1, 0);
-  cx.vfn = (float)jstart;
-  if (DISP) { cx.template load_dtaps<true>(jstart); cx.Dnext = cx.finish_depth(jstart); }
-  else cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)jstart*cx.w4);
-  cx.Dcur = cx.Dnext;
-  cx.issue(0, cx.Dnext, cx.vfn);
-  cx.py = bld3(cx.rs_pk, cx.lane4*3u, cx.so_y + (unsigned)jstart*cx.w4*3u);
-  if (DISP) cx.template load_dtaps<false>(jstart + 1); else cx.Dnext = bld(cx.rs_depth, cx.lane4, (unsigned)(jstart + 1)*cx.w4);
-  cx.vfn += 1.f;
-
   float XA[N][3], XB[N][3], YA[3], YB[3];
   int j = jstart + 1;
   if (cx.r0 > 0) {
-    cx.init(XB, YB, jstart);
-    cx.template step<false, false>(j, XB, XA, YB, YA);
+    cx.template prologue<SB>(jstart);
+    cx.template init<SB>(XB, YB, jstart);
+    cx.template step<false, false, SA>(j, XB, XA, YB, YA);
     ++j;
   } else {
-    cx.init(XA, YA, jstart);
+    cx.template prologue<SA>(jstart);
+    cx.template init<SA>(XA, YA, jstart);
   }
   bool cur_is_a = true;
   for (; j <= cx.jlast; j += 2) {
-    cx.template step<true, false>(j, XA, XB, YA, YB);
+    cx.template step<true, false, SB>(j, XA, XB, YA, YB);
     if (j + 1 > cx.jlast) { cur_is_a = false; break; }
-    cx.template step<true, false>(j + 1, XB, XA, YB, YA);
+    cx.template step<true, false, SA>(j + 1, XB, XA, YB, YA);
   }
   if (cx.r1 == a.h) {   // the strip owns the last image row: one more step whose new row is the reflected row h-2
     if (!cur_is_a) {
@@ -643,7 +669,7 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
 #pragma unroll
         for (int c = 0; c < 3; ++c) XA[k][c] = XB[k][c];
     }
-    cx.template step<true, true>(a.h, XA, XB, YA, YB);
+    cx.template step<true, true, SB>(a.h, XA, XB, YA, YB);
   }
 
   return cx.lsum;
@@ -704,8 +730,8 @@ __device__ __forceinline__ void recon_main_reduce(const ReconMainArgs& a, MainTa
 #ifdef SMD_TRACE_WAVES   // diagnosis builds only (scripts/dev/wave_trace.py): when and where every wave of the last launch ran
 __device__ unsigned long long g_wave_trace[1 << 16][3];
 #endif
-template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP>
-__global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 4 : 3)) void k_recon_main(const ReconMainArgs a) {
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA = 1>
+__global__ __launch_bounds__(64*kWavesPerBlock, ((N <= 2 && LA == 1) ? 4 : 3)) void k_recon_main(const ReconMainArgs a) {
 #ifdef SMD_TRACE_WAVES
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -715,7 +741,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, (N <= 2 ? 4 : 3)) void k_recon_m
     if (threadIdx.x == 0) tail.arrived = 0u;
     __syncthreads();
   }
-  const float lane_sum = recon_main_body<N, SSIM, SINGLE, AUX, DISP>(a);
+  const float lane_sum = recon_main_body<N, SSIM, SINGLE, AUX, DISP, LA>(a);
 #ifdef SMD_TRACE_WAVES
   if ((threadIdx.x & 63) == 0) {
     const unsigned widx = blockIdx.x*kWavesPerBlock + (threadIdx.x >> 6);
@@ -742,7 +768,8 @@ hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
   // hot: every support in one launch, no extras; otherwise the general instantiation (carried min / sum, noise tensor, warp output)
 #define SMD_MAIN(N_) do { \
     if (ssim && single && !aux) { \
-      if (disp) hipLaunchKernelGGL((k_recon_main<N_, true, true, false, true>), grid, block, 0, st, a); \
+      if (disp && N_ <= 2 && a.lookahead == 2) hipLaunchKernelGGL((k_recon_main<(N_ <= 2 ? N_ : 2), true, true, false, true, 2>), grid, block, 0, st, a); \
+      else if (disp) hipLaunchKernelGGL((k_recon_main<N_, true, true, false, true>), grid, block, 0, st, a); \
       else hipLaunchKernelGGL((k_recon_main<N_, true, true, false, false>), grid, block, 0, st, a); \
     } else if (ssim) { \
       if (disp) hipLaunchKernelGGL((k_recon_main<N_, true, false, true, true>), grid, block, 0, st, a); \

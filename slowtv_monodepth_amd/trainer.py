@@ -36,6 +36,10 @@ class HipLossBackend:
         from . import handlers
         return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), K_inv=K_inv, want_warp=want_warp, prepared=prepared)
 
+    def inv_intrinsics(self, K):
+        from . import functional as F
+        return F.inv_intrinsics(K.float()) if K.is_cuda else None
+
     def prepare_frames(self, crit, imgs, supp_imgs, pyramid, stream):
         """The frame-only half of the reconstruction forward (texel repack, target window sums, identity error of the automask:
         everything `handlers.image_recon` needs that no network output enters), enqueued on `stream` so that it runs under the
@@ -164,6 +168,12 @@ class MonoDepthModule(nn.Module):
                     produced = self._forward_pose(net, x, idxs_all)
                     if self.prep_ahead == 'pose' and side is not None and getattr(self, '_y', None) is not None:
                         self._prepared = self._prepare_frames(self._y, stream=side)
+                        # the inverse of the dataset's intrinsics needs no network output either: same stream, same place (main waits
+                        # for this stream before the loss); with a learned K the pose network's own K_inv is used instead
+                        inv = getattr(self.backend, 'inv_intrinsics', None)
+                        if inv is not None and 'K' not in produced and 'K' in self._y:
+                            self._K_inv = inv(self._y['K'])
+                            if self._K_inv is not None: self._K_inv.record_stream(main)
                 if side is not None:
                     for v in produced.values(): v.record_stream(main)
                 fwd.update(produced)
@@ -207,8 +217,9 @@ class MonoDepthModule(nn.Module):
             with self.timer(f'Loss-{k}'):
                 if k == 'img_recon':
                     kw = {'prepared': self._prepared} if self._prepared is not None else {}
+                    K_inv = fwd.get('K_inv') if 'K' in fwd else getattr(self, '_K_inv', None)
                     l, ld = self.backend.image_recon(crit, self.synth, fwd['depth_up'], fwd.get('mask_up'), y['imgs'], y['supp_imgs'],
-                                                     fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux, K_inv=fwd.get('K_inv'), **kw)
+                                                     fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux, K_inv=K_inv, **kw)
                 elif k == 'disp_smooth':
                     l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'], want_aux=self.want_aux)
                 elif k == 'depth_regr':   # proxy-depth (Depth Hints) regression, src/core/trainer.py:425-433
@@ -246,7 +257,7 @@ class MonoDepthModule(nn.Module):
         x, y, m = batch
         self.synth = ViewSynth(x['imgs'].shape[-2:])
         self._prepared = self._prepare_frames(y) if self.prep_ahead == 'own' else None
-        self._y = y
+        self._y, self._K_inv = y, None
         with self.timer('Total'):
             with self.timer('Forward'): fwd = self.forward(x)
             with self.timer('Post-Process'): fwd = self.forward_postprocess(fwd, x, y)

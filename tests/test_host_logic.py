@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.smd_image_recon_workspace_bytes(12, 2, 4, 192, 640) > 2*12*4*12*4   # at least the pose partials
     assert _lib.lib.smd_image_recon_workspace_bytes(0, 2, 4, 192, 640) == 0
     # image part (texels + target pixels + two window-term planes) + the tail: K0 row table for SMD_MAX_SCALES pyramid levels + 1 + b arrival counters (padded to 16 B)
-    assert _lib.lib.smd_packed_supports_bytes(12, 2, 192, 640) == 2*12*193*641*12 + 12*192*640*(12 + 32) + 8*(192 + 2)*16 + 16*4
+    assert _lib.lib.smd_packed_supports_bytes(12, 2, 192, 640) == 2*12*193*641*12 + 12*192*640*(12 + 32) + 8*(192 + 4)*16 + 16*4
 
 
 def test_abi_rejects_bad_arguments_without_touching_the_gpu():
