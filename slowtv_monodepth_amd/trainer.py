@@ -9,6 +9,7 @@ events that are only read when someone asks for them.  The Lightning shell is re
 from __future__ import annotations
 
 import copy
+import os
 from contextlib import contextmanager, nullcontext
 
 import torch
@@ -128,7 +129,6 @@ class MonoDepthModule(nn.Module):
         self._side_streams = {}
         self._prep_streams = {}
         self._prepared = None
-        import os
         # frame-only half of the reconstruction loss ahead of the networks: 'own' = on its own side stream at the start of the step,
         # 'pose' = on the pose network's side stream behind that network, False = inline, inside the loss (after the networks)
         self.prep_ahead = tcfg.get('prep_ahead', os.environ.get('SMD_PREP_AHEAD', 'pose'))
