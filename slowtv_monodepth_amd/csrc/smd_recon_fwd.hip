@@ -293,7 +293,16 @@ struct MainCtx {
   unsigned hw4, w4, rowbytes;
   float xmax, ymax, wpf;
   Cam2 cam[N];
-  float hx0[N], hy0[N], hz0[N];
+  // per-lane column part of the homography rows.  Up to two supports: registers.  Three and four (168-VGPR budget, 3 waves per
+  // SIMD): parked in this lane's LDS column and read back every row step — the allocator otherwise spills nine loop-invariant
+  // values to scratch and reloads 5.5 of them per row step through the texture path (round 3; -DSMD_FWD_CAM_REGS restores it).
+#ifdef SMD_FWD_CAM_REGS
+  static constexpr bool kCamLds = false;
+#else
+  static constexpr bool kCamLds = N > 2;
+#endif
+  float hx0[kCamLds ? 1 : N], hy0[kCamLds ? 1 : N], hz0[kCamLds ? 1 : N];
+  const float* camcol;     // kCamLds: [support][3][64 lanes] of this wave, + lane
   unsigned so_tex[N], so_y, so_ta, so_tb;   // wave-uniform byte offsets into `packed`: texel image of support k, this sample's ypix / ta / tb
   const float* nz_sb;               // noise of this (scale, sample) (AUX)
   rsrc_t rs_pk, rs_depth, rs_err, rs_sel;
@@ -370,7 +379,10 @@ struct MainCtx {
       const int k = 2*g + kk;
       if (k < N) {
         const Cam2& cm = cam[k];
-        const float hx = fmaf(cm.H1, vf, hx0[k]), hy = fmaf(cm.H4, vf, hy0[k]), hz = fmaf(cm.H7, vf, hz0[k]);
+        const float bx = kCamLds ? camcol[(k*3 + 0)*64] : hx0[kCamLds ? 0 : k];
+        const float by = kCamLds ? camcol[(k*3 + 1)*64] : hy0[kCamLds ? 0 : k];
+        const float bz = kCamLds ? camcol[(k*3 + 2)*64] : hz0[kCamLds ? 0 : k];
+        const float hx = fmaf(cm.H1, vf, bx), hy = fmaf(cm.H4, vf, by), hz = fmaf(cm.H7, vf, bz);
         const float nx = fmaf(D, hx, cm.a0), ny = fmaf(D, hy, cm.a1), yz = fmaf(D, hz, cm.tz);
         const float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
         const float sx = fmaf(nx, rz, -0.5f), sy = fmaf(ny, rz, -0.5f);
@@ -590,7 +602,10 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
   if (tail) bi_ += a.b1;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
 
-  MainCtx<N, SSIM, SINGLE, AUX, DISP, LA> cx{a};
+  using Ctx = MainCtx<N, SSIM, SINGLE, AUX, DISP, LA>;
+  __shared__ float cam_lds[Ctx::kCamLds ? kWavesPerBlock*N*3*64 : 1];   // own-lane columns: written and read by the same lane, no synchronisation
+  Ctx cx{a};
+  cx.camcol = cam_lds + (Ctx::kCamLds ? wid*N*3*64 + lane : 0);
   cx.bi = bi_; cx.s = s_; cx.h = a.h; cx.w = a.w;
   cx.r0 = syi*seg_rh; cx.r1 = min(cx.r0 + seg_rh, a.h);
   cx.jlast = min(cx.r1, a.h - 1);
@@ -612,8 +627,10 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int i = a.i0 + k;
-    make_cam2(cx.cam[k], cx.hx0[k], cx.hy0[k], cx.hz0[k], a.T + ((size_t)i*a.b + bi_)*16, a.K + (size_t)bi_*16, a.Kinv + (size_t)bi_*16,
-              a.wscale, a.hscale, uf);
+    float bx, by, bz;
+    make_cam2(cx.cam[k], bx, by, bz, a.T + ((size_t)i*a.b + bi_)*16, a.K + (size_t)bi_*16, a.Kinv + (size_t)bi_*16, a.wscale, a.hscale, uf);
+    if (Ctx::kCamLds) { cam_lds[(wid*N + k)*3*64 + lane] = bx; cam_lds[((wid*N + k)*3 + 1)*64 + lane] = by; cam_lds[((wid*N + k)*3 + 2)*64 + lane] = bz; }
+    else { cx.hx0[Ctx::kCamLds ? 0 : k] = bx; cx.hy0[Ctx::kCamLds ? 0 : k] = by; cx.hz0[Ctx::kCamLds ? 0 : k] = bz; }
     cx.so_tex[k] = (unsigned)(i*a.b + bi_)*texel_bytes;
   }
   const size_t sb = ((size_t)s_*a.b + bi_)*hw;
