@@ -251,6 +251,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_FWD_TAPER_B", "SMD_FWD_TAPER_RH");
   if (a.rh2 > 58) { a.rh2 = 58; a.nsy2 = smd::ceil_div(h, a.rh2); }   // as plan(): one row-table entry per lane
   a.lookahead = env_int("SMD_FWD_AHEAD", 1) == 2 ? 2 : 1;
+  a.share = (env_int("SMD_FWD_SHARE", 1) != 0 && a.S == 4 && a.rh % 4 == 0 && (a.b1 >= a.b || a.rh2 % 4 == 0)) ? 1 : 0;
   for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
     a.i0 = i0; a.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
     a.first_pass = (i0 == 0); a.last_pass = (i0 + a.ni >= n);

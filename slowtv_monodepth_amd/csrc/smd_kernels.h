@@ -105,6 +105,7 @@ struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over suppo
   uint32_t seed_lo, seed_hi;
   int first_pass, last_pass;
   int lookahead;           // 1 or 2 row steps between a tap gather and its first use (2: the hot K0-fused instantiation with N <= 2 only)
+  int share;               // 1: a block is the FOUR scales of one strip and the target-side rows reach them through one LDS ring (S == 4, strip heights multiples of 4)
 };
 
 struct ReconBwdArgs {

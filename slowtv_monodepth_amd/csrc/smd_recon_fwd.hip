@@ -282,12 +282,59 @@ struct MainPend {          // gathers in flight for one pair of supports
 // taps of row j+2 — two sets of pending registers, each tied to the row buffer (XA / XB) its row will be blended into, so the
 // unrolled loop still never moves a register; 28 more VGPRs (3 waves per SIMD instead of 4) for twice the distance between a
 // gather and its first use.
-template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA>
+// SH (round 3): the block's four waves are the FOUR SCALES of one strip.  What a row step reads on the target side — the target
+// pixel of the new row, {S_y, c} and the identity error of the centre row: 40 bytes per pixel, the same for every scale — is
+// fetched ONCE per block into an LDS ring by LDS-DMA (`buffer_load_dwordx3/x4 ... lds`: no registers, lane l lands at
+// base + 16 l) instead of by every wave through the texture path: wave q brings in rows 4e + q of the next group of four rows
+// ("epoch") while the block works on the current one, and the four waves meet at one s_barrier per epoch.  3 of 16 vector-memory
+// instructions per row step become 0.75, and the L2 sees the target side once instead of four times.
+//   ring: 8 slots (two epochs) x {ypix, ta, tb} x 64 lanes x 16 bytes; slot i & 7 holds {ypix[i], ta[i-1], tb[i-1]}: what step i reads.
+constexpr int kRingSlotFloats = 3*64*4;
+constexpr int kRingFloats = 8*kRingSlotFloats;
+
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA, bool SH = false>
 struct MainCtx {
   static_assert(LA == 1 || (LA == 2 && N <= 2), "two rows of look-ahead only with a single pair of supports");
+  static_assert(!SH || (SSIM && SINGLE && !AUX && DISP && LA == 1), "the shared target ring exists for the hot instantiation only");
   static constexpr int NG = (N + 1)/2;
   const ReconMainArgs& a;
   int bi, s, h, w, r0, r1, jlast;
+  // SH state: LDS byte address of the ring (scalar), this lane's float pointer into it, this wave's index in the block
+  unsigned ring_lds;
+  const float* ring_lane;
+  int ring_q, ring_last;   // rows beyond ring_last are never read by this strip
+
+  // One LDS-DMA piece: 64 lanes x `16 or 12` bytes from packed[voff + soff] to LDS[dst + 16*lane].  M0 carries the LDS address and is
+  // compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md, LDS-DMA recipe).  hipcc does not count
+  // this load in its s_waitcnt bookkeeping: epoch_sync() waits for it explicitly.
+  __device__ __forceinline__ void dma16(unsigned voff, unsigned soff, unsigned dst) const {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs_pk), "s"(soff), "s"(dst) : "memory");
+  }
+  __device__ __forceinline__ void dma12(unsigned voff, unsigned soff, unsigned dst) const {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx3 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs_pk), "s"(soff), "s"(dst) : "memory");
+  }
+  // This wave's row of epoch `e` (rows 4e .. 4e+3): slot i <- {ypix[i], ta[i-1], tb[i-1]}, rows clamped into the image.
+  __device__ __forceinline__ void dma_epoch(int e) const {
+    const int i = __builtin_amdgcn_readfirstlane(4*e + ring_q);
+    if (i > ring_last) return;
+    const unsigned ry = (unsigned)min(i, h - 1), rt = (unsigned)min(max(i - 1, 0), h - 1);
+    const unsigned dst = ring_lds + (unsigned)(i & 7)*(unsigned)(kRingSlotFloats*4);
+    dma12(lane4*3u, so_y + ry*w4*3u, dst);
+    dma16(lane4*4u, so_ta + rt*w4*4u, dst + 1024u);
+    dma16(lane4*4u, so_tb + rt*w4*4u, dst + 2048u);
+  }
+  // Start of an epoch: the rows the block brought in during the previous one are complete and visible to all four waves
+  // (placed where the wave has just consumed its tap gathers: every load older than them — the DMA pieces — has landed).
+  __device__ __forceinline__ void epoch_sync() const {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
   unsigned lane4;          // byte offset of this lane's (reflected) column inside a row of floats
   bool interior, use_min, automask, has_noise, want_w0, has_err;
   unsigned hw4, w4, rowbytes;
@@ -418,7 +465,7 @@ struct MainCtx {
 #if (SMD_ABLATE & 16)
     py = f3{vfn*0.001f, 0.5f, vfn*0.002f};
 #else
-    py = bld3(rs_pk, lane4*3u, so_y + (unsigned)(j + 1)*w4*3u);
+    if (!SH) py = bld3(rs_pk, lane4*3u, so_y + (unsigned)(j + 1)*w4*3u);
 #endif
     Dcur = Dn;
     if (DISP) load_dtaps<false>(j + LA + 1); else Dnext = bld(rs_depth, lane4, (unsigned)(j + LA + 1)*w4);
@@ -462,7 +509,7 @@ struct MainCtx {
     f4 t0 = {0.f, 0.f, 0.f, 0.f};
     f3 t1 = {0.f, 0.f, 0.f};
     float nz = 0.f;
-    if (EMIT) {   // what the centre row shares across scales and supports: {S_y[3], cy2[3], identity error, -}
+    if (EMIT && !SH) {   // what the centre row shares across scales and supports: {S_y[3], cy2[3], identity error, -}
       const unsigned to = (unsigned)v*w4*4u;
 #if (SMD_ABLATE & (2 | 8))
       t0 = f4{4.5f + vfn*0.01f, 4.4f, 4.3f, 0.2f}; t1 = f3{0.25f, 0.3f, 0.05f}; (void)to;
@@ -472,8 +519,8 @@ struct MainCtx {
 #endif
       if (AUX && has_noise) nz = nz_sb[(size_t)v*w + (lane4 >> 2)];
     }
-    if (!VIRT) { Yn[0] = py.x; Yn[1] = py.y; Yn[2] = py.z; }
-    else { const f3 yy = bld3(rs_pk, lane4*3u, so_y + (unsigned)(h - 2)*w4*3u); Yn[0] = yy.x; Yn[1] = yy.y; Yn[2] = yy.z; }
+    if (!SH && !VIRT) { Yn[0] = py.x; Yn[1] = py.y; Yn[2] = py.z; }
+    if (VIRT) { const f3 yy = bld3(rs_pk, lane4*3u, so_y + (unsigned)(h - 2)*w4*3u); Yn[0] = yy.x; Yn[1] = yy.y; Yn[2] = yy.z; }
     const float m = (v == 0) ? 2.f : 1.f;                 // row -1 is row 1: the new row counts twice for the first image row
     float best = 0.f, acc = 0.f;
     int bsel = a.i0;
@@ -485,6 +532,18 @@ struct MainCtx {
         for (int kk = 0; kk < 2; ++kk) { const int k = 2*g + kk; if (k < N) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) Xn[k][c] = Px[k][c] - Xo[k][c]; } }
+      }
+      if (SH && g == 0) {
+        // the taps of this row have just been waited for.  First step of an epoch: meet the other scales, then send for this
+        // wave's row of the next epoch; every step: this row's slot of the ring.
+        if ((j & 3) == 0) { epoch_sync(); dma_epoch((j >> 2) + 1); }
+        const float* slot = ring_lane + (j & 7)*kRingSlotFloats;
+        if (!VIRT) { const f4 yv = *reinterpret_cast<const f4*>(slot); Yn[0] = yv.x; Yn[1] = yv.y; Yn[2] = yv.z; }
+        if (EMIT) {
+          t0 = *reinterpret_cast<const f4*>(slot + 256);
+          const f4 tv = *reinterpret_cast<const f4*>(slot + 512);
+          t1 = f3{tv.x, tv.y, tv.z};
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // keep the memory pipe busy: next pair of this row, or the first pair of the next row
@@ -570,6 +629,10 @@ struct MainCtx {
   // with LA = 2 also those of row jstart + 1 into the other set, the target row jstart, the depth pipeline LA rows ahead.
   template <int PSF>
   __device__ __forceinline__ void prologue(int jstart) {
+    if (SH) {   // the epoch of the first row step (r0 = 0: the loop starts at row 1 and only meets an epoch boundary at row 4 — both epochs)
+      dma_epoch(r0 >> 2);
+      if (r0 == 0) dma_epoch(1);
+    }
     vfn = (float)jstart;
     if (DISP) { load_dtaps<true>(jstart); Dnext = finish_depth(jstart); }
     else Dnext = bld(rs_depth, lane4, (unsigned)jstart*w4);
@@ -585,10 +648,11 @@ struct MainCtx {
       vfn += 1.f;
     }
     if (DISP) load_dtaps<false>(jstart + LA); else Dnext = bld(rs_depth, lane4, (unsigned)(jstart + LA)*w4);
+    if (SH) epoch_sync();   // (waits for what `init` needs next anyway)
   }
 };
 
-template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA>
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA, bool SH>
 __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // -> this lane's share of the loss sum (0 for a wave without a strip)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -597,12 +661,17 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
   const unsigned nblk1 = recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S);
   const bool tail = blockIdx.x >= nblk1;
   const int nstr = a.nsx*(tail ? a.nsy2 : a.nsy), seg_b = tail ? a.b - a.b1 : a.b1, seg_rh = tail ? a.rh2 : a.rh;
-  decode_wave(tail ? blockIdx.x - nblk1 : blockIdx.x, wid, nstr, seg_b, a.S, strip, bi_, s_);
-  if (strip >= nstr) return 0.f;
+  if (SH) {   // block = the four scales of one strip; the XCD-aware decode places four adjacent strips on consecutive blocks of an XCD
+    int xb, sub;
+    decode_tile(tail ? blockIdx.x - nblk1 : blockIdx.x, ceil_div(nstr, kWavesPerBlock), seg_b, kWavesPerBlock, xb, bi_, sub);
+    strip = xb*kWavesPerBlock + sub; s_ = wid;
+  } else decode_wave(tail ? blockIdx.x - nblk1 : blockIdx.x, wid, nstr, seg_b, a.S, strip, bi_, s_);
+  if (strip >= nstr) return 0.f;   // (SH: the whole block)
   if (tail) bi_ += a.b1;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
 
-  using Ctx = MainCtx<N, SSIM, SINGLE, AUX, DISP, LA>;
+  using Ctx = MainCtx<N, SSIM, SINGLE, AUX, DISP, LA, SH>;
+  __shared__ __attribute__((aligned(16))) float ring_mem[SH ? kRingFloats : 4];
   __shared__ float cam_lds[Ctx::kCamLds ? kWavesPerBlock*N*3*64 : 1];   // own-lane columns: written and read by the same lane, no synchronisation
   Ctx cx{a};
   cx.camcol = cam_lds + (Ctx::kCamLds ? wid*N*3*64 + lane : 0);
@@ -656,6 +725,12 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
   cx.rs_err = make_rsrc(cx.has_err ? a.err + sb : nullptr, cx.has_err ? hw*4 : 0);
   cx.rs_sel = make_rsrc(a.sel + sb, hw);
   cx.lsum = 0.f;
+  if (SH) {
+    cx.ring_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)ring_mem);
+    cx.ring_lane = ring_mem + lane*4;
+    cx.ring_q = wid;
+    cx.ring_last = (cx.r1 == a.h) ? a.h : cx.jlast;
+  }
 
   // The pending set of a row is tied to the buffer the row is blended into: XA <-> set 0, XB <-> set (LA == 2 ? 1 : 0).
   constexpr int SA = 0, SB = (LA == 2) ? 1 : 0;
@@ -747,7 +822,7 @@ __device__ __forceinline__ void recon_main_reduce(const ReconMainArgs& a, MainTa
 #ifdef SMD_TRACE_WAVES   // diagnosis builds only (scripts/dev/wave_trace.py): when and where every wave of the last launch ran
 __device__ unsigned long long g_wave_trace[1 << 16][3];
 #endif
-template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA = 1>
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA = 1, bool SH = false>
 __global__ __launch_bounds__(64*kWavesPerBlock, ((N <= 2 && LA == 1) ? 4 : 3)) void k_recon_main(const ReconMainArgs a) {
 #ifdef SMD_TRACE_WAVES
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -758,7 +833,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, ((N <= 2 && LA == 1) ? 4 : 3)) v
     if (threadIdx.x == 0) tail.arrived = 0u;
     __syncthreads();
   }
-  const float lane_sum = recon_main_body<N, SSIM, SINGLE, AUX, DISP, LA>(a);
+  const float lane_sum = recon_main_body<N, SSIM, SINGLE, AUX, DISP, LA, SH>(a);
 #ifdef SMD_TRACE_WAVES
   if ((threadIdx.x & 63) == 0) {
     const unsigned widx = blockIdx.x*kWavesPerBlock + (threadIdx.x >> 6);
@@ -786,6 +861,7 @@ hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
 #define SMD_MAIN(N_) do { \
     if (ssim && single && !aux) { \
       if (disp && N_ <= 2 && a.lookahead == 2) hipLaunchKernelGGL((k_recon_main<(N_ <= 2 ? N_ : 2), true, true, false, true, 2>), grid, block, 0, st, a); \
+      else if (disp && a.share) hipLaunchKernelGGL((k_recon_main<N_, true, true, false, true, 1, true>), grid, block, 0, st, a); \
       else if (disp) hipLaunchKernelGGL((k_recon_main<N_, true, true, false, true>), grid, block, 0, st, a); \
       else hipLaunchKernelGGL((k_recon_main<N_, true, true, false, false>), grid, block, 0, st, a); \
     } else if (ssim) { \
