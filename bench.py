@@ -238,7 +238,7 @@ def main():
                        'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6),
                        'rccl_ranks': rccl_ranks, 'dp_impl': (os.environ.get('SMD_DP_IMPL', 'flat') if rccl_ranks > 1 or os.environ.get('SMD_FORCE_DDP') == '1' else None),
                        'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3)},
-            'roofline': {'kernel': f'smd::k_recon_main<{n}, true, true, false, true> (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; name as rocprofv3 prints it)', 'bound': 'hbm',
+            'roofline': {'kernel': f'smd::k_recon_main<{n}, true, true, false, true, 1, true> (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch, the four scales of a strip per block; name as rocprofv3 prints it)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,
                          'whole_forward_ms': round(fa_ms, 5), 'whole_forward_launches': 'the forward entry point on the critical path: k_recon_main (all 4 scales; the loss is reduced inside it by the last block)',

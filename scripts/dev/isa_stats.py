@@ -67,13 +67,16 @@ def regs(lines, key):
 if __name__ == '__main__':
     f, bw = isa('smd_recon_fwd.hip'), isa('smd_recon_bwd.hip')
     print('Instruction statistics of the fused kernels\' row loops (hipcc ROCm 7.2, gfx950), produced by scripts/dev/isa_stats.py\n')
-    for key, what in (('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb1EEE', 'k_recon_main<2, true, true, false, true>  (two supports, K0 fused: the bench\'s forward kernel)'),
-                      ('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb0EEE', 'k_recon_main<2, true, true, false, false> (two supports, depth read from a K0 launch)'),
-                      ('_ZN3smd12k_recon_mainILi4ELb1ELb1ELb0ELb1EEE', 'k_recon_main<4, true, true, false, true>  (four supports, cfg 5)')):
+    for key, what in (('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb1ELi1ELb1EEE', 'k_recon_main<2, true, true, false, true, 1, true>  (two supports, K0 fused, shared target ring: the bench\'s forward kernel; the static count includes the once-per-four-rows epoch block)'),
+                      ('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb1ELi1ELb0EEE', 'k_recon_main<2, true, true, false, true, 1, false> (the same without the shared ring: SMD_FWD_SHARE=0, or a pyramid that is not four scales)'),
+                      ('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb0ELi1ELb0EEE', 'k_recon_main<2, true, true, false, false, 1, false> (two supports, depth read from a K0 launch)'),
+                      ('_ZN3smd12k_recon_mainILi4ELb1ELb1ELb0ELb1ELi1ELb1EEE', 'k_recon_main<4, true, true, false, true, 1, true>  (four supports, cfg 5)')):
         loop_stats(f, key, 2, what); print('  ' + regs(f, key) + '\n')
     for key, what in (('_ZN3smd11k_recon_bwdILb1ELi0ELi2ELb1EEE', 'k_recon_bwd<true, 0, 2, true> (per support pass; every row does the full adjoint)'),
                       ('_ZN3smd11k_recon_bwdILb1ELi2ELi2ELb1EEE', 'k_recon_bwd<true, 2, 2, true> (per support pass; dead-row skipping; the static count includes the rarely taken clear paths)')):
         loop_stats(bw, key, 3, what, nested=True); print('  ' + regs(bw, key) + '\n')
     print('History (same method): round 1 forward 425 per row for two supports; backward 421 per support row step at the start of round 2 (73 of them v_mov),\n'
-          '328 after the (row mod 3) slot rewrite, 300 / 313 at the end of round 2; round 3 left the row loops as they were (301 / 313: the launch structure changed).\n'
+          '328 after the (row mod 3) slot rewrite, 300 / 313 at the end of round 2; round 3 left the backward\'s row loop as it was (301 / 313: the launch structure changed).\n'
+          'Forward with the shared target ring: of the 16 vector-memory instructions counted per row step, 3 are the LDS-DMA pieces of the epoch block, which runs once\n'
+          'every four row steps: a row step executes 13 + 0.75 (without the ring: 16).\n'
           'The SKIP=2 build keeps its rarely taken clear paths inside the loop body: its static count is an upper bound of what a live row executes.')

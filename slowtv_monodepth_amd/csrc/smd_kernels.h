@@ -156,8 +156,10 @@ __device__ __forceinline__ void decode_tile(unsigned p, int nbx, int b, int S, i
   bi = (int)(q/(unsigned)nbx); xb = (int)(q - (unsigned)bi*(unsigned)nbx);
 }
 
-// (Tried and dropped: one block = the four scales of ONE strip, so that they also share the CU's vector L1.  L2 requests fell
-// by 20 %, but neighbouring strips then land on different XCDs and HBM reads went back up from 143 to 196 MB; no gain in time.)
+// (Round 2 tried one block = the four scales of ONE strip with strips scattered over the XCDs: L2 requests fell by 20 %, but
+// neighbouring strips then land on different XCDs and HBM reads went back up from 143 to 196 MB; no gain in time.  Round 3's
+// shared-ring forward (smd_recon_fwd.hip, SH) uses that block shape with THIS decode, reading `s` as the strip within a tile of
+// four adjacent strips: the tile stays on one XCD.)
 __host__ __device__ inline unsigned recon_grid_blocks(int nstrips, int b, int S, int spb = kWavesPerBlock) {
   return (unsigned)ceil_div(nstrips, spb)*(unsigned)b*(unsigned)S;
 }
