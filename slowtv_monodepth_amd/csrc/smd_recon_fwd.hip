@@ -387,7 +387,9 @@ struct MainCtx {
   unsigned cur_o0, cur_o1;   // byte offsets of the rows h0 / h1 will belong to once the pending update is applied
   bool pend;                 // finish_depth must first shift h1 -> h0 and blend the taps in flight into h1
 
-  __device__ __forceinline__ float hblend(float a, float b) const { return (1.f - dlx)*a + dlx*b; }
+  // (explicit fma: with -ffp-contract=fast the compiler otherwise picks, per inlined copy — prologue, first row, row loop — which
+  // of the two products it fuses, and the same row then differs by an ulp depending on where in a strip it falls)
+  __device__ __forceinline__ float hblend(float a, float b) const { return fmaf(dlx, b, (1.f - dlx)*a); }
   // FIRST: the first row of the strip — both rows, not pipelined.  Afterwards the pair either stays or advances by one row (the
   // launcher uses this instantiation only for pyramid levels that are not taller than the image).
   template <bool FIRST>
@@ -410,7 +412,7 @@ struct MainCtx {
     { const float hn = hblend(p2, p3); h0 = pend ? h1 : h0; h1 = pend ? hn : h1; }
     unsigned o0_, o1_; float ly;
     tab_entry(row, o0_, o1_, ly);
-    const float val = (1.f - ly)*h0 + ly*h1;
+    const float val = fmaf(ly, h1, (1.f - ly)*h0);
     const float d = fmaf(a_scale, val, a_off);
     const float dep = (d > 0.f) ? __builtin_amdgcn_rcpf(fmaxf(d, kEps32)) : 0.f;
     if (row >= r0 && row < r1 && interior) bst(rs_dout, lane4, (unsigned)row*w4, dep);   // each row is interior to one strip

@@ -1148,6 +1148,35 @@ def test_k0_fused_path_at_non_integer_ratios_and_with_a_second_consumer_of_depth
     for x, y in zip(ga + [ta], gb + [tb]): assert rel_to_max(x, y) < (1e-3 if flips == 0 else 5e-2)
 
 
+@pytest.mark.parametrize('b,h,w,n,lows,rh,b2', [(2, 33, 47, 2, [(33, 47), (16, 23), (8, 11), (4, 5)], 8, 0), (3, 50, 130, 1, [(50, 130), (25, 65), (12, 32), (6, 16)], 16, 1),
+                                                 (5, 96, 200, 4, [(96, 200), (48, 100), (24, 50), (12, 25)], 16, 2), (2, 7, 66, 3, [(7, 66), (3, 33), (2, 16), (1, 8)], 4, 0),
+                                                 (12, 192, 640, 2, [(192, 640), (96, 320), (48, 160), (24, 80)], 0, -1)])
+def test_shared_target_ring_equals_per_wave_loads(F, monkeypatch, b, h, w, n, lows, rh, b2):
+    """Round 3: with four scales the hot forward instantiation runs the four scales of a strip in one block and brings the target-side
+    rows in once per block through an LDS ring (LDS-DMA + one barrier per four rows).  Only the way those rows reach the wave
+    changes: error map, selection and adopted depth must be bit-identical to the per-wave loads (`SMD_FWD_SHARE=0`), at image
+    heights that are not multiples of four, strips shorter than an epoch, a tapered partition and the BASELINE size; the loss up to
+    the order of the block partials."""
+    gen = torch.Generator(device='cuda').manual_seed(h*w + n)
+    imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen); supp = torch.rand(n, b, 3, h, w, device='cuda', generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    T = torch.eye(4, device='cuda').repeat(n, b, 1, 1); T[..., :3, 3] = 0.05*torch.randn(n, b, 3, device='cuda', generator=gen)
+    d = [0.05 + 0.9*torch.rand(b, 1, hs, ws, device='cuda', generator=gen) for hs, ws in lows]
+    flags = F.recon_flags('ssim', True, True)
+    if rh:
+        monkeypatch.setenv('SMD_FWD_RH', str(rh)); monkeypatch.setenv('SMD_FWD_TAPER_B', str(b2)); monkeypatch.setenv('SMD_FWD_TAPER_RH', str(max(rh//2, 4)))
+
+    def run(share):
+        monkeypatch.setenv('SMD_FWD_SHARE', str(share))
+        loss, err, sel, _, dep = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=flags, min_depth=0.1, max_depth=100, seed=7, want_err=True)
+        return loss, err, sel, dep
+    l1, e1, s1, d1 = run(1)
+    l0, e0, s0, d0 = run(0)
+    assert torch.equal(d1, d0) and torch.equal(e1, e0) and torch.equal(s1, s0)
+    torch.testing.assert_close(l1, l0, rtol=1e-6, atol=0)
+    assert torch.isfinite(l1) and (s1 != 255).any() and (s1 == 255).any()   # both the warped supports and the automask win somewhere
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 1, 1), (2, 5, 6, 20), (1, 4, 33, 65), (3, 8, 48, 160), (2, 6, 40, 70)])
 def test_depthwise_conv7x7_kernel(F, shape):
     import torch.nn.functional as TF
