@@ -40,7 +40,9 @@ int env_int(const char* name, int dflt) {
 // Tuning knobs (environment, read per call; unset = built-in heuristics): SMD_BWD_SKIP (0..2, dead-row skipping of the fused
 // backward, default 2), SMD_FWD_RH / SMD_BWD_RH rows per strip (>= 4), SMD_FWD_TAPER_B / SMD_BWD_TAPER_B samples at the end of the
 // dispatch order that get short strips (0: none) and SMD_FWD_TAPER_RH / SMD_BWD_TAPER_RH their height, SMD_FWD_NI supports per
-// forward launch (1..4).
+// forward launch (1..4), SMD_FWD_SHARE (default 1: with four scales a block of the hot forward is the four scales of one strip
+// and the target-side rows reach it through an LDS ring; needs strip heights that are multiples of four), SMD_FWD_AHEAD (2: tap
+// gathers two rows ahead, measured slower), SMD_BWD_WPS (waves per strip of the backward), SMD_BWD_GUEST_FINALIZE.
 StripPlan plan(int b, int S, int h, int w, int cols) {
   StripPlan p;
   p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
