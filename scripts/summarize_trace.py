@@ -28,6 +28,16 @@ for r in rows:
                            'grid': (r.get('Grid_Size_X', ''), r.get('Grid_Size_Y', ''), r.get('Grid_Size_Z', '')), 'wg': r.get('Workgroup_Size_X', '')})
     a['n'] += 1; a['t'] += d; a['min'] = min(a['min'], d); a['max'] = max(a['max'], d)
 tot = sum(a['t'] for a in agg.values())
+# how much of the wall time at least one kernel was running (union of the dispatch intervals over all streams)
+iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows)
+busy, cur_s, cur_e = 0, None, None
+for s_, e_ in iv:
+    if cur_e is None or s_ > cur_e:
+        if cur_e is not None: busy += cur_e - cur_s
+        cur_s, cur_e = s_, e_
+    else: cur_e = max(cur_e, e_)
+if cur_e is not None: busy += cur_e - cur_s
+if iv: print(f'GPU busy (union of kernel intervals): {busy/1e6:.3f} ms of {(max(e for _, e in iv) - iv[0][0])/1e6:.3f} ms spanned' + (f'  ({busy/1e6/steps:.3f} ms per step)' if steps else ''))
 print(f'total kernel time {tot/1e3:.3f} ms over {len(rows)} dispatches' + (f'  ({tot/1e3/steps:.3f} ms, {len(rows)//steps} dispatches per step)' if steps else ''))
 smd = sum(a['t'] for k, a in agg.items() if 'smd::' in k)
 print(f'smd:: kernels (this library): {smd/1e3:.3f} ms = {100*smd/max(tot, 1e-9):.2f} % of kernel time' + (f'  ({smd/steps:.1f} us per step)' if steps else ''))
