@@ -18,7 +18,7 @@ _HERE = Path(__file__).resolve().parent
 lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
 
 FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10, 'loss_l2': 0x20, 'packed_ready': 0x40,
-         'mask_explainability': 0x80, 'mask_uncertainty': 0x100, 'use_laplacian': 0x200}
+         'mask_explainability': 0x80, 'mask_uncertainty': 0x100, 'use_laplacian': 0x200, 'bwd_skip_rows': 0x400}
 REGR_FLAGS = {'l1': 0x0, 'log_l1': 0x1, 'berhu': 0x2, 'invert': 0x4}
 SEL_MASKED = 255
 MAX_SCALES = 8

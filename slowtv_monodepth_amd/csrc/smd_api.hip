@@ -37,8 +37,8 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// Tuning knobs (environment, read per call; unset = built-in heuristics): SMD_BWD_SKIP (0..2, dead-row skipping of the fused
-// backward, default 2), SMD_FWD_RH / SMD_BWD_RH rows per strip (>= 4), SMD_FWD_TAPER_B / SMD_BWD_TAPER_B samples at the end of the
+// Tuning knobs (environment, read per call; unset = built-in heuristics): SMD_BWD_SKIP (0 / 2: dead-row skipping of the fused
+// backward off / on, overriding the SMD_BWD_SKIP_DEAD_ROWS flag of the call), SMD_FWD_RH / SMD_BWD_RH rows per strip (>= 4), SMD_FWD_TAPER_B / SMD_BWD_TAPER_B samples at the end of the
 // dispatch order that get short strips (0: none) and SMD_FWD_TAPER_RH / SMD_BWD_TAPER_RH their height, SMD_FWD_NI supports per
 // forward launch (1..4), SMD_FWD_SHARE (default 1: with four scales a block of the hot forward is the four scales of one strip
 // and the target-side rows reach it through an LDS ring; needs strip heights that are multiples of four), SMD_FWD_AHEAD (2: tap
@@ -329,7 +329,7 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_BWD_TAPER_B", "SMD_BWD_TAPER_RH");
   if (n >= 2 && a.rh2 > kBwdAccRows) { a.rh2 = kBwdAccRows; a.nsy2 = smd::ceil_div(h, a.rh2); }
   a.pose_stride = S*pl.nsx*(a.nsy2 > pl.nsy ? a.nsy2 : pl.nsy);
-  a.skip_level = env_int("SMD_BWD_SKIP", 2);
+  a.skip_level = env_int("SMD_BWD_SKIP", (flags & SMD_BWD_SKIP_DEAD_ROWS) ? 2 : 0);
   // Waves per strip.  min(n, 4) (default): one support per wave — half as long work units (a launch is only ~2 generations of waves,
   // so its tail is a fraction of a unit) and the waves of a strip share the target-side rows through one L1; 1: a wave takes every
   // support of its strip in turn.  cfg 2, rocprofv3: 113 vs 115 us on coherent masks, 187 vs 212 us on incoherent inputs, 140 vs

@@ -7,12 +7,13 @@ CPU tensors are rejected.
 """
 from __future__ import annotations
 
+import os
 import threading
 
 import torch
 
 from . import _lib
-from ._lib import FLAGS, REGR_FLAGS, int_array, ptr_array
+from ._lib import FLAGS, REGR_FLAGS, SEL_MASKED, int_array, ptr_array
 from ._lib import call as _raw_call
 
 __all__ = ['crop_resize', 'disp_to_depth', 'image_recon_prep', 'PreparedFrames', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
@@ -170,6 +171,55 @@ def _need_err(want_err: bool, n: int) -> bool:
     return bool(want_err) or n > _lib.lib.smd_image_recon_supports_per_pass()
 
 
+def dead_tile_fraction(sel: torch.Tensor, use_min: bool, n: int = 1, cols: int = 60) -> torch.Tensor:
+    """Share of (image row, `cols`-column tile) units in which NO pixel routes gradient to a support — the rows the fused backward's
+    dead-row skipping (`k_recon_bwd<…, SKIP=2>`) passes over in that support's wave.  Per scale the support with the FEWEST such
+    units counts (the waves of a strip, one per support, leave together: the busiest sets the pace); the scales are averaged.
+    sel: (S,b,1,h,w)|(S,b,h,w) uint8."""
+    S = sel.shape[0]
+    s4 = sel.reshape(S, -1, sel.shape[-2], sel.shape[-1])
+    pad = (-s4.shape[-1]) % cols
+    def dead(live):                                  # -> (S,)
+        live = torch.nn.functional.pad(live, (0, pad))
+        return 1.0 - live.view(S, live.shape[1], live.shape[2], -1, cols).any(-1).float().mean(dim=(1, 2, 3))
+    if not use_min: return dead(s4 != SEL_MASKED).mean()   # the mean over the supports: every support is live wherever the automask is not
+    return torch.stack([dead(s4 == i) for i in range(max(int(n), 1))]).min(dim=0).values.mean()
+
+
+class _RowSkipTuner:
+    """Turns the dead-row skipping of the fused backward on when the data make it pay, without ever stalling the stream.
+
+    The backward gives the same gradients bit for bit with or without skipping; which is faster depends on the selection masks
+    (`profiles/r03_skip_regimes.txt`, cfg 2): the plain row loop takes 116-118 us whatever they look like; with skipping it is
+    92 us when every unit is skippable, breaks even near 60 % and costs 3-12 % on noise-like masks (a randomly initialised
+    network: 125 vs 118 us in the bench).  Every `period` forwards the share of skippable (row, strip) units is computed on the
+    device from the `sel` the forward just wrote and copied to pinned memory; a later call picks the value up once its event has
+    completed.  `SMD_BWD_SKIP` in the environment pins the choice."""
+    period, threshold = 64, 0.8
+
+    def __init__(self):
+        self.calls, self.skip, self.pending, self.last = 0, False, None, None
+
+    def flag(self) -> int:
+        return FLAGS['bwd_skip_rows'] if self.skip else 0
+
+    def observe(self, sel: torch.Tensor, flags: int, n: int = 1) -> None:
+        if 'SMD_BWD_SKIP' in os.environ or not sel.is_cuda: return
+        if self.pending is not None and self.pending[1].query():
+            self.last = float(self.pending[0]); self.skip = self.last >= self.threshold; self.pending = None
+        if self.calls % self.period == 0 and self.pending is None:
+            host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            host.copy_(dead_tile_fraction(sel, bool(flags & FLAGS['use_min']), n), non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(sel.device))
+            self.pending = (host, ev)
+        self.calls += 1
+
+
+_tuners: dict = {}
+def row_skip_tuner(device) -> _RowSkipTuner:
+    return _tuners.setdefault(torch.device(device).index, _RowSkipTuner())
+
+
 class _ImageRecon(torch.autograd.Function):
     """Fused `handlers.image_recon` (src/core/handlers.py:14-67)."""
 
@@ -194,6 +244,7 @@ class _ImageRecon(torch.autograd.Function):
         call('smd_image_recon_fwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), supp_pk.data_ptr(), err.data_ptr() if err is not None else None, sel.data_ptr(), loss.data_ptr(),
              warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, cflags, _stream())
+        if any(ctx.needs_input_grad): row_skip_tuner(dev).observe(sel, int(flags), n)
         ctx.save_for_backward(depth, tgt, supp_pk, T, K, K_inv, sel)
         ctx.meta = (b, n, S, h, w, int(flags))
         ctx.need_k = bool(ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
@@ -212,6 +263,7 @@ class _ImageRecon(torch.autograd.Function):
         g_K = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
         g_Ki = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
         if ctx.need_k: flags |= FLAGS['need_k_grad']
+        flags |= row_skip_tuner(dev).flag()
         nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         call('smd_image_recon_bwd', depth.data_ptr(), tgt.data_ptr(), supp_pk.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
@@ -265,6 +317,7 @@ class _ImageReconDisp(torch.autograd.Function):
              tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(), noise.data_ptr() if noise is not None else None,
              int(seed) & (2**64 - 1), packed.data_ptr(), depth_up.data_ptr(), err.data_ptr() if err is not None else None, sel.data_ptr(), loss.data_ptr(),
              warp0.data_ptr() if want_warp else None, wsp.data_ptr(), nbytes, b, n, h, w, cflags, _stream())
+        if any(ctx.needs_input_grad): row_skip_tuner(dev).observe(sel, int(flags), n)
         ctx.save_for_backward(depth_up, packed, T, K, K_inv, sel)
         # `depth_up` is a differentiable output that usually has no other consumer: without this autograd would hand the backward
         # a materialised zero tensor for it (one more (S,b,h,w) read, and no dead-row skipping on the last support pass)
@@ -287,6 +340,7 @@ class _ImageReconDisp(torch.autograd.Function):
         g_K = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
         g_Ki = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
         if ctx.need_k: flags |= FLAGS['need_k_grad']
+        flags |= row_skip_tuner(dev).flag()
         hs_a, ws_a = int_array(hs), int_array(ws)
         nbytes = _lib.lib.smd_image_recon_disp_workspace_bytes(hs_a, ws_a, S, b, n, h, w)
         wsp = torch.empty(nbytes, device=dev, dtype=torch.uint8)

@@ -341,3 +341,24 @@ def test_trainer_applies_the_aspect_ratio_augmentation_in_training_mode_only():
     batch2 = make_batch(1, 128, 192, (-1, 1), seed=1)
     m.step(batch2, mode='val')
     assert tuple(batch2[0]['imgs'].shape[-2:]) == (128, 192) and 'augs' not in batch2[2]
+
+
+def test_dead_tile_fraction_counts_what_the_backward_could_skip():
+    """`functional.dead_tile_fraction`: share of (row, 60-column tile) units of scale 0 where no pixel routes gradient to a support,
+    for the busiest support (the row-skip tuner's statistic).  Pure torch, so it runs on the host."""
+    import torch
+    from slowtv_monodepth_amd import functional as F
+    S, b, h, w = 2, 3, 8, 130                       # 130 columns = tiles of 60, 60 and 10
+    sel = torch.full((S, b, 1, h, w), 255, dtype=torch.uint8)
+    assert float(F.dead_tile_fraction(sel, True, 2)) == 1.0 and float(F.dead_tile_fraction(sel, False, 2)) == 1.0
+    sel[0] = 1                                      # support 1 wins everywhere: its wave is busy in every row, whatever support 0's does
+    assert float(F.dead_tile_fraction(sel, True, 2)) == 0.5 and float(F.dead_tile_fraction(sel, True, 1)) == 1.0     # (the second scale is still all masked)
+    assert float(F.dead_tile_fraction(sel, False, 2)) == 0.5
+    sel[0] = 255; sel[0, :, :, :4, 125] = 0; sel[0, :, :, :, 3] = 1     # support 0: one pixel of the last (10-wide) tile in half of the rows; support 1: the first tile of every row
+    assert abs(float(F.dead_tile_fraction(sel, True, 2)) - ((1 - 1/3) + 1)/2) < 1e-6      # support 1 is the busier one at scale 0: 1 of 3 tiles live
+    assert abs(float(F.dead_tile_fraction(sel, True, 1)) - ((1 - 0.5/3) + 1)/2) < 1e-6
+    sel[1] = 0                                      # second scale: support 0 everywhere -> nothing to skip there; the scales are averaged
+    assert abs(float(F.dead_tile_fraction(sel, True, 2)) - (1 - 1/3)/2) < 1e-6
+    t = F._RowSkipTuner()
+    t.observe(sel, 1, 2)                            # host tensors: nothing is launched, the default (skipping on) stays
+    assert t.flag() == 0 and t.pending is None
