@@ -39,10 +39,10 @@ def time_bwd(sel_syn, skip):
     _lib.lib.smd_profile_collect(1, buf, iters, C.byref(k)); v = sorted(buf[i] for i in range(k.value))
     return v[len(v)//2]*1e3
 
-print(f'{name}: fused backward, HIP events around the kernel, median of {iters}; "skippable" = functional.dead_tile_fraction of the synthetic map')
+print(f'{name}: fused backward, HIP events around the kernel, median of {iters}; "skippable" = mean of functional.dead_tile_shares of the synthetic map')
 for kind in ('pixel', 'tile', 'blob'):
     for masked in (0.0, 0.2, 0.4, 0.6, 0.8, 0.95, 1.0):
         sel_syn = make_sel(kind, masked)
-        dead = float(F.dead_tile_fraction(sel_syn, True, n))
+        dead = float(F.dead_tile_shares(sel_syn, True, n).mean())
         t2, t0 = time_bwd(sel_syn, 2), time_bwd(sel_syn, 0)
         print(f'  {kind:5s} masked {masked:4.2f}  skippable {dead:5.3f}   skipping {t2:6.1f} us   plain {t0:6.1f} us   ratio {t2/t0:5.3f}', flush=True)

@@ -171,10 +171,9 @@ def _need_err(want_err: bool, n: int) -> bool:
     return bool(want_err) or n > _lib.lib.smd_image_recon_supports_per_pass()
 
 
-def dead_tile_fraction(sel: torch.Tensor, use_min: bool, n: int = 1, cols: int = 60) -> torch.Tensor:
-    """Share of (image row, `cols`-column tile) units in which NO pixel routes gradient to a support — the rows the fused backward's
-    dead-row skipping (`k_recon_bwd<…, SKIP=2>`) passes over in that support's wave.  Per scale the support with the FEWEST such
-    units counts (the waves of a strip, one per support, leave together: the busiest sets the pace); the scales are averaged.
+def dead_tile_shares(sel: torch.Tensor, use_min: bool, n: int = 1, cols: int = 60) -> torch.Tensor:
+    """(n, S): per support and scale, the share of (image row, `cols`-column tile) units in which NO pixel routes gradient to that
+    support — the rows the fused backward's dead-row skipping (`k_recon_bwd<…, SKIP=2>`) passes over in that support's wave.
     sel: (S,b,1,h,w)|(S,b,h,w) uint8."""
     S = sel.shape[0]
     s4 = sel.reshape(S, -1, sel.shape[-2], sel.shape[-1])
@@ -182,37 +181,57 @@ def dead_tile_fraction(sel: torch.Tensor, use_min: bool, n: int = 1, cols: int =
     def dead(live):                                  # -> (S,)
         live = torch.nn.functional.pad(live, (0, pad))
         return 1.0 - live.view(S, live.shape[1], live.shape[2], -1, cols).any(-1).float().mean(dim=(1, 2, 3))
-    if not use_min: return dead(s4 != SEL_MASKED).mean()   # the mean over the supports: every support is live wherever the automask is not
-    return torch.stack([dead(s4 == i) for i in range(max(int(n), 1))]).min(dim=0).values.mean()
+    if not use_min: return dead(s4 != SEL_MASKED)[None].expand(max(int(n), 1), S)   # the mean over the supports: all live wherever the automask is not
+    return torch.stack([dead(s4 == i) for i in range(max(int(n), 1))])
 
 
 class _RowSkipTuner:
-    """Turns the dead-row skipping of the fused backward on when the data make it pay, without ever stalling the stream.
+    """Chooses between the two row loops of the fused backward by timing them on the live data, without ever stalling the stream.
 
-    The backward gives the same gradients bit for bit with or without skipping; which is faster depends on the selection masks
-    (`profiles/r03_skip_regimes.txt`, cfg 2): the plain row loop takes 116-118 us whatever they look like; with skipping it is
-    92 us when every unit is skippable, breaks even near 60 % and costs 3-12 % on noise-like masks (a randomly initialised
-    network: 125 vs 118 us in the bench).  Every `period` forwards the share of skippable (row, strip) units is computed on the
-    device from the `sel` the forward just wrote and copied to pinned memory; a later call picks the value up once its event has
-    completed.  `SMD_BWD_SKIP` in the environment pins the choice."""
-    period, threshold = 64, 0.8
+    The backward gives the same gradients bit for bit with or without dead-row skipping (`SMD_BWD_SKIP_DEAD_ROWS`); which is faster
+    depends on the selection masks and on the geometry (`profiles/r03_skip_regimes.txt`): the plain loop is 6 % faster on the noise-
+    like masks of a randomly initialised network at 192x640 (118 vs 125 us), skipping is 14 % faster at 384x640 with learned
+    intrinsics (201 vs 233 us) and 21 % faster when the automask takes everything — and the share of skippable rows alone does not
+    predict the sign.  So it is measured: the first `2*trials` backward calls of every `period` alternate between the two loops with
+    a pair of HIP events around the launch; later calls harvest the pairs that have completed (`Event.query`, no wait) and from then
+    on the loop with the smaller minimum is used.  `SMD_BWD_SKIP` in the environment pins the choice."""
+    period, trials, margin = 256, 3, 0.99
 
     def __init__(self):
-        self.calls, self.skip, self.pending, self.last = 0, False, None, None
+        self.calls, self.skip, self.pending, self.samples, self.last = 0, False, [], {True: [], False: []}, None
 
-    def flag(self) -> int:
-        return FLAGS['bwd_skip_rows'] if self.skip else 0
+    def _flag(self, skip: bool) -> int:
+        return FLAGS['bwd_skip_rows'] if skip else 0
 
-    def observe(self, sel: torch.Tensor, flags: int, n: int = 1) -> None:
-        if 'SMD_BWD_SKIP' in os.environ or not sel.is_cuda: return
-        if self.pending is not None and self.pending[1].query():
-            self.last = float(self.pending[0]); self.skip = self.last >= self.threshold; self.pending = None
-        if self.calls % self.period == 0 and self.pending is None:
-            host = torch.empty((), dtype=torch.float32, pin_memory=True)
-            host.copy_(dead_tile_fraction(sel, bool(flags & FLAGS['use_min']), n), non_blocking=True)
-            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(sel.device))
-            self.pending = (host, ev)
+    def _harvest(self) -> None:
+        still = []
+        for mode, e0, e1 in self.pending:
+            if e1.query(): self.samples[mode].append(e0.elapsed_time(e1))
+            else: still.append((mode, e0, e1))
+        self.pending = still
+        if len(self.samples[True]) >= self.trials and len(self.samples[False]) >= self.trials:
+            t_skip, t_plain = min(self.samples[True]), min(self.samples[False])
+            self.skip = t_skip < self.margin*t_plain
+            self.last = {'skipping_ms': round(t_skip, 5), 'plain_ms': round(t_plain, 5)}
+            self.samples = {True: [], False: []}
+
+    def begin(self, dev):
+        """-> (flag bits for this backward call, token for `end`)."""
+        if 'SMD_BWD_SKIP' in os.environ: return 0, None
+        if self.pending: self._harvest()
+        phase = self.calls % self.period
         self.calls += 1
+        if phase < 2*self.trials:
+            mode = phase % 2 == 0
+            e0 = torch.cuda.Event(enable_timing=True); e0.record(torch.cuda.current_stream(dev))
+            return self._flag(mode), (mode, e0, dev)
+        return self._flag(self.skip), None
+
+    def end(self, token) -> None:
+        if token is None: return
+        mode, e0, dev = token
+        e1 = torch.cuda.Event(enable_timing=True); e1.record(torch.cuda.current_stream(dev))
+        self.pending.append((mode, e0, e1))
 
 
 _tuners: dict = {}
@@ -244,7 +263,6 @@ class _ImageRecon(torch.autograd.Function):
         call('smd_image_recon_fwd', depth.data_ptr(), tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              noise.data_ptr() if noise is not None else None, int(seed) & (2**64 - 1), supp_pk.data_ptr(), err.data_ptr() if err is not None else None, sel.data_ptr(), loss.data_ptr(),
              warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, cflags, _stream())
-        if any(ctx.needs_input_grad): row_skip_tuner(dev).observe(sel, int(flags), n)
         ctx.save_for_backward(depth, tgt, supp_pk, T, K, K_inv, sel)
         ctx.meta = (b, n, S, h, w, int(flags))
         ctx.need_k = bool(ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
@@ -263,13 +281,14 @@ class _ImageRecon(torch.autograd.Function):
         g_K = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
         g_Ki = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
         if ctx.need_k: flags |= FLAGS['need_k_grad']
-        flags |= row_skip_tuner(dev).flag()
         nbytes = _lib.lib.smd_image_recon_workspace_bytes(b, n, S, h, w)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        tuner = row_skip_tuner(dev); tflag, token = tuner.begin(dev)
         call('smd_image_recon_bwd', depth.data_ptr(), tgt.data_ptr(), supp_pk.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              sel.data_ptr(), g_loss.data_ptr(), g_depth.data_ptr(), g_T.data_ptr(),
              g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
-             ws.data_ptr(), nbytes, b, n, S, h, w, flags, _stream())
+             ws.data_ptr(), nbytes, b, n, S, h, w, flags | tflag, _stream())
+        tuner.end(token)
         return g_depth, None, None, g_T, (g_K if ctx.needs_input_grad[4] else None), (g_Ki if ctx.needs_input_grad[5] else None), None, None, None, None, None, None
 
 
@@ -317,7 +336,6 @@ class _ImageReconDisp(torch.autograd.Function):
              tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(), noise.data_ptr() if noise is not None else None,
              int(seed) & (2**64 - 1), packed.data_ptr(), depth_up.data_ptr(), err.data_ptr() if err is not None else None, sel.data_ptr(), loss.data_ptr(),
              warp0.data_ptr() if want_warp else None, wsp.data_ptr(), nbytes, b, n, h, w, cflags, _stream())
-        if any(ctx.needs_input_grad): row_skip_tuner(dev).observe(sel, int(flags), n)
         ctx.save_for_backward(depth_up, packed, T, K, K_inv, sel)
         # `depth_up` is a differentiable output that usually has no other consumer: without this autograd would hand the backward
         # a materialised zero tensor for it (one more (S,b,h,w) read, and no dead-row skipping on the last support pass)
@@ -340,14 +358,15 @@ class _ImageReconDisp(torch.autograd.Function):
         g_K = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
         g_Ki = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
         if ctx.need_k: flags |= FLAGS['need_k_grad']
-        flags |= row_skip_tuner(dev).flag()
         hs_a, ws_a = int_array(hs), int_array(ws)
         nbytes = _lib.lib.smd_image_recon_disp_workspace_bytes(hs_a, ws_a, S, b, n, h, w)
         wsp = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        tuner = row_skip_tuner(dev); tflag, token = tuner.begin(dev)
         call('smd_image_recon_disp_bwd', hs_a, ws_a, S, mn, mx, depth_up.data_ptr(), packed.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              sel.data_ptr(), g_loss.data_ptr(), g_depth_up.data_ptr() if g_depth_up is not None else None,
              ptr_array([g.data_ptr() for g in g_disps]), g_T.data_ptr(), g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
-             wsp.data_ptr(), nbytes, b, n, h, w, flags, _stream())
+             wsp.data_ptr(), nbytes, b, n, h, w, flags | tflag, _stream())
+        tuner.end(token)
         return (None, None, g_T, (g_K if ctx.needs_input_grad[3] else None), (g_Ki if ctx.needs_input_grad[4] else None),
                 None, None, None, None, None, None, None, None, *g_disps)
 

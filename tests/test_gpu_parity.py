@@ -1177,11 +1177,10 @@ def test_shared_target_ring_equals_per_wave_loads(F, monkeypatch, b, h, w, n, lo
     assert torch.isfinite(l1) and (s1 != 255).any() and (s1 == 255).any()   # both the warped supports and the automask win somewhere
 
 
-def test_row_skip_tuner_picks_the_row_loop_from_the_masks_and_gradients_do_not_depend_on_it(F, monkeypatch):
+def test_row_skip_tuner_times_both_row_loops_and_gradients_do_not_depend_on_the_choice(F, monkeypatch):
     """The fused backward has two row loops (with / without dead-row skipping) that give the same gradients bit for bit;
-    `functional.row_skip_tuner` turns the skipping on from the share of skippable units it measures asynchronously on the device."""
-    from slowtv_monodepth_amd._lib import FLAGS
-    b, h, w, n = 3, 64, 200, 2
+    `functional.row_skip_tuner` alternates them over the first calls of a period, times them with HIP events and keeps the faster."""
+    b, h, w, n = 4, 96, 320, 2
     gen = torch.Generator(device='cuda').manual_seed(3)
     imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
     K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
@@ -1196,27 +1195,24 @@ def test_row_skip_tuner_picks_the_row_loop_from_the_masks_and_gradients_do_not_d
         loss.backward()
         return sel, [v.grad for v in d] + [T.grad]
 
-    def run(supp, skip):                             # with the tuner parked: no probe is launched or harvested
-        tuner.pending, tuner.calls, tuner.skip = None, 1, skip
-        out = step(supp)
-        assert tuner.flag() == (FLAGS['bwd_skip_rows'] if skip else 0)
-        return out
-
-    monkeypatch.delenv('SMD_BWD_SKIP', raising=False)
     for name, supp in (('noise', torch.rand(n, b, 3, h, w, device='cuda', generator=gen)),                  # every support wins somewhere in every row
                        ('static', (imgs[None] + 0.2*torch.rand(n, b, 3, h, w, device='cuda', generator=gen)).clamp(0, 1))):   # the un-warped frames win: masked
-        sel, g_skip = run(supp, True)
-        _, g_plain = run(supp, False)
-        assert all(torch.equal(x, y) for x, y in zip(g_skip, g_plain)), name
-        dead = float(F.dead_tile_fraction(sel, True, n))
-        # the tuner's own measurement: a probe is launched, lands, and is harvested by the next forward
-        tuner.pending, tuner.calls, tuner.skip, tuner.last = None, 0, False, None
-        step(supp); assert tuner.pending is not None and tuner.last is None
-        torch.cuda.synchronize(); step(supp)
-        assert tuner.pending is None and tuner.last is not None and abs(tuner.last - dead) < 1e-6
-        assert tuner.skip == (dead >= tuner.threshold), (name, dead)
-        print(f'row-skip tuner, {name} masks: skippable share {dead:.3f} -> {"dead-row skipping" if tuner.skip else "plain rows"}')
-    tuner.skip, tuner.calls, tuner.pending = False, 0, None
+        grads = {}
+        for mode in ('2', '0'):                      # pinned by the environment: the tuner stays out of it
+            monkeypatch.setenv('SMD_BWD_SKIP', mode)
+            sel, grads[mode] = step(supp)
+        assert all(torch.equal(x, y) for x, y in zip(grads['2'], grads['0'])), name
+        monkeypatch.delenv('SMD_BWD_SKIP')
+        tuner.calls, tuner.pending, tuner.samples, tuner.last, tuner.skip = 0, [], {True: [], False: []}, None, False
+        for _ in range(2*tuner.trials): _, g = step(supp)
+        assert all(torch.equal(x, y) for x, y in zip(g, grads['0'])), name
+        torch.cuda.synchronize(); step(supp)         # the next call harvests the six event pairs
+        assert tuner.last is not None and not tuner.pending
+        assert tuner.skip == (tuner.last['skipping_ms'] < tuner.margin*tuner.last['plain_ms'])
+        shares = F.dead_tile_shares(sel, True, n).mean(1).tolist()
+        print(f'row-skip tuner, {name} masks (skippable share per support {[round(v, 3) for v in shares]}): with skipping {tuner.last["skipping_ms"]*1e3:.1f} us, '
+              f'plain {tuner.last["plain_ms"]*1e3:.1f} us -> {"dead-row skipping" if tuner.skip else "plain rows"}')
+    tuner.calls, tuner.pending, tuner.samples, tuner.skip = 0, [], {True: [], False: []}, False
 
 
 @pytest.mark.parametrize('shape', [(2, 3, 1, 1), (2, 5, 6, 20), (1, 4, 33, 65), (3, 8, 48, 160), (2, 6, 40, 70)])

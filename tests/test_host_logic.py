@@ -343,22 +343,45 @@ def test_trainer_applies_the_aspect_ratio_augmentation_in_training_mode_only():
     assert tuple(batch2[0]['imgs'].shape[-2:]) == (128, 192) and 'augs' not in batch2[2]
 
 
-def test_dead_tile_fraction_counts_what_the_backward_could_skip():
-    """`functional.dead_tile_fraction`: share of (row, 60-column tile) units of scale 0 where no pixel routes gradient to a support,
-    for the busiest support (the row-skip tuner's statistic).  Pure torch, so it runs on the host."""
+def test_dead_tile_shares_count_what_the_backward_could_skip():
+    """`functional.dead_tile_shares`: per support and scale, the share of (row, 60-column tile) units where no pixel routes gradient to
+    the support (a reporting statistic of `profiles/r03_skip_regimes.txt`).  Pure torch, so it runs on the host."""
     import torch
     from slowtv_monodepth_amd import functional as F
     S, b, h, w = 2, 3, 8, 130                       # 130 columns = tiles of 60, 60 and 10
     sel = torch.full((S, b, 1, h, w), 255, dtype=torch.uint8)
-    assert float(F.dead_tile_fraction(sel, True, 2)) == 1.0 and float(F.dead_tile_fraction(sel, False, 2)) == 1.0
-    sel[0] = 1                                      # support 1 wins everywhere: its wave is busy in every row, whatever support 0's does
-    assert float(F.dead_tile_fraction(sel, True, 2)) == 0.5 and float(F.dead_tile_fraction(sel, True, 1)) == 1.0     # (the second scale is still all masked)
-    assert float(F.dead_tile_fraction(sel, False, 2)) == 0.5
+    assert torch.equal(F.dead_tile_shares(sel, True, 2), torch.ones(2, S)) and torch.equal(F.dead_tile_shares(sel, False, 2), torch.ones(2, S))
+    sel[0] = 1                                      # scale 0: support 1 wins everywhere (its waves are busy in every row, support 0's never)
+    assert F.dead_tile_shares(sel, True, 2).tolist() == [[1.0, 1.0], [0.0, 1.0]] and F.dead_tile_shares(sel, False, 2).tolist() == [[0.0, 1.0], [0.0, 1.0]]
     sel[0] = 255; sel[0, :, :, :4, 125] = 0; sel[0, :, :, :, 3] = 1     # support 0: one pixel of the last (10-wide) tile in half of the rows; support 1: the first tile of every row
-    assert abs(float(F.dead_tile_fraction(sel, True, 2)) - ((1 - 1/3) + 1)/2) < 1e-6      # support 1 is the busier one at scale 0: 1 of 3 tiles live
-    assert abs(float(F.dead_tile_fraction(sel, True, 1)) - ((1 - 0.5/3) + 1)/2) < 1e-6
-    sel[1] = 0                                      # second scale: support 0 everywhere -> nothing to skip there; the scales are averaged
-    assert abs(float(F.dead_tile_fraction(sel, True, 2)) - (1 - 1/3)/2) < 1e-6
-    t = F._RowSkipTuner()
-    t.observe(sel, 1, 2)                            # host tensors: nothing is launched, the default (skipping on) stays
-    assert t.flag() == 0 and t.pending is None
+    sh = F.dead_tile_shares(sel, True, 2)
+    assert abs(float(sh[0, 0]) - (1 - 0.5/3)) < 1e-6 and abs(float(sh[1, 0]) - (1 - 1/3)) < 1e-6 and sh[:, 1].tolist() == [1.0, 1.0]
+
+
+def test_row_skip_tuner_schedule(monkeypatch):
+    """`functional._RowSkipTuner`: the first 2*trials backward calls of a period alternate between the two row loops, afterwards the
+    chosen one is used; `SMD_BWD_SKIP` in the environment switches the tuner off.  (Events are only created on a GPU: the schedule
+    itself is checked here with the event calls stubbed out.)"""
+    import torch
+    from slowtv_monodepth_amd import functional as F
+    from slowtv_monodepth_amd._lib import FLAGS
+
+    class FakeEvent:
+        def __init__(self, enable_timing=False): pass
+        def record(self, stream=None): pass
+        def query(self): return True
+        def elapsed_time(self, other): return FakeEvent.times.pop(0)
+    monkeypatch.setattr(torch.cuda, 'Event', FakeEvent); monkeypatch.setattr(torch.cuda, 'current_stream', lambda dev=None: None)
+    monkeypatch.delenv('SMD_BWD_SKIP', raising=False)
+    t = F._RowSkipTuner(); t.period, t.trials = 10, 2
+    FakeEvent.times = [0.100, 0.120, 0.101, 0.119,    # period 1: skipping 0.100 / 0.101, plain 0.120 / 0.119 -> skipping
+                       0.130, 0.120, 0.131, 0.121]    # period 2: the other way round -> plain
+    seen = []
+    for _ in range(20):
+        flag, token = t.begin('cuda:0'); t.end(token)
+        seen.append(flag != 0)
+    assert seen[:4] == [True, False, True, False] and all(seen[4:10]) and t.last is not None
+    assert seen[10:14] == [True, False, True, False] and not any(seen[14:20])
+    assert t.last == {'skipping_ms': 0.13, 'plain_ms': 0.12}
+    monkeypatch.setenv('SMD_BWD_SKIP', '2')
+    assert t.begin('cuda:0') == (0, None)
