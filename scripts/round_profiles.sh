@@ -3,12 +3,18 @@
 # traffic passes, and the one-rank RCCL lines.  usage: scripts/round_profiles.sh r03      (outputs under gpurun_out/)
 tag=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
+# The backward picks its row loop by timing both on the live data (functional.row_skip_tuner); a profiler perturbs that timing, so the
+# traced and counter runs are pinned (SMD_BWD_SKIP) to what the un-traced bench of the same workload chose.
 for wl in cfg2 cfg4 cfg5; do
-  bash scripts/gpu_profile.sh ${tag}_$wl --workload $wl > gpurun_out/prof_${tag}_$wl.log 2>&1
+  skip=$(python bench.py --workload $wl --no-cpu-baseline 2>/dev/null | python -c "import json,sys; print(2 if json.loads(sys.stdin.read().strip().splitlines()[-1])['roofline_bwd']['row_loop']['dead_row_skipping'] else 0)")
+  echo "$wl: un-traced bench chose SMD_BWD_SKIP=$skip" | tee gpurun_out/row_loop_$wl.txt
+  SMD_BWD_SKIP=$skip bash scripts/gpu_profile.sh ${tag}_$wl --workload $wl > gpurun_out/prof_${tag}_$wl.log 2>&1
   grep -m1 '"metric"' gpurun_out/prof_${tag}_$wl/bench.log | cut -c1-200
+  SMD_BWD_SKIP=$skip PMC_TIMEOUT=400 bash scripts/pmc_traffic.sh ${tag}_tmp $wl > gpurun_out/pmc_traffic_${tag}_$wl.log 2>&1
+  rm -rf gpurun_out/pmc_${tag}_bench_$wl; mv gpurun_out/pmc_${tag}_tmp_bench_$wl gpurun_out/pmc_${tag}_bench_$wl
 done
-PMC_TIMEOUT=400 bash scripts/pmc_traffic.sh $tag cfg2 cfg4 cfg5 > gpurun_out/pmc_traffic_$tag.log 2>&1
-tail -5 gpurun_out/pmc_traffic_$tag.log
+python scripts/make_traffic_json.py $tag cfg2 cfg4 cfg5 > gpurun_out/traffic_$tag.json
+tail -5 gpurun_out/traffic_$tag.json
 {
   echo "# bench.py under torch.distributed.run --nproc-per-node 1 with the RCCL process group forced on one rank (SMD_FORCE_DDP=1): the data-parallel wrappers' own cost"
   echo "# command: SMD_FORCE_DDP=1 SMD_DP_IMPL=<impl> python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"

@@ -192,10 +192,11 @@ class _RowSkipTuner:
     depends on the selection masks and on the geometry (`profiles/r03_skip_regimes.txt`): the plain loop is 6 % faster on the noise-
     like masks of a randomly initialised network at 192x640 (118 vs 125 us), skipping is 14 % faster at 384x640 with learned
     intrinsics (201 vs 233 us) and 21 % faster when the automask takes everything — and the share of skippable rows alone does not
-    predict the sign.  So it is measured: the first `2*trials` backward calls of every `period` alternate between the two loops with
-    a pair of HIP events around the launch; later calls harvest the pairs that have completed (`Event.query`, no wait) and from then
-    on the loop with the smaller minimum is used.  `SMD_BWD_SKIP` in the environment pins the choice."""
-    period, trials, margin = 256, 3, 0.99
+    predict the sign.  So it is measured: after `settle` calls, `2*trials` backward calls of every `period` alternate between the two
+    loops with a pair of HIP events around the entry point; later calls harvest the pairs that have completed (`Event.query`, no
+    wait), and skipping is used from then on if its fastest trial beats the plain loop's by more than 3 %.  `SMD_BWD_SKIP` in the
+    environment pins the choice (a profiler perturbs the timing: `scripts/round_profiles.sh` pins what the un-traced run chose)."""
+    period, settle, trials, margin = 256, 2, 3, 0.97
 
     def __init__(self):
         self.calls, self.skip, self.pending, self.samples, self.last = 0, False, [], {True: [], False: []}, None
@@ -219,9 +220,9 @@ class _RowSkipTuner:
         """-> (flag bits for this backward call, token for `end`)."""
         if 'SMD_BWD_SKIP' in os.environ: return 0, None
         if self.pending: self._harvest()
-        phase = self.calls % self.period
+        phase = self.calls % self.period - self.settle     # (the first calls of a process carry one-off costs)
         self.calls += 1
-        if phase < 2*self.trials:
+        if 0 <= phase < 2*self.trials:
             mode = phase % 2 == 0
             e0 = torch.cuda.Event(enable_timing=True); e0.record(torch.cuda.current_stream(dev))
             return self._flag(mode), (mode, e0, dev)

@@ -373,15 +373,15 @@ def test_row_skip_tuner_schedule(monkeypatch):
         def elapsed_time(self, other): return FakeEvent.times.pop(0)
     monkeypatch.setattr(torch.cuda, 'Event', FakeEvent); monkeypatch.setattr(torch.cuda, 'current_stream', lambda dev=None: None)
     monkeypatch.delenv('SMD_BWD_SKIP', raising=False)
-    t = F._RowSkipTuner(); t.period, t.trials = 10, 2
+    t = F._RowSkipTuner(); t.period, t.settle, t.trials = 10, 1, 2
     FakeEvent.times = [0.100, 0.120, 0.101, 0.119,    # period 1: skipping 0.100 / 0.101, plain 0.120 / 0.119 -> skipping
                        0.130, 0.120, 0.131, 0.121]    # period 2: the other way round -> plain
     seen = []
     for _ in range(20):
         flag, token = t.begin('cuda:0'); t.end(token)
         seen.append(flag != 0)
-    assert seen[:4] == [True, False, True, False] and all(seen[4:10]) and t.last is not None
-    assert seen[10:14] == [True, False, True, False] and not any(seen[14:20])
+    assert seen[:5] == [False, True, False, True, False] and all(seen[5:10]) and t.last is not None
+    assert seen[10:15] == [True, True, False, True, False] and not any(seen[15:20])
     assert t.last == {'skipping_ms': 0.13, 'plain_ms': 0.12}
     monkeypatch.setenv('SMD_BWD_SKIP', '2')
     assert t.begin('cuda:0') == (0, None)
