@@ -196,7 +196,7 @@ class _RowSkipTuner:
     loops with a pair of HIP events around the entry point; later calls harvest the pairs that have completed (`Event.query`, no
     wait), and skipping is used from then on if its fastest trial beats the plain loop's by more than 3 %.  `SMD_BWD_SKIP` in the
     environment pins the choice (a profiler perturbs the timing: `scripts/round_profiles.sh` pins what the un-traced run chose)."""
-    period, settle, trials, margin = 128, 2, 3, 0.97   # (the masks of a young network change within a few optimiser steps: re-timed often)
+    period, settle, trials, margin = 128, 1, 2, 0.97   # (the masks of a young network change within a few optimiser steps: re-timed often)
 
     def __init__(self):
         self.calls, self.skip, self.pending, self.samples, self.last = 0, False, [], {True: [], False: []}, None

@@ -1206,7 +1206,7 @@ def test_row_skip_tuner_times_both_row_loops_and_gradients_do_not_depend_on_the_
         tuner.calls, tuner.pending, tuner.samples, tuner.last, tuner.skip = 0, [], {True: [], False: []}, None, False
         for _ in range(tuner.settle + 2*tuner.trials): _, g = step(supp)
         assert all(torch.equal(x, y) for x, y in zip(g, grads['0'])), name
-        torch.cuda.synchronize(); step(supp)         # the next call harvests the six event pairs
+        torch.cuda.synchronize(); step(supp)         # the next call harvests the event pairs
         assert tuner.last is not None and not tuner.pending
         assert tuner.skip == (tuner.last['skipping_ms'] < tuner.margin*tuner.last['plain_ms'])
         shares = F.dead_tile_shares(sel, True, n).mean(1).tolist()
