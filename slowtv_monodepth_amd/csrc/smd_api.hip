@@ -305,7 +305,8 @@ int smd_image_recon_disp_fwd(const float* const* disp, const int* hs, const int*
 static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T, const float* K,
                           const float* K_inv, const uint8_t* sel, const float* g_loss, const float* g_in, float k0_scale,
                           float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
-                          int b, int n, int S, int h, int w, int flags, void* stream, smd::PoseFinJob* guest = nullptr) {
+                          int b, int n, int S, int h, int w, int flags, void* stream, smd::PoseFinJob* guest = nullptr,
+                          float* g_direct = nullptr, int direct_scale = -1) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
   if (!depth || !supp_packed || !T || !K || !K_inv || !sel || !g_loss || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if ((flags & SMD_NEED_K_GRAD) && (!g_K || !g_Kinv)) return fail(SMD_E_INVALID, "SMD_NEED_K_GRAD requires g_K and g_Kinv");
@@ -319,6 +320,7 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
   a.g_depth = g_depth; a.pose_partial = ws.pose_partial;
   a.g_in = g_in; a.k0_scale = k0_scale;
+  a.g_direct = g_direct; a.direct_scale = g_direct ? direct_scale : -1;
   a.arrive = packed_arrive(supp_packed, b, n, h, w) + 1;
   a.g_T = g_T; a.g_K = (flags & SMD_NEED_K_GRAD) ? g_K : nullptr; a.g_Kinv = (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
@@ -387,10 +389,17 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
   smd::PoseFinJob guest;
   memset(&guest, 0, sizeof(guest));
   const bool ride = env_int("SMD_BWD_GUEST_FINALIZE", 1) != 0;   // 0: the in-launch hand-off of smd_image_recon_bwd instead
+  // A pyramid level that already has the image size (normally level 0) needs no resampling adjoint: the fused backward stores its rows
+  // straight into that level's gradient tensor and the K0 adjoint launches no blocks for it (one (b,h,w) read + write less; needs another
+  // level to carry the launch the pose epilogue rides in).
+  int direct = -1;
+  if (S > 1 && env_int("SMD_BWD_DIRECT_LEVEL", 1) != 0)
+    for (int s = 0; s < S && direct < 0; ++s) if (hs[s] == h && ws[s] == w) direct = s;
   if (int rc = recon_bwd_impl(depth_up, supp_packed, T, K, K_inv, sel, g_loss, g_depth_up_in, a_scale,
-                              g_depth, g_T, g_K, g_Kinv, workspace, base, b, n, S, h, w, flags, stream, ride ? &guest : nullptr)) return rc;
+                              g_depth, g_T, g_K, g_Kinv, workspace, base, b, n, S, h, w, flags, stream, ride ? &guest : nullptr,
+                              direct >= 0 ? g_disp[direct] : nullptr, direct)) return rc;
   return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth, k0_tmp, true, (hipStream_t)stream,
-                                                    ride ? &guest : nullptr), "disp_to_depth_bwd");
+                                                    ride ? &guest : nullptr, direct), "disp_to_depth_bwd");
 }
 
 // ------------------------------------------------------------------------------------------------

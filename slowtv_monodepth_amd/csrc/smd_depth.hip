@@ -168,7 +168,7 @@ size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, Bwd
 
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
                                     const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st,
-                                    const PoseFinJob* job) {
+                                    const PoseFinJob* job, int skip_scale) {
   float a_scale = 1.f;
   if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
   if (premultiplied) { a_scale = 1.f; depth_up = nullptr; }
@@ -181,6 +181,7 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
     m1.first_block[s] = n1; m2.first_block[s] = n2;
     if (s < sc.S) {
       const bool ident = sc.hs[s] == h && sc.ws[s] == w;
+      if (s == skip_scale) continue;   // the producer of g_depth_up already wrote this (identity) level's gradient in place: no blocks
       n1 += ident ? ceil_div(h*w, 1024) : ceil_div(sc.hs[s]*w, 256);
       n2 += ident ? 0 : ceil_div(sc.hs[s]*sc.ws[s], 256);
       resampled |= !ident;

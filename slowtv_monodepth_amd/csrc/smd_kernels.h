@@ -128,6 +128,8 @@ struct ReconBwdArgs {
   int wps;                // waves per strip (1 .. min(n, 4)): the supports of a strip are split over this many waves of one block
   float wscale, hscale;
   int skip_level;         // 0..2, see k_recon_bwd
+  float* g_direct;        // K0 fused: rows of scale `direct_scale` (a pyramid level that already has the image size: its K0 adjoint is the
+  int direct_scale;       //   identity) go straight to that level's gradient tensor (b,h,w) instead of g_depth; -1: none
 };
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1)/b; }
@@ -185,7 +187,7 @@ size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, Bwd
 struct PoseFinJob { ReconBwdArgs a; int entries1, entries2, b1; };   // the per-sample epilogue of the fused backward as guest work of the K0 adjoint
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
                                     const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st,
-                                    const PoseFinJob* job = nullptr);
+                                    const PoseFinJob* job = nullptr, int skip_scale = -1);
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st);

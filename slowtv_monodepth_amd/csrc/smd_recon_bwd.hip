@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     cx.rs_pk = make_rsrc(a.packed, packed_image_floats(a.b, a.n, h, w)*4);
     cx.rs_depth = make_rsrc(a.depth + sb, hw*4);
     cx.rs_sel = make_rsrc(a.sel + sb, hw);
-    cx.rs_gd = make_rsrc(a.g_depth + sb, hw*4);
+    cx.rs_gd = make_rsrc(s == a.direct_scale ? a.g_direct + (size_t)bi*hw : a.g_depth + sb, hw*4);
     const bool has_gin = a.g_in != nullptr;
     cx.rs_gin = make_rsrc(has_gin ? a.g_in + sb : nullptr, has_gin ? hw*4 : 0);
     const unsigned texel_bytes = (unsigned)(h + 1)*(unsigned)(w + 1)*12u;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   if (ACC && o_strip == (unsigned)nw - 1u) {
     // dL/d depth of the strip = sum over its waves' LDS rows in wave order (deterministic whichever wave adds them up)
     const float* base = hist_lds + (sib*NS)*kWaveFloats + 3*kHist*64 + lane;
-    const rsrc_t rs_gd = make_rsrc(a.g_depth + sb, hw*4);
+    const rsrc_t rs_gd = make_rsrc(s == a.direct_scale ? a.g_direct + (size_t)bi*hw : a.g_depth + sb, hw*4);
 #pragma unroll 4
     for (int r = 0; r < r1 - r0; ++r) {
       float g = base[r*64];
