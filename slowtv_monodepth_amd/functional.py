@@ -195,7 +195,8 @@ class _RowSkipTuner:
     predict the sign.  So it is measured: after `settle` calls, `2*trials` backward calls of every `period` alternate between the two
     loops with a pair of HIP events around the entry point; later calls harvest the pairs that have completed (`Event.query`, no
     wait), and skipping is used from then on if its fastest trial beats the plain loop's by more than 3 %.  `SMD_BWD_SKIP` in the
-    environment pins the choice (a profiler perturbs the timing: `scripts/round_profiles.sh` pins what the un-traced run chose)."""
+    environment pins the choice (a profiler perturbs the timing: `scripts/round_profiles.sh` pins what the un-traced run chose; pin it
+    as well when capturing the step into a HIP graph — timing events cannot be recorded during capture)."""
     period, settle, trials, margin = 128, 1, 2, 0.97   # (the masks of a young network change within a few optimiser steps: re-timed often)
 
     def __init__(self):
