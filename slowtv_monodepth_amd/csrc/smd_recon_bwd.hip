@@ -58,7 +58,7 @@ __device__ __forceinline__ float usel(bool c, float x, float y) {
 // partials, and rows whose three coefficient rows and L1 term are all dead skip the chain rule.  Same gradients bit for bit.  What it
 // is worth depends on the share of such rows (profiles/r03_skip_regimes.txt, cfg 2): the plain loop takes 116-118 us whatever the
 // masks; with skipping 92 us when every row is dead, break-even near 60 %, +3..12 % on noise-like masks.  The launcher therefore
-// defaults to 0 and the caller turns 2 on per call (SMD_BWD_SKIP_DEAD_ROWS; functional.row_skip_tuner does it from the data).
+// defaults to 0 and the caller turns 2 on per call (SMD_BWD_SKIP_DEAD_ROWS; functional.row_skip_tuner decides by timing both loops on the live data).
 //
 // Register discipline: everything with a lifetime of more than one row step lives in a slot indexed by (row mod 3) — raw
 // rows X/Y, the h-summed coefficient rows HC, `sel` — and the row loop is unrolled by three with the phase as a template
