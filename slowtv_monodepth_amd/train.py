@@ -125,7 +125,13 @@ class FlatAllReduce(nn.Module):
             cur = torch.cuda.current_stream(bk[0].device)
             for st in self._streams[i]:
                 if st != cur: cur.wait_stream(st)
-        torch.cat([p.grad.reshape(-1) for p in bk], out=self.flats[i])      # pack: one launch per bucket
+        # pack: one launch per bucket.  A gradient that already IS its slice of the bucket (the caller kept the views of the last step:
+        # `zero_grad(set_to_none=False)`, or a second backward accumulated into them) must not be an input of a `cat` whose output it aliases.
+        alias = [p.grad.data_ptr() == v.data_ptr() for p, v in zip(bk, self.views[i])]
+        if not any(alias): torch.cat([p.grad.reshape(-1) for p in bk], out=self.flats[i])
+        elif not all(alias):
+            for p, v, a in zip(bk, self.views[i], alias):
+                if not a: v.copy_(p.grad)
         self._works[i] = dist.all_reduce(self.flats[i], op=self.avg_op, async_op=True)
 
     @torch.no_grad()
@@ -248,8 +254,11 @@ def main(argv=None):
         from .networks.checkpoint import load_reference_checkpoint
         ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)
         load_reference_checkpoint(module, ckpt)
-        if ckpt.get('optimizer_states'): opt.load_state_dict(ckpt['optimizer_states'][0])
-        if sched is not None and ckpt.get('lr_schedulers'): sched.load_state_dict(ckpt['lr_schedulers'][0])
+        try:   # a reference checkpoint carries timm's parameter-group layout: continue weights-only rather than refuse it
+            if ckpt.get('optimizer_states'): opt.load_state_dict(ckpt['optimizer_states'][0])
+            if sched is not None and ckpt.get('lr_schedulers'): sched.load_state_dict(ckpt['lr_schedulers'][0])
+        except (ValueError, KeyError) as e:
+            if rank == 0: print(f'--resume: optimizer / scheduler state not restored ({e}); continuing with the weights only', flush=True)
         first_epoch = int(ckpt.get('epoch', -1)) + 1
         if rank == 0: print(f'resumed from {args.resume}: epoch {first_epoch}, global step {ckpt.get("global_step", 0)}', flush=True)
     for epoch in range(first_epoch, tcfg.get('max_epochs', 1)):

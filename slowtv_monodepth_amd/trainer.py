@@ -47,6 +47,7 @@ class HipLossBackend:
         networks instead of after them.  None when the fused operator will not be used for these tensors."""
         from . import functional as F
         if not imgs.is_cuda or imgs.shape[1] != 3 or crit.loss_name == 'l2' or imgs.dtype != torch.float32: return None
+        if getattr(crit, 'mask_name', None): return None   # a masked criterion takes the un-fused operators (handlers.image_recon): nothing would read the buffer
         return F.image_recon_prep(imgs, supp_imgs, flags=F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask), pyramid=pyramid, stream=stream)
 
     def pose_matrices(self, aa, t, invert):
@@ -258,10 +259,15 @@ class MonoDepthModule(nn.Module):
         self.synth = ViewSynth(x['imgs'].shape[-2:])
         self._prepared = self._prepare_frames(y) if self.prep_ahead == 'own' else None
         self._y, self._K_inv = y, None
-        with self.timer('Total'):
-            with self.timer('Forward'): fwd = self.forward(x)
-            with self.timer('Post-Process'): fwd = self.forward_postprocess(fwd, x, y)
-            with self.timer('Loss'): loss, loss_dict = self.forward_loss(fwd, x, y)
+        try:
+            with self.timer('Total'):
+                with self.timer('Forward'): fwd = self.forward(x)
+                with self.timer('Post-Process'): fwd = self.forward_postprocess(fwd, x, y)
+                with self.timer('Loss'): loss, loss_dict = self.forward_loss(fwd, x, y)
+        finally:
+            # the prep-ahead state belongs to THIS step: a later `module.forward(x)` (validation, inference) must neither launch the
+            # prep for the previous batch nor keep that batch (and its 150 MB packed buffer) alive
+            self._y = self._prepared = self._K_inv = None
         return loss, loss_dict, fwd
 
     def _prepare_frames(self, y: dict, stream=None):
