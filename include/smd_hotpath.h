@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 4
+#define SMD_ABI_VERSION 5
 
 #define SMD_OK 0
 #define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
@@ -45,6 +45,7 @@ extern "C" {
                                         * them, the chain rule).  Same result bit for bit; pays when >= ~80 % of the (row, strip) units are such rows (up to
                                         * -21 %), costs 3-12 % otherwise (profiles/r03_skip_regimes.txt).  Default: off.  SMD_BWD_SKIP in the environment overrides. */
 #define SMD_USE_LAPLACIAN 0x200        /* smd_disp_smooth_*: SmoothReg(use_laplacian=True): second-order differences (smooth.py:33-48) */
+#define SMD_EDGES_READY 0x800  /* smd_disp_smooth_fwd: `edge_weights` was already filled by smd_disp_smooth_prep() for this frame and pyramid */
 #define SMD_PACKED_READY 0x40  /* smd_image_recon_*_fwd: `supp_packed` was already filled by smd_image_recon_prep() for these frames */
 /* RegressionLoss (src/losses/regression.py:40-75) */
 #define SMD_REGR_L1 0x0
@@ -148,11 +149,15 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
  *   NULL -> key = s)
  *   loss (1) out;  stats (S,b,2) out: per (scale, sample) {mean disparity, un-normalised edge sum E} kept for backward
  *   disp_grad, image_grad: (b,1,hs[0],ws[0]) out or NULL (aux maps of the first scale, smooth.py:86,89)
- *   edge_weights: out or NULL; smd_disp_smooth_edge_weight_bytes() bytes holding {exp(-|dI/dx|), exp(-|dI/dy|)} per pixel
- *   of every scale (with SMD_USE_EDGES).  Handing the same buffer to the backward spares it every image access.
+ *   edge_weights: required with SMD_USE_EDGES, else NULL; smd_disp_smooth_edge_weight_bytes() bytes holding
+ *   {exp(-mean_c |dI/dx|), exp(-mean_c |dI/dy|)} per pixel of every scale (and a few launch counters behind them).  They depend on the frames
+ *   alone: smd_disp_smooth_prep() fills the buffer ahead of time (e.g. on a side stream while the networks run, next to
+ *   smd_image_recon_prep) and the forward is then called with SMD_EDGES_READY; without that flag the forward fills it first itself.
+ *   Handing the same buffer to the backward spares it every image access.
  * Backward: g_disp[s] (b,1,hs,ws) out. */
 size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int b);
 size_t smd_disp_smooth_edge_weight_bytes(const int* hs, const int* ws, int S, int b);
+int smd_disp_smooth_prep(const float* img, const int* hs, const int* ws, int S, int b, int h, int w, int flags, float* edge_weights, void* stream);
 int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
                         const float* img, int h, int w, int flags, float* loss, float* stats, float* disp_grad, float* image_grad,
                         float* edge_weights, void* workspace, size_t workspace_bytes, void* stream);
@@ -294,10 +299,12 @@ int smd_intrinsics_bwd(const float* fs, const float* cs, int b, int h, int w, co
  * GPU-side aspect-ratio augmentation.  Replaces `crop_aug` + `resize_aug` of
  * src/core/aspect_ratio.py:67-151 for the image tensors of a batch and `centre_crop_K` + `resize_K`
  * (src/tools/geometry.py:233-263) for its intrinsics, in one launch: every plane of every segment (a tensor viewed as
- * (planes[k], H, W): x.imgs, y.imgs, x.supp_imgs, y.supp_imgs, depth ...) is centre-cropped to (crop_h, crop_w) — the integer
- * window of kornia's `center_crop`, start = int(H/2 - crop_h/2) — and the crop resized to (out_h, out_w) with
+ * (planes[k], H, W): x.imgs, y.imgs, x.supp_imgs, y.supp_imgs, depth ...) is centre-cropped to (crop_h, crop_w) as kornia's
+ * `center_crop(size, mode='bilinear', align_corners=False)` does it (aspect_ratio.py:78) — the integer window starting at
+ * int(H/2 - crop_h/2), bilinearly RE-SAMPLED at x(i) = ((i + 0.5)(w - 1)/w + x0) W/(W - 1) - 0.5 with zero padding: kornia's
+ * (n - 1)-normalised warp under align_corners=False grids — and the crop resized to (out_h, out_w) with
  * `F.interpolate(mode='bilinear', align_corners=False)` semantics; dst[k] is (planes[k], out_h, out_w).  crop == input size:
- * resize only; out == crop size: crop only.  K_in / K_out (nK,4,4) or both NULL.  The shapes are sampled on the host
+ * resize only, no resampling of the frame (the augmentation's not-applied branch); out == crop size: crop only.  H, W >= 2.  K_in / K_out (nK,4,4) or both NULL.  The shapes are sampled on the host
  * (`slowtv_monodepth_amd.aspect_ratio`, same random streams as the reference). */
 int smd_crop_resize(const float* const* src, float* const* dst, const int* planes, int nseg, int H, int W, int crop_h, int crop_w,
                     int out_h, int out_w, const float* K_in, float* K_out, int nK, void* stream);

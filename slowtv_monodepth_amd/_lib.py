@@ -18,7 +18,7 @@ _HERE = Path(__file__).resolve().parent
 lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
 
 FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10, 'loss_l2': 0x20, 'packed_ready': 0x40,
-         'mask_explainability': 0x80, 'mask_uncertainty': 0x100, 'use_laplacian': 0x200, 'bwd_skip_rows': 0x400}
+         'mask_explainability': 0x80, 'mask_uncertainty': 0x100, 'use_laplacian': 0x200, 'bwd_skip_rows': 0x400, 'edges_ready': 0x800}
 REGR_FLAGS = {'l1': 0x0, 'log_l1': 0x1, 'berhu': 0x2, 'invert': 0x4}
 SEL_MASKED = 255
 MAX_SCALES = 8
@@ -44,6 +44,7 @@ PROTOTYPES = {
     'smd_image_recon_disp_bwd': (_i, [_vp, _vp, _i, _f, _f] + [_vp]*13 + [_sz] + [_i]*5 + [_vp]),
     'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_disp_smooth_edge_weight_bytes': (_sz, [_vp, _vp, _i, _i]),
+    'smd_disp_smooth_prep': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'smd_disp_smooth_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'smd_disp_smooth_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'smd_view_synth_workspace_bytes': (_sz, [_i, _i, _i]),
@@ -99,7 +100,7 @@ def _load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if handle.smd_abi_version() != 4: raise ImportError(f'ABI version mismatch in {lib_path}')
+    if handle.smd_abi_version() != 5: raise ImportError(f'ABI version mismatch in {lib_path}')
     return handle
 
 

@@ -1,9 +1,13 @@
 """GPU-side aspect-ratio augmentation (reference: `src/core/aspect_ratio.py:35-166`; call site `src/core/trainer.py:54-60, 106`).
 
-Same sampling as the reference — the same draws from `random` and `torch`'s generators in the same order, so a seeded run
-samples the same crops — and the same `m['augs']` bookkeeping; what differs is what runs underneath: the reference materialises
-the crop of all 2(1+n)b images with kornia's `center_crop` and then resizes it with `F.interpolate`; here both steps, for every
-image tensor of the batch and for the intrinsics, are ONE launch (`smd_crop_resize`, `csrc/smd_aspect.hip`).
+Same sampling as the reference — the same draws from `random` and `torch`'s generators in the same order (`MonoDepthModule.step`
+calls this on every training step, as the reference's `training_step` does, so `random.random()` is drawn even at probability 0) —
+and the same `m['augs']` bookkeeping; what differs is what runs underneath: the reference materialises the crop of all 2(1+n)b images
+with kornia's `center_crop(mode='bilinear', align_corners=False)` and then resizes it with `F.interpolate`; here both steps, for every
+image tensor of the batch and for the intrinsics, are ONE launch (`smd_crop_resize`, `csrc/smd_aspect.hip`).  The crop is kornia's
+re-sampled window (NOT a slice: its (n - 1)-normalised warp under align_corners=False grids samples 0.25 px off the integer window at
+640 -> 320), restated from kornia 0.6.10's published call chain — kornia is absent from the build image, so that half is "parity
+unpinned"; the resize half, the sampling and the K updates are pinned on reference fixtures (`oracle/aspect_ratio_oracle.py`).
 """
 from __future__ import annotations
 

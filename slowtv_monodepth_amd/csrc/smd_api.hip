@@ -28,6 +28,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct StripPlan { int rh, nsx, nsy; };
 constexpr int kBwdAccRows = 16;    // = smd::kAccRows of smd_recon_bwd.hip
+constexpr int kBwdMaskRows = 24;   // tallest backward strip: its per-row liveness masks (rows r0-3 .. r1+3) must fit 32 bits
 constexpr int kMinStripRows = 4;   // lower bound of the rows-per-strip override; the workspace is sized for it
 int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil_div(h, kMinStripRows); }
 
@@ -326,9 +327,11 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   StripPlan pl = plan(b, S, h, w, smd::kBwdCols);
+  if (pl.rh > kBwdMaskRows) { pl.rh = kBwdMaskRows; pl.nsy = smd::ceil_div(h, pl.rh); }            // a strip's row masks are 32-bit words (k_recon_bwd: rows r0-3 .. r1+3)
   if (n >= 2 && pl.rh > kBwdAccRows) { pl.rh = kBwdAccRows; pl.nsy = smd::ceil_div(h, pl.rh); }   // the supports' shares of dL/d depth are summed from LDS rows
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
   taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_BWD_TAPER_B", "SMD_BWD_TAPER_RH");
+  if (a.rh2 > kBwdMaskRows) { a.rh2 = kBwdMaskRows; a.nsy2 = smd::ceil_div(h, a.rh2); }
   if (n >= 2 && a.rh2 > kBwdAccRows) { a.rh2 = kBwdAccRows; a.nsy2 = smd::ceil_div(h, a.rh2); }
   a.pose_stride = S*pl.nsx*(a.nsy2 > pl.nsy ? a.nsy2 : pl.nsy);
   a.skip_level = env_int("SMD_BWD_SKIP", (flags & SMD_BWD_SKIP_DEAD_ROWS) ? 2 : 0);
@@ -418,10 +421,18 @@ size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int 
 }
 
 size_t smd_disp_smooth_edge_weight_bytes(const int* hs, const int* ws, int S, int b) {
-  if (!hs || !ws || S < 1 || S > SMD_MAX_SCALES || b < 1) return 0;
-  size_t px = 0;
-  for (int s = 0; s < S; ++s) px += (size_t)b*hs[s]*ws[s];
-  return align256(px*2*sizeof(float));
+  smd::ScaleSet sc;
+  if (b < 1 || fill_scales(sc, nullptr, nullptr, hs, ws, nullptr, S)) return 0;
+  return smd::smooth_edge_bytes(sc, b);   // {wx, wy} per pixel of every level + the arrival counters of the sweep's in-launch second stage
+}
+
+int smd_disp_smooth_prep(const float* img, const int* hs, const int* ws, int S, int b, int h, int w, int flags, float* edge_weights, void* stream) {
+  if (!img || !edge_weights) return fail(SMD_E_INVALID, "null pointer");
+  if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");
+  if (!(flags & SMD_USE_EDGES) || (flags & SMD_USE_LAPLACIAN)) return fail(SMD_E_INVALID, "smd_disp_smooth_prep serves SmoothReg(use_edges=True) without use_laplacian");
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, nullptr, nullptr, hs, ws, nullptr, S)) return rc;
+  return check_launch(smd::launch_smooth_edges(sc, b, img, h, w, edge_weights, (hipStream_t)stream), "disp_smooth_prep");
 }
 
 int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
@@ -434,8 +445,10 @@ int smd_disp_smooth_fwd(const float* const* disp, const int* hs, const int* ws, 
   for (int s = 0; s < S; ++s) if (!disp[s]) return fail(SMD_E_INVALID, "null disparity pointer for scale %d", s);
   const size_t need = smd_disp_smooth_workspace_bytes(hs, ws, S, b);
   if (workspace_bytes < need) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  if ((flags & SMD_USE_EDGES) && !edge_weights) return fail(SMD_E_INVALID, "SMD_USE_EDGES needs the edge_weights buffer (smd_disp_smooth_edge_weight_bytes)");
+  if ((flags & SMD_EDGES_READY) && (!(flags & SMD_USE_EDGES) || (flags & SMD_USE_LAPLACIAN))) return fail(SMD_E_INVALID, "SMD_EDGES_READY goes with SMD_USE_EDGES (first-order form)");
   return check_launch(smd::launch_smooth_fwd(sc, b, img, h, w, flags, loss, stats, disp_grad, image_grad, (float*)workspace,
-                                             edge_weights, (hipStream_t)stream), "disp_smooth_fwd");
+                                             edge_weights, (flags & SMD_EDGES_READY) != 0, (hipStream_t)stream), "disp_smooth_fwd");
 }
 
 int smd_disp_smooth_bwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, int b,
@@ -690,7 +703,7 @@ int smd_crop_resize(const float* const* src, float* const* dst, const int* plane
                     int out_h, int out_w, const float* K_in, float* K_out, int nK, void* stream) {
   if (!src || !dst || !planes) return fail(SMD_E_INVALID, "null pointer");
   if (nseg < 1 || nseg > smd::SMD_MAX_AR_SEGMENTS) return fail(SMD_E_INVALID, "nseg=%d outside [1, %d]", nseg, smd::SMD_MAX_AR_SEGMENTS);
-  if (H < 1 || W < 1 || crop_h < 1 || crop_w < 1 || crop_h > H || crop_w > W || out_h < 1 || out_w < 1)
+  if (H < 2 || W < 2 || crop_h < 1 || crop_w < 1 || crop_h > H || crop_w > W || out_h < 1 || out_w < 1)
     return fail(SMD_E_INVALID, "invalid sizes: input %dx%d, crop %dx%d, output %dx%d", H, W, crop_h, crop_w, out_h, out_w);
   if ((K_in != nullptr) != (K_out != nullptr) || (K_in && nK < 1)) return fail(SMD_E_INVALID, "K_in / K_out / nK must be given together");
   smd::CropResizeArgs a;
@@ -703,8 +716,10 @@ int smd_crop_resize(const float* const* src, float* const* dst, const int* plane
   }
   if (total + 1 > 65535) return fail(SMD_E_INVALID, "too many image planes for one launch (%lld)", total);
   a.nseg = nseg; a.H = H; a.W = W; a.ch = crop_h; a.cw = crop_w; a.oh = out_h; a.ow = out_w;
-  // kornia.geometry.transform.center_crop: start = int(src/2 - dst/2) (truncation), an integer window
+  // kornia.geometry.transform.center_crop: start = int(src/2 - dst/2) (truncation); the window is then RESAMPLED (smd_aspect.hip), unless
+  // it is the whole frame — the augmentation's resize-only branch (src/core/aspect_ratio.py:60)
   a.y0 = (int)((double)H/2.0 - (double)crop_h/2.0); a.x0 = (int)((double)W/2.0 - (double)crop_w/2.0);
+  a.resample = (crop_h != H || crop_w != W) ? 1 : 0;
   a.K_in = K_in; a.K_out = K_out; a.nK = nK;
   return check_launch(smd::launch_crop_resize(a, (hipStream_t)stream), "crop_resize");
 }

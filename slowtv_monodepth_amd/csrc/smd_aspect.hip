@@ -2,13 +2,20 @@
 // tensor of a training batch, and the matching update of the intrinsics, as ONE launch.
 //
 // Restates `aspect_ratio_aug` = `crop_aug` + `resize_aug` (src/core/aspect_ratio.py:35-166): the reference crops
-// x.imgs / y.imgs / x.supp_imgs / y.supp_imgs (and depth maps) with `kornia.geometry.transform.center_crop` (:78-84), then
-// resizes the crops with `F.interpolate(bilinear, align_corners=False)` (:141-151); `centre_crop_K` and `resize_K`
-// (src/tools/geometry.py:233-263) follow the images.  Here the two passes are composed: an output pixel is the bilinear sample
-// of the CROP (neighbour indices clamped to the crop's own border, exactly what interpolating the materialised crop does), read
-// straight from the un-cropped tensor — the crop is never written.  kornia's centre crop is an integer window
-// (start = int(H/2 - h/2)) warped with a pure translation, i.e. a slice; kornia is absent from the build image, so that half is
-// restated from its published algorithm ("parity unpinned"), the resize half is pinned on reference fixtures.
+// x.imgs / y.imgs / x.supp_imgs / y.supp_imgs (and depth maps) with `kornia.geometry.transform.center_crop(size, mode='bilinear',
+// align_corners=False)` (:78-84), then resizes the crops with `F.interpolate(bilinear, align_corners=False)` (:141-151);
+// `centre_crop_K` and `resize_K` (src/tools/geometry.py:233-263) follow the images.  Here the two passes are composed: an output
+// pixel is the bilinear sample of the CROP (neighbour indices clamped to the crop's own border, exactly what interpolating the
+// materialised crop does), and each of the up to four crop pixels it blends is evaluated on the fly from the un-cropped tensor —
+// the crop is never written.
+// What a crop pixel is (round 4; oracle/aspect_ratio_oracle.py has the derivation from kornia 0.6.10's call chain): kornia warps
+// between the integer window (start = int(H/2 - h/2)) and the output box with `warp_affine`, whose homography is normalised with
+// (n - 1) denominators (align_corners=True convention) while `affine_grid` / `grid_sample` run with the caller's align_corners=False
+// and zero padding.  The conventions do not cancel: crop column i is the bilinear sample of the source at
+//     x(i) = ((i + 0.5)(w - 1)/w + x0) * W/(W - 1) - 0.5          (likewise in y; taps outside the image read 0)
+// — a slightly zoomed resample, not the slice x0 + i (which it is for align_corners=True only).  kornia is absent from the build
+// image, so this half stays "parity unpinned" (DESIGN.md §2); the resize half is pinned on reference fixtures.  A crop of the full
+// frame means "no crop" (the augmentation's not-applied branch resizes only, aspect_ratio.py:60) and reads the pixels themselves.
 #include "smd_common.h"
 #include "smd_kernels.h"
 
@@ -41,17 +48,30 @@ __global__ __launch_bounds__(256) void k_crop_resize(const CropResizeArgs a) {
     return;
   }
   if (plane >= a.planes[seg]) return;
-  const float* __restrict__ src = a.src[seg] + (size_t)plane*a.H*a.W + (size_t)a.y0*a.W + a.x0;   // top-left of the crop window
+  const float* __restrict__ img = a.src[seg] + (size_t)plane*a.H*a.W;
   float* __restrict__ dst = a.dst[seg] + (size_t)plane*a.oh*a.ow;
   const float sy = (float)a.ch/(float)a.oh, sx = (float)a.cw/(float)a.ow;
   const bool same = (a.ch == a.oh && a.cw == a.ow);
+  // source coordinate of crop row / column i (double: the product reaches ~10^3 and the fraction is a blend weight)
+  const double ky = (double)(a.ch - 1)/(double)a.ch, my = (double)a.H/(double)(a.H - 1), kx = (double)(a.cw - 1)/(double)a.cw, mx = (double)a.W/(double)(a.W - 1);
+  auto crop_px = [&](int yc, int xc) -> float {
+    if (!a.resample) return img[(size_t)(a.y0 + yc)*a.W + (a.x0 + xc)];
+    const double ys = (((double)yc + 0.5)*ky + (double)a.y0)*my - 0.5, xs = (((double)xc + 0.5)*kx + (double)a.x0)*mx - 0.5;
+    const double yf = floor(ys), xf = floor(xs);
+    const int iy = (int)yf, ix = (int)xf;
+    const float fy = (float)(ys - yf), fx = (float)(xs - xf);
+    // grid_sample(bilinear, zeros): nw * v(iy, ix) + ne * v(iy, ix+1) + sw * v(iy+1, ix) + se * v(iy+1, ix+1), taps outside the image are 0
+    auto tap = [&](int y, int x) -> float { return (y >= 0 && y < a.H && x >= 0 && x < a.W) ? img[(size_t)y*a.W + x] : 0.f; };
+    const float nw = (1.f - fx)*(1.f - fy), ne = fx*(1.f - fy), sw = (1.f - fx)*fy, se = fx*fy;
+    return nw*tap(iy, ix) + ne*tap(iy, ix + 1) + sw*tap(iy + 1, ix) + se*tap(iy + 1, ix + 1);
+  };
   for (int pix = blockIdx.x*256 + threadIdx.x; pix < a.oh*a.ow; pix += gridDim.x*256) {
     const int v = pix/a.ow, u = pix - v*a.ow;
-    if (same) { dst[pix] = src[(size_t)v*a.W + u]; continue; }
+    if (same) { dst[pix] = crop_px(v, u); continue; }
     int ya, yb, xa, xb; float ly, lx;
     ar_src_index(v, sy, a.ch, ya, yb, ly);
     ar_src_index(u, sx, a.cw, xa, xb, lx);
-    const float p00 = src[(size_t)ya*a.W + xa], p01 = src[(size_t)ya*a.W + xb], p10 = src[(size_t)yb*a.W + xa], p11 = src[(size_t)yb*a.W + xb];
+    const float p00 = crop_px(ya, xa), p01 = crop_px(ya, xb), p10 = crop_px(yb, xa), p11 = crop_px(yb, xb);
     dst[pix] = (1.f - ly)*((1.f - lx)*p00 + lx*p01) + ly*((1.f - lx)*p10 + lx*p11);
   }
 }

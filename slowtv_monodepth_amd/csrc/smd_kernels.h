@@ -141,6 +141,7 @@ struct CropResizeArgs {    // k_crop_resize: centre crop + bilinear resize of up
   int nseg;
   int H, W;                // input size
   int y0, x0, ch, cw;      // crop window
+  int resample;            // 1: a crop pixel is kornia's center_crop(align_corners=False) resample of the window; 0: the window's pixel itself (crop == frame)
   int oh, ow;              // output size
   const float* K_in; float* K_out; int nK;
 };
@@ -178,7 +179,6 @@ hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st);
 hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st);
 hipError_t launch_pose_finalize(const float* pose_partial, int entries, int stride, const float* T, const float* K, const float* Kinv,
                                 float* g_T, float* g_K, float* g_Kinv, int b, int n, hipStream_t st);
-unsigned* arrive_slots(int count);   // smd_misc.hip: `count` zeroed, self-resetting arrival counters for one launch on the current device (or null)
 
 hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
                                     float* depth_up, float* disp_up, hipStream_t st);
@@ -190,7 +190,9 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
                                     const PoseFinJob* job = nullptr, int skip_scale = -1);
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
-                             float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st);
+                             float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, bool edges_ready, hipStream_t st);
+hipError_t launch_smooth_edges(const ScaleSet& sc, int b, const float* img, int h, int w, float* edge_w, hipStream_t st);   // frame-only: edge weights of every level + zeroed arrival counters
+size_t smooth_edge_bytes(const ScaleSet& sc, int b);
 hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
                              const float* g_loss, const float* edge_w, hipStream_t st);
 

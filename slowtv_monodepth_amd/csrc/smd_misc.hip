@@ -30,29 +30,6 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__
   }
 }
 
-// Arrival counters for in-launch reductions of operators that own no caller buffer that outlives the call (the smoothness
-// forward).  A pool in device memory, zero at module load; a launch takes the next `count` consecutive slots (bump allocation with
-// wrap-around on the host) and its last arrivers reset them, so slots are only ever shared by two launches if a whole pool's
-// worth of launches is in flight on different streams at once.  Returns null when `count` exceeds a quarter of the pool (the
-// caller then uses its two-launch form).
-constexpr unsigned kArriveSlots = 4096;
-__device__ unsigned g_arrive_pool[kArriveSlots];
-unsigned* arrive_slots(int count) {
-  static unsigned next = 0;
-  static void* base_of[64] = {};     // the symbol's address on each device, looked up once
-  if (count < 1 || (unsigned)count > kArriveSlots/4) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  void* base = __atomic_load_n(&base_of[dev], __ATOMIC_ACQUIRE);
-  if (!base) {
-    if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_arrive_pool)) != hipSuccess) return nullptr;
-    __atomic_store_n(&base_of[dev], base, __ATOMIC_RELEASE);
-  }
-  unsigned at = __atomic_load_n(&next, __ATOMIC_RELAXED), start;
-  do { start = (at + (unsigned)count > kArriveSlots) ? 0u : at; } while (!__atomic_compare_exchange_n(&next, &at, start + (unsigned)count, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
-  return (unsigned*)base + start;
-}
-
 hipError_t launch_sum_partials(const float* partial, int count, double scale, float* out, hipStream_t st) {
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st, partial, count, scale, out);
   return hipGetLastError();

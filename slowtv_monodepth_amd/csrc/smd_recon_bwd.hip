@@ -54,46 +54,66 @@ __device__ __forceinline__ float usel(bool c, float x, float y) {
   return __builtin_bit_cast(float, c ? __builtin_bit_cast(unsigned, x) : __builtin_bit_cast(unsigned, y));
 }
 
-// SKIP: 0 = every row does the full adjoint; 2 = rows where no pixel of the wave selected the current support skip the SSIM
-// partials, and rows whose three coefficient rows and L1 term are all dead skip the chain rule.  Same gradients bit for bit.  What it
-// is worth depends on the share of such rows (profiles/r03_skip_regimes.txt, cfg 2): the plain loop takes 116-118 us whatever the
-// masks; with skipping 92 us when every row is dead, break-even near 60 %, +3..12 % on noise-like masks.  The launcher therefore
-// defaults to 0 and the caller turns 2 on per call (SMD_BWD_SKIP_DEAD_ROWS; functional.row_skip_tuner decides by timing both loops on the live data).
+// SKIP: 0 = every row does the full adjoint; >= 1 (round 4) = the row loop is GATED by what the selection maps route to this wave's
+// support.  Before the row loop a wave reads the `sel` bytes of its centre rows once (in batches whose loads overlap) and keeps
+//   selbits  (per lane)      bit i: the pixel (row rb + i, this lane's column) routes gradient to the current support
+//   L        (wave-uniform)  bit i: centre row rb + i has at least one such pixel in the wave's 64 columns
+//   N = L | L << 1 | L >> 1  bit i: row rb + i enters a live 3x3 window: it has to be re-synthesised, and its gradient is not zero
+// A row step then runs stage A only for a row of N (and the loads of the next row are only issued if that one is in N), stage B only
+// for a centre row of L, stage C only for a row of N; everything else costs a few scalar instructions.  With every pixel masked the
+// kernel is its prologue and the zero fill (round 3's skipping still re-synthesised every row: 92 us at cfg 2).  Same gradients bit for
+// bit as SKIP = 0: a skipped row contributes exact zeros there.  The window sums are formed from the three raw rows of a centre
+// (no running state to keep consistent across skipped rows).
 //
 // Register discipline: everything with a lifetime of more than one row step lives in a slot indexed by (row mod 3) — raw
-// rows X/Y, the h-summed coefficient rows HC, `sel` — and the row loop is unrolled by three with the phase as a template
+// rows X/Y, the h-summed coefficient rows HC — and the row loop is unrolled by three with the phase as a template
 // parameter, so nothing is ever moved between "current / previous / one before" registers (the rolled version spent 73 of
-// its 421 vector instructions per row on v_mov).  The bilinear partials of a row wait two steps in LDS (own column only, no
-// synchronisation), the depth of the row stage C handles is simply loaded a second time (an L1/L2 hit).
+// its 421 vector instructions per row on v_mov).  The bilinear partials of a row and its depth wait two steps in LDS (own column
+// only, no synchronisation).
 constexpr int kHist = 7;   // values per lane and row slot of the LDS history: dx/dsx[3], dx/dsy[3], depth
+constexpr int kSelBatch = 10;   // `sel` rows requested at once by the prologue (8 + 2 rows of a tapered strip in one batch, 16 + 2 in two)
+
+// Experiment switches of the row loop (scripts/dev/bwd_lib_variants.sh builds one library per combination; the defaults are what won):
+#ifndef SMD_BWD_PEEL
+#define SMD_BWD_PEEL 0       // 1: the pipeline's fill (two A-only steps, two A+B steps) is peeled off and the steady-state body has no range checks
+#endif
+#ifndef SMD_BWD_ROWSEL
+#define SMD_BWD_ROWSEL 1     // the plain loop (SKIP = 0) reads `sel` one row per step, as part of the row's loads, instead of scanning the strip up front
+#endif
+#ifndef SMD_BWD_STATEFUL
+#define SMD_BWD_STATEFUL 1   // the plain loop keeps sliding vertical sums P = r(j-2) + r(j-1) (the forward's scheme) instead of re-adding three raw rows
+#endif
 
 template <bool SSIM, int SKIP, bool ACC>
 struct BwdCtx {
+  static constexpr bool kScan = (SKIP >= 1) || !SMD_BWD_ROWSEL;        // `sel` of the whole strip scanned before the row loop
+  static constexpr bool kSliding = (SKIP == 0) && SMD_BWD_STATEFUL;    // (a gated loop skips rows: no running state)
+  static constexpr bool kPeel = SMD_BWD_PEEL;
   const ReconBwdArgs& a;
   // wave-uniform
   int h, w, r0, r1, pb0, pb1;
+  int rb;                            // image row of bit 0 of selbits / L / N (r0 - 3: every row a step looks at has a bit index >= 0)
+  unsigned L, N;
   bool use_min, add_gin, acc_prev;   // add_gin: this pass adds the gradient that reaches the depth from other consumers; acc_prev: a
                                      // previous pass of this wave (n > 4) left its share in the LDS rows
   unsigned w4, rowbytes, so_tex, so_y, so_ta, so_tb;
   float xmax, ymax, wpf;
+  float g_ssim, g_l1;                // upstream gradient x term weight of a pixel that routes gradient to this support
   Cam2 cm;
   rsrc_t rs_pk, rs_depth, rs_sel, rs_gd, rs_gin;
   // per-lane constants
   unsigned lane4, lane1;
-  bool interior;
+  bool interior, col_ok;
   float wla, wra, hx0, hy0, hz0;
-  // upstream gradient x term weight for the columns of the image (0 for halo lanes outside it), as the values a pixel gets
-  // when its `sel` equals / differs from `sel_key` (min-reprojection: the support index; mean: the "masked" code)
-  float gs_eq, gs_ne, gl_eq, gl_ne;
   unsigned sel_key;
+  unsigned selbits;            // kScan: bit i = the pixel (row rb + i, this lane's column) routes gradient to the current support
+  unsigned SELR[3];            // !kScan: `sel` of the rows in flight, [row mod 3]
   float* hist;                 // this lane's column of the wave's LDS history: 3 row slots x {gx, gy} x 3 channels
   float* gacc;                 // ACC: this lane's column of the wave's dL/d depth rows (this wave's supports), one slot per strip row (LDS)
   // state
   float X[3][3], Y[3][3];      // [row mod 3][channel]: re-synthesised warped pixel / target pixel
-  float Px[3], Pxx[3], Pxy[3]; // sliding vertical sums: rows j-1 + j-2 once row j is in
+  float Px[3], Pxx[3], Pxy[3]; // kSliding: vertical sums of rows j-1 + j-2 once row j is in
   float HC[3][3][3];           // [row mod 3][channel][{A, B, C}]: h-summed partials d/d(Sx, Sxx (x2), Sxy) of a centre row
-  unsigned SEL[3];
-  unsigned live_hist;          // bit k: the k-th most recent centre row produced coefficients (wave-uniform)
   f3 t0, t1, t2, t3, py;       // loads in flight for the next row
   float pfx, pfy;
   float Dn;                    // depth of row j+1 (for the next issue); it then waits in LDS for stage C three steps later
@@ -127,12 +147,51 @@ struct BwdCtx {
 #endif
   }
 
-  __device__ __forceinline__ int reflect_row(int r) const { return (r > h - 1) ? max(2*(h - 1) - r, 0) : r; }
+  // ReflectionPad2d(1) by data, above and below the image: row -1 is row 1, row h is row h-2 (rows further out only feed the dummy
+  // centre rows -1 / h of the peeled form, whose coefficients are exact zeros: any valid row will do)
+  __device__ __forceinline__ int reflect_row(int r) const { return (r < 0) ? min(-r, h - 1) : ((r > h - 1) ? max(2*(h - 1) - r, 0) : r); }
+  __device__ __forceinline__ bool bit(unsigned m, int row) const { return (m >> (unsigned)(row - rb)) & 1u; }
+  __device__ __forceinline__ bool routes(unsigned v) const { return (v == sel_key) == use_min; }   // min-reprojection: sel == support; mean: sel != "masked"
+
+  // kScan: `sel` of the centre rows pb0 .. pb1, once per support pass: which pixels / rows route gradient to the current support.  All of
+  // a strip's rows are requested before the first is looked at (two batches of ten: 8 + 2 rows of a tapered strip, 16 + 2 of a full
+  // one), and so are the depths of the first two rows of the pipeline: one round trip for the whole prologue.
+  __device__ __forceinline__ void sel_rows(int base, unsigned (&v)[kSelBatch]) const {
+#pragma unroll
+    for (int k = 0; k < kSelBatch; ++k)
+#if (SMD_ABLATE_BWD & 2)
+      v[k] = (lane1 + (unsigned)(base + k)) & 1u;
+#else
+      v[k] = bld8(rs_sel, lane1, (unsigned)min(max(base + k, 0), h - 1)*(unsigned)w);
+#endif
+  }
+  __device__ __forceinline__ void sel_bits(int base, const unsigned (&v)[kSelBatch]) {
+#pragma unroll
+    for (int k = 0; k < kSelBatch; ++k) {
+      const int p = base + k;
+      if (p <= pb1 && p >= 0 && p < h) {     // (dummy centre rows route nothing)
+        const bool on = col_ok && routes(v[k]);
+        const unsigned sh = (unsigned)(p - rb);
+        selbits |= (on ? 1u : 0u) << sh;
+        if (SKIP >= 1) L |= (__builtin_amdgcn_ballot_w64(on) != 0 ? 1u : 0u) << sh;
+      }
+    }
+  }
 
   __device__ __forceinline__ void begin(int jstart) {
+    selbits = 0u; L = 0xffffffffu; N = 0xffffffffu;
+    unsigned va[kSelBatch], vb[kSelBatch];
+    const bool two = pb1 - pb0 >= kSelBatch;
+    if (kScan) {
+      L = 0u;
+      sel_rows(pb0, va);
+      if (two) sel_rows(pb0 + kSelBatch, vb);
+    }
+    const float Dfirst = bld(rs_depth, lane4, (unsigned)reflect_row(jstart)*w4);          // (speculative with SKIP: two loads per wave)
+    Dn = bld(rs_depth, lane4, (unsigned)reflect_row(jstart + 1)*w4);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      SEL[r] = SMD_SEL_MASKED;
+      SELR[r] = SMD_SEL_MASKED;
 #pragma unroll
       for (int c = 0; c < 3; ++c) { X[r][c] = 0.f; Y[r][c] = 0.f; HC[r][c][0] = 0.f; HC[r][c][1] = 0.f; HC[r][c][2] = 0.f; }
     }
@@ -140,81 +199,105 @@ struct BwdCtx {
     for (int c = 0; c < 3; ++c) { Px[c] = 0.f; Pxx[c] = 0.f; Pxy[c] = 0.f; }
 #pragma unroll
     for (int k = 0; k < 9; ++k) ps[k] = 0.f;
-    live_hist = 0;
-    const float Dfirst = bld(rs_depth, lane4, (unsigned)jstart*w4);
-    issue(jstart, Dfirst);
-    hist[(0*kHist + 6)*64] = Dfirst;               // row jstart lives in slot 0 (read by stage C only when the strip starts at row 0)
-    Dn = bld(rs_depth, lane4, (unsigned)reflect_row(jstart + 1)*w4);
+    t0 = f3{0.f, 0.f, 0.f}; t1 = t0; t2 = t0; t3 = t0; py = t0; pfx = 0.f; pfy = 0.f;
+    if (kScan) {
+      sel_bits(pb0, va);
+      if (two) sel_bits(pb0 + kSelBatch, vb);
+      for (int base = pb0 + 2*kSelBatch; base <= pb1; base += kSelBatch) { sel_rows(base, va); sel_bits(base, va); }   // strips taller than 18 rows (single support only)
+      if (SKIP >= 1) N = L | (L << 1) | (L >> 1); else L = 0xffffffffu;
+    }
+    if (SKIP == 0 || bit(N, jstart)) {
+      issue(reflect_row(jstart), Dfirst);
+      hist[(0*kHist + 6)*64] = Dfirst;             // row jstart lives in slot 0
+    }
   }
 
   // One row step: stage A on row j (slot PH), stage B on centre row p = j-1, stage C on row q = j-2.
-  template <int PH>
+  // DOB / DOC: 0 / 1 = the stage is compiled out / in (peeled form: the first two steps of a strip only synthesise, the next two also
+  // have a centre row, from the fifth on every step carries all three stages and the body has no range checks); 2 = decided per step
+  // from the rows' ranges (the compact form: one body per phase).
+  template <int PH, int DOB, int DOC>
   __device__ __forceinline__ void step(int j_) {
     const int j = __builtin_amdgcn_readfirstlane(j_);   // pin the row counter to an SGPR (row offsets are scalar operands of the buffer accesses)
     constexpr int SN = PH, SP = (PH + 2) % 3, SQ = (PH + 1) % 3;
     constexpr float c1 = 81.f*kC1;     // window sums stay un-normalised (x9), see smd_recon_fwd.hip
     const int p = j - 1, q = j - 2;
-    const bool doB = SSIM && p >= pb0 && p <= pb1;
-    const bool doC = q >= r0 && q < r1;
+    const bool inB = SSIM && DOB != 0 && (DOB == 1 || (p >= pb0 && p <= pb1));
+    const bool inC = DOC != 0 && (DOC == 1 || (q >= r0 && q < r1));
+    const bool doB = inB && (SKIP == 0 || bit(L, p));
+    const bool doC = inC && (SKIP == 0 || bit(N, q));
+    const bool doA = SKIP == 0 || bit(N, j);
+    const bool doI = SKIP == 0 || bit(N, j + 1);      // row j+1 is needed: request its taps now, park its depth at the end of the step
+    const bool doD = SKIP == 0 || bit(N, j + 2);      // row j+2 is needed: request its depth now
+
     f4 ta; f3 tb;                                   // read only where doB holds
-#if (SMD_ABLATE_BWD & 2)
-    SEL[SP] = (lane1 + (unsigned)p) & 1u;
-    if (doB) { ta = f4{pfx + 1.f, pfy + 1.f, 1.5f, 0.3f}; tb = f3{0.2f, 0.4f, 0.1f}; }
-#else
-    SEL[SP] = bld8(rs_sel, lane1, (unsigned)p*(unsigned)w);   // rows outside the image read 0 and are never used
+#if !(SMD_ABLATE_BWD & 2)
+    if (!kScan) SELR[SP] = bld8(rs_sel, lane1, (unsigned)min(max(p, 0), h - 1)*(unsigned)w);
+#endif
     if (doB) {
-      ta = bld4(rs_pk, lane4*4u, so_ta + (unsigned)p*w4*4u);
-      const f2 tb2 = bld2(rs_pk, lane4*4u, so_tb + (unsigned)p*w4*4u);   // {c1, c2}; the third entry is the forward's static error
-      tb = f3{tb2.x, tb2.y, 0.f};
-    }
-#endif
-    // ================= stage A: row j — the warped pixel and its bilinear partials from the taps issued one step earlier
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float dn = t1[c] - t0[c], ds = t3[c] - t2[c];
-      const float top = fmaf(pfx, dn, t0[c]), bot = fmaf(pfx, ds, t2[c]);
-      const float ddy = bot - top;
-      X[SN][c] = fmaf(pfy, ddy, top);
-      Y[SN][c] = py[c];
-#if (SMD_ABLATE_BWD & 8)
-      GH[SN][c] = fmaf(pfy, ds - dn, dn); GH[SN][3 + c] = ddy;
-#else
-      hist[(SN*kHist + c)*64] = fmaf(pfy, ds - dn, dn);   // dx/dsx; the border-clamp mask is applied in stage C
-      hist[(SN*kHist + 3 + c)*64] = ddy;                  // dx/dsy
-#endif
-    }
-    // Next row's loads, unconditionally (also after the last row, where nothing consumes them): a conditional issue would turn
-    // every register of the in-flight loads into a loop phi with a second copy.  Below the image the next row is the
-    // reflected one (ReflectionPad2d(1): row h is row h-2), re-synthesised like any other row: no special case in vector code.
-    issue(reflect_row(j + 1), Dn);
-    const float Dkeep = Dn;                          // depth of row j+1: parked in LDS at the end of the step (slot SQ is read first)
 #if (SMD_ABLATE_BWD & 2)
-    Dn = 1.f + pfx;
+      ta = f4{pfx + 1.f, pfy + 1.f, 1.5f, 0.3f}; tb = f3{0.2f, 0.4f, 0.1f};
 #else
-    Dn = bld(rs_depth, lane4, (unsigned)reflect_row(j + 2)*w4);
+      const unsigned pc = (unsigned)min(max(p, 0), h - 1);               // (dummy centre rows read a real row: their weight is an exact zero, their values must be finite)
+      ta = bld4(rs_pk, lane4*4u, so_ta + pc*w4*4u);
+      const f2 tb2 = bld2(rs_pk, lane4*4u, so_tb + pc*w4*4u);   // {c1, c2}; the third entry is the forward's static error
+      tb = f3{tb2.x, tb2.y, 0.f};
 #endif
+    }
+    // ================= stage A: row j — the warped pixel and its bilinear partials from the taps issued one step earlier
+    if (doA) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float dn = t1[c] - t0[c], ds = t3[c] - t2[c];
+        const float top = fmaf(pfx, dn, t0[c]), bot = fmaf(pfx, ds, t2[c]);
+        const float ddy = bot - top;
+        X[SN][c] = fmaf(pfy, ddy, top);
+        Y[SN][c] = py[c];
+#if (SMD_ABLATE_BWD & 8)
+        GH[SN][c] = fmaf(pfy, ds - dn, dn); GH[SN][3 + c] = ddy;
+#else
+        hist[(SN*kHist + c)*64] = fmaf(pfy, ds - dn, dn);   // dx/dsx; the border-clamp mask is applied in stage C
+        hist[(SN*kHist + 3 + c)*64] = ddy;                  // dx/dsy
+#endif
+      }
+    }
+    // Next row's loads.  SKIP = 0: unconditionally (also after the last row, where nothing consumes them).  Rows outside the image are
+    // reflected ones (ReflectionPad2d(1): row -1 is row 1, row h is row h-2), re-synthesised like any other row: no special case in vector code.
+    if (doI) issue(reflect_row(j + 1), Dn);
+    const float Dkeep = Dn;                          // depth of row j+1: parked in LDS at the end of the step (slot SQ is read first)
+    if (doD) {
+#if (SMD_ABLATE_BWD & 2)
+      Dn = 1.f + pfx;
+#else
+      Dn = bld(rs_depth, lane4, (unsigned)reflect_row(j + 2)*w4);
+#endif
+    }
 
     // ================= stage B: centre row p — SSIM partials, h-summed with the adjoint reflection weights
     if (SSIM) {
-      const float m = usel(p == 0, 2.f, 1.f);       // row -1 is row 1
+      // window sums of centre p from its three raw rows (slots SQ = p-1, SP = p, SN = p+1); the image's top and bottom rows get their
+      // reflected neighbour by data ("row -1" is a re-synthesised row 1, "row h" a re-synthesised row h-2)
       float Vx[3], Vxx[3], Vxy[3];
+      if (kSliding) {   // the forward's sliding scheme: V = P + r(j), then P' = r(j-1) + r(j); every step, whatever its centre row
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float xn = X[SN][c], xo = X[SP][c];
-        const float xx = xn*xn, xy = xn*Y[SN][c];
-        Vx[c] = fmaf(m, xn, Px[c]); Vxx[c] = fmaf(m, xx, Pxx[c]); Vxy[c] = fmaf(m, xy, Pxy[c]);
-        Px[c] = xo + xn; Pxx[c] = fmaf(xo, xo, xx); Pxy[c] = fmaf(xo, Y[SP][c], xy);
+        for (int c = 0; c < 3; ++c) {
+          const float xn = X[SN][c], xo = X[SP][c];
+          const float xx = xn*xn, xy = xn*Y[SN][c];
+          Vx[c] = Px[c] + xn; Vxx[c] = Pxx[c] + xx; Vxy[c] = Pxy[c] + xy;
+          Px[c] = xo + xn; Pxx[c] = fmaf(xo, xo, xx); Pxy[c] = fmaf(xo, Y[SP][c], xy);
+        }
       }
-      bool row_live = false;
-      float g2 = 0.f;
       if (doB) {
-        g2 = (SEL[SP] == sel_key) ? gs_eq : gs_ne;
-        // Rows in which no pixel of this wave selected the current support carry no gradient through their windows:
-        // skip the SSIM partials (wave-uniform branch; coherent regions of the min-reprojection / automask are common).
-        row_live = SKIP >= 1 ? (__builtin_amdgcn_ballot_w64(g2 != 0.f) != 0) : true;
-      }
-      live_hist = (live_hist << 1) | (row_live ? 1u : 0u);
-      if (row_live) {
+        float g2;
+        if (kScan) g2 = ((selbits >> (unsigned)(p - rb)) & 1u) ? g_ssim : 0.f;
+        else g2 = (col_ok && routes(SELR[SP])) ? g_ssim : 0.f;
+        if (!kSliding) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float xq = X[SQ][c], xp = X[SP][c], xn = X[SN][c];
+            Vx[c] = (xq + xp) + xn; Vxx[c] = fmaf(xn, xn, fmaf(xp, xp, xq*xq)); Vxy[c] = fmaf(xn, Y[SN][c], fmaf(xp, Y[SP][c], xq*Y[SQ][c]));
+          }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           float sx, sxx, sxy;
@@ -237,27 +320,27 @@ struct BwdCtx {
           const float dSxy = p9*a1;
           hsum_w3(dSx, dSxx2, dSxy, wla, wra, HC[SP][c][0], HC[SP][c][1], HC[SP][c][2]);
         }
-      } else if (SKIP >= 1) {
-        // (Without row skipping nothing needs clearing: every coefficient row that a stage C reads with a non-zero weight
-        // was computed, the others are stale-but-finite values times a zero weight.)
-        asm volatile("" ::: "memory");               // keep the clears inside the rarely taken branch
+      } else if (SKIP >= 1 && inB && ((N >> (unsigned)(p - 1 - rb)) & 7u) != 0u) {
+        // a dead centre row next to a live one: a stage C will read its coefficient row — as zeros
+        // (Without gating nothing needs clearing: every coefficient row that a stage C reads with a non-zero weight was computed.)
 #pragma unroll
         for (int c = 0; c < 3; ++c) { HC[SP][c][0] = 0.f; HC[SP][c][1] = 0.f; HC[SP][c][2] = 0.f; }
       }
     }
 
     // ================= stage C: row q — dL/dx -> dL/d(sx, sy) -> depth, pose sums
-    if (doC) {
-      // weights of coefficient rows q-1 / q+1 in the gradient of row q (reflect_weights_adj, on the scalar unit)
-      float lo_q = usel(q == 0, 0.f, usel(q == 1, 2.f, 1.f)), hi_q = usel(q == h - 1, 0.f, usel(q == h - 2, 2.f, 1.f));
-      if (h == 2) { lo_q = usel(q == 1, 2.f, 0.f); hi_q = usel(q == 0, 2.f, 0.f); }
-      const float gl = (SEL[SQ] == sel_key) ? gl_eq : gl_ne;
-      // coefficient rows q-1, q, q+1 all skipped and no L1 term anywhere in the wave: the gradient of this row is zero
-      const bool dead = SKIP >= 2 ? ((live_hist & 7u) == 0u && __builtin_amdgcn_ballot_w64(gl != 0.f) == 0) : false;
+    if (inC) {
       const unsigned qro = (unsigned)q*w4;
-      const float D2 = hist[(SQ*kHist + 6)*64];
       float gD = 0.f;
-      if (!dead) {
+      float D2 = 0.f;
+      if (doC) {
+        // weights of coefficient rows q-1 / q+1 in the gradient of row q (reflect_weights_adj, on the scalar unit)
+        float lo_q = usel(q == 0, 0.f, usel(q == 1, 2.f, 1.f)), hi_q = usel(q == h - 1, 0.f, usel(q == h - 2, 2.f, 1.f));
+        if (h == 2) { lo_q = usel(q == 1, 2.f, 0.f); hi_q = usel(q == 0, 2.f, 0.f); }
+        float gl;
+        if (kScan) gl = ((selbits >> (unsigned)(q - rb)) & 1u) ? g_l1 : 0.f;
+        else gl = (col_ok && routes(SELR[SQ])) ? g_l1 : 0.f;
+        D2 = hist[(SQ*kHist + 6)*64];
         float gpx = 0.f, gpy = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -296,30 +379,46 @@ struct BwdCtx {
       }
       // dL/d depth of this support.  K0 fused: d depth / d(up-sampled, scaled disparity) is applied here, where the depth is at
       // hand (linear, so per support); what reaches the depth from other consumers is added once, by the wave of support 0.
-      if (add_gin) gD += bld(rs_gin, lane4, qro);
+      if (add_gin) {
+        gD += bld(rs_gin, lane4, qro);
+        if (SKIP >= 1 && !doC) D2 = bld(rs_depth, lane4, qro);     // a skipped row never had its depth parked
+      }
       if (a.k0_scale != 0.f) gD *= (D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f;
 #if (SMD_ABLATE_BWD & 4)
       if (gD == 12345.678f) bst(rs_gd, lane4, qro, gD);
       else
 #endif
       if (ACC) {
-        // The supports of a strip are summed from LDS after the block barrier (k_recon_bwd): each lane parks its own column, one
+        // The supports of a strip are summed from LDS by the strip's last wave (k_recon_bwd): each lane parks its own column, one
         // slot per strip row; no read-modify-write of g_depth, one global store per pixel.
         float* slot = gacc + (q - r0)*64;
         if (acc_prev) gD += *slot;
         *slot = gD;
       } else if (interior) bst(rs_gd, lane4, qro, gD);   // a single support: the row is final
     }
-    hist[(SQ*kHist + 6)*64] = Dkeep;               // row j+1's slot: stage C reads it at step j+3 (no second load of the depth)
+    if (doI) hist[(SQ*kHist + 6)*64] = Dkeep;      // row j+1's slot: stage C reads it at step j+3 (no second load of the depth)
   }
 
   __device__ __forceinline__ void run(int jstart) {
     begin(jstart);
     const int jend = r1 + 1;
-    for (int j = jstart;;) {
-      step<0>(j); if (++j > jend) break;
-      step<1>(j); if (++j > jend) break;
-      step<2>(j); if (++j > jend) break;
+    int j = jstart;
+    if (kPeel) {                           // jstart = r0 - 2: r1 - r0 + 4 >= 5 steps
+      step<0, 0, 0>(j); ++j;
+      step<1, 0, 0>(j); ++j;
+      step<2, 1, 0>(j); ++j;
+      step<0, 1, 0>(j); ++j;
+      for (;;) {
+        step<1, 1, 1>(j); if (++j > jend) break;
+        step<2, 1, 1>(j); if (++j > jend) break;
+        step<0, 1, 1>(j); if (++j > jend) break;
+      }
+    } else {
+      for (;;) {
+        step<0, 2, 2>(j); if (++j > jend) break;
+        step<1, 2, 2>(j); if (++j > jend) break;
+        step<2, 2, 2>(j); if (++j > jend) break;
+      }
     }
   }
 };
@@ -380,9 +479,9 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     cx.hist = wave_lds + lane;
     cx.gacc = cx.hist + 3*kHist*64;
     cx.h = h; cx.w = w;
-    cx.r0 = r0; cx.r1 = r1;
+    cx.r0 = r0; cx.r1 = r1; cx.rb = r0 - 3;
     const bool col_ok = (u >= 0) && (u < w);
-    cx.interior = interior;
+    cx.interior = interior; cx.col_ok = col_ok;
     cx.lane4 = (unsigned)uc*4u; cx.lane1 = (unsigned)uc;
     reflect_weights_adj(min(max(u, 0), w - 1), w, cx.wla, cx.wra);   // how much column u receives from u-1 / u+1
     if (!col_ok) { cx.wla = 0.f; cx.wra = 0.f; }
@@ -393,10 +492,8 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     cx.w4 = (unsigned)w*4u;
     float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
     if (!cx.use_min) gscale /= (float)a.n;
-    const float gm_ssim = col_ok ? gscale*(SSIM ? kWSsim/3.f : 0.f) : 0.f;
-    const float gm_l1 = col_ok ? gscale*(SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f) : 0.f;
-    cx.gs_eq = cx.use_min ? gm_ssim : 0.f; cx.gs_ne = cx.use_min ? 0.f : gm_ssim;
-    cx.gl_eq = cx.use_min ? gm_l1 : 0.f; cx.gl_ne = cx.use_min ? 0.f : gm_l1;
+    cx.g_ssim = uniform(gscale*(SSIM ? kWSsim/3.f : 0.f));      // (columns outside the image never route: scan_sel)
+    cx.g_l1 = uniform(gscale*(SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f));
     cx.xmax = (float)(w - 1); cx.ymax = (float)(h - 1); cx.wpf = (float)(w + 1);
 
     cx.rs_pk = make_rsrc(a.packed, packed_image_floats(a.b, a.n, h, w)*4);
@@ -411,8 +508,11 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, h, w) + packed_ypix_floats(a.b, h, w))*4) + (unsigned)bi*hw4*4u;
     cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, h, w)*4);
 
-    const int jstart = max(r0 - 2, 0);
-    cx.pb0 = max(r0 - 1, 0); cx.pb1 = min(r1, h - 1); // centre rows whose coefficients are needed
+    // rows outside the image are reflected ones (BwdCtx::reflect_row).  Peeled form: every strip runs rows r0-2 .. r1+1 with centre
+    // rows r0-1 .. r1 (-1 and h: dummy rows, exact zeros); compact form: the image's top strip starts at row -1 (= row 1) and no dummy rows
+    const bool peel = BwdCtx<SSIM, SKIP, ACC>::kPeel;
+    const int jstart = peel ? r0 - 2 : max(r0 - 2, -1);
+    cx.pb0 = peel ? r0 - 1 : max(r0 - 1, 0); cx.pb1 = peel ? r1 : min(r1, h - 1);   // centre rows whose coefficients are needed
 
     for (int i = kw; i < a.n; i += NS) {
       make_cam2(cx.cm, cx.hx0, cx.hy0, cx.hz0, a.T + ((size_t)i*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16,

@@ -8,6 +8,8 @@
 // Per image the loss is E/N with E = sum_edges w|dhat_p - dhat_q|, dhat = d / max(mean(d), eps).  E is 1-homogeneous
 // in dhat, so sum_p (dE/ddhat_p) dhat_p = E and the mean-normalisation term of the adjoint needs only (mean, E):
 //   dL/dd_q = g_s/N * [ G_q / m  -  [mean >= eps] * E / (m * hs*ws) ],   G_q = dE/ddhat_q.
+#include <stdlib.h>
+
 #include "smd_common.h"
 #include "smd_kernels.h"
 
@@ -55,57 +57,40 @@ __host__ __device__ inline size_t edge_offset(const ScaleSet& sc, int b, int s) 
   return off;
 }
 
-// Pass 1: per wave, partial sums of the UN-normalised edge energy E' = sum w |d_p - d_q| and of d itself.  Because
-// dhat = d / m with one m > 0 per image, E = E' / m: the mean is not needed inside the pixel loop, so the reference's
-// mean pass and its stencil pass collapse into one sweep.
-// Streaming form (round 2): a wave owns 63 columns + one halo lane and walks down kSmoothRows rows.  A row costs one disparity
-// load and the (resized) image pixel once — 3 loads at the image's own scale, 6 eight-byte loads at the coarser ones; the
-// right-hand neighbour is the next lane (DPP), the neighbour below is the next row's registers.  The texture unit charges a
-// wave load ~16.5 cycles whatever its width (scripts/dev/ta_probe.hip): the per-pixel form issued 13 / 40 loads per 64 pixels
-// (own scale / coarser scales), this one 4-5 / 8 per 63.
-struct SmoothRow { float d, ic[3]; };
+// Offset (bytes) of the arrival counters behind the edge weights: [S*b] pairs + 1 (smd_disp_smooth_edge_weight_bytes).
+__host__ __device__ inline size_t edge_arrive_offset(const ScaleSet& sc, int b) { return (edge_offset(sc, b, sc.S)*sizeof(float2) + 255) & ~(size_t)255; }
 
-// `arrive` != null: the second stage runs inside this launch (round 3; the former k_smooth_finalize launch) as a chain of wave-level
-// hand-offs without a block barrier (cdna_hip_programming.md, Guideline 16): a wave publishes its partial write-through and
-// drains; the LAST wave of a block counts the block's arrival for its (scale, sample) pair; the wave that completes a pair
-// reduces it to (mean, E) -> stats and publishes the pair's share of the loss; the wave that completes the last pair adds
-// the shares up in a fixed order.  fp64, deterministic whichever waves end up doing it.
-//   arrive[0 .. S*b): arrival counters of the pairs, arrive[S*b]: pairs done (zero on entry, reset by their last arrivers)
-//   contrib: [S*b] doubles behind the partials in the workspace
-__global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, int flags,
-                                                     float* partial, int max_units, float* __restrict__ edge_w, float* stats, float* loss,
-                                                     unsigned* arrive, double* contrib) {
-  const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y;   // coarse scales first
+// Frame-only half (round 4): the edge weights {exp(-mean_c |dI/dx|), exp(-mean_c |dI/dy|)} of every pyramid level depend on the target
+// frames alone — `SmoothReg` resizes the image to each level and differentiates it (src/core/handlers.py:272-277, smooth.py:12-30,
+// 91-94) — so they are computed by a launch of their own that the trainer enqueues with the reconstruction's frame-only prep, under
+// the networks; the sweep over the disparities (k_smooth_main) and the adjoint then read 8 bytes per pixel and never touch the image.
+// Streaming form: a wave owns 63 columns + one halo lane and walks down kSmoothRows rows; the (resized) image pixel is computed once
+// per pixel — 3 loads at the image's own scale, 6 eight-byte tap pairs at the coarser ones; the right-hand neighbour is the next lane
+// (DPP), the neighbour below the next row's registers.  Also zeroes the arrival counters of the sweep's in-launch second stage.
+__global__ __launch_bounds__(256) void k_smooth_edges(const ScaleSet sc, int b, const float* __restrict__ img, int h, int w, float* __restrict__ edge_w,
+                                                      unsigned* __restrict__ arrive) {
+  const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y;   // coarse scales first (few pixels, strided taps: the longest latency chains)
+  if (arrive != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int e = threadIdx.x; e < sc.S*b + 1; e += 256) arrive[e] = 0u;
   const int lane = threadIdx.x & 63, unit = blockIdx.x*4 + (threadIdx.x >> 6);
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
-  const int units = smooth_units_of(hs, ws);
-  __shared__ unsigned waves_done;
-  if (arrive != nullptr) {            // the only block barrier: at the start, where every wave still is
-    if (threadIdx.x == 0) waves_done = 0u;
-    __syncthreads();
-  }
-  if (unit >= units) return;
-  {
+  if (unit >= smooth_units_of(hs, ws)) return;
   const int nsx = (ws + kSmoothCols - 1)/kSmoothCols;
   const int sxi = unit % nsx, syi = unit/nsx;
   const int r0 = syi*kSmoothRows, r1 = min(r0 + kSmoothRows, hs);
-  const int u = sxi*kSmoothCols + lane, uc = min(u, ws - 1);        // lanes right of the image repeat its last column: |d - d| = 0
+  const int u = sxi*kSmoothCols + lane, uc = min(u, ws - 1);        // lanes right of the image repeat its last column
   const bool live = lane < kSmoothCols && u < ws;
-  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
   const float* __restrict__ im = img + (size_t)bi*3*h*w;
-  const bool edges = flags & SMD_USE_EDGES, ident = (hs == h && ws == w);
-  float2* __restrict__ ew = (edges && edge_w) ? (float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
+  const bool ident = (hs == h && ws == w);
+  float2* __restrict__ ew = (float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n;
   // horizontal half of the bilinear resize: constant per lane
   int x0 = uc, x1 = uc; float lx = 0.f;
   if (!ident) src_index_s(uc, (float)w/(float)ws, w, x0, x1, lx);
   const bool pair = (x1 == x0 + 1);                                  // false only where the right tap is clamped onto the left one
   const size_t hw = (size_t)h*w;
-
+  struct Row { float ic[3]; };
   auto load_row = [&](int v) {
-    SmoothRow r;
-    r.d = d[(size_t)v*ws + uc];
-    r.ic[0] = r.ic[1] = r.ic[2] = 0.f;
-    if (!edges) return r;
+    Row r;
     if (ident) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) r.ic[c] = im[(size_t)c*hw + (size_t)v*w + uc];
@@ -127,29 +112,67 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
     }
     return r;
   };
-
-  // every row of the strip (and the one below it) is requested before the first is used: the loop is latency-, not
-  // bandwidth-shaped (8 rows x 4-13 loads per wave), so all of them have to be in flight together
-  SmoothRow rows[kSmoothRows + 1];
+  // every row of the strip (and the one below it) is requested before the first is used: the loop is latency-shaped
+  Row rows[kSmoothRows + 1];
 #pragma unroll
   for (int k = 0; k <= kSmoothRows; ++k) rows[k] = load_row(min(r0 + k, hs - 1));   // the last image row pairs with itself
-  float accE = 0.f, accD = 0.f;
 #pragma unroll
   for (int k = 0; k < kSmoothRows; ++k) {
     const int v = r0 + k;
-    const SmoothRow& cur = rows[k];
-    const SmoothRow& nxt = rows[k + 1];
-    const float dr = lane_right(cur.d);
-    float wx = 1.f, wy = 1.f;
-    if (edges) {
-      const float ir0 = lane_right(cur.ic[0]), ir1 = lane_right(cur.ic[1]), ir2 = lane_right(cur.ic[2]);
-      wx = __expf(-(fabsf(cur.ic[0] - ir0) + fabsf(cur.ic[1] - ir1) + fabsf(cur.ic[2] - ir2))*(1.f/3.f));
-      wy = __expf(-(fabsf(cur.ic[0] - nxt.ic[0]) + fabsf(cur.ic[1] - nxt.ic[1]) + fabsf(cur.ic[2] - nxt.ic[2]))*(1.f/3.f));
-    }
-    if (live && v < r1) {
-      if (ew) ew[(size_t)v*ws + u] = make_float2(wx, wy);            // kept for the adjoint: it then never touches the image
-      accD += cur.d;
-      accE += fabsf(cur.d - dr)*wx + fabsf(cur.d - nxt.d)*wy;
+    const Row& cur = rows[k];
+    const Row& nxt = rows[k + 1];
+    const float ir0 = lane_right(cur.ic[0]), ir1 = lane_right(cur.ic[1]), ir2 = lane_right(cur.ic[2]);
+    const float wx = __expf(-(fabsf(cur.ic[0] - ir0) + fabsf(cur.ic[1] - ir1) + fabsf(cur.ic[2] - ir2))*(1.f/3.f));
+    const float wy = __expf(-(fabsf(cur.ic[0] - nxt.ic[0]) + fabsf(cur.ic[1] - nxt.ic[1]) + fabsf(cur.ic[2] - nxt.ic[2]))*(1.f/3.f));
+    if (live && v < r1) ew[(size_t)v*ws + u] = make_float2(wx, wy);
+  }
+}
+
+// The sweep over the disparities: per wave, partial sums of the UN-normalised edge energy E' = sum w |d_p - d_q| and of d itself.
+// Because dhat = d / m with one m > 0 per image, E = E' / m: the mean is not needed inside the pixel loop, so the reference's
+// mean pass and its stencil pass collapse into one sweep.  A wave owns 63 columns + one halo lane and kSmoothRows rows: one
+// disparity load and one 8-byte weight load per row, all in flight together; `edge_w` null = no edge weighting (weights 1).
+//
+// `arrive` != null: the second stage runs inside this launch (round 3; the former k_smooth_finalize launch) as a chain of wave-level
+// hand-offs without a block barrier (cdna_hip_programming.md, Guideline 16): a wave publishes its partial write-through and
+// drains; the LAST wave of a block counts the block's arrival for its (scale, sample) pair; the wave that completes a pair
+// reduces it to (mean, E) -> stats and publishes the pair's share of the loss; the wave that completes the last pair adds
+// the shares up in a fixed order.  fp64, deterministic whichever waves end up doing it.
+//   arrive[0 .. S*b): arrival counters of the pairs, arrive[S*b]: pairs done (zeroed by k_smooth_edges, reset by their last arrivers)
+//   contrib: [S*b] doubles behind the partials in the workspace
+__global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ edge_w, float* partial, int max_units,
+                                                     float* stats, float* loss, unsigned* arrive, double* contrib) {
+  const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y;   // coarse scales first
+  const int lane = threadIdx.x & 63, unit = blockIdx.x*4 + (threadIdx.x >> 6);
+  const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
+  const int units = smooth_units_of(hs, ws);
+  __shared__ unsigned waves_done;
+  if (arrive != nullptr) {            // the only block barrier: at the start, where every wave still is
+    if (threadIdx.x == 0) waves_done = 0u;
+    __syncthreads();
+  }
+  if (unit >= units) return;
+  {
+  const int nsx = (ws + kSmoothCols - 1)/kSmoothCols;
+  const int sxi = unit % nsx, syi = unit/nsx;
+  const int r0 = syi*kSmoothRows, r1 = min(r0 + kSmoothRows, hs);
+  const int u = sxi*kSmoothCols + lane, uc = min(u, ws - 1);        // lanes right of the image repeat its last column: |d - d| = 0
+  const bool live = lane < kSmoothCols && u < ws;
+  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
+  const float2* __restrict__ ew = edge_w ? (const float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
+  float dr_[kSmoothRows + 1];
+  float2 wr_[kSmoothRows];
+#pragma unroll
+  for (int k = 0; k <= kSmoothRows; ++k) dr_[k] = d[(size_t)min(r0 + k, hs - 1)*ws + uc];   // the last image row pairs with itself
+#pragma unroll
+  for (int k = 0; k < kSmoothRows; ++k) wr_[k] = ew ? ew[(size_t)min(r0 + k, hs - 1)*ws + uc] : make_float2(1.f, 1.f);
+  float accE = 0.f, accD = 0.f;
+#pragma unroll
+  for (int k = 0; k < kSmoothRows; ++k) {
+    const float cur = dr_[k], right = lane_right(cur);
+    if (live && r0 + k < r1) {
+      accD += cur;
+      accE += fabsf(cur - right)*wr_[k].x + fabsf(cur - dr_[k + 1])*wr_[k].y;
     }
   }
   const float totE = wave_sum(accE), totD = wave_sum(accD);
@@ -399,8 +422,16 @@ __global__ __launch_bounds__(256) void k_smooth_aux(const ScaleSet sc, int b, co
   }
 }
 
+hipError_t launch_smooth_edges(const ScaleSet& sc, int b, const float* img, int h, int w, float* edge_w, hipStream_t st) {
+  int max_chunks = 1;
+  for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_units_of(sc.hs[s], sc.ws[s]));
+  hipLaunchKernelGGL(k_smooth_edges, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, edge_w, (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)));
+  return hipGetLastError();
+}
+size_t smooth_edge_bytes(const ScaleSet& sc, int b) { return edge_arrive_offset(sc, b) + ((((size_t)sc.S*b + 1)*sizeof(unsigned) + 255) & ~(size_t)255); }
+
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
-                             float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, hipStream_t st) {
+                             float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, bool edges_ready, hipStream_t st) {
   int max_chunks = 1;   // units (waves) of the largest scale; the partial sums of a (scale, sample) are strided by it
   for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_units_of(sc.hs[s], sc.ws[s]));
   if (flags & SMD_USE_LAPLACIAN) {   // second-order form: one thread per pixel, two-launch second stage
@@ -413,10 +444,14 @@ hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h,
       hipLaunchKernelGGL(k_smooth_lap_aux, dim3(min(ceil_div(sc.hs[0]*sc.ws[0], 256), 480), b), dim3(256), 0, st, sc, b, img, h, w, stats, disp_grad, image_grad);
     return hipGetLastError();
   }
-  // in-launch second stage when the pairs fit the arrival-slot pool; `contrib` sits behind the partials in the workspace
-  unsigned* arrive = arrive_slots(sc.S*b + 1);
+  // Edge-aware: the weights come from k_smooth_edges (already run by smd_disp_smooth_prep when `edges_ready`), whose buffer also
+  // carries the arrival counters of the in-launch second stage; without edge weighting: the two-launch form.
+  const bool edges = (flags & SMD_USE_EDGES) && edge_w;
+  unsigned* arrive = edges ? (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)) : nullptr;
+  if (getenv("SMD_SMOOTH_CHAIN") && atoi(getenv("SMD_SMOOTH_CHAIN")) == 0) arrive = nullptr;   // A/B switch: second stage as a launch of its own
+  if (edges && !edges_ready) hipLaunchKernelGGL(k_smooth_edges, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, edge_w, (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)));
   double* contrib = (double*)(ws_sums + (size_t)sc.S*b*max_chunks*2);
-  hipLaunchKernelGGL(k_smooth_main, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, flags, ws_sums, max_chunks, edge_w,
+  hipLaunchKernelGGL(k_smooth_main, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, edges ? edge_w : nullptr, ws_sums, max_chunks,
                      stats, loss, arrive, contrib);
   if (!arrive) hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss, 0);
   if (disp_grad || image_grad)

@@ -110,11 +110,17 @@ def disp_to_depth(disps, size, min_depth=None, max_depth=None, want_disp_up=Fals
 
 # ---------------------------------------------------------------------------------------------------
 class PreparedFrames:
-    """What the reconstruction forward needs from the FRAMES alone (`smd_image_recon_prep`): the packed texel / target-window
-    buffer, the HIP event after which it is complete, and what it was built for.  It does not depend on any network output, so
-    the training step fills it on a side stream while the networks run (`MonoDepthModule.step`)."""
-    def __init__(self, packed, event, key):
-        self.packed, self.event, self.key = packed, event, key
+    """What the loss path needs from the FRAMES alone: the packed texel / target-window buffer of the reconstruction forward
+    (`smd_image_recon_prep`), optionally the edge weights of the smoothness term for the same pyramid (`smd_disp_smooth_prep`), the HIP
+    event after which they are complete, and what they were built for.  None of it depends on a network output, so the training step
+    fills it on a side stream while the networks run (`MonoDepthModule.step`)."""
+    def __init__(self, packed, event, key, edge_w=None):
+        self.packed, self.event, self.key, self.edge_w = packed, event, key, edge_w
+
+    def edges_for(self, imgs, hs, ws):
+        """The edge-weight buffer if it was built for this frame and pyramid, else None."""
+        if self.edge_w is None or self.key[0] != imgs.data_ptr() or self.key[2] != tuple(imgs.shape): return None
+        return self.edge_w if (self.key[5] == tuple(hs) and self.key[6] == tuple(ws)) else None
 
     def matches(self, imgs, supp_imgs, flags, hs, ws) -> bool:
         k = (imgs.data_ptr(), supp_imgs.data_ptr(), tuple(imgs.shape), tuple(supp_imgs.shape), int(flags) & _PREP_FLAGS,
@@ -125,13 +131,14 @@ class PreparedFrames:
 _PREP_FLAGS = FLAGS['use_min'] | FLAGS['use_automask'] | FLAGS['loss_l1']
 
 
-def image_recon_prep(imgs, supp_imgs, *, flags: int, pyramid=None, stream=None) -> PreparedFrames:
+def image_recon_prep(imgs, supp_imgs, *, flags: int, pyramid=None, stream=None, smooth_edges: bool = False) -> PreparedFrames:
     """Fill the frame-only buffer of the fused reconstruction for (imgs (b,3,h,w), supp_imgs (n,b,3,h,w)).
 
     :param flags: `recon_flags(...)` of the criterion that will consume it (the identity error of the automask is part of it).
     :param pyramid: [(hs, ws), ...] of the disparity pyramid when the K0-fused forward follows (its row table is built here).
     :param stream: `torch.cuda.Stream` to run on (default: the current one).  The returned object carries the completion event;
-        the forward that consumes it waits for that event on ITS stream."""
+        the forward that consumes it waits for that event on ITS stream.
+    :param smooth_edges: also compute the edge weights of `SmoothReg(use_edges=True)` for `pyramid` (`disp_smooth_fused(prepared=...)`)."""
     b, _, h, w = imgs.shape
     n = supp_imgs.shape[0]
     imgs_c = _check('imgs', imgs, (b, 3, h, w)); supp_c = _check('supp_imgs', supp_imgs, (n, b, 3, h, w))
@@ -145,14 +152,20 @@ def image_recon_prep(imgs, supp_imgs, *, flags: int, pyramid=None, stream=None) 
         packed = torch.empty(_lib.lib.smd_packed_supports_bytes(b, n, h, w)//4, device=dev, dtype=torch.float32)
         call('smd_image_recon_prep', imgs_c.data_ptr(), supp_c.data_ptr(), packed.data_ptr(), int_array(hs) if hs else None, int_array(ws) if ws else None,
              len(hs) if hs else 0, b, n, h, w, int(flags) & _PREP_FLAGS, st.cuda_stream)
+        edge_w = None
+        if smooth_edges and hs:
+            hs_a, ws_a = int_array(hs), int_array(ws)
+            edge_w = torch.empty(_lib.lib.smd_disp_smooth_edge_weight_bytes(hs_a, ws_a, len(hs), b), device=dev, dtype=torch.uint8)
+            call('smd_disp_smooth_prep', imgs_c.data_ptr(), hs_a, ws_a, len(hs), b, h, w, FLAGS['use_edges'], edge_w.data_ptr(), st.cuda_stream)
         event = torch.cuda.Event()
         event.record(st)
     if st is not cur:
         for t in (imgs_c, supp_c): t.record_stream(st)
         packed.record_stream(cur)
+        if edge_w is not None: edge_w.record_stream(cur)
     key = (imgs.data_ptr(), supp_imgs.data_ptr(), tuple(imgs.shape), tuple(supp_imgs.shape), int(flags) & _PREP_FLAGS,
            tuple(hs) if hs else None, tuple(ws) if ws else None)
-    return PreparedFrames(packed, event, key)
+    return PreparedFrames(packed, event, key, edge_w)
 
 
 def _packed_for(prepared, imgs, supp, flags, hs, ws, b, n, h, w, dev):
@@ -390,8 +403,9 @@ class _DispSmooth(torch.autograd.Function):
     """Fused `handlers.disp_smooth` (src/core/handlers.py:262-281) over every scale."""
 
     @staticmethod
-    def forward(ctx, img, flags, keys, want_aux, *disps):
+    def forward(ctx, img, flags, keys, want_aux, prepared, *disps):
         b, _, h, w = img.shape
+        img_in = img
         img = _check('imgs', img, (b, 3, h, w))
         disps = [_check(f'disp[{i}]', d) for i, d in enumerate(disps)]
         for d in disps:
@@ -407,9 +421,17 @@ class _DispSmooth(torch.autograd.Function):
         hs_a, ws_a, keys_a = int_array(hs), int_array(ws), int_array(keys)
         nbytes = _lib.lib.smd_disp_smooth_workspace_bytes(hs_a, ws_a, S, b)
         wsp = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
-        need_bwd = any(ctx.needs_input_grad[4:]) and (int(flags) & FLAGS['use_edges'])
-        ew = torch.empty(_lib.lib.smd_disp_smooth_edge_weight_bytes(hs_a, ws_a, S, b), device=dev, dtype=torch.uint8) if need_bwd else None
-        call('smd_disp_smooth_fwd', ptr_array([d.data_ptr() for d in disps]), hs_a, ws_a, keys_a, S, b, img.data_ptr(), h, w, int(flags),
+        # the edge weights depend on the frame alone: taken from `prepared` when it carries them for this frame and pyramid (filled on a side
+        # stream under the networks), otherwise the forward call fills a fresh buffer first; the backward reads them instead of the image
+        ew, cflags = None, int(flags)
+        if cflags & FLAGS['use_edges']:
+            if prepared is not None and not (cflags & FLAGS['use_laplacian']): ew = prepared.edges_for(img_in, hs, ws)
+            if ew is not None:
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(prepared.event); ew.record_stream(cur)
+                cflags |= FLAGS['edges_ready']
+            else: ew = torch.empty(_lib.lib.smd_disp_smooth_edge_weight_bytes(hs_a, ws_a, S, b), device=dev, dtype=torch.uint8)
+        call('smd_disp_smooth_fwd', ptr_array([d.data_ptr() for d in disps]), hs_a, ws_a, keys_a, S, b, img.data_ptr(), h, w, cflags,
              loss.data_ptr(), stats.data_ptr(), dg.data_ptr() if aux else None, ig.data_ptr() if aux else None,
              ew.data_ptr() if ew is not None else None, wsp.data_ptr(), nbytes, _stream())
         ctx.save_for_backward(img, stats, ew, *disps)
@@ -427,15 +449,17 @@ class _DispSmooth(torch.autograd.Function):
         call('smd_disp_smooth_bwd', ptr_array([d.data_ptr() for d in disps]), int_array(hs), int_array(ws), int_array(keys), S, b,
              img.data_ptr(), h, w, flags, stats.data_ptr(), ew.data_ptr() if ew is not None else None, g_loss.data_ptr(),
              ptr_array([g.data_ptr() for g in g_disps]), _stream())
-        return (None, None, None, None, *g_disps)
+        return (None, None, None, None, None, *g_disps)
 
 
-def disp_smooth_fused(disps: dict, imgs, *, use_edges: bool = False, want_aux: bool = True, use_laplacian: bool = False):
+def disp_smooth_fused(disps: dict, imgs, *, use_edges: bool = False, want_aux: bool = True, use_laplacian: bool = False, prepared: PreparedFrames | None = None):
     """disps {key: (b,1,hs,ws)} -> (loss, disp_grad|None, image_grad|None); aux maps are those of key 0.
-    `use_laplacian`: second-order differences, `SmoothReg(use_laplacian=True)` (src/regularizers/smooth.py:33-48)."""
+    `use_laplacian`: second-order differences, `SmoothReg(use_laplacian=True)` (src/regularizers/smooth.py:33-48).
+    `prepared`: `image_recon_prep(imgs, ..., pyramid=..., smooth_edges=True)` — its edge weights are used if they were built for `imgs` and
+    this pyramid (silently ignored otherwise)."""
     keys = [int(k) for k in disps.keys()]
     flags = (FLAGS['use_edges'] if use_edges else 0) | (FLAGS['use_laplacian'] if use_laplacian else 0)
-    return _DispSmooth.apply(imgs, flags, keys, want_aux, *disps.values())
+    return _DispSmooth.apply(imgs, flags, keys, want_aux, prepared, *disps.values())
 
 
 # ---------------------------------------------------------------------------------------------------

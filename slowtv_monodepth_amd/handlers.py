@@ -191,11 +191,12 @@ def depth_regr(crit, synth, photo, depths: dict, targets: torch.Tensor, imgs: to
     return loss, {'mask_regr': ld['mask_regr'].unflatten(0, (S, -1))[0]}
 
 
-def disp_smooth(crit, disps: dict, imgs: torch.Tensor, *, want_aux: bool = True):
+def disp_smooth(crit, disps: dict, imgs: torch.Tensor, *, want_aux: bool = True, prepared=None):
     """Smoothness over the raw (not up-sampled) multi-scale disparities: mean_s(loss_s / 2^s) (src/core/handlers.py:262-281).
 
     :param want_aux: also produce the two logging maps (one extra small launch); the training loop turns this off.
+    :param prepared: optional `functional.PreparedFrames` carrying the edge weights of `imgs` for this pyramid (frame-only, launched ahead).
     :return: (loss, {'disp_grad', 'image_grad'} of scale 0)
     """
-    loss, dg, ig = F.disp_smooth_fused(disps, imgs, use_edges=crit.use_edges, want_aux=want_aux, use_laplacian=getattr(crit, 'use_laplacian', False))
+    loss, dg, ig = F.disp_smooth_fused(disps, imgs, use_edges=crit.use_edges, want_aux=want_aux, use_laplacian=getattr(crit, 'use_laplacian', False), prepared=prepared)
     return loss, ({'disp_grad': dg, 'image_grad': ig} if want_aux and dg is not None else {})

@@ -41,14 +41,15 @@ class HipLossBackend:
         from . import functional as F
         return F.inv_intrinsics(K.float()) if K.is_cuda else None
 
-    def prepare_frames(self, crit, imgs, supp_imgs, pyramid, stream):
+    def prepare_frames(self, crit, imgs, supp_imgs, pyramid, stream, smooth_edges=False):
         """The frame-only half of the reconstruction forward (texel repack, target window sums, identity error of the automask:
         everything `handlers.image_recon` needs that no network output enters), enqueued on `stream` so that it runs under the
         networks instead of after them.  None when the fused operator will not be used for these tensors."""
         from . import functional as F
         if not imgs.is_cuda or imgs.shape[1] != 3 or crit.loss_name == 'l2' or imgs.dtype != torch.float32: return None
         if getattr(crit, 'mask_name', None): return None   # a masked criterion takes the un-fused operators (handlers.image_recon): nothing would read the buffer
-        return F.image_recon_prep(imgs, supp_imgs, flags=F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask), pyramid=pyramid, stream=stream)
+        return F.image_recon_prep(imgs, supp_imgs, flags=F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask), pyramid=pyramid, stream=stream,
+                                  smooth_edges=smooth_edges)
 
     def pose_matrices(self, aa, t, invert):
         """(N,3),(N,3) + python bool list -> (N,4,4); one launch for Rodrigues + the backward-in-time inverses."""
@@ -60,9 +61,9 @@ class HipLossBackend:
         from . import functional as F
         return F.intrinsics(fs.float(), cs.float(), size)
 
-    def disp_smooth(self, crit, disps, imgs, want_aux=True):
+    def disp_smooth(self, crit, disps, imgs, want_aux=True, prepared=None):
         from . import handlers
-        return handlers.disp_smooth(crit, {k: d.float() for k, d in disps.items()}, imgs, want_aux=want_aux)
+        return handlers.disp_smooth(crit, {k: d.float() for k, d in disps.items()}, imgs, want_aux=want_aux, prepared=prepared)
 
 
 class EventTimer:
@@ -222,7 +223,8 @@ class MonoDepthModule(nn.Module):
                     l, ld = self.backend.image_recon(crit, self.synth, fwd['depth_up'], fwd.get('mask_up'), y['imgs'], y['supp_imgs'],
                                                      fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux, K_inv=K_inv, **kw)
                 elif k == 'disp_smooth':
-                    l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'], want_aux=self.want_aux)
+                    kw = {'prepared': self._prepared} if self._prepared is not None else {}
+                    l, ld = self.backend.disp_smooth(crit, fwd['disp'], y['imgs'], want_aux=self.want_aux, **kw)
                 elif k == 'depth_regr':   # proxy-depth (Depth Hints) regression, src/core/trainer.py:425-433
                     if 'depth_hints' not in y: raise KeyError('Missing proxy depth prediction "depth_hints".')
                     from . import handlers
@@ -252,7 +254,7 @@ class MonoDepthModule(nn.Module):
 
     def step(self, batch, mode: str = 'train'):
         """One forward pass + losses (src/core/trainer.py:115-190) -> (loss, loss_dict, fwd)."""
-        if mode == 'train' and (self.ar_kwargs['p'] > 0 or self.ar_kwargs['ref_shape']):   # `training_step`: `batch = self.ar_aug(batch)` (trainer.py:106)
+        if mode == 'train':   # `training_step`: `batch = self.ar_aug(batch)` on every step (trainer.py:106) — at p = 0 it only draws `random.random()`
             from .aspect_ratio import aspect_ratio_aug
             batch = aspect_ratio_aug(batch, **self.ar_kwargs, resample=getattr(self.backend, 'crop_resize', None))
         x, y, m = batch
@@ -281,7 +283,9 @@ class MonoDepthModule(nn.Module):
         st = stream if stream is not None else self._prep_streams.setdefault(dev.index, torch.cuda.Stream(device=dev))
         h, w = y['imgs'].shape[-2:]
         pyramid = None if self.want_aux else [(max(h >> s, 1), max(w >> s, 1)) for s in self.scales]   # want_aux: depth comes from the K0 launch
-        return fn(crit, y['imgs'], y['supp_imgs'], pyramid, st)
+        reg = self.losses['disp_smooth'] if 'disp_smooth' in self.losses else None                    # its edge weights are frame-only too
+        edges = bool(pyramid) and reg is not None and getattr(reg, 'use_edges', False) and not getattr(reg, 'use_laplacian', False)
+        return fn(crit, y['imgs'], y['supp_imgs'], pyramid, st, **({'smooth_edges': True} if edges else {}))
 
     # ------------------------------------------------------------------------------------------------
     def configure_optimizers(self):

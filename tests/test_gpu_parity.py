@@ -1328,7 +1328,8 @@ def test_decoder_glue_bf16_io(F):
 def test_crop_resize_kernel_matches_reference_resize_and_oracle(F, golden):
     """`smd_crop_resize` (one launch for every image tensor of the batch + K): (1) the resize half against the REFERENCE's
     `resize_aug` output (pinned fixture), (2) crop + resize at odd / even window offsets against the oracle (crop = kornia's
-    published integer window, parity unpinned), (3) crop only and identity."""
+    `center_crop(align_corners=False)` resample restated from its published call chain, parity unpinned; 3e-5: the oracle builds its
+    sampling grid in fp32 like kornia, the kernel evaluates the closed form in fp64), (3) crop only, identity, windows that touch the border."""
     from oracle import aspect_ratio_oracle as A
     g = golden('ar_reference')
     x = {k[5:]: v for k, v in g.items() if k.startswith('in_x_')}; y = {k[5:]: v for k, v in g.items() if k.startswith('in_y_')}
@@ -1341,10 +1342,11 @@ def test_crop_resize_kernel_matches_reference_resize_and_oracle(F, golden):
     gen = torch.Generator().manual_seed(3)
     big = [torch.rand(2, 3, 37, 61, generator=gen), torch.rand(3, 2, 3, 37, 61, generator=gen), torch.rand(2, 1, 37, 61, generator=gen)]
     Kc = torch.rand(2, 4, 4, generator=gen)
-    for crop, out in (((20, 33), (32, 64)), ((21, 32), (32, 32)), ((37, 61), (64, 96)), ((19, 40), (19, 40)), ((37, 61), (37, 61)), ((2, 3), (32, 32))):
+    for crop, out in (((20, 33), (32, 64)), ((21, 32), (32, 32)), ((37, 61), (64, 96)), ((19, 40), (19, 40)), ((37, 61), (37, 61)), ((2, 3), (32, 32)),
+                      ((36, 61), (32, 64)), ((37, 60), (37, 60)), ((36, 60), (18, 30))):
         o_hip, K_hip = F.crop_resize([t.cuda() for t in big], crop, out, Kc.cuda())
         o_ref, K_ref = A.crop_resize(big, crop, out, Kc)
-        for a, r in zip(o_hip, o_ref): torch.testing.assert_close(a.cpu(), r, rtol=1e-5, atol=1e-6)
+        for a, r in zip(o_hip, o_ref): torch.testing.assert_close(a.cpu(), r, rtol=1e-5, atol=(1e-6 if crop == (37, 61) else 3e-5))
         torch.testing.assert_close(K_hip.cpu(), K_ref, rtol=1e-6, atol=1e-6)
     with pytest.raises(ValueError): F.crop_resize([big[0].cuda()], (40, 10), (32, 32))          # crop larger than the image
 
@@ -1365,7 +1367,7 @@ def test_aspect_ratio_aug_on_a_training_batch(F):
     xo, yo, mo = AR.aspect_ratio_aug((clone(xb, 'cpu'), clone(yb, 'cpu'), {}), p=1.0, ref_shape=(96, 320), resample=A.crop_resize)
     assert mh['augs'] == mo['augs'] and xh['imgs'].shape == xo['imgs'].shape and xh['imgs'].shape[-1] % 32 == 0
     for k in ('imgs', 'supp_imgs'):
-        torch.testing.assert_close(xh[k].cpu(), xo[k], rtol=1e-5, atol=1e-5); torch.testing.assert_close(yh[k].cpu(), yo[k], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(xh[k].cpu(), xo[k], rtol=1e-5, atol=2e-4); torch.testing.assert_close(yh[k].cpu(), yo[k], rtol=1e-5, atol=3e-5)   # (x: standardised, range ~ +-2.6/0.22)
     torch.testing.assert_close(yh['K'].cpu(), yo['K'], rtol=1e-6, atol=1e-6)
     cfg = {'net': {'depth': {'enc_name': 'resnet18', 'pretrained': False, 'dec_name': 'monodepth', 'out_scales': [0, 1, 2, 3]},
                    'pose': {'enc_name': 'resnet18', 'pretrained': False}},

@@ -43,7 +43,7 @@ def _handler_run(F, y, disps, aa, t, *, prepared_on, skip_env=None, monkeypatch=
     prepared = None
     if prepared_on is not None:
         side = torch.cuda.Stream() if prepared_on == 'side' else None
-        prepared = F.image_recon_prep(imgs, sup, flags=flags, pyramid=[tuple(v.shape[-2:]) for v in d.values()], stream=side)
+        prepared = F.image_recon_prep(imgs, sup, flags=flags, pyramid=[tuple(v.shape[-2:]) for v in d.values()], stream=side, smooth_edges=True)
         if side is not None:
             # unrelated traffic on the main stream between prep and its consumer: the consumer must wait for the EVENT, not be lucky
             junk = torch.empty(1 << 26, device=dev); junk.add_(1.0); del junk
@@ -61,12 +61,12 @@ def _handler_run(F, y, disps, aa, t, *, prepared_on, skip_env=None, monkeypatch=
         l_rec, ld = amd.handlers.image_recon(crit, amd.geometry.ViewSynth((h, w)), depths, None, imgs, sup, Ts, K, want_warp=False, prepared=prepared)
     finally:
         F.image_recon_fused_disp = real
-    l_sm, _ = amd.handlers.disp_smooth(reg, d, imgs, want_aux=False)
+    l_sm, _ = amd.handlers.disp_smooth(reg, d, imgs, want_aux=False, prepared=prepared)   # (its edge weights ride in the same prepared object)
     loss = l_rec + 0.001*l_sm
     loss.backward()
     torch.cuda.synchronize()
     assert (seen['prepared'] is not None) == (prepared_on is not None), 'the handler dropped (or invented) the prepared frames'
-    out = {'loss': loss.detach().clone(), 'l_rec': l_rec.detach().clone(), 'sel': seen['sel'].clone(), 'depth_up': seen['depth_up'].detach().clone(),
+    out = {'loss': loss.detach().clone(), 'l_rec': l_rec.detach().clone(), 'l_sm': l_sm.detach().clone(), 'sel': seen['sel'].clone(), 'depth_up': seen['depth_up'].detach().clone(),
            'automask': ld['automask'].clone(), 'aa': a_.grad.clone(), 't': t_.grad.clone()}
     out.update({f'disp_{s}': v.grad.clone() for s, v in d.items()})
     return out

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), f'{name} declared in include/smd_hotpath.h but not exported by {_lib.lib_path}'
         assert name in _lib.PROTOTYPES, f'{name} has no ctypes prototype'
     assert set(_lib.PROTOTYPES) <= declared
-    assert _lib.lib.smd_abi_version() == 4
+    assert _lib.lib.smd_abi_version() == 5
     assert _lib.lib.smd_image_recon_workspace_bytes(12, 2, 4, 192, 640) > 2*12*4*12*4   # at least the pose partials
     assert _lib.lib.smd_image_recon_workspace_bytes(0, 2, 4, 192, 640) == 0
     # image part (texels + target pixels + two window-term planes) + the tail: K0 row table for SMD_MAX_SCALES pyramid levels + 1 + b arrival counters (padded to 16 B)

@@ -255,7 +255,8 @@ def test_laplacian_smoothness_matches_reference(golden, use_edges):
 def test_aspect_ratio_sampling_and_resize_match_reference(golden):
     """Everything of src/core/aspect_ratio.py that runs without kornia, against the reference's own outputs: the seeded crop / resize
     shape sampling of this package's mirror, the oracle's resize of a whole batch (images, depth, K) and the not-applied branch
-    with a `ref_shape`.  (The crop itself: kornia's `center_crop`, restated — "parity unpinned", oracle/aspect_ratio_oracle.py.)"""
+    with a `ref_shape`.  (The crop itself: kornia's `center_crop`, restated — "parity unpinned", oracle/aspect_ratio_oracle.py; its
+    only anchors are in `test_center_crop_restatement_of_kornia` below.)"""
     import random
     from oracle import aspect_ratio_oracle as A
     from slowtv_monodepth_amd import aspect_ratio as AR
@@ -283,3 +284,33 @@ def test_aspect_ratio_sampling_and_resize_match_reference(golden):
         torch.testing.assert_close(xb[k], g[f'out2_x_{k}'], rtol=1e-6, atol=1e-6); torch.testing.assert_close(yb[k], g[f'out2_y_{k}'], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(yb['K'], g['out2_y_K'], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(yb['depth'], g['out2_y_depth'], rtol=1e-6, atol=1e-6)
+
+
+def test_center_crop_restatement_of_kornia():
+    """The crop half of the augmentation is `kornia.geometry.transform.center_crop(size, mode='bilinear', align_corners=False)`
+    (src/core/aspect_ratio.py:78); kornia is not in this image, so it cannot be pinned on reference vectors.  The restatement of
+    kornia 0.6.10's chain (`crop_by_boxes` -> `warp_affine` with (n - 1)-normalised matrices -> `affine_grid` / `grid_sample`) is
+    anchored on what IS known: (1) with `align_corners=True` — kornia's documented behaviour — it reduces to the integer slice
+    `[int(H/2 - h/2) : + h]`; (2) with the reference's `align_corners=False` it equals the closed form
+    x(i) = ((i + 0.5)(w - 1)/w + x0) W/(W - 1) - 0.5 sampled bilinearly with zero padding (what `smd_crop_resize` implements), which is
+    NOT the slice: at 640 -> 320 column 0 reads x = 160.25; (3) a crop of the whole frame is the identity in both conventions."""
+    from oracle import aspect_ratio_oracle as A
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 37, 61, generator=gen)
+    assert A.crop_window((192, 640), (96, 320)) == (48, 160) and A.crop_window((37, 61), (20, 33)) == (8, 14) and A.crop_window((37, 61), (21, 32)) == (8, 14)
+    assert abs(A.crop_source_coords(320, 160, 640)[0].item() - 160.2496) < 1e-3
+    for crop in ((20, 33), (21, 32), (2, 3), (19, 40), (37, 61), (36, 61), (37, 60)):
+        y0, x0 = A.crop_window((37, 61), crop)
+        sl = x[..., y0:y0 + crop[0], x0:x0 + crop[1]]
+        torch.testing.assert_close(A.center_crop(x, crop, align_corners=True), sl, rtol=0, atol=2e-5)          # (1)
+        got = A.center_crop(x, crop)
+        ys, xs = A.crop_source_coords(crop[0], y0, 37), A.crop_source_coords(crop[1], x0, 61)
+        yf, xf = ys.floor().long(), xs.floor().long()
+        ly, lx = (ys - ys.floor()).float()[:, None], (xs - xs.floor()).float()[None, :]
+        def tap(yy, xx):
+            ok = ((yy >= 0) & (yy < 37))[:, None] & ((xx >= 0) & (xx < 61))[None, :]
+            return x[..., yy.clamp(0, 36)[:, None], xx.clamp(0, 60)[None, :]]*ok
+        want = (1 - ly)*((1 - lx)*tap(yf, xf) + lx*tap(yf, xf + 1)) + ly*((1 - lx)*tap(yf + 1, xf) + lx*tap(yf + 1, xf + 1))
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-5)                                               # (2)
+        if crop == (37, 61): torch.testing.assert_close(got, x, rtol=0, atol=2e-5)                               # (3)
+        elif crop[0] < 37 and crop[1] < 61: assert (got - sl).abs().max() > 0.05, 'align_corners=False must NOT be the slice'

@@ -81,7 +81,7 @@ def fake_recon(stacked, imgs, supp, Ts, Ks, K_inv=None, *, flags, noise=None, se
     calls.append(('image_recon_fused', tuple(stacked.shape), flags))
     S, b = stacked.shape[:2]; h, w = imgs.shape[-2:]
     return stacked.mean(), torch.zeros(S, b, 1, h, w), torch.zeros(S, b, 1, h, w, dtype=torch.uint8), torch.zeros_like(supp)
-def fake_smooth(disps, img, use_edges=False, want_aux=True, use_laplacian=False):
+def fake_smooth(disps, img, use_edges=False, want_aux=True, use_laplacian=False, prepared=None):
     calls.append(('disp_smooth_fused', len(disps), bool(use_edges)))
     d0 = disps[min(disps)]
     return sum(d.mean() for d in disps.values()), torch.zeros_like(d0), torch.zeros_like(d0)
