@@ -202,6 +202,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    kernel_variants = (_lib.lib.smd_last_kernel_variant(0).decode() or 'unknown', _lib.lib.smd_last_kernel_variant(1).decode() or 'unknown')
     fwd_ms = collect_profile(_lib.lib, 0, args.steps); bwd_ms = collect_profile(_lib.lib, 1, args.steps)
     fwd_all_ms = collect_profile(_lib.lib, 2, args.steps); bwd_all_ms = collect_profile(_lib.lib, 3, args.steps)
     prep_ms = collect_profile(_lib.lib, 4, args.steps)
@@ -229,6 +230,7 @@ def main():
         from slowtv_monodepth_amd import functional as _F
         tuner = _F.row_skip_tuner(torch.cuda.current_device())
         skipping = (int(os.environ['SMD_BWD_SKIP']) >= 1) if 'SMD_BWD_SKIP' in os.environ else tuner.skip
+        k_fwd, k_bwd = kernel_variants
         out = {
             'metric': BASELINE_METRIC,
             'value': round(wl['b']*world*args.steps/elapsed, 2), 'unit': 'images/s',
@@ -241,7 +243,7 @@ def main():
                        'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6),
                        'rccl_ranks': rccl_ranks, 'dp_impl': (os.environ.get('SMD_DP_IMPL', 'flat') if rccl_ranks > 1 or os.environ.get('SMD_FORCE_DDP') == '1' else None),
                        'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3)},
-            'roofline': {'kernel': f'smd::k_recon_main<{n}, true, true, false, true, 1, true> (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch, the four scales of a strip per block; name as rocprofv3 prints it)', 'bound': 'hbm',
+            'roofline': {'kernel': f'{k_fwd} (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; the instantiation the library reports for the last forward launch, name as rocprofv3 prints it)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,
                          'whole_forward_ms': round(fa_ms, 5), 'whole_forward_launches': 'the forward entry point on the critical path: k_recon_main (all 4 scales; the loss is reduced inside it by the last block)',
@@ -250,7 +252,7 @@ def main():
                          'forward_incl_prep_frac': round(B_fwd/((fa_ms + p_ms)*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
                          'algorithmic_bytes': B_fwd, 'avg_kernel_ms': round(f_ms, 5), 'launches_timed': len(fwd_ms),
                          'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
-            'roofline_bwd': {'kernel': f'smd::k_recon_bwd<true, {2 if skipping else 0}, {min(n, 4)}, true> (fused adjoint, one wave per (strip, support); the pose / intrinsics epilogue rides in the K0-adjoint launch that follows; name as rocprofv3 prints it)', 'bound': 'hbm',
+            'roofline_bwd': {'kernel': f'{k_bwd} (fused adjoint, one wave per (strip, support); the pose / intrinsics epilogue rides in the K0-adjoint launch that follows; the instantiation the library reports for the last backward launch)', 'bound': 'hbm',
                              'row_loop': {'dead_row_skipping': skipping, 'timed': tuner.last,
                                           'chosen_by': 'SMD_BWD_SKIP' if 'SMD_BWD_SKIP' in os.environ else 'functional.row_skip_tuner: four early backward calls of every 128 alternate between the two row loops (same gradients bit for bit) with HIP events around the entry point; skipping is kept if it is more than 3 % faster (profiles/r03_skip_regimes.txt)'},
                              'achieved': round(B_bwd/(b_ms*1e-3)/1e9, 1) if b_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

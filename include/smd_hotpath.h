@@ -320,6 +320,9 @@ int smd_crop_resize(const float* const* src, float* const* dst, const int* plane
 #define SMD_PROF_RECON_FWD_ALL 2   /* smd_image_recon_fwd, every launch */
 #define SMD_PROF_RECON_BWD_ALL 3   /* smd_image_recon_bwd, every launch */
 #define SMD_PROF_RECON_PREP 4      /* k_recon_prep launches (inside the forward entry point or smd_image_recon_prep) */
+/* The template instantiation the process's last fused forward (which = SMD_PROF_RECON_FWD) / backward (SMD_PROF_RECON_BWD) launch
+ * picked, spelled as rocprofv3 prints kernel names ("smd::k_recon_main<2, true, true, false, true, 1, true>"); "" before the first launch. */
+const char* smd_last_kernel_variant(int which);
 int smd_profile_enable(int which, int capacity);
 int smd_profile_collect(int which, float* ms_out, int max_out, int* n_out);
 

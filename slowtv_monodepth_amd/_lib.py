@@ -30,6 +30,7 @@ _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 PROTOTYPES = {
     'smd_last_error': (C.c_char_p, []),
     'smd_abi_version': (_i, []),
+    'smd_last_kernel_variant': (C.c_char_p, [_i]),
     'smd_disp_to_depth_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     'smd_disp_to_depth_workspace_bytes': (_sz, [_vp, _vp, _i, _i, _i, _i]),
     'smd_disp_to_depth_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),

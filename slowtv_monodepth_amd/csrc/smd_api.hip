@@ -129,9 +129,21 @@ int fill_scales(smd::ScaleSet& sc, const float* const* p, float* const* g, const
 
 }  // namespace
 
+namespace smd {
+char g_variant[2][128] = {"", ""};   // process-wide on purpose: autograd launches the backward from its own thread, the caller asks from another (a diagnostic label, last writer wins)
+void note_variant(int which, const char* fmt, ...) {
+  if (which < 0 || which > 1) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_variant[which], sizeof(g_variant[which]), fmt, ap);
+  va_end(ap);
+}
+}  // namespace smd
+
 extern "C" {
 
 const char* smd_last_error(void) { return g_err; }
+const char* smd_last_kernel_variant(int which) { return (which == 0 || which == 1) ? smd::g_variant[which] : ""; }
 int smd_abi_version(void) { return SMD_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------

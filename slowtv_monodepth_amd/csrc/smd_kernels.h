@@ -172,6 +172,7 @@ __device__ __forceinline__ void decode_wave(unsigned p, int wid, int nstrips, in
   strip = xb*kWavesPerBlock + wid;
 }
 
+void note_variant(int which, const char* fmt, ...);   // smd_api.hip: the instantiation a fused launch picked (which: 0 forward, 1 backward), process-wide
 // launchers (return hipError_t from hipGetLastError after the launch)
 hipError_t launch_recon_prep(const ReconPrepArgs& a, hipStream_t st);
 hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st);

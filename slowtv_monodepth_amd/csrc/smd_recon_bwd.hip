@@ -22,6 +22,11 @@
 #include "smd_kernels.h"
 #include "smd_pose_fin.h"
 
+// The row-loop variants (plain / gated, and whatever the experiment switches select) promise the SAME gradients bit for bit: every
+// fused multiply-add in this file is written as one (fmaf); left to -ffp-contract=fast the compiler decides per instantiation which
+// a*b + c it fuses, and two instantiations of the same source then differ in the last bit.
+#pragma clang fp contract(off)
+
 #ifndef SMD_ABLATE_BWD
 #define SMD_ABLATE_BWD 0   // diagnosis builds only (scripts/dev/ablate_bwd.sh): bit 0 no tap gathers, bit 1 no row loads, bit 2 no g_depth traffic, bit 3 no LDS
 #endif
@@ -75,13 +80,13 @@ constexpr int kSelBatch = 10;   // `sel` rows requested at once by the prologue 
 
 // Experiment switches of the row loop (scripts/dev/bwd_lib_variants.sh builds one library per combination; the defaults are what won):
 #ifndef SMD_BWD_PEEL
-#define SMD_BWD_PEEL 0       // 1: the pipeline's fill (two A-only steps, two A+B steps) is peeled off and the steady-state body has no range checks
+#define SMD_BWD_PEEL 1       // 1: the pipeline's fill (two A-only steps, two A+B steps) is peeled off and the steady-state body has no range checks
 #endif
 #ifndef SMD_BWD_ROWSEL
 #define SMD_BWD_ROWSEL 1     // the plain loop (SKIP = 0) reads `sel` one row per step, as part of the row's loads, instead of scanning the strip up front
 #endif
 #ifndef SMD_BWD_STATEFUL
-#define SMD_BWD_STATEFUL 1   // the plain loop keeps sliding vertical sums P = r(j-2) + r(j-1) (the forward's scheme) instead of re-adding three raw rows
+#define SMD_BWD_STATEFUL 0   // the plain loop keeps sliding vertical sums P = r(j-2) + r(j-1) (the forward's scheme) instead of re-adding three raw rows
 #endif
 
 template <bool SSIM, int SKIP, bool ACC>
@@ -602,6 +607,12 @@ hipError_t launch_pose_finalize(const float* pose_partial, int entries, int stri
   return hipGetLastError();
 }
 
+template <bool SSIM, int SKIP, int NS, bool ACC>
+static void launch_bwd_t(dim3 grid, dim3 block, hipStream_t st, const ReconBwdArgs& a) {
+  note_variant(1, "smd::k_recon_bwd<%s, %d, %d, %s>", SSIM ? "true" : "false", SKIP, NS, ACC ? "true" : "false");
+  hipLaunchKernelGGL((k_recon_bwd<SSIM, SKIP, NS, ACC>), grid, block, 0, st, a);
+}
+
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
   const int ns = a.wps, spb = kWavesPerBlock/ns;
   if (ns < 1 || ns > 4 || ns > a.n) return hipErrorInvalidValue;
@@ -609,12 +620,12 @@ hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
   const bool ssim = !(a.flags & SMD_LOSS_L1);
   if (a.n > 1 && (a.rh > kAccRows || (a.b1 < a.b && a.rh2 > kAccRows))) return hipErrorInvalidValue;   // the strip's rows must fit the LDS sum (smd_api.hip clamps)
 #define SMD_BWD_NS(SSIM_, SKIP_) do { \
-    if (a.n == 1) hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 1, false>), grid, block, 0, st, a); \
+    if (a.n == 1) launch_bwd_t<SSIM_, SKIP_, 1, false>(grid, block, st, a); \
     else switch (ns) { \
-    case 1: hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 1, true>), grid, block, 0, st, a); break; \
-    case 2: hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 2, true>), grid, block, 0, st, a); break; \
-    case 3: hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 3, true>), grid, block, 0, st, a); break; \
-    default: hipLaunchKernelGGL((k_recon_bwd<SSIM_, SKIP_, 4, true>), grid, block, 0, st, a); break; } } while (0)
+    case 1: launch_bwd_t<SSIM_, SKIP_, 1, true>(grid, block, st, a); break; \
+    case 2: launch_bwd_t<SSIM_, SKIP_, 2, true>(grid, block, st, a); break; \
+    case 3: launch_bwd_t<SSIM_, SKIP_, 3, true>(grid, block, st, a); break; \
+    default: launch_bwd_t<SSIM_, SKIP_, 4, true>(grid, block, st, a); break; } } while (0)
   if (ssim) {
     if (a.skip_level >= 1) SMD_BWD_NS(true, 2); else SMD_BWD_NS(true, 0);
   } else SMD_BWD_NS(false, 0);

@@ -853,6 +853,14 @@ extern "C" int smd_debug_wave_trace(unsigned long long* host_out, int max_waves)
 }
 #endif
 
+// A launch records which instantiation it is (smd_last_kernel_variant): the label bench.py prints is the kernel that ran.
+template <int N, bool SSIM, bool SINGLE, bool AUX, bool DISP, int LA = 1, bool SH = false>
+static void launch_main_t(dim3 grid, dim3 block, hipStream_t st, const ReconMainArgs& a) {
+  auto tf = [](bool v) { return v ? "true" : "false"; };
+  note_variant(0, "smd::k_recon_main<%d, %s, %s, %s, %s, %d, %s>", N, tf(SSIM), tf(SINGLE), tf(AUX), tf(DISP), LA, tf(SH));
+  hipLaunchKernelGGL((k_recon_main<N, SSIM, SINGLE, AUX, DISP, LA, SH>), grid, block, 0, st, a);
+}
+
 hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
   dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S) : 0u)), block(64*kWavesPerBlock);
   const bool ssim = !(a.flags & SMD_LOSS_L1);
@@ -862,14 +870,14 @@ hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
   // hot: every support in one launch, no extras; otherwise the general instantiation (carried min / sum, noise tensor, warp output)
 #define SMD_MAIN(N_) do { \
     if (ssim && single && !aux) { \
-      if (disp && N_ <= 2 && a.lookahead == 2) hipLaunchKernelGGL((k_recon_main<(N_ <= 2 ? N_ : 2), true, true, false, true, 2>), grid, block, 0, st, a); \
-      else if (disp && a.share) hipLaunchKernelGGL((k_recon_main<N_, true, true, false, true, 1, true>), grid, block, 0, st, a); \
-      else if (disp) hipLaunchKernelGGL((k_recon_main<N_, true, true, false, true>), grid, block, 0, st, a); \
-      else hipLaunchKernelGGL((k_recon_main<N_, true, true, false, false>), grid, block, 0, st, a); \
+      if (disp && N_ <= 2 && a.lookahead == 2) launch_main_t<(N_ <= 2 ? N_ : 2), true, true, false, true, 2>(grid, block, st, a); \
+      else if (disp && a.share) launch_main_t<N_, true, true, false, true, 1, true>(grid, block, st, a); \
+      else if (disp) launch_main_t<N_, true, true, false, true>(grid, block, st, a); \
+      else launch_main_t<N_, true, true, false, false>(grid, block, st, a); \
     } else if (ssim) { \
-      if (disp) hipLaunchKernelGGL((k_recon_main<N_, true, false, true, true>), grid, block, 0, st, a); \
-      else hipLaunchKernelGGL((k_recon_main<N_, true, false, true, false>), grid, block, 0, st, a); \
-    } else hipLaunchKernelGGL((k_recon_main<N_, false, false, true, false>), grid, block, 0, st, a); } while (0)
+      if (disp) launch_main_t<N_, true, false, true, true>(grid, block, st, a); \
+      else launch_main_t<N_, true, false, true, false>(grid, block, st, a); \
+    } else launch_main_t<N_, false, false, true, false>(grid, block, st, a); } while (0)
   switch (a.ni) { case 1: SMD_MAIN(1); break; case 2: SMD_MAIN(2); break; case 3: SMD_MAIN(3); break; default: SMD_MAIN(4); break; }
 #undef SMD_MAIN
   return hipGetLastError();

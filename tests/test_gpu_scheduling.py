@@ -91,21 +91,58 @@ def test_prepared_frames_on_a_side_stream_equal_the_inline_prep(F, monkeypatch, 
     assert torch.isfinite(inline['loss']) and (inline['sel'] != 255).any() and (inline['sel'] == 255).any()
 
 
+class _DepthStub(torch.nn.Module):
+    """A stand-in for the depth network with the same output contract ({'disp': {s: (b,1,h>>s,w>>s) sigmoid}}) built from element-wise
+    ops and fixed-order reductions only.  The real networks are NOT bit-reproducible run to run on this stack (MIOpen: two identical runs
+    of the same placement differ in ~2 % of the disparities' last bits, scripts/dev/dbg_sched.py), so a bit-equality test of the loss
+    path's SCHEDULING has to feed it from something that is; the stream choreography of `MonoDepthModule.step` is unchanged."""
+    out_scales = [0, 1, 2, 3]
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Parameter(torch.tensor([0.9, -0.7, 0.5, 0.6])); self.b = torch.nn.Parameter(torch.tensor([-1.2, -0.9, -1.5, -1.0]))
+
+    def forward(self, x):
+        g = x.mean(1, keepdim=True)
+        b, _, h, w = g.shape
+        out = {}
+        for s in self.out_scales:
+            f = 2**s
+            gs = g.view(b, 1, h//f, f, w//f, f).mean((3, 5)) if s else g
+            out[s] = torch.sigmoid(self.a[s]*gs + self.b[s])
+        return {'disp': out}
+
+
+class _PoseStub(torch.nn.Module):
+    """(N,6,h,w) image pair -> {'R', 't'} (N,2,3) like `PoseNet` (0.01-scaled), from channel means and a fixed-order weighted sum."""
+    def __init__(self):
+        super().__init__()
+        gen = torch.Generator().manual_seed(5)
+        self.W = torch.nn.Parameter(torch.randn(6, 12, generator=gen))
+
+    def forward(self, x):
+        m = x.mean((2, 3))                                       # (N,6)
+        v = 0.01*(m[:, :, None]*self.W[None]).sum(1).view(-1, 2, 6)
+        return {'R': v[..., :3], 't': v[..., 3:]}
+
+
 def _make_module(prep_ahead, seed=0):
     import bench
     from slowtv_monodepth_amd.trainer import MonoDepthModule
     torch.manual_seed(seed)
     cfg = bench.make_cfg(bench.WORKLOADS['cfg2'])
     cfg['trainer']['prep_ahead'] = prep_ahead
-    return MonoDepthModule(cfg).cuda().train()
+    m = MonoDepthModule(cfg)
+    m.nets['depth'], m.nets['pose'] = _DepthStub(), _PoseStub()   # same keys, same output contracts; see _DepthStub
+    return m.cuda().train()
 
 
 @pytest.mark.parametrize('skip', [None, '0', '2'])
 def test_two_steps_in_flight_with_prep_ahead_equal_inline_prep(F, monkeypatch, skip):
     """(ii) + (iii): two `MonoDepthModule.step` + backward iterations back to back with NO synchronisation between them — the second
     step's prep launch, packed buffer and arrival counters are in flight while the first step's backward still reads its own —
-    with `prep_ahead='pose'` (what the bench runs) against the same two steps with `prep_ahead=False`: losses and every parameter
-    gradient of both steps bit-equal.  BatchNorm running statistics advance identically (same kernels, same order per stream)."""
+    with `prep_ahead='pose'` (what the bench runs) against the same two steps with `prep_ahead=False`: losses, every gradient the loss
+    path hands back to the networks and every parameter gradient of both steps bit-equal.  (Deterministic stand-in networks: `_DepthStub`.)"""
     from slowtv_monodepth_amd.synthetic import make_batch
     if skip is not None: monkeypatch.setenv('SMD_BWD_SKIP', skip)
     batches = [make_batch(12, 192, 640, (-1, 1), seed=42 + k, device='cuda') for k in range(2)]
