@@ -36,13 +36,13 @@ WORKLOADS = {  # BASELINE.json configs[1..4]
 }
 
 
-def make_cfg(wl: dict, channels_last: bool = False) -> dict:
+def make_cfg(wl: dict, channels_last: bool = False, capturable: bool = False) -> dict:
     return {
         'net': {'depth': {'enc_name': wl['depth'], 'pretrained': False, 'dec_name': 'monodepth', 'out_scales': [0, 1, 2, 3]},
                 'pose': {'enc_name': wl['pose'], 'pretrained': False, 'learn_K': wl['learn_K']}},
         'loss': {'img_recon': {'weight': 1, 'loss_name': 'ssim', 'use_min': True, 'use_automask': True},
                  'disp_smooth': {'weight': 0.001, 'use_edges': True}},
-        'optimizer': {'type': 'adamw', 'lr': 1e-4, 'weight_decay': 1e-3},
+        'optimizer': {'type': 'adamw', 'lr': 1e-4, 'weight_decay': 1e-3, **({'capturable': True} if capturable else {})},
         'trainer': {'min_depth': 0.1, 'max_depth': 100, 'precision': wl['precision'], 'channels_last': channels_last,
                     'overlap_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0'},
     }
@@ -147,6 +147,9 @@ def main():
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     ap.add_argument('--channels-last', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='capture one whole training step (networks, loss path, backward, optimizer) into a HIP graph after the warm-up and time its '
+                                                          'replays: what the host has to enqueue per step drops from ~1000 launches to one (multi-GPU readiness: eight ranks\' Python '
+                                                          'threads); the library\'s event profile is off in this mode, so the roofline fields are null')
     ap.add_argument('--precision', default=None, choices=['32', 'bf16'], help='override the network autocast precision of the workload (the loss path is always fp32)')
     args = ap.parse_args()
 
@@ -173,7 +176,7 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.precision: wl['precision'] = 32 if args.precision == '32' else 'bf16'
     torch.manual_seed(42)
-    module = MonoDepthModule(make_cfg(wl, args.channels_last)).to(device)
+    module = MonoDepthModule(make_cfg(wl, args.channels_last, capturable=args.graph)).to(device)
     opt = module.configure_optimizers()['optimizer']
     batch = make_batch(wl['b'], wl['h'], wl['w'], wl['supp'], seed=42 + rank, device=device)
     model = wrap_ddp(StepModule(module), device)
@@ -191,10 +194,44 @@ def main():
         losses = train_steps(model, opt, batch_fn, 1)
         if i == 0: fence(); note('first step done')
     fence()
+    graph_note = None
+    run_steps = lambda k: train_steps(model, opt, batch_fn, k)
+    if args.graph:
+        # One training step as ONE HIP graph.  The row loop of the fused backward is whatever the tuner chose during the warm-up (it does not
+        # time inside a capture); nothing in the step reads the host: inputs, the in-kernel tie-break seed and the optimizer's step counter
+        # (capturable AdamW) live on the device.  NOTE: the tie-break seed of `ReconstructionLoss` is a launch argument, so every replay
+        # draws the SAME tie-break noise (it only decides exact ties of the automask).
+        from slowtv_monodepth_amd.train import FlatAllReduce
+        try:
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):                     # PyTorch's capture recipe: a few eager steps on a side stream first
+                for _ in range(2): train_steps(model, opt, batch_fn, 1)
+            torch.cuda.current_stream(device).wait_stream(side)
+            fence()
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss_static, _ = model(batch)
+                loss_static.backward()
+                if isinstance(model, FlatAllReduce): model.sync_gradients()
+                opt.step()
+            def run_steps(k):
+                for _ in range(k): graph.replay()
+                return [loss_static.detach()]
+            run_steps(2); fence()
+            graph_note = 'whole step captured (forward of both networks on two streams, loss path, backward, optimizer step) and replayed'
+        except Exception as e:   # e.g. a collective that cannot be captured: report it, time the eager loop
+            graph_note = f'capture failed ({type(e).__name__}: {str(e)[:200]}); eager loop timed instead'
+            torch.cuda.synchronize()
+            run_steps = lambda k: train_steps(model, opt, batch_fn, k)
+        note(graph_note)
     note('warm-up done; timing')
-    for which in range(5): _lib.lib.smd_profile_enable(which, args.steps)
+    profiled = not (args.graph and graph_note and graph_note.startswith('whole step'))
+    if profiled:
+        for which in range(5): _lib.lib.smd_profile_enable(which, args.steps)
     t0 = time.perf_counter()
-    losses = train_steps(model, opt, batch_fn, args.steps)
+    losses = run_steps(args.steps)
     host_enqueue = time.perf_counter() - t0      # nothing in the loop synchronises: this is the Python / ATen front end's time to ENQUEUE the steps
     fence()
     elapsed = time.perf_counter() - t0
@@ -207,6 +244,18 @@ def main():
     fwd_all_ms = collect_profile(_lib.lib, 2, args.steps); bwd_all_ms = collect_profile(_lib.lib, 3, args.steps)
     prep_ms = collect_profile(_lib.lib, 4, args.steps)
     for which in range(5): _lib.lib.smd_profile_enable(which, 0)
+    # The same kernel with the frame-only prep run INLINE, right before it (packed buffer warm in the caches), outside the timed region:
+    # prep-ahead takes 36 us off the critical path but hands the kernel a buffer that went cold under the networks.
+    fwd_inline_ms = []
+    if profiled and rank == 0 and not dist.is_initialized():
+        ahead = module.prep_ahead
+        module.prep_ahead = False
+        train_steps(model, opt, batch_fn, 2)
+        _lib.lib.smd_profile_enable(0, 8)
+        train_steps(model, opt, batch_fn, 8); torch.cuda.synchronize()
+        fwd_inline_ms = collect_profile(_lib.lib, 0, 8)
+        _lib.lib.smd_profile_enable(0, 0)
+        module.prep_ahead = ahead
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
     last_loss = losses[-1].item()
     assert last_loss == last_loss, 'loss is NaN'
@@ -242,7 +291,7 @@ def main():
                        'global_batch': wl['b']*world, 'per_gpu_batch': wl['b'], 'parallelism': f'dp{world}',
                        'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6),
                        'rccl_ranks': rccl_ranks, 'dp_impl': (os.environ.get('SMD_DP_IMPL', 'flat') if rccl_ranks > 1 or os.environ.get('SMD_FORCE_DDP') == '1' else None),
-                       'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3)},
+                       'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3), 'hip_graph': graph_note},
             'roofline': {'kernel': f'{k_fwd} (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; the instantiation the library reports for the last forward launch, name as rocprofv3 prints it)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,
@@ -251,6 +300,8 @@ def main():
                          'whole_forward_frac': round(B_fwd/(fa_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
                          'forward_incl_prep_frac': round(B_fwd/((fa_ms + p_ms)*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
                          'algorithmic_bytes': B_fwd, 'avg_kernel_ms': round(f_ms, 5), 'launches_timed': len(fwd_ms),
+                         'avg_kernel_ms_inline_prep': round(avg(fwd_inline_ms), 5) if fwd_inline_ms else None,
+                         'frac_inline_prep': round(B_fwd/(avg(fwd_inline_ms)*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fwd_inline_ms else None,
                          'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
             'roofline_bwd': {'kernel': f'{k_bwd} (fused adjoint, one wave per (strip, support); the pose / intrinsics epilogue rides in the K0-adjoint launch that follows; the instantiation the library reports for the last backward launch)', 'bound': 'hbm',
                              'row_loop': {'dead_row_skipping': skipping, 'timed': tuner.last,

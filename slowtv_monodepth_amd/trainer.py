@@ -38,8 +38,16 @@ class HipLossBackend:
         return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), K_inv=K_inv, want_warp=want_warp, prepared=prepared)
 
     def inv_intrinsics(self, K):
+        """K^-1 of the dataset's intrinsics.  A loader that hands out the SAME tensor object again (a fixed-camera dataset collated once, the
+        synthetic batches of the bench) gets the inverse of the previous step back: keyed on the object (kept alive here, so that its address
+        cannot be recycled for another batch's K) and its version counter."""
         from . import functional as F
-        return F.inv_intrinsics(K.float()) if K.is_cuda else None
+        if not K.is_cuda: return None
+        hit = self.__dict__.get('_kinv_cache')
+        if hit is not None and hit[0] is K and hit[1] == K._version: return hit[2]
+        Ki = F.inv_intrinsics(K.float())
+        self.__dict__['_kinv_cache'] = (K, K._version, Ki)
+        return Ki
 
     def prepare_frames(self, crit, imgs, supp_imgs, pyramid, stream, smooth_edges=False):
         """The frame-only half of the reconstruction forward (texel repack, target window sums, identity error of the automask:
@@ -54,7 +62,12 @@ class HipLossBackend:
     def pose_matrices(self, aa, t, invert):
         """(N,3),(N,3) + python bool list -> (N,4,4); one launch for Rodrigues + the backward-in-time inverses."""
         from . import functional as F
-        inv = torch.tensor(invert, dtype=torch.uint8).to(aa.device, non_blocking=True) if any(invert) else None
+        inv = None
+        if any(invert):   # the same flags every step: keep the device copy (and no host-to-device copy inside a HIP-graph capture)
+            key = (tuple(invert), aa.device)
+            cache = self.__dict__.setdefault('_invert_masks', {})
+            inv = cache.get(key)
+            if inv is None: inv = cache[key] = torch.tensor(invert, dtype=torch.uint8).to(aa.device)
         return F.pose_matrices(aa.float(), t.float(), inv)
 
     def intrinsics(self, fs, cs, size):

@@ -173,7 +173,7 @@ def test_two_steps_in_flight_with_prep_ahead_equal_inline_prep(F, monkeypatch, s
             loss.backward()
             losses.append(loss.detach())           # no .item(): nothing here waits for the device
             path_grads.append([o.grad for o in outs])
-            param_grads.append([p.grad for p in m.parameters()])
+            param_grads.append([p.grad for p in m.parameters() if p.requires_grad])
         torch.cuda.synchronize()
         return m, ref_state, [l.clone() for l in losses], path_grads, param_grads, dict(calls)
 
