@@ -176,7 +176,12 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.precision: wl['precision'] = 32 if args.precision == '32' else 'bf16'
     torch.manual_seed(42)
-    module = MonoDepthModule(make_cfg(wl, args.channels_last, capturable=args.graph)).to(device)
+    cfg = make_cfg(wl, args.channels_last, capturable=args.graph)
+    # Under capture the frame-only prep runs inline (on the capturing stream): with the prep enqueued on the pose network's side stream
+    # `hipStreamEndCapture` crashes on this stack (scripts/dev/graph_probe.py: every piece of the step captures, the whole step with inline prep
+    # captures, only that cross-stream hand-off of a buffer allocated inside the capture does not).  Costs the graph 36 + 16 us of a 16.7 ms step.
+    if args.graph: cfg['trainer']['prep_ahead'] = False
+    module = MonoDepthModule(cfg).to(device)
     opt = module.configure_optimizers()['optimizer']
     batch = make_batch(wl['b'], wl['h'], wl['w'], wl['supp'], seed=42 + rank, device=device)
     model = wrap_ddp(StepModule(module), device)

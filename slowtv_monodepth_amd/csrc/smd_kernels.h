@@ -27,6 +27,9 @@ __host__ __device__ inline int smooth_chunks_of(int n) { return (n + smooth_chun
 // The forward sweep streams: a wave owns 63 columns (+ 1 halo lane for the right-hand neighbour) and walks down kSmoothRows rows.
 constexpr int kSmoothCols = 63, kSmoothRows = 8;
 __host__ __device__ inline int smooth_units_of(int hs, int ws) { return ((ws + kSmoothCols - 1)/kSmoothCols)*((hs + kSmoothRows - 1)/kSmoothRows); }
+// The sweep over the disparities (k_smooth_main) reads 12 bytes per pixel and does almost nothing with them: taller units, fewer waves and partials.
+constexpr int kSmoothRowsMain = 16;
+__host__ __device__ inline int smooth_units_main(int hs, int ws) { return ((ws + kSmoothCols - 1)/kSmoothCols)*((hs + kSmoothRowsMain - 1)/kSmoothRowsMain); }
 constexpr int kPoseSums = 12;  // accumulated d/d(H[9], a0, a1, tz) per (support, sample)
 
 struct ScaleSet {  // the multi-scale disparity pyramid, passed by value

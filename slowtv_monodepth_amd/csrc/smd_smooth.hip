@@ -142,10 +142,13 @@ __global__ __launch_bounds__(256) void k_smooth_edges(const ScaleSet sc, int b, 
 //   contrib: [S*b] doubles behind the partials in the workspace
 __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ edge_w, float* partial, int max_units,
                                                      float* stats, float* loss, unsigned* arrive, double* contrib) {
-  const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y;   // coarse scales first
-  const int lane = threadIdx.x & 63, unit = blockIdx.x*4 + (threadIdx.x >> 6);
+  // 1-D grid of exactly the blocks that have work: for s = S-1 .. 0 (coarse scales first), for each sample, ceil(units_s / 4) blocks
+  int s = sc.S - 1, blk = (int)blockIdx.x;
+  for (; s > 0; --s) { const int nb = ceil_div(smooth_units_main(sc.hs[s], sc.ws[s]), 4)*b; if (blk < nb) break; blk -= nb; }
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
-  const int units = smooth_units_of(hs, ws);
+  const int units = smooth_units_main(hs, ws), bpi = ceil_div(units, 4);
+  const int bi = blk/bpi, bx = blk - bi*bpi;
+  const int lane = threadIdx.x & 63, unit = bx*4 + (threadIdx.x >> 6);
   __shared__ unsigned waves_done;
   if (arrive != nullptr) {            // the only block barrier: at the start, where every wave still is
     if (threadIdx.x == 0) waves_done = 0u;
@@ -155,20 +158,20 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
   {
   const int nsx = (ws + kSmoothCols - 1)/kSmoothCols;
   const int sxi = unit % nsx, syi = unit/nsx;
-  const int r0 = syi*kSmoothRows, r1 = min(r0 + kSmoothRows, hs);
+  const int r0 = syi*kSmoothRowsMain, r1 = min(r0 + kSmoothRowsMain, hs);
   const int u = sxi*kSmoothCols + lane, uc = min(u, ws - 1);        // lanes right of the image repeat its last column: |d - d| = 0
   const bool live = lane < kSmoothCols && u < ws;
   const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
   const float2* __restrict__ ew = edge_w ? (const float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
-  float dr_[kSmoothRows + 1];
-  float2 wr_[kSmoothRows];
+  float dr_[kSmoothRowsMain + 1];
+  float2 wr_[kSmoothRowsMain];
 #pragma unroll
-  for (int k = 0; k <= kSmoothRows; ++k) dr_[k] = d[(size_t)min(r0 + k, hs - 1)*ws + uc];   // the last image row pairs with itself
+  for (int k = 0; k <= kSmoothRowsMain; ++k) dr_[k] = d[(size_t)min(r0 + k, hs - 1)*ws + uc];   // the last image row pairs with itself
 #pragma unroll
-  for (int k = 0; k < kSmoothRows; ++k) wr_[k] = ew ? ew[(size_t)min(r0 + k, hs - 1)*ws + uc] : make_float2(1.f, 1.f);
+  for (int k = 0; k < kSmoothRowsMain; ++k) wr_[k] = ew ? ew[(size_t)min(r0 + k, hs - 1)*ws + uc] : make_float2(1.f, 1.f);
   float accE = 0.f, accD = 0.f;
 #pragma unroll
-  for (int k = 0; k < kSmoothRows; ++k) {
+  for (int k = 0; k < kSmoothRowsMain; ++k) {
     const float cur = dr_[k], right = lane_right(cur);
     if (live && r0 + k < r1) {
       accD += cur;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
   if (arrive == nullptr) return;      // two-launch form: k_smooth_finalize follows
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const int pair = s*b + bi, npairs = sc.S*b;
-  const unsigned live = (unsigned)min(4, units - (int)blockIdx.x*4);
+  const unsigned live = (unsigned)min(4, units - bx*4);
   unsigned flag = 0;
   if (lane == 0) {
     if (__hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == live - 1u)
@@ -238,25 +241,46 @@ __global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int
                                                           float* __restrict__ stats, float* __restrict__ loss, int per_pixel_units) {
   __shared__ double contrib[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int npairs = sc.S*b;
   double mine = 0.0;
-  for (int pair = wv; pair < sc.S*b; pair += 16) {
-    const int s = pair/b;
-    const int n = sc.hs[s]*sc.ws[s];
-    const int chunks = per_pixel_units ? ceil_div(n, 256) : smooth_units_of(sc.hs[s], sc.ws[s]);
-    double e = 0.0, dsum = 0.0;
-    const float2* __restrict__ pp = (const float2*)partial + (size_t)pair*max_chunks;
-    int c = lane;
-    for (; c + 192 < chunks; c += 256) {   // four independent loads in flight; the order of the additions is fixed
-      const float2 v0 = pp[c], v1 = pp[c + 64], v2 = pp[c + 128], v3 = pp[c + 192];
-      e += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x); dsum += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-    }
-    for (; c < chunks; c += 64) { const float2 v = pp[c]; e += (double)v.x; dsum += (double)v.y; }
+  // A wave takes pairs wv, wv + 16, ...: the partials of up to four of them are requested before the first is summed (the kernel is a
+  // handful of dependent round trips, nothing else: 6.7 -> ~4 us at cfg 2); the order of the additions does not depend on the batching.
+  constexpr int kBatch = 4, kPer = 4;      // pairs in flight per wave, loads per lane and pair in flight (kPer*64 = 256 partials)
+  for (int p0 = wv; p0 < npairs; p0 += 16*kBatch) {
+    float2 v[kBatch][kPer];
+    int chunks[kBatch];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); dsum += __shfl_xor(dsum, off, 64); }
-    const float mean = (float)(dsum/n);
-    const float E = (float)(e/(double)fmaxf(mean, kEps32));
-    if (lane == 0) { stats[(size_t)pair*2] = mean; stats[(size_t)pair*2 + 1] = E; }
-    mine += ldexp((double)E/((double)b*n), -sc.key[s]);   // 2^-key exactly, without the double-precision exp2 routine
+    for (int q = 0; q < kBatch; ++q) {
+      const int pair = p0 + 16*q;
+      const int s = min(pair, npairs - 1)/b;
+      const int n = sc.hs[s]*sc.ws[s];
+      chunks[q] = (pair < npairs) ? (per_pixel_units ? ceil_div(n, 256) : smooth_units_main(sc.hs[s], sc.ws[s])) : 0;
+      const float2* __restrict__ pp = (const float2*)partial + (size_t)min(pair, npairs - 1)*max_chunks;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) { const int c = lane + 64*k; v[q][k] = (c < chunks[q]) ? pp[c] : make_float2(0.f, 0.f); }
+    }
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const int pair = p0 + 16*q;
+      if (pair >= npairs) continue;
+      const int s = pair/b;
+      const int n = sc.hs[s]*sc.ws[s];
+      const float2* __restrict__ pp = (const float2*)partial + (size_t)pair*max_chunks;
+      double e = ((double)v[q][0].x + (double)v[q][1].x) + ((double)v[q][2].x + (double)v[q][3].x);
+      double dsum = ((double)v[q][0].y + (double)v[q][1].y) + ((double)v[q][2].y + (double)v[q][3].y);
+      int c = lane + 256;
+      for (; c + 192 < chunks[q]; c += 256) {   // (more than 256 partials per pair: four independent loads in flight; the order of the additions is fixed)
+        const float2 v0 = pp[c], v1 = pp[c + 64], v2 = pp[c + 128], v3 = pp[c + 192];
+        e += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x); dsum += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+      }
+      for (; c < chunks[q]; c += 64) { const float2 vv = pp[c]; e += (double)vv.x; dsum += (double)vv.y; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); dsum += __shfl_xor(dsum, off, 64); }
+      const float mean = (float)(dsum/n);
+      const float E = (float)(e/(double)fmaxf(mean, kEps32));
+      if (lane == 0) { stats[(size_t)pair*2] = mean; stats[(size_t)pair*2 + 1] = E; }
+      mine += ldexp((double)E/((double)b*n), -sc.key[s]);   // 2^-key exactly, without the double-precision exp2 routine
+    }
   }
   if (lane == 0) contrib[wv] = mine;
   __syncthreads();
@@ -448,10 +472,15 @@ hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h,
   // carries the arrival counters of the in-launch second stage; without edge weighting: the two-launch form.
   const bool edges = (flags & SMD_USE_EDGES) && edge_w;
   unsigned* arrive = edges ? (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)) : nullptr;
-  if (getenv("SMD_SMOOTH_CHAIN") && atoi(getenv("SMD_SMOOTH_CHAIN")) == 0) arrive = nullptr;   // A/B switch: second stage as a launch of its own
+  // The second stage is a launch of its own unless SMD_SMOOTH_CHAIN=1: measured at cfg 2 (rocprofv3, profiles/r04_smooth_ab.txt) the
+  // in-launch chain of round 3 costs the sweep 11 us (18.0 vs 7.1 us) where the separate kernel costs 6.7 (now ~4): five dependent round
+  // trips at the very end of a launch that is itself only one generation of tiny waves.
+  if (!(getenv("SMD_SMOOTH_CHAIN") && atoi(getenv("SMD_SMOOTH_CHAIN")) == 1)) arrive = nullptr;
   if (edges && !edges_ready) hipLaunchKernelGGL(k_smooth_edges, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, edge_w, (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)));
   double* contrib = (double*)(ws_sums + (size_t)sc.S*b*max_chunks*2);
-  hipLaunchKernelGGL(k_smooth_main, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, edges ? edge_w : nullptr, ws_sums, max_chunks,
+  int main_blocks = 0;
+  for (int s = 0; s < sc.S; ++s) main_blocks += ceil_div(smooth_units_main(sc.hs[s], sc.ws[s]), 4)*b;
+  hipLaunchKernelGGL(k_smooth_main, dim3(main_blocks), dim3(256), 0, st, sc, b, edges ? edge_w : nullptr, ws_sums, max_chunks,
                      stats, loss, arrive, contrib);
   if (!arrive) hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss, 0);
   if (disp_grad || image_grad)
