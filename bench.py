@@ -235,9 +235,10 @@ def main():
     profiled = not (args.graph and graph_note and graph_note.startswith('whole step'))
     if profiled:
         for which in range(5): _lib.lib.smd_profile_enable(which, args.steps)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     losses = run_steps(args.steps)
     host_enqueue = time.perf_counter() - t0      # nothing in the loop synchronises: this is the Python / ATen front end's time to ENQUEUE the steps
+    host_cpu = time.process_time() - c0          # ... and the CPU time of this process over the same span (all threads: a blocked launch call does not count)
     fence()
     elapsed = time.perf_counter() - t0
     if dist.is_initialized():
@@ -296,7 +297,7 @@ def main():
                        'global_batch': wl['b']*world, 'per_gpu_batch': wl['b'], 'parallelism': f'dp{world}',
                        'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6),
                        'rccl_ranks': rccl_ranks, 'dp_impl': (os.environ.get('SMD_DP_IMPL', 'flat') if rccl_ranks > 1 or os.environ.get('SMD_FORCE_DDP') == '1' else None),
-                       'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3), 'hip_graph': graph_note},
+                       'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3), 'host_cpu_ms_per_step': round(host_cpu/args.steps*1e3, 3), 'hip_graph': graph_note},
             'roofline': {'kernel': f'{k_fwd} (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; the instantiation the library reports for the last forward launch, name as rocprofv3 prints it)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,

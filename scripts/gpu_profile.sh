@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/raw" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline "$@" > "$out/bench.log" 2>&1
+timeout ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --stats --output-format csv -d "$out/raw" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline "$@" > "$out/bench.log" 2>&1
 cd "$GRAFT_REPO_ROOT"
 find "$out/raw" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
 find "$out/raw" -name '*kernel_trace.csv' -exec sh -c 'python scripts/summarize_trace.py "$1" > "$2"; python scripts/summarize_trace.py "$1" --steady k_recon_bwd 5 > "$3"' _ {} "$out/trace_summary.txt" "$out/steady_summary.txt" \;

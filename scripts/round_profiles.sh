@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/rNN_* is regenerated from, in one GPU call (GPU box): kernel-trace summaries of the bench at cfg 2/4/5, the PMC
 # traffic passes, and the one-rank RCCL lines.  usage: scripts/round_profiles.sh r03      (outputs under gpurun_out/)
-tag=${1:-r03}
+tag=${1:-r04}
 cd "$GRAFT_REPO_ROOT"
 # The backward picks its row loop by timing both on the live data (functional.row_skip_tuner); a profiler perturbs that timing, so the
 # traced and counter runs are pinned (SMD_BWD_SKIP) to what the un-traced bench of the same workload chose.
@@ -24,5 +24,10 @@ tail -5 gpurun_out/traffic_$tag.json
   done
   echo "## no process group (same box, same run)"
   timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"'
+  echo "## the same three with the whole step captured into ONE HIP graph and replayed (bench.py --graph; config.hip_graph says what happened): what the host enqueues per step"
+  echo "## SMD_DP_IMPL=flat --graph"
+  SMD_FORCE_DDP=1 SMD_DP_IMPL=flat timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --graph 2>/dev/null | grep '"metric"'
+  echo "## no process group --graph"
+  timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --graph 2>/dev/null | grep '"metric"'
 } > gpurun_out/rccl_one_rank_$tag.txt
 cut -c1-160 gpurun_out/rccl_one_rank_$tag.txt

@@ -239,48 +239,29 @@ __global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, c
 // and E = E'/max(m, eps) -> stats; loss = mean_s( 2^-key_s * sum_b E / (b*hs*ws) ).  One wave per pair, 16 waves, one block.
 __global__ __launch_bounds__(1024) void k_smooth_finalize(const ScaleSet sc, int b, const float* __restrict__ partial, int max_chunks,
                                                           float* __restrict__ stats, float* __restrict__ loss, int per_pixel_units) {
+  // (Tried in round 4: requesting the partials of a wave's three pairs before summing the first — 8.2 us instead of 6.7: the kernel is
+  // launch + a few dependent round trips whichever way they are arranged.)
   __shared__ double contrib[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int npairs = sc.S*b;
   double mine = 0.0;
-  // A wave takes pairs wv, wv + 16, ...: the partials of up to four of them are requested before the first is summed (the kernel is a
-  // handful of dependent round trips, nothing else: 6.7 -> ~4 us at cfg 2); the order of the additions does not depend on the batching.
-  constexpr int kBatch = 4, kPer = 4;      // pairs in flight per wave, loads per lane and pair in flight (kPer*64 = 256 partials)
-  for (int p0 = wv; p0 < npairs; p0 += 16*kBatch) {
-    float2 v[kBatch][kPer];
-    int chunks[kBatch];
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-      const int pair = p0 + 16*q;
-      const int s = min(pair, npairs - 1)/b;
-      const int n = sc.hs[s]*sc.ws[s];
-      chunks[q] = (pair < npairs) ? (per_pixel_units ? ceil_div(n, 256) : smooth_units_main(sc.hs[s], sc.ws[s])) : 0;
-      const float2* __restrict__ pp = (const float2*)partial + (size_t)min(pair, npairs - 1)*max_chunks;
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) { const int c = lane + 64*k; v[q][k] = (c < chunks[q]) ? pp[c] : make_float2(0.f, 0.f); }
+  for (int pair = wv; pair < sc.S*b; pair += 16) {
+    const int s = pair/b;
+    const int n = sc.hs[s]*sc.ws[s];
+    const int chunks = per_pixel_units ? ceil_div(n, 256) : smooth_units_main(sc.hs[s], sc.ws[s]);
+    double e = 0.0, dsum = 0.0;
+    const float2* __restrict__ pp = (const float2*)partial + (size_t)pair*max_chunks;
+    int c = lane;
+    for (; c + 192 < chunks; c += 256) {   // four independent loads in flight; the order of the additions is fixed
+      const float2 v0 = pp[c], v1 = pp[c + 64], v2 = pp[c + 128], v3 = pp[c + 192];
+      e += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x); dsum += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
     }
+    for (; c < chunks; c += 64) { const float2 v = pp[c]; e += (double)v.x; dsum += (double)v.y; }
 #pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-      const int pair = p0 + 16*q;
-      if (pair >= npairs) continue;
-      const int s = pair/b;
-      const int n = sc.hs[s]*sc.ws[s];
-      const float2* __restrict__ pp = (const float2*)partial + (size_t)pair*max_chunks;
-      double e = ((double)v[q][0].x + (double)v[q][1].x) + ((double)v[q][2].x + (double)v[q][3].x);
-      double dsum = ((double)v[q][0].y + (double)v[q][1].y) + ((double)v[q][2].y + (double)v[q][3].y);
-      int c = lane + 256;
-      for (; c + 192 < chunks[q]; c += 256) {   // (more than 256 partials per pair: four independent loads in flight; the order of the additions is fixed)
-        const float2 v0 = pp[c], v1 = pp[c + 64], v2 = pp[c + 128], v3 = pp[c + 192];
-        e += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x); dsum += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-      }
-      for (; c < chunks[q]; c += 64) { const float2 vv = pp[c]; e += (double)vv.x; dsum += (double)vv.y; }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); dsum += __shfl_xor(dsum, off, 64); }
-      const float mean = (float)(dsum/n);
-      const float E = (float)(e/(double)fmaxf(mean, kEps32));
-      if (lane == 0) { stats[(size_t)pair*2] = mean; stats[(size_t)pair*2 + 1] = E; }
-      mine += ldexp((double)E/((double)b*n), -sc.key[s]);   // 2^-key exactly, without the double-precision exp2 routine
-    }
+    for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); dsum += __shfl_xor(dsum, off, 64); }
+    const float mean = (float)(dsum/n);
+    const float E = (float)(e/(double)fmaxf(mean, kEps32));
+    if (lane == 0) { stats[(size_t)pair*2] = mean; stats[(size_t)pair*2 + 1] = E; }
+    mine += ldexp((double)E/((double)b*n), -sc.key[s]);   // 2^-key exactly, without the double-precision exp2 routine
   }
   if (lane == 0) contrib[wv] = mine;
   __syncthreads();
