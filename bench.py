@@ -225,7 +225,11 @@ def main():
                 for _ in range(k): graph.replay()
                 return [loss_static.detach()]
             run_steps(2); fence()
-            graph_note = 'whole step captured (forward of both networks on two streams, loss path, backward, optimizer step) and replayed'
+            launch_ms = []
+            for _ in range(5):                                # what ONE replay costs the host when the queue is empty (the timed loop below runs into the
+                t_l = time.perf_counter(); graph.replay()     # runtime's back-pressure: its enqueue time tends to the GPU time)
+                launch_ms.append((time.perf_counter() - t_l)*1e3); fence()
+            graph_note = f'whole step captured (forward of both networks on two streams, loss path, backward, optimizer step) and replayed; one replay costs the host {sorted(launch_ms)[2]:.3f} ms (median of 5, queue empty)'
         except Exception as e:   # e.g. a collective that cannot be captured: report it, time the eager loop
             graph_note = f'capture failed ({type(e).__name__}: {str(e)[:200]}); eager loop timed instead'
             torch.cuda.synchronize()
@@ -253,7 +257,7 @@ def main():
     # The same kernel with the frame-only prep run INLINE, right before it (packed buffer warm in the caches), outside the timed region:
     # prep-ahead takes 36 us off the critical path but hands the kernel a buffer that went cold under the networks.
     fwd_inline_ms = []
-    if profiled and rank == 0 and not dist.is_initialized():
+    if profiled and rank == 0 and not dist.is_initialized() and not args.no_cpu_baseline:   # (a profiler's steady-state window is the LAST steps of the process: the profile scripts pass --no-cpu-baseline)
         ahead = module.prep_ahead
         module.prep_ahead = False
         train_steps(model, opt, batch_fn, 2)

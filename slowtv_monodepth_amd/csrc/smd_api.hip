@@ -355,6 +355,10 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   if (a.wps < 1) a.wps = 1;
   if (a.wps > 4) a.wps = 4;
   if (a.wps > n) a.wps = n;
+  // Two supports per wave (SMD_BWD_PAIR=1; experiment of round 4): the strips of a block must be those of the one-support-per-wave kernel
+  // with wps = n, so that the K0-adjoint guest epilogue finds the same per-block pose entries.
+  a.pair = (env_int("SMD_BWD_PAIR", 0) != 0 && (n == 2 || n == 4) && (flags & SMD_USE_MIN) && a.skip_level == 0) ? 1 : 0;
+  if (a.pair) a.wps = n;
   if (guest) {   // the caller's next launch finalises the pose sums: no in-launch hand-off (the kernel skips it when `arrive` is null)
     a.arrive = nullptr;
     const int spb = smd::kWavesPerBlock/a.wps;

@@ -131,6 +131,7 @@ struct ReconBwdArgs {
   int wps;                // waves per strip (1 .. min(n, 4)): the supports of a strip are split over this many waves of one block
   float wscale, hscale;
   int skip_level;         // 0..2, see k_recon_bwd
+  int pair;               // 1: two supports per wave (k_recon_bwd_pair; n = 2 or 4, min-reprojection, plain row loop)
   float* g_direct;        // K0 fused: rows of scale `direct_scale` (a pyramid level that already has the image size: its K0 adjoint is the
   int direct_scale;       //   identity) go straight to that level's gradient tensor (b,h,w) instead of g_depth; -1: none
 };

@@ -233,6 +233,7 @@ class MonoDepthModule(nn.Module):
                 if k == 'img_recon':
                     kw = {'prepared': self._prepared} if self._prepared is not None else {}
                     K_inv = fwd.get('K_inv') if 'K' in fwd else getattr(self, '_K_inv', None)
+                    if K_inv is None and 'K' not in fwd and hasattr(self.backend, 'inv_intrinsics'): K_inv = self.backend.inv_intrinsics(y['K'])   # (inline prep: same cache)
                     l, ld = self.backend.image_recon(crit, self.synth, fwd['depth_up'], fwd.get('mask_up'), y['imgs'], y['supp_imgs'],
                                                      fwd['Ts'], fwd.get('K', y['K']), want_warp=self.want_aux, K_inv=K_inv, **kw)
                 elif k == 'disp_smooth':
