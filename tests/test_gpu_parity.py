@@ -1215,6 +1215,33 @@ def test_row_skip_tuner_times_both_row_loops_and_gradients_do_not_depend_on_the_
     tuner.calls, tuner.pending, tuner.samples, tuner.skip = 0, [], {True: [], False: []}, False
 
 
+@pytest.mark.parametrize('b,h,w,n', [(4, 96, 320, 2), (2, 50, 130, 2), (3, 96, 200, 4), (1, 7, 66, 2)])
+def test_two_supports_per_wave_backward_equals_one_support_per_wave(F, monkeypatch, b, h, w, n):
+    """Round 4 built the variant VERDICT r3 item 1b asked for — both supports of a strip in ONE backward wave, the SSIM partials evaluated once per
+    pixel for the support `sel` picked (`k_recon_bwd_pair`, `SMD_BWD_PAIR=1`).  It performs the same operations on the same operands as the
+    one-support-per-wave kernel, so every gradient must be BIT-equal (it is slower — `profiles/r04_pair_backward.txt` — and stays an experiment switch)."""
+    from slowtv_monodepth_amd import _lib
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    T0 = torch.eye(4, device='cuda').repeat(n, b, 1, 1); T0[..., :3, 3] = 0.05*torch.randn(n, b, 3, device='cuda', generator=gen)
+    S = 4 if h >= 48 else 2
+    d0 = [0.05 + 0.9*torch.rand(b, 1, max(h >> s, 1), max(w >> s, 1), device='cuda', generator=gen) for s in range(S)]
+    supp = (imgs[None] + 0.3*torch.rand(n, b, 3, h, w, device='cuda', generator=gen)).clamp(0, 1)
+    monkeypatch.setenv('SMD_BWD_SKIP', '0')
+
+    def step(pair):
+        monkeypatch.setenv('SMD_BWD_PAIR', pair)
+        d = [v.clone().requires_grad_(True) for v in d0]; T = T0.clone().requires_grad_(True)
+        loss, _, sel, _, _ = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=F.recon_flags('ssim', True, True), min_depth=0.1, max_depth=100, seed=2, want_err=False)
+        loss.backward(); torch.cuda.synchronize()
+        return sel, [v.grad for v in d] + [T.grad], _lib.lib.smd_last_kernel_variant(1).decode()
+    sel, g1, k1 = step('1'); _, g0, k0 = step('0')
+    assert 'k_recon_bwd_pair' in k1 and 'k_recon_bwd<' in k0, (k1, k0)
+    assert all(torch.equal(x, y) for x, y in zip(g1, g0)) and all(torch.isfinite(x).all() for x in g1)
+    assert (sel != 255).any()
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 1, 1), (2, 5, 6, 20), (1, 4, 33, 65), (3, 8, 48, 160), (2, 6, 40, 70)])
 def test_depthwise_conv7x7_kernel(F, shape):
     import torch.nn.functional as TF
