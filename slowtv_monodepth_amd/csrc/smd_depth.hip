@@ -76,6 +76,47 @@ __device__ __forceinline__ void footprint(int j, float f, int n_lo, int n_hi, in
   if (j == n_lo - 1) hi = n_hi - 1;
 }
 
+// Streaming form of pass 1 for the pyramid levels a decoder produces (integer, even ratio f = h/hs; premultiplied gradient): a thread owns one image
+// column and a chunk of C low-resolution rows, requests the C*f + f full-resolution rows that feed them at once (coalesced along the row, all
+// independent) and adds each into the one or two low-resolution rows it belongs to.  Which rows and with what weight is known at compile time
+// — row k of the chunk's window sits at (k + 0.5)/f - 1 low-resolution rows below the chunk's first — except at the image's top and bottom,
+// where ATen clamps the source index: a row whose upper neighbour would be row -1 gives its whole weight to row 0, one whose lower neighbour
+// would be row hs gives it to row hs-1 (area_pixel_compute_source_index + the index clamp of upsample_bilinear2d).  The per-thread gather it
+// replaces walked 2f + 2 rows per low-resolution row, i.e. read every gradient 2.3 times, one dependent-latency loop per thread
+// (15.9 -> ~7 us at cfg 2; round 4).  Rows that belong to a neighbouring chunk's low-resolution rows are read by both (f of C*f + f).
+constexpr int k0_chunk_rows(int f) { return f == 2 ? 8 : (f == 4 ? 4 : (f == 8 ? 2 : 1)); }
+__host__ __device__ inline bool k0_streamable(int h, int w, int hs, int ws) {
+  if (hs < 1 || h % hs != 0) return false;
+  const int f = h/hs;
+  return (f == 2 || f == 4 || f == 8 || f == 16) && hs >= 2;
+}
+template <int F>
+__device__ __forceinline__ void k0_bwd_v_stream(const float* __restrict__ g, float* __restrict__ out, int h, int w, int hs, int chunk, int u) {
+  constexpr int C = k0_chunk_rows(F), R = C*F + F;
+  const int j0 = chunk*C, vb = F*j0 - F/2;
+  float r[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) { const int v = vb + k; r[k] = (v >= 0 && v < h) ? g[(size_t)v*w + u] : 0.f; }
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    // un-clamped source row of window row k, relative to j0: (k + 0.5)/F - 1 = c_lo + ly
+    constexpr float invF = 1.f/(float)F;
+    const int c_lo = (2*k + 1 >= 2*F) ? (2*k + 1 - 2*F)/(2*F) : -1;            // floor((k + 0.5)/F) - 1, compile-time after unrolling
+    const float ly = ((float)k + 0.5f)*invF - 1.f - (float)c_lo;
+    const int a_lo = j0 + c_lo;                                                // absolute low-resolution rows a_lo, a_lo + 1 (wave-uniform)
+    float w_lo = 1.f - ly, w_hi = ly;
+    if (a_lo < 0) { w_lo = 0.f; w_hi = 1.f; }                                  // source index clamped at 0: everything to row 0
+    if (a_lo + 1 > hs - 1) { w_lo = 1.f; w_hi = 0.f; }                         // neighbour index clamped at hs-1: everything to row hs-1
+    if (c_lo >= 0 && c_lo < C) acc[c_lo] = fmaf(w_lo, r[k], acc[c_lo]);
+    if (c_lo + 1 >= 0 && c_lo + 1 < C) acc[c_lo + 1] = fmaf(w_hi, r[k], acc[c_lo + 1]);
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) if (j0 + c < hs) out[(size_t)(j0 + c)*w + u] = acc[c];
+}
+
 __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
                                                              const float* __restrict__ depth_up, const float* __restrict__ g_depth_up,
                                                              float* __restrict__ tmp, const PoseFinJob job) {
@@ -109,6 +150,19 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, 
         if (depth_up) { const float dep = depth_up[ibase + pix]; gout[pix] = g_depth_up[ibase + pix]*((dep < dmax) ? -dep*dep : 0.f)*a_scale; }
         else gout[pix] = g_depth_up[ibase + pix];
       }
+    }
+    return;
+  }
+  if (!depth_up && k0_streamable(h, w, hs, ws)) {   // streaming form: blocks of 256 columns x one chunk of low-resolution rows
+    const int nbc = ceil_div(w, 256), chunk = blk/nbc, u = (blk - chunk*nbc)*256 + (int)threadIdx.x;
+    if (u >= w) return;
+    const float* g = g_depth_up + ibase;
+    float* out = tmp + map.tmp_off[s] + (size_t)bi*hs*w;
+    switch (h/hs) {
+      case 2: k0_bwd_v_stream<2>(g, out, h, w, hs, chunk, u); break;
+      case 4: k0_bwd_v_stream<4>(g, out, h, w, hs, chunk, u); break;
+      case 8: k0_bwd_v_stream<8>(g, out, h, w, hs, chunk, u); break;
+      default: k0_bwd_v_stream<16>(g, out, h, w, hs, chunk, u); break;
     }
     return;
   }
@@ -182,7 +236,8 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
     if (s < sc.S) {
       const bool ident = sc.hs[s] == h && sc.ws[s] == w;
       if (s == skip_scale) continue;   // the producer of g_depth_up already wrote this (identity) level's gradient in place: no blocks
-      n1 += ident ? ceil_div(h*w, 1024) : ceil_div(sc.hs[s]*w, 256);
+      const bool stream = premultiplied && !ident && k0_streamable(h, w, sc.hs[s], sc.ws[s]);
+      n1 += ident ? ceil_div(h*w, 1024) : (stream ? ceil_div(w, 256)*ceil_div(sc.hs[s], k0_chunk_rows(h/sc.hs[s])) : ceil_div(sc.hs[s]*w, 256));
       n2 += ident ? 0 : ceil_div(sc.hs[s]*sc.ws[s], 256);
       resampled |= !ident;
     }

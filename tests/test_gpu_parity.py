@@ -1227,7 +1227,7 @@ def test_two_supports_per_wave_backward_equals_one_support_per_wave(F, monkeypat
     T0 = torch.eye(4, device='cuda').repeat(n, b, 1, 1); T0[..., :3, 3] = 0.05*torch.randn(n, b, 3, device='cuda', generator=gen)
     S = 4 if h >= 48 else 2
     d0 = [0.05 + 0.9*torch.rand(b, 1, max(h >> s, 1), max(w >> s, 1), device='cuda', generator=gen) for s in range(S)]
-    supp = (imgs[None] + 0.3*torch.rand(n, b, 3, h, w, device='cuda', generator=gen)).clamp(0, 1)
+    supp = torch.rand(n, b, 3, h, w, device='cuda', generator=gen)          # unrelated frames: every support wins somewhere, and so does the automask
     monkeypatch.setenv('SMD_BWD_SKIP', '0')
 
     def step(pair):
@@ -1239,7 +1239,7 @@ def test_two_supports_per_wave_backward_equals_one_support_per_wave(F, monkeypat
     sel, g1, k1 = step('1'); _, g0, k0 = step('0')
     assert 'k_recon_bwd_pair' in k1 and 'k_recon_bwd<' in k0, (k1, k0)
     assert all(torch.equal(x, y) for x, y in zip(g1, g0)) and all(torch.isfinite(x).all() for x in g1)
-    assert (sel != 255).any()
+    assert all((sel == k).any() for k in range(n)) and (sel == 255).any()
 
 
 @pytest.mark.parametrize('shape', [(2, 3, 1, 1), (2, 5, 6, 20), (1, 4, 33, 65), (3, 8, 48, 160), (2, 6, 40, 70)])
