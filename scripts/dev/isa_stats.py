@@ -72,11 +72,17 @@ if __name__ == '__main__':
                       ('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb0ELi1ELb0EEE', 'k_recon_main<2, true, true, false, false, 1, false> (two supports, depth read from a K0 launch)'),
                       ('_ZN3smd12k_recon_mainILi4ELb1ELb1ELb0ELb1ELi1ELb1EEE', 'k_recon_main<4, true, true, false, true, 1, true>  (four supports, cfg 5)')):
         loop_stats(f, key, 2, what); print('  ' + regs(f, key) + '\n')
-    for key, what in (('_ZN3smd11k_recon_bwdILb1ELi0ELi2ELb1EEE', 'k_recon_bwd<true, 0, 2, true> (per support pass; every row does the full adjoint)'),
-                      ('_ZN3smd11k_recon_bwdILb1ELi2ELi2ELb1EEE', 'k_recon_bwd<true, 2, 2, true> (per support pass; dead-row skipping; the static count includes the rarely taken clear paths)')):
+    for key, what in (('_ZN3smd11k_recon_bwdILb1ELi0ELi2ELb1EEE', 'k_recon_bwd<true, 0, 2, true> (one support per wave, plain row loop: the steady-state body of the peeled pipeline, every row does the full adjoint)'),
+                      ('_ZN3smd11k_recon_bwdILb1ELi2ELi2ELb1EEE', 'k_recon_bwd<true, 2, 2, true> (one support per wave, liveness-gated row loop; the static count includes the clear / dead-row paths)'),
+                      ('_ZN3smd11k_recon_bwdILb1ELi0ELi4ELb1EEE', 'k_recon_bwd<true, 0, 4, true> (cfg 5: four supports, one per wave)')):
         loop_stats(bw, key, 3, what, nested=True); print('  ' + regs(bw, key) + '\n')
+    key = '_ZN3smd16k_recon_bwd_pairILb1ELi1EEE'
+    loop_stats(bw, key, 3, 'k_recon_bwd_pair<true, 1> (experiment: TWO supports per wave, per row step and PAIR; "vector memory" includes the scratch instructions of its spills)', nested=False)
+    print('  ' + regs(bw, key) + '\n')
     print('History (same method): round 1 forward 425 per row for two supports; backward 421 per support row step at the start of round 2 (73 of them v_mov),\n'
           '328 after the (row mod 3) slot rewrite, 300 / 313 at the end of round 2; round 3 left the backward\'s row loop as it was (301 / 313: the launch structure changed).\n'
           'Forward with the shared target ring: of the 16 vector-memory instructions counted per row step, 3 are the LDS-DMA pieces of the epoch block, which runs once\n'
           'every four row steps: a row step executes 13 + 0.75 (without the ring: 16).\n'
-          'The SKIP=2 build keeps its rarely taken clear paths inside the loop body: its static count is an upper bound of what a live row executes.')
+          'The SKIP=2 build keeps its rarely taken clear paths inside the loop body: its static count is an upper bound of what a live row executes.\n'
+          'Round 4: backward 302 plain (peeled pipeline, re-added window sums: 126 -> 111 VGPRs) / 333 gated (static); two supports per wave: 539 per PAIR of row steps against 2 x 302.\n'
+          'The forward\'s one spilled VGPR is a loop-invariant value stored in the prologue and reloaded outside the row loop (no scratch instruction inside it).')

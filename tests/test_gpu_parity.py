@@ -1219,7 +1219,7 @@ def test_row_skip_tuner_times_both_row_loops_and_gradients_do_not_depend_on_the_
 def test_two_supports_per_wave_backward_equals_one_support_per_wave(F, monkeypatch, b, h, w, n):
     """Round 4 built the variant VERDICT r3 item 1b asked for — both supports of a strip in ONE backward wave, the SSIM partials evaluated once per
     pixel for the support `sel` picked (`k_recon_bwd_pair`, `SMD_BWD_PAIR=1`).  It performs the same operations on the same operands as the
-    one-support-per-wave kernel, so every gradient must be BIT-equal (it is slower — `profiles/r04_pair_backward.txt` — and stays an experiment switch)."""
+    one-support-per-wave kernel, so at n = 2 every gradient must be BIT-equal (it is slower — `profiles/r04_pair_backward.txt` — and stays an experiment switch)."""
     from slowtv_monodepth_amd import _lib
     gen = torch.Generator(device='cuda').manual_seed(3)
     imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
@@ -1238,7 +1238,10 @@ def test_two_supports_per_wave_backward_equals_one_support_per_wave(F, monkeypat
         return sel, [v.grad for v in d] + [T.grad], _lib.lib.smd_last_kernel_variant(1).decode()
     sel, g1, k1 = step('1'); _, g0, k0 = step('0')
     assert 'k_recon_bwd_pair' in k1 and 'k_recon_bwd<' in k0, (k1, k0)
-    assert all(torch.equal(x, y) for x, y in zip(g1, g0)) and all(torch.isfinite(x).all() for x in g1)
+    if n == 2: assert all(torch.equal(x, y) for x, y in zip(g1, g0))
+    else:      # two pair waves per strip: (g0 + g1) + (g2 + g3) instead of ((g0 + g1) + g2) + g3 — one addition in another order
+        for x, y in zip(g1, g0): assert rel_to_max(x, y) < 2e-6
+    assert all(torch.isfinite(x).all() for x in g1)
     assert all((sel == k).any() for k in range(n)) and (sel == 255).any()
 
 
