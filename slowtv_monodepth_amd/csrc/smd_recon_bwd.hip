@@ -205,15 +205,15 @@ struct BwdCtx {
 #pragma unroll
     for (int k = 0; k < 9; ++k) ps[k] = 0.f;
     t0 = f3{0.f, 0.f, 0.f}; t1 = t0; t2 = t0; t3 = t0; py = t0; pfx = 0.f; pfy = 0.f;
+    // The first row's gathers go out BEFORE the scan is evaluated (its ~100 scalar / vector instructions then run under their latency;
+    // a gated wave whose first row turns out dead wastes five loads)
+    issue(reflect_row(jstart), Dfirst);
+    hist[(0*kHist + 6)*64] = Dfirst;               // row jstart lives in slot 0
     if (kScan) {
       sel_bits(pb0, va);
       if (two) sel_bits(pb0 + kSelBatch, vb);
       for (int base = pb0 + 2*kSelBatch; base <= pb1; base += kSelBatch) { sel_rows(base, va); sel_bits(base, va); }   // strips taller than 18 rows (single support only)
       if (SKIP >= 1) N = L | (L << 1) | (L >> 1); else L = 0xffffffffu;
-    }
-    if (SKIP == 0 || bit(N, jstart)) {
-      issue(reflect_row(jstart), Dfirst);
-      hist[(0*kHist + 6)*64] = Dfirst;             // row jstart lives in slot 0
     }
   }
 
@@ -221,7 +221,9 @@ struct BwdCtx {
   // DOB / DOC: 0 / 1 = the stage is compiled out / in (peeled form: the first two steps of a strip only synthesise, the next two also
   // have a centre row, from the fifth on every step carries all three stages and the body has no range checks); 2 = decided per step
   // from the rows' ranges (the compact form: one body per phase).
-  template <int PH, int DOB, int DOC>
+  // GATED: the step consults the row masks (false: every stage of the step runs — the plain loop, and the gated loop's fast path through
+  // stretches where everything is live).
+  template <int PH, int DOB, int DOC, bool GATED>
   __device__ __forceinline__ void step(int j_) {
     const int j = __builtin_amdgcn_readfirstlane(j_);   // pin the row counter to an SGPR (row offsets are scalar operands of the buffer accesses)
     constexpr int SN = PH, SP = (PH + 2) % 3, SQ = (PH + 1) % 3;
@@ -229,11 +231,11 @@ struct BwdCtx {
     const int p = j - 1, q = j - 2;
     const bool inB = SSIM && DOB != 0 && (DOB == 1 || (p >= pb0 && p <= pb1));
     const bool inC = DOC != 0 && (DOC == 1 || (q >= r0 && q < r1));
-    const bool doB = inB && (SKIP == 0 || bit(L, p));
-    const bool doC = inC && (SKIP == 0 || bit(N, q));
-    const bool doA = SKIP == 0 || bit(N, j);
-    const bool doI = SKIP == 0 || bit(N, j + 1);      // row j+1 is needed: request its taps now, park its depth at the end of the step
-    const bool doD = SKIP == 0 || bit(N, j + 2);      // row j+2 is needed: request its depth now
+    const bool doB = inB && (!GATED || bit(L, p));
+    const bool doC = inC && (!GATED || bit(N, q));
+    const bool doA = !GATED || bit(N, j);
+    const bool doI = !GATED || bit(N, j + 1);      // row j+1 is needed: request its taps now, park its depth at the end of the step
+    const bool doD = !GATED || bit(N, j + 2);      // row j+2 is needed: request its depth now
 
     f4 ta; f3 tb;                                   // read only where doB holds
 #if !(SMD_ABLATE_BWD & 2)
@@ -325,7 +327,7 @@ struct BwdCtx {
           const float dSxy = p9*a1;
           hsum_w3(dSx, dSxx2, dSxy, wla, wra, HC[SP][c][0], HC[SP][c][1], HC[SP][c][2]);
         }
-      } else if (SKIP >= 1 && inB && ((N >> (unsigned)(p - 1 - rb)) & 7u) != 0u) {
+      } else if (GATED && inB && ((N >> (unsigned)(p - 1 - rb)) & 7u) != 0u) {
         // a dead centre row next to a live one: a stage C will read its coefficient row — as zeros
         // (Without gating nothing needs clearing: every coefficient row that a stage C reads with a non-zero weight was computed.)
 #pragma unroll
@@ -386,7 +388,7 @@ struct BwdCtx {
       // hand (linear, so per support); what reaches the depth from other consumers is added once, by the wave of support 0.
       if (add_gin) {
         gD += bld(rs_gin, lane4, qro);
-        if (SKIP >= 1 && !doC) D2 = bld(rs_depth, lane4, qro);     // a skipped row never had its depth parked
+        if (GATED && !doC) D2 = bld(rs_depth, lane4, qro);     // a skipped row never had its depth parked
       }
       if (a.k0_scale != 0.f) gD *= (D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f;
 #if (SMD_ABLATE_BWD & 4)
@@ -404,25 +406,39 @@ struct BwdCtx {
     if (doI) hist[(SQ*kHist + 6)*64] = Dkeep;      // row j+1's slot: stage C reads it at step j+3 (no second load of the depth)
   }
 
+  // -DSMD_BWD_FASTPATH (experiment, off): a gated wave takes the branch-free body wherever its masks say that everything the step touches is
+  // live — rows j, j+1, j+2 needed, centre row j-1 live, row j-2 needed; one scalar test per step.
+  template <int PH, int DOB, int DOC>
+  __device__ __forceinline__ void step_any(int j) {
+    if (SKIP == 0) { step<PH, DOB, DOC, false>(j); return; }
+#ifdef SMD_BWD_FASTPATH   // (off: with both bodies in one loop the register allocator spills ~70 values at 128 VGPRs — as round 3's per-wave choice did)
+    if (DOB == 1 && DOC == 1) {                                   // steady state of the peeled pipeline: j - 2 >= r0 > rb
+      const unsigned nb = N >> (unsigned)(j - 2 - rb);            // bit 0: row j-2 ... bit 4: row j+2
+      if ((nb & 0x1du) == 0x1du && bit(L, j - 1)) { step<PH, DOB, DOC, false>(j); return; }
+    }
+#endif
+    step<PH, DOB, DOC, true>(j);
+  }
+
   __device__ __forceinline__ void run(int jstart) {
     begin(jstart);
     const int jend = r1 + 1;
     int j = jstart;
     if (kPeel) {                           // jstart = r0 - 2: r1 - r0 + 4 >= 5 steps
-      step<0, 0, 0>(j); ++j;
-      step<1, 0, 0>(j); ++j;
-      step<2, 1, 0>(j); ++j;
-      step<0, 1, 0>(j); ++j;
+      step_any<0, 0, 0>(j); ++j;
+      step_any<1, 0, 0>(j); ++j;
+      step_any<2, 1, 0>(j); ++j;
+      step_any<0, 1, 0>(j); ++j;
       for (;;) {
-        step<1, 1, 1>(j); if (++j > jend) break;
-        step<2, 1, 1>(j); if (++j > jend) break;
-        step<0, 1, 1>(j); if (++j > jend) break;
+        step_any<1, 1, 1>(j); if (++j > jend) break;
+        step_any<2, 1, 1>(j); if (++j > jend) break;
+        step_any<0, 1, 1>(j); if (++j > jend) break;
       }
     } else {
       for (;;) {
-        step<0, 2, 2>(j); if (++j > jend) break;
-        step<1, 2, 2>(j); if (++j > jend) break;
-        step<2, 2, 2>(j); if (++j > jend) break;
+        step_any<0, 2, 2>(j); if (++j > jend) break;
+        step_any<1, 2, 2>(j); if (++j > jend) break;
+        step_any<2, 2, 2>(j); if (++j > jend) break;
       }
     }
   }
