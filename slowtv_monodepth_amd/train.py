@@ -252,7 +252,9 @@ def main(argv=None):
     first_epoch = 0
     if args.resume is not None:
         from .networks.checkpoint import load_reference_checkpoint
-        ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)
+        try: ckpt = torch.load(args.resume, map_location='cpu', weights_only=True)
+        except Exception:   # a Lightning checkpoint pickles hyper-parameter objects: fall back to the full unpickler for a file the user named
+            ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)
         load_reference_checkpoint(module, ckpt)
         try:   # a reference checkpoint carries timm's parameter-group layout: continue weights-only rather than refuse it
             if ckpt.get('optimizer_states'): opt.load_state_dict(ckpt['optimizer_states'][0])
