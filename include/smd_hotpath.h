@@ -41,9 +41,10 @@ extern "C" {
 #define SMD_LOSS_L2 0x20       /* DenseL2Error (photometric.py:17-20; loss_name='l2', un-fused operators only) */
 #define SMD_MASK_EXPLAINABILITY 0x80   /* smd_recon_reduce_*: ReconstructionLoss(mask_name='explainability'): err * mask (reconstruction.py:55) */
 #define SMD_MASK_UNCERTAINTY 0x100     /* smd_recon_reduce_*: mask_name='uncertainty': err * exp(-mask) + mask (reconstruction.py:56) */
-#define SMD_BWD_SKIP_DEAD_ROWS 0x400   /* smd_image_recon*_bwd: rows of a wave in which no pixel selected its support skip the SSIM partials (and, after three of
-                                        * them, the chain rule).  Same result bit for bit; pays when >= ~80 % of the (row, strip) units are such rows (up to
-                                        * -21 %), costs 3-12 % otherwise (profiles/r03_skip_regimes.txt).  Default: off.  SMD_BWD_SKIP in the environment overrides. */
+#define SMD_BWD_SKIP_DEAD_ROWS 0x400   /* smd_image_recon*_bwd: the liveness-gated row loop — a wave scans the `sel` rows of its strip first and then re-synthesises,
+                                        * scores and back-propagates only the rows a pixel of its columns routes gradient through.  Same result bit for bit; all-masked
+                                        * input: 52 instead of 117 us at 12x192x640; pays from ~75 % dead (row, strip) units on, costs 12-24 % where every row is live
+                                        * (profiles/r04_skip_regimes.txt).  Default: off.  SMD_BWD_SKIP in the environment overrides. */
 #define SMD_USE_LAPLACIAN 0x200        /* smd_disp_smooth_*: SmoothReg(use_laplacian=True): second-order differences (smooth.py:33-48) */
 #define SMD_EDGES_READY 0x800  /* smd_disp_smooth_fwd: `edge_weights` was already filled by smd_disp_smooth_prep() for this frame and pyramid */
 #define SMD_PACKED_READY 0x40  /* smd_image_recon_*_fwd: `supp_packed` was already filled by smd_image_recon_prep() for these frames */

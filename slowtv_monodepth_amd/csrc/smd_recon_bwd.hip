@@ -1,22 +1,23 @@
-// smd_recon_bwd.hip — hand-written adjoint of the fused view-synthesis photometric loss (gfx950), round-2 structure.
+// smd_recon_bwd.hip — hand-written adjoint of the fused view-synthesis photometric loss (gfx950).
 //
 // Same wave-strip streaming as the forward (smd_recon_fwd.hip): 60 interior columns + 2 halo lanes per side, rows
-// r0-2 .. r1+1, one support per wave (the state of one support is ~90 registers; two at once would halve the occupancy of a
-// kernel whose gathers need the waves to hide their latency).  Round 3: the supports of a strip are handled by DIFFERENT waves
-// of one block, concurrently (n = 2: a block is 2 strips x 2 supports), instead of by one wave in consecutive passes: a work
-// unit is half as long (a launch is only ~2 generations of waves, so its tail is a fraction of a unit), the waves of a strip
-// pull the same target-side rows (`sel`, target pixel, window terms, depth) through one L1, and the per-pixel sum of dL/d depth
-// over the supports is formed once, from LDS, after a block barrier.  Three stages per row step j:
+// r0-2 .. r1+1, one support per wave (the state of one support is ~90 registers; two at once were built in round 4 —
+// k_recon_bwd_pair below — and are slower: profiles/r04_pair_backward.txt).  Since round 3 the supports of a strip are handled by
+// DIFFERENT waves of one block, concurrently (n = 2: a block is 2 strips x 2 supports): a work unit is half as long (a launch is only
+// ~3 generations of waves, so its tail is a fraction of a unit), the waves of a strip pull the same target-side rows (`sel`, target
+// pixel, window terms, depth) through one L1, and the per-pixel sum of dL/d depth over the supports is formed once, from LDS, by the
+// strip's last wave.  Three stages per row step j:
 //   stage A (row j)   : re-synthesise the warped pixel x and its bilinear partials dx/dsx, dx/dsy from the four RGB taps
 //                       whose loads were issued one step earlier; issue the loads of row j+1
-//   stage B (row j-1) : window sums by the forward's sliding scheme (P = r(j-2) + r(j-1); reflection by data in the halo
-//                       lanes, by a multiplier / a recovered row at the image's top / bottom), the target-side sums read
-//                       back from the packed buffer the forward filled; SSIM partials d e/d(Sx, Sxx, Sxy) times the upstream
-//                       gradient routed by `sel` (min-reprojection / automask); box-summed horizontally with the ADJOINT
-//                       reflection weights (avg_pool2d + reflection_pad2d backward) and accumulated vertically
+//   stage B (row j-1) : window sums of the centre row from its three raw rows (reflection by data: in the halo lanes horizontally,
+//                       by re-synthesised rows -1 = 1 and h = h-2 vertically), the target-side sums read back from the packed buffer
+//                       the forward filled; SSIM partials d e/d(Sx, Sxx, Sxy) times the upstream gradient routed by `sel`
+//                       (min-reprojection / automask); box-summed horizontally with the ADJOINT reflection weights
+//                       (avg_pool2d + reflection_pad2d backward) and accumulated vertically
 //   stage C (row j-2) : dL/dx -> dL/d(sx, sy) (zero where the border clamp is active) -> projective chain rule ->
 //                       dL/d depth (this support's share, parked in LDS) and nine per-lane sums that become dL/d(H, a);
-//                       the block that finishes a sample last turns the sums into dL/dT, dL/dK and dL/dK^-1.
+//                       the K0-adjoint launch that follows (or the block that finishes a sample last) turns the sums into
+//                       dL/dT, dL/dK and dL/dK^-1.
 // Nothing of the forward is stored except the packed texels / target sums (which the forward needs itself) and `sel`.
 #include "smd_common.h"
 #include "smd_kernels.h"
