@@ -1117,7 +1117,10 @@ def test_k0_fused_path_matches_reference_fixtures(F, golden, name):
 
 
 @pytest.mark.parametrize('b,h,w,lows', [(2, 33, 47, [(33, 47), (16, 23), (8, 11)]), (1, 24, 36, [(24, 36), (12, 18), (6, 9), (3, 4)]),
-                                        (1, 96, 128, [(48, 64), (12, 16)]), (2, 21, 30, [(7, 10), (5, 30)])])
+                                        (1, 96, 128, [(48, 64), (12, 16)]), (2, 21, 30, [(7, 10), (5, 30)]),
+                                        # even integer row ratios take the STREAMING vertical pass of the K0 adjoint (round 4): odd chunk counts, more than one
+                                        # 256-column block, ratio 16, a column ratio unrelated to the row ratio
+                                        (2, 50, 520, [(50, 520), (25, 260)]), (1, 64, 300, [(64, 300), (32, 150), (16, 75), (4, 19)]), (1, 48, 70, [(24, 70), (6, 9)])])
 def test_k0_fused_path_at_non_integer_ratios_and_with_a_second_consumer_of_depth(F, b, h, w, lows):
     """Pyramids that are not exact halvings / have no full-resolution scale, and a second consumer of `depth_up` (as `depth_regr`
     is in the trainer): fused path == K0 kernel followed by the plain fused path, values and gradients."""
