@@ -72,9 +72,9 @@ if __name__ == '__main__':
                       ('_ZN3smd12k_recon_mainILi2ELb1ELb1ELb0ELb0ELi1ELb0EEE', 'k_recon_main<2, true, true, false, false, 1, false> (two supports, depth read from a K0 launch)'),
                       ('_ZN3smd12k_recon_mainILi4ELb1ELb1ELb0ELb1ELi1ELb1EEE', 'k_recon_main<4, true, true, false, true, 1, true>  (four supports, cfg 5)')):
         loop_stats(f, key, 2, what); print('  ' + regs(f, key) + '\n')
-    for key, what in (('_ZN3smd11k_recon_bwdILb1ELi0ELi2ELb1EEE', 'k_recon_bwd<true, 0, 2, true> (one support per wave, plain row loop: the steady-state body of the peeled pipeline, every row does the full adjoint)'),
-                      ('_ZN3smd11k_recon_bwdILb1ELi2ELi2ELb1EEE', 'k_recon_bwd<true, 2, 2, true> (one support per wave, liveness-gated row loop; the static count includes the clear / dead-row paths)'),
-                      ('_ZN3smd11k_recon_bwdILb1ELi0ELi4ELb1EEE', 'k_recon_bwd<true, 0, 4, true> (cfg 5: four supports, one per wave)')):
+    for key, what in (('_ZN3smd11k_recon_bwdILb1ELi0ELi2ELb1ELb0EEE', 'k_recon_bwd<true, 0, 2, true, false> (one support per wave, plain row loop: the steady-state body of the peeled pipeline, every row does the full adjoint)'),
+                      ('_ZN3smd11k_recon_bwdILb1ELi2ELi2ELb1ELb0EEE', 'k_recon_bwd<true, 2, 2, true, false> (one support per wave, liveness-gated row loop; the static count includes the clear / dead-row paths)'),
+                      ('_ZN3smd11k_recon_bwdILb1ELi0ELi4ELb1ELb0EEE', 'k_recon_bwd<true, 0, 4, true, false> (cfg 5: four supports, one per wave)')):
         loop_stats(bw, key, 3, what, nested=True); print('  ' + regs(bw, key) + '\n')
     key = '_ZN3smd16k_recon_bwd_pairILb1ELi1EEE'
     loop_stats(bw, key, 3, 'k_recon_bwd_pair<true, 1> (experiment: TWO supports per wave, per row step and PAIR; "vector memory" includes the scratch instructions of its spills)', nested=False)

@@ -90,7 +90,9 @@ constexpr int kSelBatch = 10;   // `sel` rows requested at once by the prologue 
 #define SMD_BWD_STATEFUL 0   // the plain loop keeps sliding vertical sums P = r(j-2) + r(j-1) (the forward's scheme) instead of re-adding three raw rows
 #endif
 
-template <bool SSIM, int SKIP, bool ACC>
+// XTRA: the instantiation also serves the two rare cases that cost every row step two scalar branches at the end of its basic block — a
+// gradient that reaches the depth from another consumer (g_in) and a wave that takes several supports in turn (n > 4, or SMD_BWD_WPS < n).
+template <bool SSIM, int SKIP, bool ACC, bool XTRA>
 struct BwdCtx {
   static constexpr bool kScan = (SKIP >= 1) || !SMD_BWD_ROWSEL;        // `sel` of the whole strip scanned before the row loop
   static constexpr bool kSliding = (SKIP == 0) && SMD_BWD_STATEFUL;    // (a gated loop skips rows: no running state)
@@ -155,7 +157,9 @@ struct BwdCtx {
 
   // ReflectionPad2d(1) by data, above and below the image: row -1 is row 1, row h is row h-2 (rows further out only feed the dummy
   // centre rows -1 / h of the peeled form, whose coefficients are exact zeros: any valid row will do)
-  __device__ __forceinline__ int reflect_row(int r) const { return (r < 0) ? min(-r, h - 1) : ((r > h - 1) ? max(2*(h - 1) - r, 0) : r); }
+  // (branch-free on the scalar unit — s_abs / s_sub / s_max: written as nested conditionals the compiler emitted two scalar BRANCHES per call,
+  // four per row step, each one splitting the step's basic block)
+  __device__ __forceinline__ int reflect_row(int r) const { const int t = abs(r); return max((h - 1) - abs((h - 1) - t), 0); }
   __device__ __forceinline__ bool bit(unsigned m, int row) const { return (m >> (unsigned)(row - rb)) & 1u; }
   __device__ __forceinline__ bool routes(unsigned v) const { return (v == sel_key) == use_min; }   // min-reprojection: sel == support; mean: sel != "masked"
 
@@ -387,7 +391,7 @@ struct BwdCtx {
       }
       // dL/d depth of this support.  K0 fused: d depth / d(up-sampled, scaled disparity) is applied here, where the depth is at
       // hand (linear, so per support); what reaches the depth from other consumers is added once, by the wave of support 0.
-      if (add_gin) {
+      if (XTRA && add_gin) {
         gD += bld(rs_gin, lane4, qro);
         if (GATED && !doC) D2 = bld(rs_depth, lane4, qro);     // a skipped row never had its depth parked
       }
@@ -400,7 +404,7 @@ struct BwdCtx {
         // The supports of a strip are summed from LDS by the strip's last wave (k_recon_bwd): each lane parks its own column, one
         // slot per strip row; no read-modify-write of g_depth, one global store per pixel.
         float* slot = gacc + (q - r0)*64;
-        if (acc_prev) gD += *slot;
+        if (XTRA && acc_prev) gD += *slot;
         *slot = gD;
       } else if (interior) bst(rs_gd, lane4, qro, gD);   // a single support: the row is final
     }
@@ -452,7 +456,7 @@ constexpr int kAccRows = 16;   // tallest strip of the multi-support instantiati
 // NS = waves per strip: wave (strip in block, k) handles supports k, k + NS, ... of its strip (NS = 1: every support, one after
 // the other — balanced waves whatever the selection masks look like; NS = min(n, 4): half / a quarter as long work units).
 // ACC: more than one support — the strip's dL/d depth rows are summed in LDS.
-template <bool SSIM, int SKIP, int NS, bool ACC>
+template <bool SSIM, int SKIP, int NS, bool ACC, bool XTRA>
 __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconBwdArgs a) {
   static_assert(ACC || NS == 1, "several waves per strip need the LDS sum");
   constexpr int SPB = (kWavesPerBlock/NS > 0) ? kWavesPerBlock/NS : 1;   // strips per block
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   float* const wave_lds = hist_lds + wid*kWaveFloats;
 
   {
-    BwdCtx<SSIM, SKIP, ACC> cx{a};
+    BwdCtx<SSIM, SKIP, ACC, XTRA> cx{a};
     cx.hist = wave_lds + lane;
     cx.gacc = cx.hist + 3*kHist*64;
     cx.h = h; cx.w = w;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
 
     // rows outside the image are reflected ones (BwdCtx::reflect_row).  Peeled form: every strip runs rows r0-2 .. r1+1 with centre
     // rows r0-1 .. r1 (-1 and h: dummy rows, exact zeros); compact form: the image's top strip starts at row -1 (= row 1) and no dummy rows
-    const bool peel = BwdCtx<SSIM, SKIP, ACC>::kPeel;
+    const bool peel = BwdCtx<SSIM, SKIP, ACC, XTRA>::kPeel;
     const int jstart = peel ? r0 - 2 : max(r0 - 2, -1);
     cx.pb0 = peel ? r0 - 1 : max(r0 - 1, 0); cx.pb1 = peel ? r1 : min(r1, h - 1);   // centre rows whose coefficients are needed
 
@@ -649,7 +653,9 @@ struct BwdPair {
   __device__ __forceinline__ float hi_w(int r) const { return (h == 2) ? usel(r == 0, 2.f, 0.f) : usel(r == h - 1, 0.f, usel(r == h - 2, 2.f, 1.f)); }
   __device__ __forceinline__ float* hp(int k, int slot, int c) const { return hist + ((k*3 + slot)*6 + c)*64; }
   __device__ __forceinline__ float* hd(int slot) const { return hist + (36 + slot)*64; }
-  __device__ __forceinline__ int reflect_row(int r) const { return (r < 0) ? min(-r, h - 1) : ((r > h - 1) ? max(2*(h - 1) - r, 0) : r); }
+  // (branch-free on the scalar unit — s_abs / s_sub / s_max: written as nested conditionals the compiler emitted two scalar BRANCHES per call,
+  // four per row step, each one splitting the step's basic block)
+  __device__ __forceinline__ int reflect_row(int r) const { const int t = abs(r); return max((h - 1) - abs((h - 1) - t), 0); }
 
   __device__ __forceinline__ void issue(int k, int jr, float D) {
     const float vf = (float)jr;
@@ -990,8 +996,11 @@ hipError_t launch_pose_finalize(const float* pose_partial, int entries, int stri
 
 template <bool SSIM, int SKIP, int NS, bool ACC>
 static void launch_bwd_t(dim3 grid, dim3 block, hipStream_t st, const ReconBwdArgs& a) {
-  note_variant(1, "smd::k_recon_bwd<%s, %d, %d, %s>", SSIM ? "true" : "false", SKIP, NS, ACC ? "true" : "false");
-  hipLaunchKernelGGL((k_recon_bwd<SSIM, SKIP, NS, ACC>), grid, block, 0, st, a);
+  // the common case — every support has its own wave, nothing else feeds the depth — runs the instantiation without the two per-step branches
+  const bool xtra = a.g_in != nullptr || a.n > NS;
+  note_variant(1, "smd::k_recon_bwd<%s, %d, %d, %s, %s>", SSIM ? "true" : "false", SKIP, NS, ACC ? "true" : "false", xtra ? "true" : "false");
+  if (xtra) hipLaunchKernelGGL((k_recon_bwd<SSIM, SKIP, NS, ACC, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_recon_bwd<SSIM, SKIP, NS, ACC, false>), grid, block, 0, st, a);
 }
 
 template <bool SSIM, int NP>

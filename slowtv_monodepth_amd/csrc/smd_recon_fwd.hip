@@ -415,7 +415,9 @@ struct MainCtx {
     const float val = fmaf(ly, h1, (1.f - ly)*h0);
     const float d = fmaf(a_scale, val, a_off);
     const float dep = (d > 0.f) ? __builtin_amdgcn_rcpf(fmaxf(d, kEps32)) : 0.f;
-    if (row >= r0 && row < r1 && interior) bst(rs_dout, lane4, (unsigned)row*w4, dep);   // each row is interior to one strip
+    // each row is interior to one strip.  No control flow around the store (a divergent `if` ends the row step's basic block twice): a lane or a
+    // row that must not write is sent out of the buffer's range, where the bounds check drops it
+    bst(rs_dout, interior ? lane4 : 0xffffffffu, (row >= r0 && row < r1) ? (unsigned)row*w4 : 0xf0000000u, dep);
     return dep;
   }
 
@@ -583,16 +585,19 @@ struct MainCtx {
         }
       }
     }
-    if (EMIT && interior) {
+    if (EMIT) {
+      // every lane runs this (the halo lanes' values are finite and go nowhere): only the stores and the loss sum look at `interior`, through
+      // an out-of-range lane offset / a select — no exec-mask region in the row step except the rare tie-break one
       const unsigned lane1 = lane4 >> 2, cro = (unsigned)v*w4, cro1 = (unsigned)v*(unsigned)w;
+      const unsigned st4 = interior ? lane4 : 0xffffffffu, st1 = interior ? lane1 : 0xffffffffu;
       if (!SINGLE && !a.first_pass) {
         const float prev = bld(rs_err, lane4, cro);
         if (use_min) { if (!(best < prev)) { best = prev; bsel = (int)bld8(rs_sel, lane1, cro1); } }
         else acc += prev;
       }
       if (!SINGLE && !a.last_pass) {
-        bst(rs_err, lane4, cro, use_min ? best : acc);
-        bst8(rs_sel, lane1, cro1, (unsigned)bsel);
+        bst(rs_err, st4, cro, use_min ? best : acc);
+        bst8(rs_sel, st1, cro1, (unsigned)bsel);
       } else {
         float e = use_min ? best : acc*a.inv_n;
         if (!use_min) bsel = 0;
@@ -603,12 +608,12 @@ struct MainCtx {
           est = fmaf(kEps32, gauss_noise(a.seed_lo, a.seed_hi, (uint32_t)(((unsigned)s*(unsigned)a.b + (unsigned)bi)*(hw4 >> 2) + cro1 + lane1)), est);
         if (est < e) { e = est; bsel = SMD_SEL_MASKED; }
 #if (SMD_ABLATE & 4)
-        if (e == 123.456f) bst(rs_err, lane4, cro, e + (float)bsel);
+        if (e == 123.456f) bst(rs_err, st4, cro, e + (float)bsel);
 #else
-        if (has_err) bst(rs_err, lane4, cro, e);      // the error map is an optional output (logging / tests): one store less per row
-        bst8(rs_sel, lane1, cro1, (unsigned)bsel);
+        if (has_err) bst(rs_err, st4, cro, e);      // the error map is an optional output (logging / tests): one store less per row
+        bst8(rs_sel, st1, cro1, (unsigned)bsel);
 #endif
-        lsum += e;
+        lsum += interior ? e : 0.f;
       }
     }
   }
