@@ -85,4 +85,6 @@ if __name__ == '__main__':
           'every four row steps: a row step executes 13 + 0.75 (without the ring: 16).\n'
           'The SKIP=2 build keeps its rarely taken clear paths inside the loop body: its static count is an upper bound of what a live row executes.\n'
           'Round 4: backward 302 plain (peeled pipeline, re-added window sums: 126 -> 111 VGPRs) / 333 gated (static); two supports per wave: 539 per PAIR of row steps against 2 x 302.\n'
-          'The forward\'s one spilled VGPR is a loop-invariant value stored in the prologue and reloaded outside the row loop (no scratch instruction inside it).')
+          'End of round 4: no divergent control flow left inside a row step.  Backward 302 -> 298 vector / 84 -> 59 scalar (branch-free row reflection, the g_in and\n'
+          'several-supports-per-wave paths compiled out of the common instantiation); forward 352 -> 358 with the stores outside `if (interior)` (out-of-range offsets drop\n'
+          'them), which removed the one spilled VGPR (128 -> 126) and took <4,...> from 168 to 158 VGPRs (r04_bwd_variants.txt, box 3: backward -3 %, cfg 5 forward -3.4 %).')
