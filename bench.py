@@ -216,20 +216,40 @@ def main():
             fence()
             opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss_static, _ = model(batch)
-                loss_static.backward()
-                if isinstance(model, FlatAllReduce): model.sync_gradients()
-                opt.step()
-            def run_steps(k):
-                for _ in range(k): graph.replay()
-                return [loss_static.detach()]
+            # thread_local: with a process group, RCCL's watchdog thread polls the events of the warm-up steps' collectives; under the default
+            # (global) mode such a query from ANOTHER thread invalidates the capture and the watchdog dies with it
+            if isinstance(model, FlatAllReduce):
+                # data-parallel: forward + backward are one graph, the optimizer step a second one, and the gradient all-reduces run eagerly
+                # between the two (`FlatAllReduce.average_static`): no collective inside a capture
+                model.require_sync = False                    # the wrapper's gradient hooks stay inert, now and on every replay
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    loss_static, _ = model(batch)
+                    loss_static.backward()
+                grads = [[p.grad if p.grad is not None else torch.zeros_like(p) for p in bk] for bk in model.buckets]   # rewritten in place by every replay
+                for bk, views in zip(model.buckets, model.views):
+                    for p, v in zip(bk, views): p.grad = v    # what the optimizer reads: its slice of the averaged bucket
+                model.average_static(grads)
+                graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_opt, capture_error_mode='thread_local'): opt.step()
+                def run_steps(k):
+                    for _ in range(k): graph.replay(); model.average_static(grads); graph_opt.replay()
+                    return [loss_static.detach()]
+                what = 'forward of both networks on two streams, loss path and backward as one graph, the optimizer step as a second one, the gradient all-reduces eagerly between them'
+            else:
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    loss_static, _ = model(batch)
+                    loss_static.backward()
+                    opt.step()
+                def run_steps(k):
+                    for _ in range(k): graph.replay()
+                    return [loss_static.detach()]
+                what = 'forward of both networks on two streams, loss path, backward, optimizer step'
             run_steps(2); fence()
             launch_ms = []
-            for _ in range(5):                                # what ONE replay costs the host when the queue is empty (the timed loop below runs into the
-                t_l = time.perf_counter(); graph.replay()     # runtime's back-pressure: its enqueue time tends to the GPU time)
+            for _ in range(5):                                # what ONE step costs the host when the queue is empty (the timed loop below runs into the
+                t_l = time.perf_counter(); run_steps(1)       # runtime's back-pressure: its enqueue time tends to the GPU time)
                 launch_ms.append((time.perf_counter() - t_l)*1e3); fence()
-            graph_note = f'whole step captured (forward of both networks on two streams, loss path, backward, optimizer step) and replayed; one replay costs the host {sorted(launch_ms)[2]:.3f} ms (median of 5, queue empty)'
+            graph_note = f'whole step captured ({what}) and replayed; one step costs the host {sorted(launch_ms)[2]:.3f} ms (median of 5, queue empty)'
         except Exception as e:   # e.g. a collective that cannot be captured: report it, time the eager loop
             graph_note = f'capture failed ({type(e).__name__}: {str(e)[:200]}); eager loop timed instead'
             torch.cuda.synchronize()

@@ -30,9 +30,16 @@ W_SSIM = 0.85      # src/losses/reconstruction.py:38 -> PhotoError(weight_ssim=0
 # a1/a2: upsample + disparity -> depth
 # ---------------------------------------------------------------------------------------------------
 def _src_index(n_out: int, n_in: int, dtype, device):
-    """ATen `area_pixel_compute_source_index` for bilinear, align_corners=False (called at src/tools/ops.py:314)."""
-    scale = n_in/n_out
-    src = (torch.arange(n_out, dtype=dtype, device=device) + 0.5)*scale - 0.5
+    """ATen `area_pixel_compute_source_index` for bilinear, align_corners=False (called at src/tools/ops.py:314).
+    ATen computes `scale = in/out` in the tensor's dtype and evaluates `scale*(dst + 0.5) - 0.5` as ONE fused multiply-add (its CPU vector
+    kernels are built with FMA, its CUDA/HIP kernels contract the expression): one rounding, not two.  With two roundings the coordinate of
+    a wide image (ulp 1.5e-5 beyond column 128) moves lambda by up to 1e-5 against `F.interpolate` — found by tests/test_gpu_fuzz.py at
+    pyramid ratios that are not exact halvings; the single-rounding form below agrees with `F.interpolate` to one ulp of the result."""
+    dst = torch.arange(n_out, dtype=torch.float64, device=device)
+    if dtype == torch.float64: src = (dst + 0.5)*(n_in/n_out) - 0.5
+    else:
+        scale = (torch.tensor(float(n_in), dtype=dtype)/torch.tensor(float(n_out), dtype=dtype)).double().to(device)
+        src = ((dst + 0.5)*scale - 0.5).to(dtype)    # exact product and sum in fp64, rounded once = fma in `dtype`
     src = src.clamp(min=0)
     i0 = src.floor().long().clamp(max=n_in - 1)
     i1 = (i0 + 1).clamp(max=n_in - 1)

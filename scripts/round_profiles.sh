@@ -22,19 +22,5 @@ for wl in cfg2 cfg4 cfg5; do
 done
 python scripts/make_traffic_json.py $tag cfg2 cfg4 cfg5 > gpurun_out/traffic_$tag.json
 tail -5 gpurun_out/traffic_$tag.json
-{
-  echo "# bench.py under torch.distributed.run --nproc-per-node 1 with the RCCL process group forced on one rank (SMD_FORCE_DDP=1): the data-parallel wrappers' own cost"
-  echo "# command: SMD_FORCE_DDP=1 SMD_DP_IMPL=<impl> python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
-  for impl in flat ddp; do
-    echo "## SMD_DP_IMPL=$impl"
-    SMD_FORCE_DDP=1 SMD_DP_IMPL=$impl timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"'
-  done
-  echo "## no process group (same box, same run)"
-  timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"'
-  echo "## the same three with the whole step captured into ONE HIP graph and replayed (bench.py --graph; config.hip_graph says what happened): what the host enqueues per step"
-  echo "## SMD_DP_IMPL=flat --graph"
-  SMD_FORCE_DDP=1 SMD_DP_IMPL=flat timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --graph 2>/dev/null | grep '"metric"'
-  echo "## no process group --graph"
-  timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --graph 2>/dev/null | grep '"metric"'
-} > gpurun_out/rccl_one_rank_$tag.txt
+bash scripts/rccl_one_rank.sh $tag
 cut -c1-160 gpurun_out/rccl_one_rank_$tag.txt

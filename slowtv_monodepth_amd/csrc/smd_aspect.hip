@@ -22,7 +22,7 @@
 namespace smd {
 
 __device__ __forceinline__ void ar_src_index(int dst, float scale, int n_in, int& i0, int& i1, float& l1) {   // ATen area_pixel_compute_source_index, align_corners=False
-  const float src = fmaxf(scale*((float)dst + 0.5f) - 0.5f, 0.f);
+  const float src = fmaxf(fmaf(scale, (float)dst + 0.5f, -0.5f), 0.f);
   i0 = min((int)src, n_in - 1);
   i1 = min(i0 + 1, n_in - 1);
   l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);

@@ -13,7 +13,7 @@ namespace smd {
 
 // ATen area_pixel_compute_source_index (align_corners=False, non-cubic) + index/lambda split.
 __device__ __forceinline__ void src_index(int dst, float scale, int n_in, int& i0, int& i1, float& l1) {
-  float src = fmaxf(scale*((float)dst + 0.5f) - 0.5f, 0.f);
+  float src = fmaxf(fmaf(scale, (float)dst + 0.5f, -0.5f), 0.f);
   i0 = min((int)src, n_in - 1);
   i1 = min(i0 + 1, n_in - 1);
   l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);

@@ -156,6 +156,22 @@ class FlatAllReduce(nn.Module):
             self._streams[i].clear()
 
 
+    @torch.no_grad()
+    def average_static(self, grads: list) -> None:
+        """Average gradients that live in FIXED tensors (`grads[i][k]` belongs to `self.buckets[i][k]`): pack, all-reduce, wait — nothing else.
+        For a training step replayed from HIP graphs (`bench.py --graph`): forward + backward are one graph that rewrites the same gradient
+        tensors on every replay, the optimizer step is a second graph that reads the bucket views, and the collectives run here, eagerly,
+        between the two.  (A collective INSIDE a capture is at the mercy of the process group's watchdog thread, which polls events while
+        the capture is open: one run in two to four died on this stack.)  Hooks must be inert: set `require_sync = False`."""
+        works = []
+        for i, gs in enumerate(grads):
+            torch.cat([g.reshape(-1) for g in gs], out=self.flats[i])
+            works.append(dist.all_reduce(self.flats[i], op=self.avg_op, async_op=True))
+        for i, w in enumerate(works):
+            w.wait()
+            if self.avg_op == dist.ReduceOp.SUM: self.flats[i].div_(self.world)
+
+
 def wrap_ddp(step: StepModule, device: torch.device, bucket_cap_mb: int = 25) -> nn.Module:
     """Data parallelism over RCCL/xGMI, one process per GPU.  Default: `FlatAllReduce` (see there).  `SMD_DP_IMPL=ddp`:
     torch DDP with `bucket_cap_mb` buckets reduced as backward produces them, buckets aliasing the .grad tensors.

@@ -1,0 +1,89 @@
+"""Seeded random shapes and options through the whole loss path the trainer runs — K0-fused reconstruction + smoothness, forward and
+backward — against the CPU oracle.  The hand-picked sweeps of test_gpu_parity.py sit on the boundaries someone thought of (strip and
+wave widths, epochs of the target ring, streaming K0 ratios); this one draws batch, image size, number of supports, pyramid sizes
+(exact halvings or unrelated ones), depth range, loss and mask options at random so that an unlucky combination is met before a user
+meets it.  Same tolerances as test_gpu_parity.py; a pixel whose selection differs (a tie decided by rounding) moves its gradient
+between supports, so cases with flips get the coarse gradient bound.
+
+What the first run of this file found (round 4): the oracle evaluated the bilinear source index with two roundings where ATen (and the
+kernels) fuse it into one — lambda off by up to 1e-5 beyond column 128 at pyramid ratios that are not exact halvings (fixed in
+oracle/view_synth_oracle.py::_src_index, checked against F.interpolate); and one L1 sign knife edge (below)."""
+import random
+
+import pytest
+import torch
+
+from conftest import rel_to_max
+from oracle import view_synth_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = list(range(24))
+
+
+def draw(seed):
+    r = random.Random(9000 + seed)
+    b = r.choice([1, 1, 2, 3])
+    h = r.choice([r.randint(2, 12), r.randint(13, 40), r.randint(41, 90)])
+    w = r.choice([r.randint(2, 20), r.randint(55, 70), r.randint(110, 135), r.randint(21, 200)])
+    n = r.choice([1, 2, 2, 3, 4])
+    S = r.choice([1, 2, 3, 4, 4])
+    if r.random() < 0.5: lows = [(max(h >> s, 1), max(w >> s, 1)) for s in range(S)]
+    else: lows = [(r.randint(1, h), r.randint(1, w)) for _ in range(S)]
+    opts = dict(loss_name=r.choice(['ssim', 'ssim', 'ssim', 'l1']), use_min=r.random() < 0.7, use_automask=r.random() < 0.7, use_edges=r.random() < 0.7)
+    lo = r.choice([0.1, 0.01, 0.5]); hi = r.choice([100.0, 10.0, 80.0])
+    return b, h, w, n, lows, opts, lo, hi
+
+
+@pytest.mark.parametrize('seed', SEEDS)
+def test_random_shapes_and_options_match_the_oracle(seed):
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as F
+    b, h, w, n, lows, opts, lo, hi = draw(seed)
+    S = len(lows)
+    gen = torch.Generator().manual_seed(seed)
+    imgs = torch.rand(b, 3, h, w, generator=gen)
+    # supports = a blend of the target and an unrelated image: the identity error of the automask and the warped errors are of the same
+    # order, so both the automask and the supports win somewhere (a support that is the target + noise is masked everywhere)
+    mix = 0.6*torch.rand(1, generator=gen).item()
+    supp = mix*imgs[None] + (1 - mix)*torch.rand(n, b, 3, h, w, generator=gen)
+    disps = {s: 0.05 + 0.9*torch.rand(b, 1, hs, ws, generator=gen) for s, (hs, ws) in enumerate(lows)}
+    aa = 0.02*torch.randn(n*b, 3, generator=gen); t = 0.1*torch.randn(n*b, 3, generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(b, 1, 1)
+    noise = torch.randn(S*b, 1, h, w, generator=gen) if opts['use_automask'] else None
+    what = f'seed {seed}: b={b} {h}x{w} n={n} pyramid {lows} {opts} depth [{lo}, {hi}]'
+
+    # oracle (fp32, CPU)
+    dc = {s: d.clone().requires_grad_(True) for s, d in disps.items()}
+    Tc = O.T_from_AAt(aa, t).unflatten(0, (n, b)).clone().requires_grad_(True)
+    loss_c, out_c = O.loss_path(dc, imgs, supp, Tc, K, min_depth=lo, max_depth=hi, loss_name=opts['loss_name'], use_min=opts['use_min'],
+                                use_automask=opts['use_automask'], use_edges=opts['use_edges'], w_smooth=0.1, noise=noise)
+    loss_c.backward()
+
+    # HIP
+    dg = [d.cuda().requires_grad_(True) for d in disps.values()]
+    Tg = Tc.detach().cuda().requires_grad_(True)
+    l_rec, err, sel, _, dep = F.image_recon_fused_disp(dg, imgs.cuda(), supp.cuda(), Tg, K.cuda(), flags=F.recon_flags(opts['loss_name'], opts['use_min'], opts['use_automask']),
+                                                       min_depth=lo, max_depth=hi, noise=None if noise is None else noise.cuda(), want_err=True)
+    l_sm, _, _ = F.disp_smooth_fused(dict(enumerate(dg)), imgs.cuda(), use_edges=opts['use_edges'], want_aux=False)
+    (l_rec + 0.1*l_sm).backward()
+
+    for s in range(S): torch.testing.assert_close(dep[s].cpu(), out_c['depth_up'][s].detach(), rtol=2e-5, atol=1e-5, msg=lambda m: f'{what}: depth_up[{s}] {m}')
+    torch.testing.assert_close(l_sm.detach().cpu(), out_c['loss_disp_smooth'].detach(), rtol=2e-5, atol=1e-7, msg=lambda m: f'{what}: smoothness {m}')
+    full = out_c['full']
+    flips = (sel.cpu() != full['sel']).flatten()
+    share = flips.float().mean().item()
+    assert share <= 0.01, f'{what}: selection differs on {share:.2%} of the pixels'
+    torch.testing.assert_close(err.cpu().flatten()[~flips], full['err'].detach().flatten()[~flips], rtol=0, atol=3e-4, msg=lambda m: f'{what}: error map {m}')
+    torch.testing.assert_close(l_rec.detach().cpu(), out_c['loss_img_recon'].detach(), rtol=1e-4 if not flips.any() else 2e-3, atol=1e-6, msg=lambda m: f'{what}: loss {m}')
+    tol = 5e-2 if flips.any() else (1e-2 if opts['loss_name'] == 'l1' else 2e-3)
+    for s in range(S):
+        # per element, relative to the largest gradient.  A few elements may sit on a knife edge of the loss itself — |pred - target| of one
+        # channel within rounding of zero flips the sign of its L1 term (seed 16: 1.3e-6 in fp64, one pixel of 9918; tests/fuzz_case.py shows
+        # the fp32 oracle on one side and the kernel on the other) — so isolated outliers are allowed, bounded in number and in size
+        e = (dg[s].grad.cpu() - dc[s].grad).abs()/dc[s].grad.abs().max().clamp(min=1e-20)
+        n_out = int((e > tol).sum())
+        assert n_out <= max(3, int(2e-4*e.numel())) and e.max().item() < 5e-2, \
+            f'{what}: d loss / d disp_{s}: {n_out} of {e.numel()} elements off by more than {tol:.0e} of the max, worst {e.max().item():.3e}'
+    e = rel_to_max(Tg.grad.cpu()[..., :3, :], Tc.grad[..., :3, :])
+    assert e < tol, f'{what}: d loss / d T off by {e:.3e} (rel. to max)'
