@@ -335,7 +335,7 @@ def main():
                          'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
             'roofline_bwd': {'kernel': f'{k_bwd} (fused adjoint, one wave per (strip, support); the pose / intrinsics epilogue rides in the K0-adjoint launch that follows; the instantiation the library reports for the last backward launch)', 'bound': 'hbm',
                              'row_loop': {'dead_row_skipping': skipping, 'timed': tuner.last,
-                                          'chosen_by': 'SMD_BWD_SKIP' if 'SMD_BWD_SKIP' in os.environ else 'functional.row_skip_tuner: four early backward calls of every 128 alternate between the two row loops (same gradients bit for bit) with HIP events around the entry point; skipping is kept if it is more than 3 % faster (profiles/r03_skip_regimes.txt)'},
+                                          'chosen_by': 'SMD_BWD_SKIP' if 'SMD_BWD_SKIP' in os.environ else 'functional.row_skip_tuner: four early backward calls of every 128 alternate between the two row loops (same gradients bit for bit) with HIP events around the entry point; skipping is kept if it is more than 3 % faster (profiles/r04_skip_regimes.txt)'},
                              'achieved': round(B_bwd/(b_ms*1e-3)/1e9, 1) if b_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                              'frac': round(B_bwd/(b_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if b_ms else None,
                              'algorithmic_bytes': B_bwd, 'avg_kernel_ms': round(b_ms, 5), 'launches_timed': len(bwd_ms),

@@ -202,10 +202,11 @@ class _RowSkipTuner:
     """Chooses between the two row loops of the fused backward by timing them on the live data, without ever stalling the stream.
 
     The backward gives the same gradients bit for bit with or without dead-row skipping (`SMD_BWD_SKIP_DEAD_ROWS`); which is faster
-    depends on the selection masks and on the geometry (`profiles/r03_skip_regimes.txt`): the plain loop is 6 % faster on the noise-
-    like masks of a randomly initialised network at 192x640 (118 vs 125 us), skipping is 14 % faster at 384x640 with learned
-    intrinsics (201 vs 233 us) and 21 % faster when the automask takes everything — and the share of skippable rows alone does not
-    predict the sign.  So it is measured: after `settle` calls, `2*trials` backward calls of every `period` alternate between the two
+    depends on the selection masks and on the geometry (`profiles/r04_skip_regimes.txt`): the plain loop is 15-24 % faster where every
+    row of a wave's window has a live pixel (the masks of a training run at 192x640 from the second step on: 110 vs 135 us), the
+    gated loop wins once 75-80 % of the (row, 60-column window) units are dead and takes less than half the time when the automask
+    takes everything (52 vs 117 us; 384x640 with randomly initialised learned intrinsics: 110-120 vs 247 us) — and the share of
+    masked pixels alone does not predict the sign.  So it is measured: after `settle` calls, `2*trials` backward calls of every `period` alternate between the two
     loops with a pair of HIP events around the entry point; later calls harvest the pairs that have completed (`Event.query`, no
     wait), and skipping is used from then on if its fastest trial beats the plain loop's by more than 3 %.  `SMD_BWD_SKIP` in the
     environment pins the choice (a profiler perturbs the timing: `scripts/round_profiles.sh` pins what the un-traced run chose; pin it
