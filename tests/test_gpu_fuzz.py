@@ -88,3 +88,65 @@ def test_random_shapes_and_options_match_the_oracle(seed):
             f'{what}: d loss / d disp_{s}: {n_out} of {e.numel()} elements off by more than {tol:.0e} of the max, worst {e.max().item():.3e}'
     e = rel_to_max(Tg.grad.cpu()[..., :3, :], Tc.grad[..., :3, :])
     assert e < tol, f'{what}: d loss / d T off by {e:.3e} (rel. to max)'
+
+
+@pytest.mark.parametrize('seed', list(range(12)))
+def test_random_smoothness_options_match_the_oracle(seed):
+    """`handlers.disp_smooth` over random image / pyramid sizes with `use_edges` and `use_laplacian` drawn at random (the first-order form is
+    the streaming sweep with cached or in-launch edge weights, the second-order form the per-pixel kernels)."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    import slowtv_monodepth_amd as amd
+    r = random.Random(500 + seed)
+    b, h, w = r.choice([1, 2, 3]), r.randint(2, 70), r.randint(2, 150)
+    lows = [(h, w)] + [(r.randint(1, h), r.randint(1, w)) for _ in range(r.randint(0, 3))] if r.random() < 0.5 else [(max(h >> s, 1), max(w >> s, 1)) for s in range(r.randint(1, 4))]
+    use_edges, use_lap = r.random() < 0.6, r.random() < 0.5
+    gen = torch.Generator().manual_seed(seed)
+    img = torch.rand(b, 3, h, w, generator=gen)
+    dc = {s: (0.05 + 0.9*torch.rand(b, 1, *hw, generator=gen)).requires_grad_(True) for s, hw in enumerate(lows)}
+    dg = {s: v.detach().clone().cuda().requires_grad_(True) for s, v in dc.items()}
+    what = f'seed {seed}: b={b} {h}x{w} pyramid {lows} edges={use_edges} laplacian={use_lap}'
+    l_ref = torch.stack([O.smooth_reg(d, O.resize_bilinear(img, d.shape[-2:]), use_edges, use_laplacian=use_lap)[0]/2**s for s, d in dc.items()]).mean()
+    l_ref.backward()
+    reg = amd.regularizers.SmoothReg(use_edges=use_edges, use_laplacian=use_lap)
+    l_hip, _ = amd.handlers.disp_smooth(reg, dg, img.cuda(), want_aux=False)
+    l_hip.backward()
+    assert abs(l_hip.item() - l_ref.item()) <= 2e-5*abs(l_ref.item()) + 1e-8, f'{what}: loss {l_hip.item()} vs {l_ref.item()}'
+    for s in dc:
+        # |d_i - d_j| of two disparities within rounding of each other is the same kind of knife edge as the L1 term above
+        e = (dg[s].grad.cpu() - dc[s].grad).abs()/dc[s].grad.abs().max().clamp(min=1e-20)
+        n_out = int((e > 1e-3).sum())
+        assert n_out <= 2 and e.max().item() < 0.5, f'{what}: d loss / d disp_{s}: {n_out} elements off, worst {e.max().item():.3e}'
+
+
+@pytest.mark.parametrize('seed', list(range(8)))
+def test_random_shapes_with_more_than_four_supports(seed):
+    """Five to eight supports run as passes of four with a carried minimum / sum (`smd_image_recon_supports_per_pass`): the depth-input form of
+    the fused operator, forward and backward, against the oracle."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as F
+    r = random.Random(700 + seed)
+    b, h, w, n, S = r.choice([1, 2]), r.randint(3, 60), r.randint(3, 140), r.randint(5, 8), r.choice([1, 2, 3])
+    use_min, use_auto = r.random() < 0.7, r.random() < 0.6
+    gen = torch.Generator().manual_seed(100 + seed)
+    imgs = torch.rand(b, 3, h, w, generator=gen)
+    mix = 0.5*torch.rand(1, generator=gen).item()
+    supp = mix*imgs[None] + (1 - mix)*torch.rand(n, b, 3, h, w, generator=gen)
+    depth = 1 + 10*torch.rand(S, b, 1, h, w, generator=gen)
+    aa = 0.02*torch.randn(n*b, 3, generator=gen); t = 0.2*torch.randn(n*b, 3, generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(b, 1, 1)
+    noise = torch.randn(S*b, 1, h, w, generator=gen)
+    what = f'seed {seed}: b={b} {h}x{w} n={n} S={S} min={use_min} automask={use_auto}'
+    d_c = depth.clone().requires_grad_(True); T_c = O.T_from_AAt(aa, t).unflatten(0, (n, b)).clone().requires_grad_(True)
+    loss_c, _, full = O.image_recon({s: d_c[s] for s in range(S)}, imgs, supp, T_c, K, 'ssim', use_min, use_auto, noise=noise)
+    loss_c.backward()
+    d_g = depth.cuda().requires_grad_(True); T_g = T_c.detach().cuda().requires_grad_(True)
+    loss, err, sel, _ = F.image_recon_fused(d_g, imgs.cuda(), supp.cuda(), T_g, K.cuda(), flags=F.recon_flags('ssim', use_min, use_auto), noise=noise.cuda())
+    loss.backward()
+    flips = (sel.cpu() != full['sel']).flatten()
+    assert flips.float().mean().item() <= 0.01, f'{what}: selection differs on {flips.float().mean().item():.2%} of pixels'
+    torch.testing.assert_close(err.cpu().flatten()[~flips], full['err'].detach().flatten()[~flips], rtol=0, atol=3e-4, msg=lambda m: f'{what}: error map {m}')
+    torch.testing.assert_close(loss.detach().cpu(), loss_c.detach(), rtol=1e-4 if not flips.any() else 2e-3, atol=1e-6, msg=lambda m: f'{what}: loss {m}')
+    tol = 5e-2 if flips.any() else 2e-3
+    e = (d_g.grad.cpu() - d_c.grad).abs()/d_c.grad.abs().max().clamp(min=1e-20)
+    assert int((e > tol).sum()) <= max(3, int(2e-4*e.numel())) and e.max().item() < 5e-2, f'{what}: d loss / d depth: {int((e > tol).sum())} elements off, worst {e.max().item():.3e}'
+    assert rel_to_max(T_g.grad.cpu()[..., :3, :], T_c.grad[..., :3, :]) < tol, what
