@@ -62,7 +62,12 @@ StripPlan plan(int b, int S, int h, int w, int cols) {
 // cfg 2).  Default: a sixth of the batch, when the batch has at least four samples; SMD_*_TAPER_B / _RH override (B = 0: off).
 void taper(int& b1, int& rh2, int& nsy2, int b, int h, const StripPlan& pl, const char* env_b, const char* env_rh) {
   int b2 = env_int(env_b, -1), r2 = env_int(env_rh, -1);
-  if (b2 < 0) b2 = (b >= 4) ? (b + 3)/6 : 0;
+  if (b2 < 0) {
+    b2 = (b >= 4) ? (b + 3)/6 : 0;
+    // the taper buys the tail of a launch that is two or three generations of waves; a launch of five or more (384x640 at b = 12) pays for the short
+    // strips' halo rows without needing it: half as many samples (backward 268 -> 262 us at cfg 4, 497 -> 485 at cfg 5; r04_fwd_shape_sweep.txt)
+    if ((long)b*h*pl.nsx > 36000) b2 = (b2 + 1)/2;
+  }
   if (b2 > b - 1) b2 = b - 1;
   if (r2 < kMinStripRows) r2 = pl.rh/2 < kMinStripRows ? kMinStripRows : pl.rh/2;
   b1 = b - b2; rh2 = r2; nsy2 = smd::ceil_div(h, r2);
