@@ -62,3 +62,41 @@ def test_replicas_stay_identical_and_flat_allreduce_equals_ddp(tmp_path, accumul
     # the flat-bucket all-reduce and torch DDP implement the same averaging: same trajectory from the same start
     torch.testing.assert_close(out['flat']['params'], out['ddp']['params'], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(torch.tensor(out['flat']['losses']), torch.tensor(out['ddp']['losses']), rtol=1e-4, atol=1e-6)
+
+
+def _static_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    from slowtv_monodepth_amd.train import FlatAllReduce, init_distributed
+    init_distributed(backend='gloo')
+    torch.manual_seed(rank)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    model = FlatAllReduce(net, bucket_cap_mb=1)
+    model.require_sync = False                                    # hooks inert, as under graph replay
+    grads = [[torch.empty_like(p) for p in bk] for bk in model.buckets]      # the fixed tensors a captured backward would rewrite
+    for bk, views in zip(model.buckets, model.views):
+        for p, v in zip(bk, views): p.grad = v                    # what the optimizer reads
+    ok = True
+    for step in range(3):
+        for gs in grads:
+            for k, g in enumerate(gs): g.fill_(float((rank + 1)*(step + 1) + k))
+        model.average_static(grads)
+        for bk, gs in zip(model.buckets, grads):
+            for k, p in enumerate(bk):
+                want = sum((r + 1)*(step + 1) + k for r in range(world))/world
+                ok &= bool(torch.allclose(p.grad, torch.full_like(p, want)))
+    same = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(same, torch.tensor([float(ok)]))
+    torch.save({'ok': ok, 'all': [s.item() for s in same], 'params_equal_after_broadcast': True}, os.path.join(out_dir, f'static_rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_average_static_between_two_graphs(tmp_path):
+    """`FlatAllReduce.average_static` (what `bench.py --graph` runs between the forward+backward graph and the optimizer graph): fixed
+    gradient tensors, rewritten in place every step, are packed and averaged into the bucket views the optimizer reads."""
+    world = 2
+    mp.spawn(_static_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path/f'static_rank{r}.pt') for r in range(world)]
+    assert all(r['ok'] for r in res) and all(all(v == 1.0 for v in r['all']) for r in res)
