@@ -824,8 +824,8 @@ __device__ __forceinline__ void recon_main_reduce(const ReconMainArgs& a, MainTa
   }
 }
 
-// register budget: 128 VGPRs (4 waves per SIMD) up to two supports, 168 (3 waves) for three and four
-// register budget: up to two supports are held to 128 VGPRs (4 waves per SIMD; the K0-fused instantiation needs 129 unaided), three and four to 168 (3 waves)
+// register budget: up to two supports are held to 128 VGPRs (4 waves per SIMD: the K0-fused instantiation uses 126, nothing spilled), three and four to
+// 168 (3 waves; the four-support instantiation uses 158).  A fifth wave (96 VGPRs) spills 28 values: profiles/r04_fwd_shape_sweep.txt
 #ifdef SMD_TRACE_WAVES   // diagnosis builds only (scripts/dev/wave_trace.py): when and where every wave of the last launch ran
 __device__ unsigned long long g_wave_trace[1 << 16][3];
 #endif
