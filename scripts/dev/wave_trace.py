@@ -37,8 +37,12 @@ def main():
     st = np.sort(t0)
     print('start time of the k-th wave (us):', ' '.join(f'{k}:{st[min(k, len(st) - 1)]*tick:.1f}' for k in (0, 1024, 2048, 4095, 4096, 5000, 6000, 7000, 8000, len(st) - 1)))
 
-    # which waves are slow?  decode (scale, sample, strip) like smd_kernels.h: decode_tile / decode_wave (4 waves per block)
+    # which waves are slow?  decode (scale, sample, strip) like smd_kernels.h: decode_wave (4 waves per block) — the layout WITHOUT the shared ring
+    # (SMD_FWD_SHARE=0) and without a taper; the occupancy statistics above do not depend on it
     import os
+    by_hw = lambda name, keyarr: print(f'mean life by {name}:', ' '.join(f'{k}:{((t1 - t0)*tick)[keyarr == k].mean():.1f}' for k in np.unique(keyarr)[:24]))
+    by_hw('XCC', xcc); by_hw('SIMD', simd); by_hw('start decile', np.minimum(t0*10//max(t0.max(), 1), 9))
+    if os.environ.get('WAVE_DECODE') != '1': return
     b, h, w, S = 12, 192, 640, 4
     rh = int(os.environ.get('SMD_FWD_RH', '12'))
     nsx, nsy = -(-w//62), -(-h//rh)
