@@ -28,6 +28,9 @@
 #include "smd_common.h"
 #include "smd_kernels.h"
 
+#ifndef SMD_FWD_PRIO
+#define SMD_FWD_PRIO 0   // experiment: s_setprio by remaining rows in the shared-ring forward (see step())
+#endif
 #ifndef SMD_ABLATE
 #define SMD_ABLATE 0   // diagnosis builds only (scripts/dev/ablate.sh): bit 0 no tap gathers, bit 1 no row loads (incl. K0), bit 2 no stores, bit 3 no ta/tb loads, bit 4 no target-row load
 #endif
@@ -540,7 +543,16 @@ struct MainCtx {
       if (SH && g == 0) {
         // the taps of this row have just been waited for.  First step of an epoch: meet the other scales, then send for this
         // wave's row of the next epoch; every step: this row's slot of the ring.
-        if ((j & 3) == 0) { epoch_sync(); dma_epoch((j >> 2) + 1); }
+        if ((j & 3) == 0) {
+          epoch_sync(); dma_epoch((j >> 2) + 1);
+#if SMD_FWD_PRIO
+          // issue priority by the rows a wave still has to do (the arbiter otherwise serves the OLDEST wave of a SIMD first: the four waves of
+          // a SIMD then finish one after the other, and at the end of the launch the last ones run alone, latency-bound; wave traces in
+          // profiles/r04_fwd_wave_traces.txt): a wave with more rows ahead of it goes first, so co-resident waves finish closer together
+          const int rem = jlast - j;
+          if (rem < 4) __builtin_amdgcn_s_setprio(0); else if (rem < 8) __builtin_amdgcn_s_setprio(1); else if (rem < 12) __builtin_amdgcn_s_setprio(2);
+#endif
+        }
         const float* slot = ring_lane + (j & 7)*kRingSlotFloats;
         if (!VIRT) { const f4 yv = *reinterpret_cast<const f4*>(slot); Yn[0] = yv.x; Yn[1] = yv.y; Yn[2] = yv.z; }
         if (EMIT) {
@@ -732,6 +744,9 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
   cx.rs_err = make_rsrc(cx.has_err ? a.err + sb : nullptr, cx.has_err ? hw*4 : 0);
   cx.rs_sel = make_rsrc(a.sel + sb, hw);
   cx.lsum = 0.f;
+#if SMD_FWD_PRIO
+  if (SH) __builtin_amdgcn_s_setprio(3);
+#endif
   if (SH) {
     cx.ring_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)ring_mem);
     cx.ring_lane = ring_mem + lane*4;
