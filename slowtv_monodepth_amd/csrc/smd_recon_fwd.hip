@@ -550,7 +550,11 @@ struct MainCtx {
           // a SIMD then finish one after the other, and at the end of the launch the last ones run alone, latency-bound; wave traces in
           // profiles/r04_fwd_wave_traces.txt): a wave with more rows ahead of it goes first, so co-resident waves finish closer together
           const int rem = jlast - j;
+#if SMD_FWD_PRIO == 2   // the inverse: the fewer rows left, the higher the priority (oldest-first, made stronger)
+          if (rem < 4) __builtin_amdgcn_s_setprio(3); else if (rem < 8) __builtin_amdgcn_s_setprio(2); else if (rem < 12) __builtin_amdgcn_s_setprio(1);
+#else
           if (rem < 4) __builtin_amdgcn_s_setprio(0); else if (rem < 8) __builtin_amdgcn_s_setprio(1); else if (rem < 12) __builtin_amdgcn_s_setprio(2);
+#endif
 #endif
         }
         const float* slot = ring_lane + (j & 7)*kRingSlotFloats;
@@ -744,7 +748,7 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
   cx.rs_err = make_rsrc(cx.has_err ? a.err + sb : nullptr, cx.has_err ? hw*4 : 0);
   cx.rs_sel = make_rsrc(a.sel + sb, hw);
   cx.lsum = 0.f;
-#if SMD_FWD_PRIO
+#if SMD_FWD_PRIO == 1
   if (SH) __builtin_amdgcn_s_setprio(3);
 #endif
   if (SH) {
