@@ -150,3 +150,34 @@ def test_random_shapes_with_more_than_four_supports(seed):
     e = (d_g.grad.cpu() - d_c.grad).abs()/d_c.grad.abs().max().clamp(min=1e-20)
     assert int((e > tol).sum()) <= max(3, int(2e-4*e.numel())) and e.max().item() < 5e-2, f'{what}: d loss / d depth: {int((e > tol).sum())} elements off, worst {e.max().item():.3e}'
     assert rel_to_max(T_g.grad.cpu()[..., :3, :], T_c.grad[..., :3, :]) < tol, what
+
+
+def test_pose_matrices_over_the_whole_angle_range():
+    """`T_from_AAt` (+ the inverted rows of `always_fwd_pose`) from |aa| = 0 through the clip branch, small and ordinary angles, up to and
+    beyond pi (the pose network emits 0.01 x its output, so real angles are small — the kernel must still be the reference's function
+    everywhere): values and gradients against the oracle in fp64, random axes, random upstream gradients."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as F
+    import math
+    mags = [0.0, 1e-12, 1e-9, 1e-7, 3e-6, 1e-4, 1e-3, 0.03, 0.3, 1.0, 2.0, 3.0, math.pi - 1e-3, math.pi, math.pi + 1e-3, 3.5, 6.0, 2*math.pi, 7.0]
+    gen = torch.Generator().manual_seed(77)
+    N = 4*len(mags)
+    ax = torch.randn(N, 3, generator=gen); ax = ax/ax.norm(dim=1, keepdim=True)
+    aa = ax*torch.tensor(mags).repeat_interleave(4)[:, None]
+    t = torch.randn(N, 3, generator=gen)
+    inv = (torch.arange(N) % 2).to(torch.uint8)
+    gT = torch.randn(N, 4, 4, generator=gen)
+    aa_c, t_c = aa.double().requires_grad_(True), t.double().requires_grad_(True)
+    T_c = O.T_from_AAt(aa_c, t_c)
+    T_c = torch.stack([torch.linalg.inv(Ti) if f else Ti for Ti, f in zip(T_c, inv)])
+    T_c.backward(gT.double())
+    aa_g, t_g = aa.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    T_g = F.pose_matrices(aa_g, t_g, inv.cuda())
+    T_g.backward(gT.cuda())
+    torch.testing.assert_close(T_g.detach().cpu().double(), T_c.detach(), rtol=2e-5, atol=2e-6)
+    # d/d aa: relative to the largest entry of the row (the gradient's scale grows with the upstream gradient, not with |aa|)
+    for name, a, c in (('aa', aa_g.grad.cpu().double(), aa_c.grad), ('t', t_g.grad.cpu().double(), t_c.grad)):
+        e = (a - c).abs()/c.abs().amax(dim=1, keepdim=True).clamp(min=1e-3)
+        worst = e.amax(dim=1)
+        bad = (worst > 2e-4).nonzero().flatten().tolist()
+        assert not bad, f'd/d{name} off for rows {bad}: |aa| = {[mags[i//4] for i in bad]}, rel {[f"{worst[i].item():.2e}" for i in bad]}'
