@@ -181,3 +181,63 @@ def test_pose_matrices_over_the_whole_angle_range():
         worst = e.amax(dim=1)
         bad = (worst > 2e-4).nonzero().flatten().tolist()
         assert not bad, f'd/d{name} off for rows {bad}: |aa| = {[mags[i//4] for i in bad]}, rel {[f"{worst[i].item():.2e}" for i in bad]}'
+
+
+@pytest.mark.parametrize('seed', list(range(16)))
+def test_random_generic_channel_operators(seed):
+    """`ViewSynth` on C-channel inputs + `PhotoError` ('ssim' / 'l1' / 'l2') + `RegressionLoss`, the un-fused operators the other handlers
+    (feat_recon, depth_regr, stereo_const, the hints tool) are built from: random batch, channels, size; values and gradients against the oracle."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as F
+    r = random.Random(300 + seed)
+    B, C, h, w = r.randint(1, 4), r.choice([1, 2, 3, 4, 7, 16, 33]), r.randint(2, 50), r.randint(2, 130)
+    loss_name = r.choice(['ssim', 'l1', 'l2'])
+    regr, invert, use_mask = r.choice(['l1', 'log_l1', 'berhu']), r.random() < 0.5, r.random() < 0.5
+    gen = torch.Generator().manual_seed(seed)
+    inp = torch.rand(B, C, h, w, generator=gen); tgt = torch.rand(B, C, h, w, generator=gen)
+    depth = 0.5 + 8*torch.rand(B, 1, h, w, generator=gen)
+    aa = 0.03*torch.randn(B, 3, generator=gen); t = 0.2*torch.randn(B, 3, generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(B, 1, 1)
+    g_err = torch.randn(B, 1, h, w, generator=gen)
+    mask = (torch.rand(B, 1, h, w, generator=gen) > 0.3).float() if use_mask else None
+    what = f'seed {seed}: B={B} C={C} {h}x{w} {loss_name} regr={regr} invert={invert} mask={use_mask}'
+
+    def run(dev, M):
+        i_, d_, T_ = inp.to(dev).requires_grad_(True), depth.to(dev).requires_grad_(True), O.T_from_AAt(aa, t).to(dev).requires_grad_(True)
+        warp, dwarp, valid = M.view_synth(i_, d_, T_, K.to(dev))
+        err = M.photo_error(warp, tgt.to(dev), loss_name)
+        m = None if mask is None else (mask.bool().to(dev) if dev == 'cuda' else mask)   # the HIP operator takes a 0/1 mask as bool
+        l_regr = (M.regression_loss(dwarp, d_.detach() + 0.3, m, loss_name=regr, invert=invert)[0] if dev == 'cuda'
+                  else M.regression_loss(dwarp, d_.detach() + 0.3, m, regr, invert)[0])
+        ((err*g_err.to(dev)).mean() + l_regr).backward()
+        return warp.detach().cpu(), dwarp.detach().cpu(), valid.cpu(), err.detach().cpu(), l_regr.detach().cpu(), i_.grad.cpu(), d_.grad.cpu(), T_.grad.cpu()[..., :3, :]
+    hip, ref = run('cuda', F), run('cpu', O)
+    torch.testing.assert_close(hip[0], ref[0], rtol=0, atol=1e-4, msg=lambda m: f'{what}: warp {m}')   # a few ulps of a coordinate near 100 x the slope of a random image (as test_gpu_parity.py)
+    torch.testing.assert_close(hip[1], ref[1], rtol=2e-5, atol=1e-5, msg=lambda m: f'{what}: depth_warp {m}')
+    assert (hip[2] != ref[2].bool()).float().mean().item() <= 2e-3, f'{what}: mask_valid'
+    torch.testing.assert_close(hip[3], ref[3], rtol=0, atol=3e-4, msg=lambda m: f'{what}: error map {m}')
+    torch.testing.assert_close(hip[4], ref[4], rtol=1e-4, atol=1e-6, msg=lambda m: f'{what}: regression loss {m}')
+    for name, a, c in zip(('input', 'depth', 'T'), hip[5:], ref[5:]):
+        e = (a - c).abs()/c.abs().max().clamp(min=1e-20)
+        n_out = int((e > 2e-3).sum())    # isolated elements: sign(0) of an L1 term, berHu's |d| = delta switch, a sample on the border
+        assert n_out <= max(3, int(3e-4*e.numel())) and e.max().item() < 0.2, f'{what}: d/d {name}: {n_out} of {e.numel()} elements off, worst {e.max().item():.3e}'
+
+
+@pytest.mark.parametrize('seed', list(range(12)))
+def test_random_crop_resize_windows(seed):
+    """`smd_crop_resize` (aspect-ratio augmentation) at random image, window and output sizes against the oracle's restatement of
+    kornia's `center_crop(align_corners=False)` + `F.interpolate` (crop half parity-unpinned: kornia is absent)."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as F
+    from oracle import aspect_ratio_oracle as A
+    r = random.Random(900 + seed)
+    H, W = r.randint(2, 80), r.randint(2, 150)
+    crop = (r.randint(2, H), r.randint(2, W)) if r.random() < 0.8 else (H, W)
+    out = (r.randint(2, 96), r.randint(2, 160)) if r.random() < 0.8 else crop
+    gen = torch.Generator().manual_seed(seed)
+    tens = [torch.rand(2, 3, H, W, generator=gen), torch.rand(2, 2, 3, H, W, generator=gen), torch.rand(2, 1, H, W, generator=gen)]
+    Kc = torch.rand(2, 4, 4, generator=gen)
+    o_hip, K_hip = F.crop_resize([t.cuda() for t in tens], crop, out, Kc.cuda())
+    o_ref, K_ref = A.crop_resize(tens, crop, out, Kc)
+    for a, c in zip(o_hip, o_ref): torch.testing.assert_close(a.cpu(), c, rtol=1e-5, atol=3e-5, msg=lambda m: f'seed {seed}: {H}x{W} crop {crop} -> {out}: {m}')
+    torch.testing.assert_close(K_hip.cpu(), K_ref, rtol=1e-6, atol=1e-6)
