@@ -241,3 +241,43 @@ def test_random_crop_resize_windows(seed):
     o_ref, K_ref = A.crop_resize(tens, crop, out, Kc)
     for a, c in zip(o_hip, o_ref): torch.testing.assert_close(a.cpu(), c, rtol=1e-5, atol=3e-5, msg=lambda m: f'seed {seed}: {H}x{W} crop {crop} -> {out}: {m}')
     torch.testing.assert_close(K_hip.cpu(), K_ref, rtol=1e-6, atol=1e-6)
+
+
+def test_kitti_raw_size_matches_the_oracle():
+    """A full-resolution KITTI raw frame (375 x 1242, odd on both axes; the BASELINE configs train at 192 x 640 / 384 x 640): 21 strip columns,
+    24 strips, a pyramid whose levels are floor halvings of odd sizes — the whole path against the oracle once at a size no other test reaches."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as F
+    b, h, w, n = 1, 375, 1242, 2
+    lows = [(h >> s, w >> s) for s in range(4)]
+    gen = torch.Generator().manual_seed(4242)
+    low = lambda c, hh, ww: torch.nn.functional.interpolate(torch.rand(b, c, 6, 20, generator=gen), size=(hh, ww), mode='bilinear', align_corners=False)
+    imgs = (low(3, h, w) + 0.05*torch.rand(b, 3, h, w, generator=gen)).clamp(0, 1)
+    supp = torch.stack([(imgs.roll(shifts=(1, 3*(k + 1)), dims=(-2, -1)) + 0.02*torch.rand(b, 3, h, w, generator=gen)).clamp(0, 1) for k in range(n)])
+    disps = {s: (0.1 + 0.8*low(1, hs, ws)) for s, (hs, ws) in enumerate(lows)}
+    aa = 0.005*torch.randn(n*b, 3, generator=gen); t = 0.05*torch.randn(n*b, 3, generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]])[None].repeat(b, 1, 1)
+    noise = torch.randn(4*b, 1, h, w, generator=gen)
+    dc = {s: d.clone().requires_grad_(True) for s, d in disps.items()}
+    Tc = O.T_from_AAt(aa, t).unflatten(0, (n, b)).clone().requires_grad_(True)
+    loss_c, out_c = O.loss_path(dc, imgs, supp, Tc, K, min_depth=0.1, max_depth=100, loss_name='ssim', use_min=True, use_automask=True, use_edges=True, w_smooth=0.001, noise=noise)
+    loss_c.backward()
+    dg = [d.cuda().requires_grad_(True) for d in disps.values()]
+    Tg = Tc.detach().cuda().requires_grad_(True)
+    l_rec, err, sel, _, dep = F.image_recon_fused_disp(dg, imgs.cuda(), supp.cuda(), Tg, K.cuda(), flags=F.recon_flags('ssim', True, True), min_depth=0.1, max_depth=100,
+                                                       noise=noise.cuda(), want_err=True)
+    l_sm, _, _ = F.disp_smooth_fused(dict(enumerate(dg)), imgs.cuda(), use_edges=True, want_aux=False)
+    (l_rec + 0.001*l_sm).backward()
+    full = out_c['full']
+    flips = (sel.cpu() != full['sel']).flatten()
+    assert flips.float().mean().item() <= 1e-3, f'selection differs on {flips.float().mean().item():.3%} of the pixels'
+    assert 0.02 < (full['sel'] == 255).float().mean().item() < 0.98, 'the case should exercise both the automask and the supports'
+    for s in range(4): torch.testing.assert_close(dep[s].cpu(), out_c['depth_up'][s].detach(), rtol=2e-5, atol=1e-5)
+    torch.testing.assert_close(err.cpu().flatten()[~flips], full['err'].detach().flatten()[~flips], rtol=0, atol=3e-4)
+    torch.testing.assert_close(l_rec.detach().cpu(), out_c['loss_img_recon'].detach(), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(l_sm.detach().cpu(), out_c['loss_disp_smooth'].detach(), rtol=2e-5, atol=1e-7)
+    tol = 5e-2 if flips.any() else 2e-3
+    for s in range(4):
+        e = (dg[s].grad.cpu() - dc[s].grad).abs()/dc[s].grad.abs().max().clamp(min=1e-20)
+        assert int((e > tol).sum()) <= max(3, int(2e-4*e.numel())) and e.max().item() < 0.2, f'd loss / d disp_{s}: {int((e > tol).sum())} elements off, worst {e.max().item():.3e}'
+    assert rel_to_max(Tg.grad.cpu()[..., :3, :], Tc.grad[..., :3, :]) < tol
