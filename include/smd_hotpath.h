@@ -145,7 +145,7 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
  * Edge-aware disparity smoothness over all scales.  Replaces `handlers.disp_smooth(crit, disps, imgs)`
  * (src/core/handlers.py:262-281) = per scale SmoothReg.forward (src/regularizers/smooth.py:71-97) on the
  * bilinearly resized image, then mean_s(loss_s / 2^s).  SMD_USE_LAPLACIAN selects the second-order form (smooth.py:33-48);
- * use_blur (a kornia Gaussian, absent from the build image) is not part of this path.
+ * use_blur: the host side blurs the disparity and the resized image with smd_gaussian_blur3x3 and calls this path on the results (first-order form).
  *   disp[s] (b,1,hs,ws)   img (b,3,h,w)   scale_keys[s]: the dictionary key of scale s (loss_s is divided by 2^key;
  *   NULL -> key = s)
  *   loss (1) out;  stats (S,b,2) out: per (scale, sample) {mean disparity, un-normalised edge sum E} kept for backward
@@ -156,6 +156,11 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
  *   smd_image_recon_prep) and the forward is then called with SMD_EDGES_READY; without that flag the forward fills it first itself.
  *   Handing the same buffer to the backward spares it every image access.
  * Backward: g_disp[s] (b,1,hs,ws) out. */
+/* SmoothReg(use_blur=True) (smooth.py:21): `kornia.filters.gaussian_blur2d(x, kernel_size=(3, 3), sigma=(1, 1))` on `planes` planes of h x w
+ * floats — separable 3-tap Gaussian (0.27406862, 0.45186276, 0.27406862), reflect border (kornia 0.6.10 filter2d_separable; restated from its
+ * published source, parity unpinned: the library is absent from the build image).  adjoint != 0: the transpose of that linear map (backward).
+ * x != out; h, w >= 2. */
+int smd_gaussian_blur3x3(const float* x, float* out, int planes, int h, int w, int adjoint, void* stream);
 size_t smd_disp_smooth_workspace_bytes(const int* hs, const int* ws, int S, int b);
 size_t smd_disp_smooth_edge_weight_bytes(const int* hs, const int* ws, int S, int b);
 int smd_disp_smooth_prep(const float* img, const int* hs, const int* ws, int S, int b, int h, int w, int flags, float* edge_weights, void* stream);

@@ -290,15 +290,30 @@ def _abs_fwd_diff(x):
     return dx, dy
 
 
-def _laplacian(x):
-    """`compute_laplacian(x)[:2]` (src/regularizers/smooth.py:33-48, use_blur=False): (|d/dx |dx||, |d/dy |dy||)."""
-    dx, dy = _abs_fwd_diff(x)
-    return _abs_fwd_diff(dx)[0], _abs_fwd_diff(dy)[1]
+def gaussian_blur3x3(x):
+    """`kornia.filters.gaussian_blur2d(x, kernel_size=(3, 3), sigma=(1, 1))` as src/regularizers/smooth.py:21 calls it.  kornia is absent from
+    the build image (PARITY UNPINNED for this function); restated from kornia 0.6.10's published source: `get_gaussian_kernel1d(3, 1.0)` =
+    exp(-d^2 / 2) / sum over d in {-1, 0, 1}; `filter2d_separable(x, k[None], k[None], border_type='reflect')` = F.pad(mode='reflect') by one and a
+    depth-wise `F.conv2d` with the 1x3 kernel, then the same with the 3x1 kernel (cross-correlation; the kernel is symmetric)."""
+    B, C, h, w = x.shape
+    d = torch.arange(3, dtype=x.dtype, device=x.device) - 1
+    k = torch.exp(-d.pow(2)/2.0); k = k/k.sum()
+    kx = k.view(1, 1, 1, 3).expand(C, 1, 1, 3); ky = k.view(1, 1, 3, 1).expand(C, 1, 3, 1)
+    out = F.conv2d(F.pad(x, (1, 1, 0, 0), mode='reflect'), kx, groups=C)
+    return F.conv2d(F.pad(out, (0, 0, 1, 1), mode='reflect'), ky, groups=C)
 
 
-def smooth_reg(disp, img, use_edges=False, use_laplacian=False):
-    """`SmoothReg.forward` with use_blur=False (src/regularizers/smooth.py:71-97); `use_laplacian`: second-order differences."""
-    fn = _laplacian if use_laplacian else _abs_fwd_diff
+def _laplacian(x, blur=lambda t: t):
+    """`compute_laplacian(x)[:2]` (src/regularizers/smooth.py:33-48): (|d/dx |dx||, |d/dy |dy||); with use_blur every `compute_grad` blurs its input."""
+    dx, dy = _abs_fwd_diff(blur(x))
+    return _abs_fwd_diff(blur(dx))[0], _abs_fwd_diff(blur(dy))[1]
+
+
+def smooth_reg(disp, img, use_edges=False, use_laplacian=False, use_blur=False):
+    """`SmoothReg.forward` (src/regularizers/smooth.py:71-97); `use_laplacian`: second-order differences; `use_blur`: `compute_grad` blurs its
+    input first (:21; see `gaussian_blur3x3`)."""
+    blur = gaussian_blur3x3 if use_blur else (lambda t: t)
+    fn = (lambda t: _laplacian(t, blur)) if use_laplacian else (lambda t: _abs_fwd_diff(blur(t)))
     d = disp/disp.mean(dim=(2, 3), keepdim=True).clamp(min=EPS32)        # ops.mean_normalize, src/tools/ops.py:279-286
     ddx, ddy = fn(d)
     disp_grad = (ddx.pow(2) + ddy.pow(2)).clamp(min=EPS32).sqrt()        # :86

@@ -45,6 +45,7 @@ PROTOTYPES = {
     'smd_image_recon_disp_bwd': (_i, [_vp, _vp, _i, _f, _f] + [_vp]*13 + [_sz] + [_i]*5 + [_vp]),
     'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_disp_smooth_edge_weight_bytes': (_sz, [_vp, _vp, _i, _i]),
+    'smd_gaussian_blur3x3': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'smd_disp_smooth_prep': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'smd_disp_smooth_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'smd_disp_smooth_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

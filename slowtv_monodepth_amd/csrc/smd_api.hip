@@ -447,6 +447,14 @@ size_t smd_disp_smooth_edge_weight_bytes(const int* hs, const int* ws, int S, in
   return smd::smooth_edge_bytes(sc, b);   // {wx, wy} per pixel of every level + the arrival counters of the sweep's in-launch second stage
 }
 
+int smd_gaussian_blur3x3(const float* x, float* out, int planes, int h, int w, int adjoint, void* stream) {
+  if (!x || !out) return fail(SMD_E_INVALID, "null pointer");
+  if (x == out) return fail(SMD_E_INVALID, "in-place blur is not supported");
+  if (planes < 1) return fail(SMD_E_INVALID, "invalid sizes");
+  if (h < 2 || w < 2) return fail(SMD_E_INVALID, "reflect padding by one needs at least 2 x 2 pixels (got %d x %d)", h, w);   // F.pad(mode='reflect') raises too
+  return check_launch(smd::launch_blur3(x, out, planes, h, w, adjoint != 0, (hipStream_t)stream), "gaussian_blur3x3");
+}
+
 int smd_disp_smooth_prep(const float* img, const int* hs, const int* ws, int S, int b, int h, int w, int flags, float* edge_weights, void* stream) {
   if (!img || !edge_weights) return fail(SMD_E_INVALID, "null pointer");
   if (b < 1 || h < 1 || w < 1 || b > 65535) return fail(SMD_E_INVALID, "invalid sizes");

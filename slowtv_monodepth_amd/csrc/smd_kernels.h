@@ -196,6 +196,7 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, bool edges_ready, hipStream_t st);
+hipError_t launch_blur3(const float* x, float* out, int planes, int h, int w, bool adjoint, hipStream_t st);   // 3x3 Gaussian, reflect border (SmoothReg(use_blur)); adjoint: its transpose
 hipError_t launch_smooth_edges(const ScaleSet& sc, int b, const float* img, int h, int w, float* edge_w, hipStream_t st);   // frame-only: edge weights of every level + zeroed arrival counters
 size_t smooth_edge_bytes(const ScaleSet& sc, int b);
 hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,

@@ -427,6 +427,54 @@ __global__ __launch_bounds__(256) void k_smooth_aux(const ScaleSet sc, int b, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// SmoothReg(use_blur=True) (src/regularizers/smooth.py:21): kornia.filters.gaussian_blur2d(x, kernel_size=(3, 3), sigma=(1, 1)) =
+// filter2d_separable(x, k, k, border_type='reflect') with k = exp(-d^2/2)/sum, d in {-1, 0, 1}: a horizontal then a vertical 3-tap pass over
+// the reflect-padded plane (kornia 0.6.10; the library is absent from the build image: restated from its published source, parity unpinned).
+// One thread per pixel; a cold option (no reference configuration sets it), so no streaming form.
+constexpr float kBlurSide = 0.27406862f, kBlurMid = 0.45186276f;   // exp(-1/2) / (1 + 2 exp(-1/2)),  1 / (1 + 2 exp(-1/2))
+__device__ __forceinline__ int refl1(int i, int n) { return (i < 0) ? -i : ((i >= n) ? 2*(n - 1) - i : i); }   // F.pad(mode='reflect') by one
+__global__ __launch_bounds__(256) void k_blur3_fwd(const float* __restrict__ x, float* __restrict__ out, int planes, int h, int w) {
+  const size_t hw = (size_t)h*w;
+  for (size_t i = (size_t)blockIdx.x*256 + threadIdx.x; i < (size_t)planes*hw; i += (size_t)gridDim.x*256) {
+    const size_t pl = i/hw; const int v = (int)((i - pl*hw)/w), u = (int)(i - pl*hw - (size_t)v*w);
+    const float* p = x + pl*hw;
+    const int ul = refl1(u - 1, w), ur = refl1(u + 1, w);
+    float r[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float* q = p + (size_t)refl1(v + d - 1, h)*w; r[d] = fmaf(kBlurSide, q[ul], fmaf(kBlurSide, q[ur], kBlurMid*q[u])); }
+    out[i] = fmaf(kBlurSide, r[0], fmaf(kBlurSide, r[2], kBlurMid*r[1]));
+  }
+}
+// weight with which input position j enters output position i of a reflect-padded 3-tap line of n values
+__device__ __forceinline__ float blur_w(int i, int j, int n) {
+  return ((i == j) ? kBlurMid : 0.f) + kBlurSide*(float)((refl1(i - 1, n) == j) + (refl1(i + 1, n) == j));
+}
+// adjoint: g_x[v, u] = sum over the outputs (i, j) within one pixel of (v, u) of W_v(i -> v) W_h(j -> u) g_out[i, j]
+__global__ __launch_bounds__(256) void k_blur3_bwd(const float* __restrict__ g_out, float* __restrict__ g_x, int planes, int h, int w) {
+  const size_t hw = (size_t)h*w;
+  for (size_t i = (size_t)blockIdx.x*256 + threadIdx.x; i < (size_t)planes*hw; i += (size_t)gridDim.x*256) {
+    const size_t pl = i/hw; const int v = (int)((i - pl*hw)/w), u = (int)(i - pl*hw - (size_t)v*w);
+    const float* p = g_out + pl*hw;
+    float acc = 0.f;
+    for (int a = max(v - 1, 0); a <= min(v + 1, h - 1); ++a) {
+      const float wv = blur_w(a, v, h);
+      float row = 0.f;
+      for (int c = max(u - 1, 0); c <= min(u + 1, w - 1); ++c) row = fmaf(blur_w(c, u, w), p[(size_t)a*w + c], row);
+      acc = fmaf(wv, row, acc);
+    }
+    g_x[i] = acc;
+  }
+}
+hipError_t launch_blur3(const float* x, float* out, int planes, int h, int w, bool adjoint, hipStream_t st) {
+  const size_t n = (size_t)planes*h*w;
+  const size_t nb = (n + 255)/256;
+  const unsigned blocks = (unsigned)(nb < (size_t)(1u << 16) ? nb : (size_t)(1u << 16));
+  if (adjoint) hipLaunchKernelGGL(k_blur3_bwd, dim3(blocks), dim3(256), 0, st, x, out, planes, h, w);
+  else hipLaunchKernelGGL(k_blur3_fwd, dim3(blocks), dim3(256), 0, st, x, out, planes, h, w);
+  return hipGetLastError();
+}
+
 hipError_t launch_smooth_edges(const ScaleSet& sc, int b, const float* img, int h, int w, float* edge_w, hipStream_t st) {
   int max_chunks = 1;
   for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_units_of(sc.hs[s], sc.ws[s]));

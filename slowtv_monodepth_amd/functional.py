@@ -980,6 +980,54 @@ def crop_resize(tensors, crop_shape, out_shape, K=None):
     return outs, Ko
 
 
+class _Blur3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _check('x', x)
+        if x.ndim < 2: raise ValueError(f'gaussian_blur3x3 needs (..., h, w), got {tuple(x.shape)}')
+        h, w = x.shape[-2:]
+        out = torch.empty_like(x)
+        call('smd_gaussian_blur3x3', x.data_ptr(), out.data_ptr(), x.numel()//(h*w), h, w, 0, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        _on(g)
+        g = _check('grad', g)
+        h, w = g.shape[-2:]
+        gx = torch.empty_like(g)
+        call('smd_gaussian_blur3x3', g.data_ptr(), gx.data_ptr(), g.numel()//(h*w), h, w, 1, _stream())
+        return gx
+
+
+def gaussian_blur3x3(x):
+    """`kornia.filters.gaussian_blur2d(x, kernel_size=(3, 3), sigma=(1, 1))` (src/regularizers/smooth.py:21) on (..., h, w) float32: separable
+    3-tap Gaussian, reflect border; differentiable (the backward is the transposed map).  h, w >= 2."""
+    return _Blur3.apply(x)
+
+
+def disp_smooth_blurred(disps: dict, imgs, *, use_edges: bool = False, want_aux: bool = True):
+    """`handlers.disp_smooth` with `SmoothReg(use_blur=True)`, first-order form (src/regularizers/smooth.py:21, 71-97; handlers.py:262-281):
+    per scale, the mean-normalised disparity and the resized image are blurred before the absolute differences are taken.
+
+    Built from the launches that exist: the image is resized with `crop_resize` (crop = frame) and blurred; the disparity is blurred and then
+    shifted by (mean(disp) - mean(blur(disp))) per sample — the fused sweep normalises its input by that input's own mean, only DIFFERENCES of
+    the normalised field enter the loss, and with the shift the mean it divides by is mean(disp), so what it evaluates is
+    |d blur(disp / mean(disp))| exactly as the reference orders it (the blur is linear).  -> (loss, disp_grad|None, image_grad|None)."""
+    keys = [int(k) for k in disps.keys()]
+    total, aux = 0., (None, None)
+    H, W = imgs.shape[-2:]
+    for i, (k, d) in enumerate(zip(keys, disps.values())):
+        hs, ws = d.shape[-2:]
+        img_s = imgs if (hs, ws) == (H, W) else crop_resize([imgs], (H, W), (hs, ws))[0][0]
+        bd = gaussian_blur3x3(d)
+        x = bd + (d.mean(dim=(2, 3), keepdim=True) - bd.mean(dim=(2, 3), keepdim=True))
+        l, dg, ig = disp_smooth_fused({k: x}, gaussian_blur3x3(img_s), use_edges=use_edges, want_aux=want_aux and i == 0)
+        total = total + l
+        if i == 0: aux = (dg, ig)
+    return total/len(keys), aux[0], aux[1]
+
+
 def lane_shift_selftest(device='cuda'):
     """Returns (left, right): left[l] = l-1 (0 at lane 0), right[l] = l+1 (0 at lane 63) if the DPP wave shifts that the
     stencil kernels rely on behave as documented."""

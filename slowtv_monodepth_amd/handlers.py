@@ -198,5 +198,6 @@ def disp_smooth(crit, disps: dict, imgs: torch.Tensor, *, want_aux: bool = True,
     :param prepared: optional `functional.PreparedFrames` carrying the edge weights of `imgs` for this pyramid (frame-only, launched ahead).
     :return: (loss, {'disp_grad', 'image_grad'} of scale 0)
     """
-    loss, dg, ig = F.disp_smooth_fused(disps, imgs, use_edges=crit.use_edges, want_aux=want_aux, use_laplacian=getattr(crit, 'use_laplacian', False), prepared=prepared)
+    if getattr(crit, 'use_blur', False): loss, dg, ig = F.disp_smooth_blurred(disps, imgs, use_edges=crit.use_edges, want_aux=want_aux)
+    else: loss, dg, ig = F.disp_smooth_fused(disps, imgs, use_edges=crit.use_edges, want_aux=want_aux, use_laplacian=getattr(crit, 'use_laplacian', False), prepared=prepared)
     return loss, ({'disp_grad': dg, 'image_grad': ig} if want_aux and dg is not None else {})

@@ -15,17 +15,21 @@ class SmoothReg(nn.Module):
 
     :param use_edges: down-weight disparity gradients by exp(-|image gradient|) (Monodepth).
     :param use_laplacian: second-order differences (DVSO) instead of first-order ones (src/regularizers/smooth.py:33-48).
-    :param use_blur: Gaussian pre-blur through `kornia.filters.gaussian_blur2d` (smooth.py:21): kornia is absent from the build image,
-        so neither golden vectors nor a pinned oracle can be produced for it — refused rather than shipped unverified.
+    :param use_blur: blur disparity and image with `kornia.filters.gaussian_blur2d(kernel_size=(3, 3), sigma=(1, 1))` before the differences
+        (smooth.py:21).  kornia is absent from the build image: the 3x3 reflect-border Gaussian is restated from kornia 0.6.10's published source
+        (`smd_gaussian_blur3x3`; PARITY UNPINNED, checked against the oracle's restatement only).  First-order form only: with `use_laplacian`
+        the reference blurs again between the two differences, which the fused second-order kernels do not do — that combination is refused.
+        No reference configuration sets `use_blur`.
     """
     def __init__(self, use_edges: bool = False, use_laplacian: bool = False, use_blur: bool = False) -> None:
         super().__init__()
-        if use_blur: raise NotImplementedError('use_blur needs kornia.filters.gaussian_blur2d, which cannot be pinned in this build (SURVEY.md §2.1)')
+        if use_blur and use_laplacian: raise NotImplementedError('use_blur together with use_laplacian (a blur between the two differences, smooth.py:44-46) is not implemented')
         self.use_edges, self.use_laplacian, self.use_blur = use_edges, use_laplacian, use_blur
 
     def forward(self, disp: torch.Tensor, img: torch.Tensor):
         """disp (b,1,h,w), img (b,3,h',w') (resized to the disparity's size exactly as `handlers.disp_smooth` does when
         h', w' differ) -> (loss, {'disp_grad', 'image_grad'})."""
         from .. import functional as F
-        loss, dg, ig = F.disp_smooth_fused({0: disp}, img, use_edges=self.use_edges, want_aux=True, use_laplacian=self.use_laplacian)
+        if self.use_blur: loss, dg, ig = F.disp_smooth_blurred({0: disp}, img, use_edges=self.use_edges, want_aux=True)
+        else: loss, dg, ig = F.disp_smooth_fused({0: disp}, img, use_edges=self.use_edges, want_aux=True, use_laplacian=self.use_laplacian)
         return loss, {'disp_grad': dg, 'image_grad': ig}

@@ -100,7 +100,8 @@ def test_parsers_build_losses_nets_optimizer():
     with pytest.raises(ValueError): ReconstructionLoss(mask_name='bogus')
     assert ReconstructionLoss(mask_name='explainability').mask_name == 'explainability'   # predictive masks run on the un-fused operators
     assert SmoothReg(use_laplacian=True).use_laplacian
-    with pytest.raises(NotImplementedError): SmoothReg(use_blur=True)                      # kornia's Gaussian cannot be pinned here
+    with pytest.raises(NotImplementedError): SmoothReg(use_blur=True, use_laplacian=True)   # a blur between the two differences: not built
+    assert SmoothReg(use_blur=True).use_blur                                               # first-order form: kornia's 3x3 Gaussian restated (parity unpinned)
     with pytest.raises(ValueError, match="original 'source'"):
         ReconstructionLoss(use_automask=True)(torch.rand(2, 1, 3, 4, 4), torch.rand(1, 3, 4, 4))
 

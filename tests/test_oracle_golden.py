@@ -314,3 +314,27 @@ def test_center_crop_restatement_of_kornia():
         torch.testing.assert_close(got, want, rtol=0, atol=2e-5)                                               # (2)
         if crop == (37, 61): torch.testing.assert_close(got, x, rtol=0, atol=2e-5)                               # (3)
         elif crop[0] < 37 and crop[1] < 61: assert (got - sl).abs().max() > 0.05, 'align_corners=False must NOT be the slice'
+
+
+def test_gaussian_blur_restatement_of_kornia():
+    """`gaussian_blur3x3` = kornia 0.6.10 `gaussian_blur2d(kernel_size=(3, 3), sigma=(1, 1))` restated (kornia is absent: parity unpinned).  Anchors
+    that do not need kornia: the 1-D kernel is exp(-d^2/2) normalised (kornia's `gaussian(window_size=3, sigma=1)`), a constant image stays
+    constant (kernel sums to one, reflect border), the separable passes equal the explicit 3x3 sum over the reflect-padded image, and the
+    blurred first-order regulariser equals the un-blurred one on inputs blurred by hand."""
+    import math
+    from oracle import view_synth_oracle as O
+    k = [math.exp(-0.5), 1.0, math.exp(-0.5)]; k = [v/sum(k) for v in k]
+    assert abs(k[0] - 0.27406862) < 1e-7 and abs(k[1] - 0.45186276) < 1e-7
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 6, 9, generator=g)
+    torch.testing.assert_close(O.gaussian_blur3x3(torch.full((1, 2, 4, 5), 0.7)), torch.full((1, 2, 4, 5), 0.7), rtol=0, atol=1e-6)
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1), mode='reflect')
+    ref = sum(k[a]*k[b]*xp[..., a:a + 6, b:b + 9] for a in range(3) for b in range(3))
+    torch.testing.assert_close(O.gaussian_blur3x3(x), ref, rtol=0, atol=1e-6)
+    d = 0.1 + torch.rand(2, 1, 6, 9, generator=g)
+    dn = d/d.mean(dim=(2, 3), keepdim=True)
+    l_blur, _ = O.smooth_reg(d, x, use_edges=True, use_blur=True)
+    bd, bi = O.gaussian_blur3x3(dn), O.gaussian_blur3x3(x)
+    dx, dy = O._abs_fwd_diff(bd); ix, iy = O._abs_fwd_diff(bi)
+    by_hand = (dx*(-ix.mean(1, keepdim=True)).exp()).mean() + (dy*(-iy.mean(1, keepdim=True)).exp()).mean()
+    torch.testing.assert_close(l_blur, by_hand, rtol=1e-6, atol=1e-8)
