@@ -8,14 +8,17 @@ from slowtv_monodepth_amd import _lib
 import runpy
 
 def main():
+    which = 'bwd' if 'bwd' in sys.argv[2:] else 'fwd'      # usage: wave_trace.py [cfg2] [bwd]
     sys.argv = [sys.argv[0], sys.argv[1] if len(sys.argv) > 1 else 'cfg2', '3']
     runpy.run_path(str(Path(__file__).resolve().parent/'microbench.py'), run_name='__main__')   # leaves the trace of its last forward launch
     torch.cuda.synchronize()
     lib = _lib.lib
-    lib.smd_debug_wave_trace.restype = C.c_int
+    fn = lib.smd_debug_wave_trace_bwd if which == 'bwd' else lib.smd_debug_wave_trace
+    fn.restype = C.c_int
     n = 1 << 16
     buf = np.zeros((n, 3), dtype=np.uint64)
-    rc = lib.smd_debug_wave_trace(buf.ctypes.data_as(C.c_void_p), n)
+    rc = fn(buf.ctypes.data_as(C.c_void_p), n)
+    print(f'[{which}: {"k_recon_bwd, entry to end of the row loop" if which == "bwd" else "k_recon_main"}]')
     assert rc == 0, rc
     live = buf[:, 1] > 0
     t0, t1, hw = buf[live, 0].astype(np.int64), buf[live, 1].astype(np.int64), buf[live, 2]

@@ -456,8 +456,14 @@ constexpr int kAccRows = 16;   // tallest strip of the multi-support instantiati
 // NS = waves per strip: wave (strip in block, k) handles supports k, k + NS, ... of its strip (NS = 1: every support, one after
 // the other — balanced waves whatever the selection masks look like; NS = min(n, 4): half / a quarter as long work units).
 // ACC: more than one support — the strip's dL/d depth rows are summed in LDS.
+#ifdef SMD_TRACE_WAVES
+__device__ unsigned long long g_wave_trace_bwd[1 << 16][3];
+#endif
 template <bool SSIM, int SKIP, int NS, bool ACC, bool XTRA>
 __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconBwdArgs a) {
+#ifdef SMD_TRACE_WAVES
+  const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   static_assert(ACC || NS == 1, "several waves per strip need the LDS sum");
   constexpr int SPB = (kWavesPerBlock/NS > 0) ? kWavesPerBlock/NS : 1;   // strips per block
   // (a wave's region is at least the epilogue's scratch, which aliases it: single-support strips have no dL/d depth rows)
@@ -565,6 +571,15 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     }
   }
 
+#ifdef SMD_TRACE_WAVES   // diagnosis builds only (scripts/dev/wave_trace.py bwd): when and where this wave ran its row loop
+  if (lane == 0) {
+    const unsigned widx = blockIdx.x*kWavesPerBlock + wid;
+    if (widx < (1u << 16)) {
+      g_wave_trace_bwd[widx][0] = trace_t0; g_wave_trace_bwd[widx][1] = __builtin_amdgcn_s_memrealtime();
+      g_wave_trace_bwd[widx][2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    }
+  }
+#endif
   // ---- epilogue chain, no block barrier (every wave of a block would idle through two memory round trips): a wave that is
   // done bumps LDS counters; the LAST wave of a strip sums the strip's dL/d depth rows, the LAST wave of the block counts the
   // block's arrival at agent scope, and the wave that completes a sample reduces its pose sums (Guideline 16 of
@@ -1039,3 +1054,9 @@ hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
 }
 
 }  // namespace smd
+
+#ifdef SMD_TRACE_WAVES
+extern "C" int smd_debug_wave_trace_bwd(unsigned long long* host_out, int max_waves) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(smd::g_wave_trace_bwd), (size_t)max_waves*3*sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
