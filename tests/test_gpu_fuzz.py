@@ -7,7 +7,14 @@ between supports, so cases with flips get the coarse gradient bound.
 
 What the first run of this file found (round 4): the oracle evaluated the bilinear source index with two roundings where ATen (and the
 kernels) fuse it into one — lambda off by up to 1e-5 beyond column 128 at pyramid ratios that are not exact halvings (fixed in
-oracle/view_synth_oracle.py::_src_index, checked against F.interpolate); and one L1 sign knife edge (below)."""
+oracle/view_synth_oracle.py::_src_index, checked against F.interpolate); and one L1 sign knife edge (below).
+
+Reading a wider hunt (SMD_FUZZ_SEEDS=300-400): 4 % of the one-to-four-support cases and 9 % of the five-to-eight-support cases are flagged, always
+through one to four gradient elements or through the pose gradient of ONE support.  Dissected with tests/fuzz_case.py / fuzz_case_many.py against
+the fp64 oracle under the same routing, every one is a discontinuity of the loss itself that fp32 rounding decides: the sign of an L1 term with
+|pred - target| ~ 1e-6, a min-reprojection tie, or a sampling coordinate within rounding of an integer (the bilinear value is continuous there,
+its derivative is not: the two sides read different texel pairs).  The fp32 oracle shows the same events, of the same size, under a 1e-6
+perturbation of its own inputs, and in about half of the dissected cases it is the kernel that agrees with fp64 and the fp32 oracle that does not."""
 import os
 import random
 
@@ -19,7 +26,9 @@ from oracle import view_synth_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = list(range(int(os.environ.get('SMD_FUZZ_SEEDS', 24))))   # a wider net for a one-off hunt: SMD_FUZZ_SEEDS=400
+_N = int(os.environ.get('SMD_FUZZ_SEEDS', 0))                     # a wider net for a one-off hunt: SMD_FUZZ_SEEDS=400
+SEEDS = list(range(_N or 24))
+_more = lambda base: list(range(max(base, _N//2)))
 
 
 def draw(seed):
@@ -90,7 +99,7 @@ def test_random_shapes_and_options_match_the_oracle(seed):
     assert e < tol, f'{what}: d loss / d T off by {e:.3e} (rel. to max)'
 
 
-@pytest.mark.parametrize('seed', list(range(12)))
+@pytest.mark.parametrize('seed', _more(12))
 def test_random_smoothness_options_match_the_oracle(seed):
     """`handlers.disp_smooth` over random image / pyramid sizes with `use_edges` and `use_laplacian` drawn at random (the first-order form is
     the streaming sweep with cached or in-launch edge weights, the second-order form the per-pixel kernels)."""
@@ -118,7 +127,7 @@ def test_random_smoothness_options_match_the_oracle(seed):
         assert n_out <= 2 and e.max().item() < 0.5, f'{what}: d loss / d disp_{s}: {n_out} elements off, worst {e.max().item():.3e}'
 
 
-@pytest.mark.parametrize('seed', list(range(8)))
+@pytest.mark.parametrize('seed', _more(8))
 def test_random_shapes_with_more_than_four_supports(seed):
     """Five to eight supports run as passes of four with a carried minimum / sum (`smd_image_recon_supports_per_pass`): the depth-input form of
     the fused operator, forward and backward, against the oracle."""
@@ -183,7 +192,7 @@ def test_pose_matrices_over_the_whole_angle_range():
         assert not bad, f'd/d{name} off for rows {bad}: |aa| = {[mags[i//4] for i in bad]}, rel {[f"{worst[i].item():.2e}" for i in bad]}'
 
 
-@pytest.mark.parametrize('seed', list(range(16)))
+@pytest.mark.parametrize('seed', _more(16))
 def test_random_generic_channel_operators(seed):
     """`ViewSynth` on C-channel inputs + `PhotoError` ('ssim' / 'l1' / 'l2') + `RegressionLoss`, the un-fused operators the other handlers
     (feat_recon, depth_regr, stereo_const, the hints tool) are built from: random batch, channels, size; values and gradients against the oracle."""
@@ -223,7 +232,7 @@ def test_random_generic_channel_operators(seed):
         assert n_out <= max(3, int(3e-4*e.numel())) and e.max().item() < 0.2, f'{what}: d/d {name}: {n_out} of {e.numel()} elements off, worst {e.max().item():.3e}'
 
 
-@pytest.mark.parametrize('seed', list(range(12)))
+@pytest.mark.parametrize('seed', _more(12))
 def test_random_crop_resize_windows(seed):
     """`smd_crop_resize` (aspect-ratio augmentation) at random image, window and output sizes against the oracle's restatement of
     kornia's `center_crop(align_corners=False)` + `F.interpolate` (crop half parity-unpinned: kornia is absent)."""
