@@ -34,3 +34,17 @@ for seed in [int(v) for v in sys.argv[1:]]:
     print(f'  T    : hip-o32 {rel_to_max(gTh, gT32):.2e} hip-o64 {rel_to_max(gTh.double(), gT64):.2e} o32-o64 {rel_to_max(gT32.double(), gT64):.2e}')
     eT = (gTh.double() - gT64).abs()/gT64.abs().max()
     print('  T error per support (max over samples/entries):', [f'{eT[k].max().item():.1e}' for k in range(n)])
+    # the worst element of d loss / d depth and where every support samples there (fp64 geometry): a coordinate within ~1e-5 of an integer?
+    e = (gdh.double() - gd64).abs(); i = int(e.argmax()); s_, bi, _, v, u = [int(x) for x in torch.unravel_index(torch.tensor(i), e.shape)]
+    T64 = O.T_from_AAt(aa.double(), t.double()).unflatten(0, (n, b))
+    line = f'  worst depth element (scale {s_}, sample {bi}, row {v}, col {u}): hip {gdh.flatten()[i].item():.4e} fp64 {gd64.flatten()[i].item():.4e};'
+    for k in range(n):
+        sx, sy, z, _ = O.sample_coords(depth[s_].double()[bi:bi+1], T64[k, bi:bi+1], K[bi:bi+1].double())
+        # the 3x3 window of (v, u): SSIM couples the neighbours' samples to this pixel
+        near = []
+        for vv in range(max(v-1, 0), min(v+2, h)):
+            for uu in range(max(u-1, 0), min(u+2, w)):
+                for c in (sx[0, vv, uu].item(), sy[0, vv, uu].item()):
+                    if abs(c - round(c)) < 3e-5: near.append(f'{c:.6f}')
+        if near: line += f' k{k}: near-integer coordinates in the window {near};'
+    print(line)

@@ -14,7 +14,8 @@ through one to four gradient elements or through the pose gradient of ONE suppor
 the fp64 oracle under the same routing, every one is a discontinuity of the loss itself that fp32 rounding decides: the sign of an L1 term with
 |pred - target| ~ 1e-6, a min-reprojection tie, or a sampling coordinate within rounding of an integer (the bilinear value is continuous there,
 its derivative is not: the two sides read different texel pairs).  The fp32 oracle shows the same events, of the same size, under a 1e-6
-perturbation of its own inputs, and in about half of the dissected cases it is the kernel that agrees with fp64 and the fp32 oracle that does not."""
+perturbation of its own inputs, and in four of the ten dissected cases it is the kernel that agrees with fp64 and the fp32 oracle that does not.
+(Seeds 23 / 141 / 118 of the many-supports family: the worst pixel samples the flagged support at 12.000000, 20.999998, 27.999995.)"""
 import os
 import random
 
