@@ -8,7 +8,7 @@ Tolerances (fp32 path, stated per BASELINE.json: loss within 1e-4 relative of th
 import pytest
 import torch
 
-from conftest import TRAIN_CASES, case_inputs, parity_note, rel_to_max
+from conftest import TRAIN_CASES, TRAIN_CASES_BASELINE, case_inputs, parity_note, ref_map, rel_to_max
 from oracle import view_synth_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -42,16 +42,86 @@ def oracle_run(g, leaves, Ts, K, static):
     return loss, out
 
 
+def impose_reference_routing(g, sel):
+    """Compact (BASELINE-resolution) fixtures, between forward and backward: overwrite the kernel's decision map (`sel`, the tensor its
+    backward reads) with the REFERENCE's (`out_sel_all`), so that the gradients that follow are compared under identical routing.
+    Among 0.5-1 M pixels a few dozen have two candidate errors within the error map's fp32 noise (observed gap <= 5e-5; the synthetic
+    frames are integer shifts of one 8-bit scene, which makes near-ties common) and rounding decides them; each re-routes the gradient of
+    its 3x3 window by percents.  -> the kernel's own map (for the flip count / tie proof).  (`.data`: the forward saved `sel` for its
+    backward; this is a test aid, nothing in the product writes to it.)"""
+    own = sel.clone()
+    sel.data.copy_(g['out_sel_all'].reshape(sel.shape).to(sel.device))
+    return own
+
+
+_FP64_CACHE: dict = {}
+
+
+def fp64_gradients_under_reference_routing(g, name):
+    """The oracle's whole chain (aa, t, (fs, cs), disparities -> loss) in fp64 with the reference's decisions imposed: the yardstick for
+    "how far from the exactly-rounded gradient is an fp32 implementation allowed to be" at BASELINE resolution.  Cached per fixture."""
+    if name not in _FP64_CACHE:
+        leaves, static = case_inputs(g, dtype=torch.float64)
+        n, b = leaves['aa'].shape[:2]
+        h, w = static['imgs'].shape[-2:]
+        Ts = O.T_from_AAt(leaves['aa'].flatten(0, 1), leaves['t'].flatten(0, 1)).unflatten(0, (n, b))
+        if g['meta_always_fwd_pose']: Ts = torch.stack([torch.linalg.inv(T) if i < 0 else T for i, T in zip(static['supp_idxs'], Ts)])
+        K = O.resize_K(O.build_K(leaves['fs'], leaves['cs']), (h, w)) if g['meta_learn_K'] else static['K']
+        loss, _ = O.loss_path({s: leaves[f'disp_{s}'] for s in static['scales']}, static['imgs'], static['supp_imgs'], Ts, K, noise=static['noise'],
+                              aten=True, force_sel=g['out_sel_all'], w_smooth=g['meta_w_smooth'])
+        loss.backward()
+        _FP64_CACHE[name] = {k: v.grad.float() for k, v in leaves.items()}
+    return _FP64_CACHE[name]
+
+
+def judge_against_reference_at_baseline_size(g, name, grads, sel_own):
+    """Compact fixtures: the kernel's decisions (`sel_own`, before `impose_reference_routing`) and its gradients under the reference's routing
+    against the REFERENCE's own (`out_sel_all`, `grad_*`).
+    Decisions: <= 5e-4 of the pixels may differ (each proven a tie by the caller).
+    Dense gradients: besides the arg-min the loss has other knife edges — sign(pred - target) of the L1 term above all: the sampling
+    coordinates are fp32 numbers around 600 (ulp 6e-5 px), so two correct implementations' warped values differ by ~1e-6 and wherever
+    |pred - target| is smaller than that the L1 term's gradient has either sign.  With a camera motion that explains the frames (these
+    fixtures) that is a few dozen of the 10^7 (pixel, channel, support, scale) terms, each worth up to 1e-1 of the tensor's largest
+    element, spread over a 3x3 window and the bilinear footprint.  The yardstick is the oracle in fp64 under the same routing: the
+    REFERENCE's own fp32 gradient has such elements against it (37 in one tensor at 384x640, 62 over the four scales), so the kernel is held
+    to: bulk (99 % quantile of |hip - ref|) <= 2e-4 of the tensor's max, nothing beyond 0.5 (the reference vs fp64: 0.28), and over the
+    pyramid no more elements beyond 1e-3 — against the reference or against fp64 — than twice what the reference shows against fp64, + 16.
+    Pose / intrinsics gradients (sums over all pixels of ONE sample): 2e-3 against the reference."""
+    ref_sel = g['out_sel_all']
+    g64 = fp64_gradients_under_reference_routing(g, name)
+    flips = int((sel_own.cpu().reshape(ref_sel.shape) != ref_sel).sum())
+    report, ok = [f'decisions differ from the reference on {flips} of {ref_sel.numel()} pixels'], flips <= 5e-4*ref_sel.numel()
+    tot = [0, 0, 0]
+    for k, v in grads.items():
+        ref, v = g[f'grad_{k}'], v.cpu()
+        mx = ref.abs().max().clamp(min=1e-20)
+        d = (v - ref).abs()/mx
+        if k.startswith('disp_'):
+            n_out, n_hip64, n_ref64 = int((d > 1e-3).sum()), int(((v - g64[k]).abs()/mx > 1e-3).sum()), int(((ref - g64[k]).abs()/mx > 1e-3).sum())
+            q = torch.quantile(d.flatten()[:: max(1, d.numel()//2_000_000)], 0.99).item()
+            report.append(f'{k}: q99={q:.1e}, beyond 1e-3: {n_out} vs ref (largest {d.max():.1e}), {n_hip64} vs fp64; the reference vs fp64: {n_ref64}')
+            ok &= q <= 2e-4 and d.max().item() < 0.5
+            tot = [tot[0] + n_out, tot[1] + n_hip64, tot[2] + n_ref64]
+        else:
+            report.append(f'{k}={d.max():.1e} (ref vs fp64 {((ref - g64[k]).abs()/mx).max():.1e})')
+            ok &= d.max().item() < 2e-3
+    report.append(f'elements beyond 1e-3 over the pyramid: {tot[0]} vs ref, {tot[1]} vs fp64; the reference vs fp64: {tot[2]}')
+    ok &= max(tot[0], tot[1]) <= 2*tot[2] + 16
+    return report, ok
+
+
 @pytest.mark.parametrize('name', TRAIN_CASES)
 def test_fused_path_matches_oracle_and_reference(F, golden, name):
     g = golden(name)
     dev = 'cuda'
+    compact = bool(g.get('meta_compact'))
     # --- oracle (CPU) with Ts, K as differentiable leaves
     leaves_c, static_c = case_inputs(g)
     Ts_c = g['out_Ts'].clone().requires_grad_(True)
     K_c = (g['out_K'] if g['meta_learn_K'] else g['in_K']).clone().requires_grad_(True)
-    loss_c, out_c = oracle_run(g, leaves_c, Ts_c, K_c, static_c)
-    loss_c.backward()
+    if not compact:
+        loss_c, out_c = oracle_run(g, leaves_c, Ts_c, K_c, static_c)
+        loss_c.backward()
 
     # --- HIP path
     leaves, static = case_inputs(g, device=dev)
@@ -69,16 +139,42 @@ def test_fused_path_matches_oracle_and_reference(F, golden, name):
         l_sm, dgrad, igrad = F.disp_smooth_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'],
                                                  use_edges=bool(g['meta_use_edges']))
         loss = loss + g['meta_w_smooth']*l_sm
+    if compact: sel_own = impose_reference_routing(g, sel)
     loss.backward()
     torch.cuda.synchronize()
 
     # --- K0
     for k, s in enumerate(scales):
-        torch.testing.assert_close(depth_up[k].cpu(), g[f'out_depth_up_{s}'], rtol=2e-5, atol=1e-5)
-        torch.testing.assert_close(disp_up[k].cpu(), g[f'out_disp_up_{s}'], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(*ref_map(g, f'out_depth_up_{s}', depth_up[k].cpu()), rtol=2e-5, atol=1e-5)
+        torch.testing.assert_close(*ref_map(g, f'out_disp_up_{s}', disp_up[k].cpu()), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(*ref_map(g, 'out_supp_imgs_warp', warp0.cpu()), rtol=0, atol=1e-4)
+    if compact:
+        # BASELINE resolution: everything against what the REFERENCE produced — losses, the reduced error map (sampled), the decision of
+        # every pixel at every scale, every gradient; then the oracle under the kernel's routing for the gradients w.r.t. T and K
+        # (the reference differentiates through aa / t / fs / cs, tested in test_whole_chain_*).
+        e_hip, e_ref = ref_map(g, 'mid_err', err.cpu().reshape(g['out_sel_all'].shape))
+        bad = ((e_hip - e_ref).abs() > 2e-4).float().mean().item()
+        torch.testing.assert_close(l_rec.detach().cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(l_sm.detach().cpu(), g['out_loss_disp_smooth'], rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(loss.detach().cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(*ref_map(g, 'out_disp_grad', dgrad.cpu()), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(*ref_map(g, 'out_image_grad', igrad.cpu()), rtol=1e-4, atol=1e-5)
+        report, ok = judge_against_reference_at_baseline_size(g, name, {f'disp_{s}': leaves[f'disp_{s}'].grad for s in scales}, sel_own)
+        with torch.no_grad():      # every decision of the kernel that differs from the reference's must be a tie within the error map's noise
+            _, out_t = O.loss_path({s: leaves_c[f'disp_{s}'] for s in scales}, static_c['imgs'], static_c['supp_imgs'], Ts_c, K_c, noise=static_c['noise'],
+                                   aten=True, force_sel=sel_own.cpu().reshape(g['out_sel_all'].shape))
+        tie = out_t['full']['tie_gap'].abs().max().item()
+        loss_c, out_c = O.loss_path({s: leaves_c[f'disp_{s}'] for s in scales}, static_c['imgs'], static_c['supp_imgs'], Ts_c, K_c, noise=static_c['noise'],
+                                    aten=True, force_sel=g['out_sel_all'])
+        loss_c.backward()
+        eT, eK = rel_to_max(Ts.grad.cpu()[..., :3, :], Ts_c.grad[..., :3, :]), rel_to_max(K.grad.cpu(), K_c.grad)
+        parity_note(f'{name}: loss hip={loss.item():.8f} ref={g["out_loss"].item():.8f} (rel {abs(loss.item() - g["out_loss"].item())/g["out_loss"].item():.1e}); '
+                    f'|err - ref| > 2e-4 on {bad:.1e} of the sampled pixels (max {(e_hip - e_ref).abs().max():.1e}); ' + '; '.join(report)
+                    + f'; largest gap of a differing decision {tie:.1e}; dT={eT:.1e} dK={eK:.1e} (oracle, reference routing)')
+        assert bad <= 1e-3 and ok and tie <= 1e-4 and eT < 2e-3 and eK < 2e-3, report
+        return
     # --- forward values
     report = [f'{name}: loss hip={loss.item():.8f} oracle={loss_c.item():.8f} ref={g["out_loss"].item():.8f}']
-    torch.testing.assert_close(warp0.cpu(), g['out_supp_imgs_warp'], rtol=0, atol=1e-4)
     err_o = out_c['full']['err'].detach()
     bad = ((err.cpu() - err_o).abs() > 2e-4).float().mean().item()
     assert bad <= 3e-3, f'per-pixel error map differs on {bad:.2%} of pixels (max {(err.cpu() - err_o).abs().max():.3e})'
@@ -126,24 +222,26 @@ def test_handlers_match_reference_fixtures(F, golden, name, depth_form):
     K = (g['out_K'] if g['meta_learn_K'] else g['in_K']).to(dev)
     mind, maxd = g['meta_min_depth'] or None, g['meta_max_depth'] or None
     crit = amd.losses.ReconstructionLoss(loss_name=g['meta_loss_name'], use_min=bool(g['meta_use_min']), use_automask=bool(g['meta_use_automask']))
-    if depth_form == 'dict_of_tensors': depths = {s: g[f'out_depth_up_{s}'].to(dev) for s in scales}
+    if depth_form == 'dict_of_tensors':
+        if g.get('meta_compact'): pytest.skip('the compact fixtures store the up-sampled depth sampled, not whole')
+        depths = {s: g[f'out_depth_up_{s}'].to(dev) for s in scales}
     else: depths = LazyDepths(scales, [leaves[f'disp_{s}'] for s in scales], (h, w), mind, maxd)
     synth = amd.geometry.ViewSynth((h, w))
     loss, ld = amd.handlers.image_recon(crit, synth, depths, None, static['imgs'], static['supp_imgs'], Ts, K, noise=static['noise'])
     torch.testing.assert_close(loss.cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
-    torch.testing.assert_close(ld['supp_imgs_warp'].cpu(), g['out_supp_imgs_warp'], rtol=0, atol=1e-4)
+    torch.testing.assert_close(*ref_map(g, 'out_supp_imgs_warp', ld['supp_imgs_warp'].cpu()), rtol=0, atol=1e-4)
     if g['meta_use_automask']:
         flips = (ld['automask'].cpu().reshape(-1) != g['out_automask'].bool().reshape(-1)).float().mean().item()
-        assert flips <= 3e-3, f'automask differs on {flips:.2%} of pixels'
+        assert flips <= (5e-4 if g.get('meta_compact') else 3e-3), f'automask differs on {flips:.2%} of pixels'
     if depth_form == 'lazy_from_disparities':      # the depth the fused kernel wrote is what a later consumer of fwd['depth_up'] reads
         assert not depths.pending
-        for s in scales: torch.testing.assert_close(depths[s].cpu(), g[f'out_depth_up_{s}'], rtol=2e-5, atol=1e-5)
+        for s in scales: torch.testing.assert_close(*ref_map(g, f'out_depth_up_{s}', depths[s].cpu()), rtol=2e-5, atol=1e-5)
     if g['meta_w_smooth'] >= 0:
         reg = amd.regularizers.SmoothReg(use_edges=bool(g['meta_use_edges']))
         l_sm, ld_sm = amd.handlers.disp_smooth(reg, {s: leaves[f'disp_{s}'] for s in scales}, static['imgs'])
         torch.testing.assert_close(l_sm.cpu(), g['out_loss_disp_smooth'], rtol=2e-5, atol=1e-7)
-        torch.testing.assert_close(ld_sm['disp_grad'].cpu(), g['out_disp_grad'], rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(ld_sm['image_grad'].cpu(), g['out_image_grad'], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(*ref_map(g, 'out_disp_grad', ld_sm['disp_grad'].cpu()), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(*ref_map(g, 'out_image_grad', ld_sm['image_grad'].cpu()), rtol=1e-4, atol=1e-5)
 
 
 def test_in_kernel_noise_is_a_tiebreak_only(F, golden):
@@ -601,6 +699,41 @@ def test_whole_chain_from_network_outputs_matches_reference_gradients(F, golden,
     for k in ['aa', 't'] + (['fs', 'cs'] if g['meta_learn_K'] else []) + [f'disp_{s}' for s in scales]:
         e = rel_to_max(leaves[k].grad.cpu(), g[f'grad_{k}'])
         assert e < 1e-3, f'{name}: d loss / d {k} off by {e:.3e} (rel. to max) vs the reference autograd'
+
+
+@pytest.mark.parametrize('name', TRAIN_CASES_BASELINE)
+def test_whole_chain_at_baseline_resolution_matches_reference(F, golden, name):
+    """The trainer's operators at the resolutions BASELINE.json quotes, from the networks' outputs (aa, t, (fs, cs), the disparity pyramid)
+    through `pose_matrices` / `intrinsics`, the K0-FUSED reconstruction (the kernel pair `bench.py` times, here with the recorded
+    tie-break tensor instead of the in-kernel draw) and the smoothness sweep, to the loss and the gradient of every network output —
+    against what the REFERENCE produced on the same inputs (src/core/trainer.py:280-472 driven by tests/golden/make_golden.py)."""
+    g = golden(name)
+    leaves, static = case_inputs(g, device='cuda')
+    scales, idxs = static['scales'], static['supp_idxs']
+    n, b = leaves['aa'].shape[:2]
+    h, w = static['imgs'].shape[-2:]
+    inv = torch.tensor([bool(g['meta_always_fwd_pose']) and i < 0 for i in idxs for _ in range(b)], dtype=torch.uint8).cuda()
+    Ts = F.pose_matrices(leaves['aa'].flatten(0, 1), leaves['t'].flatten(0, 1), inv).unflatten(0, (n, b))
+    torch.testing.assert_close(Ts.detach().cpu(), g['out_Ts'], rtol=1e-5, atol=1e-6)
+    if g['meta_learn_K']:
+        K, K_inv = F.intrinsics(leaves['fs'], leaves['cs'], (h, w))
+        torch.testing.assert_close(K.detach().cpu(), g['out_K'], rtol=1e-6, atol=1e-5)
+    else: K, K_inv = static['K'], None
+    flags = F.recon_flags(g['meta_loss_name'], bool(g['meta_use_min']), bool(g['meta_use_automask']))
+    l_rec, err, sel, _, depth_up = F.image_recon_fused_disp([leaves[f'disp_{s}'] for s in scales], static['imgs'], static['supp_imgs'], Ts, K, K_inv, flags=flags,
+                                                            min_depth=g['meta_min_depth'] or None, max_depth=g['meta_max_depth'] or None, noise=static['noise'])
+    l_sm, _, _ = F.disp_smooth_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'], use_edges=bool(g['meta_use_edges']), want_aux=False)
+    loss = l_rec + g['meta_w_smooth']*l_sm
+    sel_own = impose_reference_routing(g, sel)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(l_rec.detach().cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
+    for k, s in enumerate(scales): torch.testing.assert_close(*ref_map(g, f'out_depth_up_{s}', depth_up[k].cpu()), rtol=2e-5, atol=1e-5)
+    e_hip, e_ref = ref_map(g, 'mid_err', err.cpu().reshape(g['out_sel_all'].shape))
+    assert ((e_hip - e_ref).abs() > 2e-4).float().mean().item() <= 1e-3
+    report, ok = judge_against_reference_at_baseline_size(g, name, {k: v.grad for k, v in leaves.items()}, sel_own)
+    parity_note(f'{name} (whole chain, K0 fused): loss hip={loss.item():.8f} ref={g["out_loss"].item():.8f}; ' + '; '.join(report))
+    assert ok, report
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1138,14 +1271,20 @@ def test_k0_fused_path_matches_reference_fixtures(F, golden, name):
                                                                 min_depth=g['meta_min_depth'] or None, max_depth=g['meta_max_depth'] or None,
                                                                 noise=static['noise'], want_warp=True)
     for k, s in enumerate(scales):
-        torch.testing.assert_close(depth_up[k].cpu(), g[f'out_depth_up_{s}'], rtol=2e-5, atol=1e-5)
+        torch.testing.assert_close(*ref_map(g, f'out_depth_up_{s}', depth_up[k].cpu()), rtol=2e-5, atol=1e-5)
     torch.testing.assert_close(l_rec.detach().cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
-    torch.testing.assert_close(warp0.cpu(), g['out_supp_imgs_warp'], rtol=0, atol=1e-4)
+    torch.testing.assert_close(*ref_map(g, 'out_supp_imgs_warp', warp0.cpu()), rtol=0, atol=1e-4)
     loss = l_rec
     if g['meta_w_smooth'] >= 0:
         l_sm, _, _ = F.disp_smooth_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'], use_edges=bool(g['meta_use_edges']), want_aux=False)
         loss = loss + g['meta_w_smooth']*l_sm
+    if g.get('meta_compact'): sel_own = impose_reference_routing(g, sel)
     loss.backward()
+    if g.get('meta_compact'):
+        report, ok = judge_against_reference_at_baseline_size(g, name, {f'disp_{s}': leaves[f'disp_{s}'].grad for s in scales}, sel_own)
+        parity_note(f'{name} (K0 fused): ' + '; '.join(report))
+        assert ok, report
+        return
     tol = 1e-2 if g['meta_loss_name'] == 'l1' else 1e-3
     for s in scales:
         e = rel_to_max(leaves[f'disp_{s}'].grad.cpu(), g[f'grad_disp_{s}'])
