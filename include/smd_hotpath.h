@@ -31,6 +31,7 @@ extern "C" {
 #define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
 #define SMD_E_LAUNCH (-2)      /* hipLaunch / hipGetLastError failure */
 #define SMD_E_WORKSPACE (-3)   /* workspace too small: call the matching *_workspace_bytes() */
+#define SMD_E_UNSUPPORTED (-4) /* the request exists, but not in this build / not for these arguments (the caller takes the general path) */
 
 /* flags for smd_image_recon_* / smd_recon_reduce_* */
 #define SMD_USE_MIN 0x1        /* ReconstructionLoss(use_min=True): min over supports, else mean (reconstruction.py:43-44) */
@@ -44,7 +45,7 @@ extern "C" {
 #define SMD_BWD_SKIP_DEAD_ROWS 0x400   /* smd_image_recon*_bwd: the liveness-gated row loop — a wave scans the `sel` rows of its strip first and then re-synthesises,
                                         * scores and back-propagates only the rows a pixel of its columns routes gradient through.  Same result bit for bit; all-masked
                                         * input: 52 instead of 117 us at 12x192x640; pays from ~75 % dead (row, strip) units on, costs 12-24 % where every row is live
-                                        * (profiles/r04_skip_regimes.txt).  Default: off.  SMD_BWD_SKIP in the environment overrides. */
+                                        * (profiles/r04_skip_regimes.txt).  Default: off.  (The knob `bwd_skip`, smd_set_knob, overrides.) */
 #define SMD_USE_LAPLACIAN 0x200        /* smd_disp_smooth_*: SmoothReg(use_laplacian=True): second-order differences (smooth.py:33-48) */
 #define SMD_EDGES_READY 0x800  /* smd_disp_smooth_fwd: `edge_weights` was already filled by smd_disp_smooth_prep() for this frame and pyramid */
 #define SMD_PACKED_READY 0x40  /* smd_image_recon_*_fwd: `supp_packed` was already filled by smd_image_recon_prep() for these frames */
@@ -60,6 +61,15 @@ extern "C" {
 
 const char* smd_last_error(void);
 int smd_abi_version(void);
+
+/* Launch-shape knobs.  Process-wide overrides of the built-in heuristics that choose between partitions / code paths which MUST give the
+ * same results: rows per strip, the tapered partition, shared LDS ring vs. per-wave loads in the forward, the backward's two row loops,
+ * guest work vs. launches of their own.  They exist so that the parity tests can pin both sides of each such choice and compare; the
+ * library never reads the environment.  Names: fwd_rh bwd_rh fwd_taper_b bwd_taper_b fwd_taper_rh bwd_taper_rh fwd_ni fwd_share bwd_skip
+ * bwd_wps bwd_guest_finalize bwd_direct_level loss_path_guests (and, in -DSMD_EXPERIMENTS builds only: fwd_ahead bwd_pair smooth_chain).
+ * smd_set_knob: 0, SMD_E_INVALID for an unknown name, SMD_E_UNSUPPORTED for an experiments-only knob in the product build. */
+int smd_set_knob(const char* name, int value);
+void smd_reset_knobs(void);
 
 /* ------------------------------------------------------------------------------------------------
  * K0 — upsample + disparity->depth.  Replaces, per scale, `ops.interpolate_like(disp, imgs, 'bilinear')`

@@ -5,7 +5,7 @@ cfg=${1:-cfg2}
 cd "$GRAFT_REPO_ROOT/slowtv_monodepth_amd/csrc"
 for abl in ${ABLS:-0 1 2 3 7}; do
   rm -f smd_recon_fwd.o
-  make -s EXTRA="-DSMD_ABLATE=$abl" >/dev/null 2>&1
+  make -s EXPERIMENTS=1 EXTRA="-DSMD_ABLATE=$abl" >/dev/null 2>&1
   echo -n "SMD_ABLATE=$abl: "
   (cd "$GRAFT_REPO_ROOT" && timeout 100 python scripts/dev/microbench.py $cfg 20 2>&1 | tail -1 | cut -c1-110)
 done

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT/slowtv_monodepth_amd/csrc"
 for abl in 0 1 2 4 3 7 8 15; do
   rm -f smd_recon_bwd.o
-  make -s EXTRA="-DSMD_ABLATE_BWD=$abl" >/dev/null 2>&1
+  make -s EXPERIMENTS=1 EXTRA="-DSMD_ABLATE_BWD=$abl" >/dev/null 2>&1
   for rough in 0 1; do
     echo -n "SMD_ABLATE_BWD=$abl rough=$rough: "
     (cd "$GRAFT_REPO_ROOT" && MB_ROUGH=$rough timeout 100 python scripts/dev/microbench.py cfg2 20 2>&1 | tail -1 | cut -c1-130)

@@ -2,7 +2,7 @@
 # Times the fused backward built with extra -D flags (GPU box).  usage: scripts/dev/bwd_defs.sh "" "-DSMD_BWD_TAP_PAIRS" ...
 cd "$GRAFT_REPO_ROOT/slowtv_monodepth_amd/csrc"
 for defs in "$@"; do
-  rm -f smd_recon_bwd.o; make -s EXTRA="$defs" >/dev/null 2>&1
+  rm -f smd_recon_bwd.o; make -s EXPERIMENTS=1 EXTRA="$defs" >/dev/null 2>&1
   for rough in 0 1; do
     echo -n "[$defs] rough=$rough: "
     (cd "$GRAFT_REPO_ROOT" && MB_ROUGH=$rough timeout 100 python scripts/dev/microbench.py cfg2 20 2>&1 | tail -1 | cut -c1-120)

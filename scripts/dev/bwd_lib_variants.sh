@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT/slowtv_monodepth_amd/csrc"
 mkdir -p ../variants
 for spec in "$@"; do
   tag=${spec%%:*}; defs=${spec#*:}
-  rm -f smd_recon_bwd.o; make -s EXTRA="$defs" >/dev/null 2>&1 && cp ../libsmd_hotpath.so ../variants/libsmd_$tag.so
+  rm -f smd_recon_bwd.o; make -s EXPERIMENTS=1 EXTRA="$defs" >/dev/null 2>&1 && cp ../libsmd_hotpath.so ../variants/libsmd_$tag.so
 done
 rm -f smd_recon_bwd.o; make -s >/dev/null 2>&1
 cd "$GRAFT_REPO_ROOT"

@@ -12,7 +12,7 @@ from pathlib import Path
 
 import torch  # noqa: F401  MUST precede the CDLL below: the library binds to the HIP runtime torch has already loaded
 
-__all__ = ['lib', 'call', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError']
+__all__ = ['lib', 'call', 'set_knob', 'reset_knobs', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError']
 
 _HERE = Path(__file__).resolve().parent
 lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
@@ -31,6 +31,8 @@ PROTOTYPES = {
     'smd_last_error': (C.c_char_p, []),
     'smd_abi_version': (_i, []),
     'smd_last_kernel_variant': (C.c_char_p, [_i]),
+    'smd_set_knob': (_i, [C.c_char_p, _i]),
+    'smd_reset_knobs': (None, []),
     'smd_disp_to_depth_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     'smd_disp_to_depth_workspace_bytes': (_sz, [_vp, _vp, _i, _i, _i, _i]),
     'smd_disp_to_depth_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -117,6 +119,18 @@ def call(name: str, *args):
         msg = lib.smd_last_error().decode()
         if rc == -1: raise ValueError(f'{name}: {msg}')
         raise HotpathError(f'{name} failed ({rc}): {msg}')
+
+
+def set_knob(name: str, value: int) -> bool:
+    """Pin a launch-shape knob of the library (`smd_set_knob`: partitions / code paths that must give identical results; the parity tests
+    compare both sides).  -> False if this build does not have the knob (experiments-only), ValueError for an unknown name."""
+    rc = lib.smd_set_knob(name.encode(), int(value))
+    if rc == -1: raise ValueError(lib.smd_last_error().decode())
+    return rc == 0
+
+
+def reset_knobs() -> None:
+    lib.smd_reset_knobs()
 
 
 def ptr_array(ptrs):

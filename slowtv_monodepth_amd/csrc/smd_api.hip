@@ -1,5 +1,6 @@
 // smd_api.hip — the extern "C" boundary (include/smd_hotpath.h): argument validation, workspace carving, launches.
 // No torch types, no allocation, no synchronisation; every launch goes to the caller's stream.
+#include <limits.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,21 +34,53 @@ constexpr int kMinStripRows = 4;   // lower bound of the rows-per-strip override
 int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil_div(h, kMinStripRows); }
 
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
+// Launch-shape knobs (smd_set_knob; unset = the built-in heuristics).  They select between partitions / code paths that must give the same
+// results — the parity tests pin them to prove exactly that (tapered vs. plain partition, shared ring vs. per-wave loads, the two row loops
+// of the backward) — and are NOT read from the environment: nothing on the call path calls getenv.  (A -DSMD_EXPERIMENTS build additionally
+// seeds them from SMD_<NAME> environment variables once, for the scripts under scripts/dev.)
+//   fwd_rh / bwd_rh rows per strip (>= 4); fwd_taper_b / bwd_taper_b samples at the end of the dispatch order that get short strips (0: none)
+//   and fwd_taper_rh / bwd_taper_rh their height; fwd_ni supports per forward launch (1..4); fwd_share (default 1: with four scales a block
+//   of the hot forward is the four scales of one strip and the target-side rows reach it through an LDS ring); bwd_skip (0 / 2: the
+//   backward's row loop, overriding the SMD_BWD_SKIP_DEAD_ROWS flag of the call); bwd_wps (waves per strip of the backward);
+//   bwd_guest_finalize; bwd_direct_level; loss_path_guests (0: the fused loss path launches its guest work as kernels of their own).
+//   Experiments builds only: fwd_ahead (2: tap gathers two rows ahead, measured slower), bwd_pair (two supports per wave, dropped), smooth_chain.
+struct KnobDef { const char* name; bool experiment; };
+constexpr KnobDef kKnobs[] = {{"fwd_rh", false}, {"bwd_rh", false}, {"fwd_taper_b", false}, {"bwd_taper_b", false}, {"fwd_taper_rh", false},
+                              {"bwd_taper_rh", false}, {"fwd_ni", false}, {"fwd_share", false}, {"bwd_skip", false}, {"bwd_wps", false},
+                              {"bwd_guest_finalize", false}, {"bwd_direct_level", false}, {"loss_path_guests", false},
+                              {"fwd_ahead", true}, {"bwd_pair", true}, {"smooth_chain", true}};
+constexpr int kNumKnobs = sizeof(kKnobs)/sizeof(kKnobs[0]);
+constexpr int kKnobUnset = INT_MIN;
+struct KnobTable {
+  int v[kNumKnobs];
+  KnobTable() {
+    for (int i = 0; i < kNumKnobs; ++i) v[i] = kKnobUnset;
+#ifdef SMD_EXPERIMENTS
+    for (int i = 0; i < kNumKnobs; ++i) {   // once, at load time: SMD_FWD_RH=12 etc. for the dev scripts
+      char env[64] = "SMD_";
+      size_t k = 4;
+      for (const char* c = kKnobs[i].name; *c && k + 1 < sizeof(env); ++c) env[k++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+      env[k] = 0;
+      const char* e = getenv(env);
+      if (e && *e) v[i] = atoi(e);
+    }
+#endif
+  }
+};
+KnobTable g_knobs;
+int knob_index(const char* name) {
+  for (int i = 0; i < kNumKnobs; ++i) if (strcmp(kKnobs[i].name, name) == 0) return i;
+  return -1;
+}
+int knob(const char* name, int dflt) {
+  const int i = knob_index(name);
+  return (i >= 0 && g_knobs.v[i] != kKnobUnset) ? g_knobs.v[i] : dflt;
 }
 
-// Tuning knobs (environment, read per call; unset = built-in heuristics): SMD_BWD_SKIP (0 / 2: dead-row skipping of the fused
-// backward off / on, overriding the SMD_BWD_SKIP_DEAD_ROWS flag of the call), SMD_FWD_RH / SMD_BWD_RH rows per strip (>= 4), SMD_FWD_TAPER_B / SMD_BWD_TAPER_B samples at the end of the
-// dispatch order that get short strips (0: none) and SMD_FWD_TAPER_RH / SMD_BWD_TAPER_RH their height, SMD_FWD_NI supports per
-// forward launch (1..4), SMD_FWD_SHARE (default 1: with four scales a block of the hot forward is the four scales of one strip
-// and the target-side rows reach it through an LDS ring; needs strip heights that are multiples of four), SMD_FWD_AHEAD (2: tap
-// gathers two rows ahead, measured slower), SMD_BWD_WPS (waves per strip of the backward), SMD_BWD_GUEST_FINALIZE.
 StripPlan plan(int b, int S, int h, int w, int cols) {
   StripPlan p;
   p.rh = smd::pick_rows_per_strip(b, S, h, w, cols, 0);
-  const int ov = env_int(cols == smd::kFwdCols ? "SMD_FWD_RH" : "SMD_BWD_RH", 0);
+  const int ov = knob(cols == smd::kFwdCols ? "fwd_rh" : "bwd_rh", 0);
   if (ov >= 1) p.rh = ov < kMinStripRows ? kMinStripRows : ov;
   if (cols == smd::kFwdCols && p.rh > 58) p.rh = 58;   // the K0-fused forward keeps the strip's rh + 3 + look-ahead row-table entries one per lane
   p.nsx = smd::ceil_div(w, cols);
@@ -59,9 +92,9 @@ StripPlan plan(int b, int S, int h, int w, int cols) {
 // strips of `rh2` = rh/2 rows.  A launch is two to three "generations" of waves on the 4096 wave slots of the chip and a wave
 // lives 30-40 us, so with equal units the last ones dispatched run almost alone for tens of microseconds (wave traces:
 // scripts/dev/wave_trace.py; time-averaged occupancy 2.96 -> 3.19 waves per SIMD with the taper, forward 93 -> 87-89 us at
-// cfg 2).  Default: a sixth of the batch, when the batch has at least four samples; SMD_*_TAPER_B / _RH override (B = 0: off).
+// cfg 2).  Default: a sixth of the batch, when the batch has at least four samples; the knobs *_taper_b / *_taper_rh override (b = 0: off).
 void taper(int& b1, int& rh2, int& nsy2, int b, int h, const StripPlan& pl, const char* env_b, const char* env_rh) {
-  int b2 = env_int(env_b, -1), r2 = env_int(env_rh, -1);
+  int b2 = knob(env_b, -1), r2 = knob(env_rh, -1);
   if (b2 < 0) {
     b2 = (b >= 4) ? (b + 3)/6 : 0;
     // the taper buys the tail of a launch that is two or three generations of waves; a launch of five or more (384x640 at b = 12) pays for the short
@@ -151,6 +184,17 @@ const char* smd_last_error(void) { return g_err; }
 const char* smd_last_kernel_variant(int which) { return (which == 0 || which == 1) ? smd::g_variant[which] : ""; }
 int smd_abi_version(void) { return SMD_ABI_VERSION; }
 
+int smd_set_knob(const char* name, int value) {
+  const int i = name ? knob_index(name) : -1;
+  if (i < 0) return fail(SMD_E_INVALID, "unknown knob '%s'", name ? name : "(null)");
+#ifndef SMD_EXPERIMENTS
+  if (kKnobs[i].experiment) return fail(SMD_E_UNSUPPORTED, "knob '%s' exists in -DSMD_EXPERIMENTS builds only", name);
+#endif
+  g_knobs.v[i] = value;
+  return SMD_OK;
+}
+void smd_reset_knobs(void) { for (int i = 0; i < kNumKnobs; ++i) g_knobs.v[i] = kKnobUnset; }
+
 // ------------------------------------------------------------------------------------------------
 int smd_disp_to_depth_fwd(const float* const* disp, const int* hs, const int* ws, int S, int b, int h, int w,
                           float min_depth, float max_depth, float* depth_up, float* disp_up, void* stream) {
@@ -199,7 +243,7 @@ size_t smd_packed_supports_bytes(int b, int n, int h, int w) {
 // also the vertical up-sampling table of the pyramid.  Zeroes the arrival counters in the tail of `packed`.
 static int recon_prep_impl(const float* tgt, const float* supp, float* supp_packed, const smd::ScaleSet* sc, int b, int n, int S, int h, int w,
                            int flags, hipStream_t st) {
-  int kMaxPerPass = env_int("SMD_FWD_NI", 4);   // supports held in registers by one launch (1..4)
+  int kMaxPerPass = knob("fwd_ni", 4);   // supports held in registers by one launch (1..4)
   if (kMaxPerPass < 1 || kMaxPerPass > 4) kMaxPerPass = 4;
   smd::ReconPrepArgs p;
   memset(&p, 0, sizeof(p));
@@ -237,7 +281,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   if (workspace_bytes < ws.bytes) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
   hipStream_t st = (hipStream_t)stream;
   prof_mark(SMD_PROF_RECON_FWD_ALL, st, true);
-  int kMaxPerPass = env_int("SMD_FWD_NI", 4);   // supports held in registers by one launch (1..4)
+  int kMaxPerPass = knob("fwd_ni", 4);   // supports held in registers by one launch (1..4)
   if (kMaxPerPass < 1 || kMaxPerPass > 4) kMaxPerPass = 4;
   if (!err && n > kMaxPerPass) return fail(SMD_E_INVALID, "err may be NULL only when all %d supports fit one pass (%d)", n, kMaxPerPass);
 
@@ -268,10 +312,10 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
-  taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_FWD_TAPER_B", "SMD_FWD_TAPER_RH");
+  taper(a.b1, a.rh2, a.nsy2, b, h, pl, "fwd_taper_b", "fwd_taper_rh");
   if (a.rh2 > 58) { a.rh2 = 58; a.nsy2 = smd::ceil_div(h, a.rh2); }   // as plan(): one row-table entry per lane
-  a.lookahead = env_int("SMD_FWD_AHEAD", 1) == 2 ? 2 : 1;
-  a.share = (env_int("SMD_FWD_SHARE", 1) != 0 && a.S == 4 && a.rh % 4 == 0 && (a.b1 >= a.b || a.rh2 % 4 == 0)) ? 1 : 0;
+  a.lookahead = knob("fwd_ahead", 1) == 2 ? 2 : 1;
+  a.share = (knob("fwd_share", 1) != 0 && a.S == 4 && a.rh % 4 == 0 && (a.b1 >= a.b || a.rh2 % 4 == 0)) ? 1 : 0;
   for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
     a.i0 = i0; a.ni = (n - i0 < kMaxPerPass) ? n - i0 : kMaxPerPass;
     a.first_pass = (i0 == 0); a.last_pass = (i0 + a.ni >= n);
@@ -284,7 +328,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   return SMD_OK;
 }
 
-int smd_image_recon_supports_per_pass(void) { const int k = env_int("SMD_FWD_NI", 4); return (k < 1 || k > 4) ? 4 : k; }
+int smd_image_recon_supports_per_pass(void) { const int k = knob("fwd_ni", 4); return (k < 1 || k > 4) ? 4 : k; }
 
 int smd_image_recon_prep(const float* tgt, const float* supp, float* supp_packed, const int* hs, const int* ws, int S,
                          int b, int n, int h, int w, int flags, void* stream) {
@@ -347,23 +391,25 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   if (pl.rh > kBwdMaskRows) { pl.rh = kBwdMaskRows; pl.nsy = smd::ceil_div(h, pl.rh); }            // a strip's row masks are 32-bit words (k_recon_bwd: rows r0-3 .. r1+3)
   if (n >= 2 && pl.rh > kBwdAccRows) { pl.rh = kBwdAccRows; pl.nsy = smd::ceil_div(h, pl.rh); }   // the supports' shares of dL/d depth are summed from LDS rows
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
-  taper(a.b1, a.rh2, a.nsy2, b, h, pl, "SMD_BWD_TAPER_B", "SMD_BWD_TAPER_RH");
+  taper(a.b1, a.rh2, a.nsy2, b, h, pl, "bwd_taper_b", "bwd_taper_rh");
   if (a.rh2 > kBwdMaskRows) { a.rh2 = kBwdMaskRows; a.nsy2 = smd::ceil_div(h, a.rh2); }
   if (n >= 2 && a.rh2 > kBwdAccRows) { a.rh2 = kBwdAccRows; a.nsy2 = smd::ceil_div(h, a.rh2); }
   a.pose_stride = S*pl.nsx*(a.nsy2 > pl.nsy ? a.nsy2 : pl.nsy);
-  a.skip_level = env_int("SMD_BWD_SKIP", (flags & SMD_BWD_SKIP_DEAD_ROWS) ? 2 : 0);
+  a.skip_level = knob("bwd_skip", (flags & SMD_BWD_SKIP_DEAD_ROWS) ? 2 : 0);
   // Waves per strip.  min(n, 4) (default): one support per wave — half as long work units (a launch is only ~2 generations of waves,
   // so its tail is a fraction of a unit) and the waves of a strip share the target-side rows through one L1; 1: a wave takes every
   // support of its strip in turn.  cfg 2, rocprofv3: 113 vs 115 us on coherent masks, 187 vs 212 us on incoherent inputs, 140 vs
   // 145 us in the bench (profiles/r03_ab_kernel_times.txt).
-  a.wps = env_int("SMD_BWD_WPS", n < 4 ? n : 4);
+  a.wps = knob("bwd_wps", n < 4 ? n : 4);
   if (a.wps < 1) a.wps = 1;
   if (a.wps > 4) a.wps = 4;
   if (a.wps > n) a.wps = n;
-  // Two supports per wave (SMD_BWD_PAIR=1; experiment of round 4): the strips of a block must be those of the one-support-per-wave kernel
+#ifdef SMD_EXPERIMENTS
+  // Two supports per wave (knob bwd_pair; experiment of round 4): the strips of a block must be those of the one-support-per-wave kernel
   // with wps = n, so that the K0-adjoint guest epilogue finds the same per-block pose entries.
-  a.pair = (env_int("SMD_BWD_PAIR", 0) != 0 && (n == 2 || n == 4) && (flags & SMD_USE_MIN) && a.skip_level == 0) ? 1 : 0;
+  a.pair = (knob("bwd_pair", 0) != 0 && (n == 2 || n == 4) && (flags & SMD_USE_MIN) && a.skip_level == 0) ? 1 : 0;
   if (a.pair) a.wps = n;
+#endif
   if (guest) {   // the caller's next launch finalises the pose sums: no in-launch hand-off (the kernel skips it when `arrive` is null)
     a.arrive = nullptr;
     const int spb = smd::kWavesPerBlock/a.wps;
@@ -412,12 +458,12 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
   // pure resampling adjoint of g_depth: it neither reads depth_up again (24 MB at cfg 2) nor multiplies.
   smd::PoseFinJob guest;
   memset(&guest, 0, sizeof(guest));
-  const bool ride = env_int("SMD_BWD_GUEST_FINALIZE", 1) != 0;   // 0: the in-launch hand-off of smd_image_recon_bwd instead
+  const bool ride = knob("bwd_guest_finalize", 1) != 0;   // 0: the in-launch hand-off of smd_image_recon_bwd instead
   // A pyramid level that already has the image size (normally level 0) needs no resampling adjoint: the fused backward stores its rows
   // straight into that level's gradient tensor and the K0 adjoint launches no blocks for it (one (b,h,w) read + write less; needs another
   // level to carry the launch the pose epilogue rides in).
   int direct = -1;
-  if (S > 1 && env_int("SMD_BWD_DIRECT_LEVEL", 1) != 0)
+  if (S > 1 && knob("bwd_direct_level", 1) != 0)
     for (int s = 0; s < S && direct < 0; ++s) if (hs[s] == h && ws[s] == w) direct = s;
   if (int rc = recon_bwd_impl(depth_up, supp_packed, T, K, K_inv, sel, g_loss, g_depth_up_in, a_scale,
                               g_depth, g_T, g_K, g_Kinv, workspace, base, b, n, S, h, w, flags, stream, ride ? &guest : nullptr,

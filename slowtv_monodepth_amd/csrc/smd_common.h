@@ -5,6 +5,20 @@
 // kernels: one wave owns a 64-column strip and streams down the rows, so the 3x3 windows live in registers
 // (horizontal taps = neighbouring lanes, vertical taps = forward-accumulated row sums).
 #pragma once
+// Experiment / diagnosis switches (ablations, wave traces, dropped kernel variants, launch-shape knobs read from the environment) exist
+// only in -DSMD_EXPERIMENTS builds (`make EXPERIMENTS=1`; scripts/dev builds those).  The product library ignores them.
+#ifndef SMD_EXPERIMENTS
+#undef SMD_ABLATE
+#undef SMD_ABLATE_BWD
+#undef SMD_FWD_PRIO
+#undef SMD_BWD_FASTPATH
+#undef SMD_NO_DPP
+#undef SMD_BWD_PEEL
+#undef SMD_BWD_ROWSEL
+#undef SMD_BWD_STATEFUL
+#undef SMD_FWD_CAM_REGS
+#undef SMD_TRACE_WAVES
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

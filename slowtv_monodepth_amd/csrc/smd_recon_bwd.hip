@@ -627,371 +627,9 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   if (lane == 0) __hip_atomic_store(a.arrive + bi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call on this buffer
 }
 
-// ---------------------------------------------------------------------------------------------
-// TWO supports per wave (round 4).  Min-reprojection routes every pixel's gradient to ONE support (or to none), so a
-// wave that holds both supports of a pair evaluates the SSIM partials once per pixel — for the window sums of the support `sel` picked —
-// instead of once per support, reads the target side (target pixel, window terms, `sel`, depth) once instead of twice, and with n = 2 adds
-// the two shares of dL/d depth in registers (no LDS rows, no last-wave pass).  What it pays: the state of two supports (~165 VGPRs, three
-// waves per SIMD instead of four).  Same arithmetic, operand for operand, as k_recon_bwd<SSIM, 0, ...>: at n = 2 the gradients are bit-identical
-// (tests/test_gpu_parity.py), at n = 4 (two pair waves per strip, summed through the LDS rows) they differ in the order of one addition.
-// Plain row loop only (no liveness gating), min-reprojection only, n even.  SMD_BWD_PAIR=1 selects it.
-// ---------------------------------------------------------------------------------------------
-#ifndef SMD_PAIR_VFIRST
-#define SMD_PAIR_VFIRST 0    // 1: a centre row's h-summed coefficients are added straight into the (<= 3) gradient rows they feed, two of which are pending at any time
-#endif                       //    (18 registers per support instead of three stored coefficient rows = 27)
-constexpr int kPairHist = 2*3*6 + 3;   // LDS history per lane: [support][row slot][dx/dsx[3], dx/dsy[3]] + depth[row slot]
-
-template <bool SSIM, bool ACC>
-struct BwdPair {
-  const ReconBwdArgs& a;
-  int h, w, r0, r1;
-  bool add_gin;
-  unsigned w4, rowbytes, so_tex[2], so_y, so_ta, so_tb;
-  float xmax, ymax, wpf, g_ssim, g_l1;
-  Cam2 cm[2];
-  rsrc_t rs_pk, rs_depth, rs_sel, rs_gd, rs_gin;
-  unsigned lane4, lane1;
-  bool interior, col_ok;
-  float wla, wra, hx0[2], hy0[2], hz0[2];
-  unsigned key0;               // support index of slot 0 of this wave (slot 1: key0 + 1)
-  unsigned SELR[3];
-  float* hist;
-  float* gacc;
-  float X[2][3][3], Y[3][3], HC[2][3][3][3];
-  f3 t0[2], t1[2], t2[2], t3[2], py;
-  float pfx[2], pfy[2];
-  float Dn;
-  float ps[2][9];
-
-  // weights of coefficient rows r-1 / r+1 in the gradient of row r (reflect_weights_adj, on the scalar unit)
-  __device__ __forceinline__ float lo_w(int r) const { return (h == 2) ? usel(r == 1, 2.f, 0.f) : usel(r == 0, 0.f, usel(r == 1, 2.f, 1.f)); }
-  __device__ __forceinline__ float hi_w(int r) const { return (h == 2) ? usel(r == 0, 2.f, 0.f) : usel(r == h - 1, 0.f, usel(r == h - 2, 2.f, 1.f)); }
-  __device__ __forceinline__ float* hp(int k, int slot, int c) const { return hist + ((k*3 + slot)*6 + c)*64; }
-  __device__ __forceinline__ float* hd(int slot) const { return hist + (36 + slot)*64; }
-  // (branch-free on the scalar unit — s_abs / s_sub / s_max: written as nested conditionals the compiler emitted two scalar BRANCHES per call,
-  // four per row step, each one splitting the step's basic block)
-  __device__ __forceinline__ int reflect_row(int r) const { const int t = abs(r); return max((h - 1) - abs((h - 1) - t), 0); }
-
-  __device__ __forceinline__ void issue(int k, int jr, float D) {
-    const float vf = (float)jr;
-    const float hx = fmaf(cm[k].H1, vf, hx0[k]), hy = fmaf(cm[k].H4, vf, hy0[k]), hz = fmaf(cm[k].H7, vf, hz0[k]);
-    const float nx = fmaf(D, hx, cm[k].a0), ny = fmaf(D, hy, cm[k].a1), yz = fmaf(D, hz, cm[k].tz);
-    const float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
-    const float sx = fmaf(nx, rz, -0.5f), sy = fmaf(ny, rz, -0.5f);
-    const float cx = __builtin_amdgcn_fmed3f(sx, 0.f, xmax), cy = __builtin_amdgcn_fmed3f(sy, 0.f, ymax);
-    const float x0 = floorf(cx), y0 = floorf(cy);
-    pfx[k] = cx - x0; pfy[k] = cy - y0;
-    const unsigned o = __umul24((unsigned)fmaf(y0, wpf, x0), 12u);
-    t0[k] = bld3(rs_pk, o, so_tex[k]); t1[k] = bld3(rs_pk, o + 12u, so_tex[k]);
-    t2[k] = bld3(rs_pk, o, so_tex[k] + rowbytes); t3[k] = bld3(rs_pk, o + 12u, so_tex[k] + rowbytes);
-    if (k == 0) py = bld3(rs_pk, lane4*3u, so_y + (unsigned)jr*w4*3u);
-  }
-
-  __device__ __forceinline__ void begin(int jstart) {
-    const float Dfirst = bld(rs_depth, lane4, (unsigned)reflect_row(jstart)*w4);
-    Dn = bld(rs_depth, lane4, (unsigned)reflect_row(jstart + 1)*w4);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      SELR[r] = SMD_SEL_MASKED;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        Y[r][c] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { X[k][r][c] = 0.f; HC[k][r][c][0] = 0.f; HC[k][r][c][1] = 0.f; HC[k][r][c][2] = 0.f; }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int q = 0; q < 9; ++q) ps[k][q] = 0.f;
-    issue(0, reflect_row(jstart), Dfirst); issue(1, reflect_row(jstart), Dfirst);
-    *hd(0) = Dfirst;
-  }
-
-  template <int PH, bool DOB, bool DOC>
-  __device__ __forceinline__ void step(int j_) {
-    const int j = __builtin_amdgcn_readfirstlane(j_);
-    constexpr int SN = PH, SP = (PH + 2) % 3, SQ = (PH + 1) % 3;
-    constexpr float c1 = 81.f*kC1;
-    const int p = j - 1, q = j - 2;
-    f4 ta; f3 tb;
-    SELR[SP] = bld8(rs_sel, lane1, (unsigned)min(max(p, 0), h - 1)*(unsigned)w);
-    if (SSIM && DOB) {
-      const unsigned pc = (unsigned)min(max(p, 0), h - 1);
-      ta = bld4(rs_pk, lane4*4u, so_ta + pc*w4*4u);
-      const f2 tb2 = bld2(rs_pk, lane4*4u, so_tb + pc*w4*4u);
-      tb = f3{tb2.x, tb2.y, 0.f};
-    }
-    // ---- stage A: row j of both supports
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float dn = t1[k][c] - t0[k][c], ds = t3[k][c] - t2[k][c];
-        const float top = fmaf(pfx[k], dn, t0[k][c]), bot = fmaf(pfx[k], ds, t2[k][c]);
-        const float ddy = bot - top;
-        X[k][SN][c] = fmaf(pfy[k], ddy, top);
-        *hp(k, SN, c) = fmaf(pfy[k], ds - dn, dn);
-        *hp(k, SN, 3 + c) = ddy;
-      }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Y[SN][c] = py[c];
-    { const int jn = reflect_row(j + 1); issue(0, jn, Dn); issue(1, jn, Dn); }
-    const float Dkeep = Dn;
-    Dn = bld(rs_depth, lane4, (unsigned)reflect_row(j + 2)*w4);
-
-    // ---- stage B: centre row p — window sums of both supports, ONE evaluation of the SSIM partials for the support the pixel selected
-    if (SSIM && DOB) {
-      const bool is1 = SELR[SP] == key0 + 1u;
-      const bool any = col_ok && (is1 || SELR[SP] == key0);
-      const float g2 = any ? g_ssim : 0.f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float sxk[2], sxxk[2], sxyk[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const float xq = X[k][SQ][c], xp = X[k][SP][c], xn = X[k][SN][c];
-          const float Vx = (xq + xp) + xn, Vxx = fmaf(xn, xn, fmaf(xp, xp, xq*xq)), Vxy = fmaf(xn, Y[SN][c], fmaf(xp, Y[SP][c], xq*Y[SQ][c]));
-          hsum3(Vx, Vxx, Vxy, sxk[k], sxxk[k], sxyk[k]);
-        }
-        const float sx = is1 ? sxk[1] : sxk[0], sxx = is1 ? sxxk[1] : sxxk[0], sxy = is1 ? sxyk[1] : sxyk[0];
-        const float sy = ta[c], cy2 = (c == 0) ? ta.w : ((c == 1) ? tb.x : tb.y), cy1 = fmaf(sy, sy, c1);
-        const float t = sx*sy;
-        const float a1 = fmaf(2.f, t, c1), a2 = fmaf(18.f, sxy, fmaf(-2.f, t, 81.f*kC2));
-        const float sx2 = sx*sx;
-        const float b1 = sx2 + cy1, b2 = fmaf(9.f, sxx, cy2 - sx2);
-        const float rden = __builtin_amdgcn_rcpf(b1*b2);
-        const float val = a1*a2*rden;
-        const float prd = (fabsf(val) <= 1.f) ? -g2*rden : 0.f;
-        const float dSx = prd*fmaf(sy, a2 - a1, -sx*(val*(b2 - b1)));
-        const float p9 = 9.f*prd;
-        const float dSxx2 = -(p9*val)*b1;
-        const float dSxy = p9*a1;
-        // route the pixel's partials to the support it selected; the other support's coefficient map gets a zero there
-#if SMD_PAIR_VFIRST
-        // ... and add the h-summed row into the gradient rows it feeds: row p-1 (slot SQ) is complete after this, row p (SP) lacks row p+1's
-        // term, row p+1 (SN) starts here.  (HC[k][slot] holds the pending SUMS in this form; lo / hi are 0, 1 or 2: the products are exact,
-        // so the sums round like the fma chain of the three-row form.)
-        const float hi_m = hi_w(p - 1), lo_p = lo_w(p + 1);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const bool mine = (k == 1) ? is1 : !is1;
-          float hA, hB, hC;
-          hsum_w3(mine ? dSx : 0.f, mine ? dSxx2 : 0.f, mine ? dSxy : 0.f, wla, wra, hA, hB, hC);
-          HC[k][SQ][c][0] = fmaf(hi_m, hA, HC[k][SQ][c][0]); HC[k][SQ][c][1] = fmaf(hi_m, hB, HC[k][SQ][c][1]); HC[k][SQ][c][2] = fmaf(hi_m, hC, HC[k][SQ][c][2]);
-          HC[k][SP][c][0] += hA; HC[k][SP][c][1] += hB; HC[k][SP][c][2] += hC;
-          HC[k][SN][c][0] = lo_p*hA; HC[k][SN][c][1] = lo_p*hB; HC[k][SN][c][2] = lo_p*hC;
-        }
-#else
-        hsum_w3(is1 ? 0.f : dSx, is1 ? 0.f : dSxx2, is1 ? 0.f : dSxy, wla, wra, HC[0][SP][c][0], HC[0][SP][c][1], HC[0][SP][c][2]);
-        hsum_w3(is1 ? dSx : 0.f, is1 ? dSxx2 : 0.f, is1 ? dSxy : 0.f, wla, wra, HC[1][SP][c][0], HC[1][SP][c][1], HC[1][SP][c][2]);
+#ifdef SMD_EXPERIMENTS
+#include "experiments/smd_recon_bwd_pair.inc"   // k_recon_bwd_pair (dropped in round 4; knob bwd_pair)
 #endif
-#ifdef SMD_PAIR_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);      // one channel at a time: the scheduler otherwise interleaves the three and keeps all their temporaries live
-#endif
-      }
-    }
-
-    // ---- stage C: row q of both supports; their shares of dL/d depth are added in registers
-    if (DOC) {
-      const unsigned qro = (unsigned)q*w4;
-      const float lo_q = lo_w(q), hi_q = hi_w(q); (void)lo_q; (void)hi_q;
-      const float D2 = *hd(SQ);
-      const float k0f = (a.k0_scale != 0.f) ? ((D2 < 1.f/kEps32) ? -D2*D2*a.k0_scale : 0.f) : 1.f;
-      const float vf = (float)q;
-      float gsum = 0.f;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float gl = (col_ok && SELR[SQ] == key0 + (unsigned)k) ? g_l1 : 0.f;
-        float gpx = 0.f, gpy = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float gxq = *hp(k, SQ, c), gyq = *hp(k, SQ, 3 + c);
-          const float xq = X[k][SQ][c], yq = Y[SQ][c];
-          const float d = xq - yq;
-          float gxc = (d != 0.f) ? __builtin_copysignf(gl, d) : 0.f;
-          if (SSIM) {
-#if SMD_PAIR_VFIRST
-            const float SA = HC[k][SQ][c][0], SB = HC[k][SQ][c][1], SC = HC[k][SQ][c][2];
-#else
-            const float SA = fmaf(hi_q, HC[k][SP][c][0], fmaf(lo_q, HC[k][SN][c][0], HC[k][SQ][c][0]));
-            const float SB = fmaf(hi_q, HC[k][SP][c][1], fmaf(lo_q, HC[k][SN][c][1], HC[k][SQ][c][1]));
-            const float SC = fmaf(hi_q, HC[k][SP][c][2], fmaf(lo_q, HC[k][SN][c][2], HC[k][SQ][c][2]));
-#endif
-            gxc += fmaf(xq, SB, fmaf(yq, SC, SA));
-          }
-          gpx = fmaf(gxc, gxq, gpx);
-          gpy = fmaf(gxc, gyq, gpy);
-        }
-        const float hx = fmaf(cm[k].H1, vf, hx0[k]), hy = fmaf(cm[k].H4, vf, hy0[k]), hz = fmaf(cm[k].H7, vf, hz0[k]);
-        const float nx = fmaf(D2, hx, cm[k].a0), ny = fmaf(D2, hy, cm[k].a1), yz = fmaf(D2, hz, cm[k].tz);
-        const float rz = __builtin_amdgcn_rcpf(fmaxf(yz, kZMin));
-        const float sx = fmaf(nx, rz, -0.5f), sy = fmaf(ny, rz, -0.5f);
-        const float gnx = (interior && sx > 0.f && sx < xmax) ? gpx*rz : 0.f;
-        const float gny = (interior && sy > 0.f && sy < ymax) ? gpy*rz : 0.f;
-        const float gz = (yz >= kZMin) ? -fmaf(gnx, nx, gny*ny)*rz : 0.f;
-        float gD = fmaf(gnx, hx, fmaf(gny, hy, gz*hz));
-        const float dnx = gnx*D2, dny = gny*D2, dz = gz*D2;
-        ps[k][0] += dnx; ps[k][1] = fmaf(dnx, vf, ps[k][1]); ps[k][2] += dny; ps[k][3] = fmaf(dny, vf, ps[k][3]); ps[k][4] += dz; ps[k][5] = fmaf(dz, vf, ps[k][5]);
-        ps[k][6] += gnx; ps[k][7] += gny; ps[k][8] += gz;
-        if (k == 0 && add_gin) gD += bld(rs_gin, lane4, qro);
-        if (a.k0_scale != 0.f) gD *= k0f;                 // per support, like the one-support-per-wave kernel (same rounding)
-        gsum = (k == 0) ? gD : gsum + gD;
-      }
-      if (ACC) gacc[(q - r0)*64] = gsum;                  // two pair waves per strip (n = 4): summed by the strip's last wave
-      else if (interior) bst(rs_gd, lane4, qro, gsum);
-    }
-    *hd(SQ) = Dkeep;
-  }
-
-  __device__ __forceinline__ void run(int jstart) {
-    begin(jstart);
-    const int jend = r1 + 1;
-    int j = jstart;
-    step<0, false, false>(j); ++j;
-    step<1, false, false>(j); ++j;
-    step<2, true, false>(j); ++j;
-    step<0, true, false>(j); ++j;
-    for (;;) {
-      step<1, true, true>(j); if (++j > jend) break;
-      step<2, true, true>(j); if (++j > jend) break;
-      step<0, true, true>(j); if (++j > jend) break;
-    }
-  }
-};
-
-constexpr int kPairWaves = kWavesPerBlock/2;   // waves per block: the strips of a block are those of the one-support-per-wave kernel (same pose partials)
-
-// NP = pair waves per strip (n = 2: one, its shares of dL/d depth added in registers; n = 4: two, added through the LDS rows).
-#ifndef SMD_PAIR_WAVES
-#define SMD_PAIR_WAVES 3     // waves per SIMD the register allocator is held to: 3 = 168 VGPRs, 2 = 256
-#endif
-template <bool SSIM, int NP>
-__global__ __launch_bounds__(64*kPairWaves, SMD_PAIR_WAVES) void k_recon_bwd_pair(const ReconBwdArgs a) {
-  constexpr bool ACC = NP > 1;
-  constexpr int SPB = kPairWaves/NP;           // strips per block (n = 2: 2, n = 4: 1 — as k_recon_bwd<.., NS = n, ..>)
-  constexpr int kWaveFloats = ((kPairHist + (ACC ? kAccRows : 0))*64 >= 2*kFinScratchDoubles) ? (kPairHist + (ACC ? kAccRows : 0))*64 : 2*kFinScratchDoubles;
-  constexpr int kPoseArea = SMD_MAX_SUPPORTS*kPoseSums;
-  constexpr int kLdsFloats = kPairWaves*(kWaveFloats + kPoseArea) + 8;
-  __shared__ __attribute__((aligned(16))) float hist_lds[kLdsFloats];
-  float* const pose_lds = hist_lds + kPairWaves*kWaveFloats;
-  unsigned* const cnt = reinterpret_cast<unsigned*>(pose_lds + kPairWaves*kPoseArea);
-  for (int e = threadIdx.x; e < kPairWaves*kPoseArea; e += 64*kPairWaves) pose_lds[e] = 0.f;
-  if (threadIdx.x < 8) cnt[threadIdx.x] = 0u;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int sib = wid/NP, kw = wid - sib*NP;
-  const unsigned nblk1 = recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S, SPB);
-  const bool tail = blockIdx.x >= nblk1;
-  const int nstrips = a.nsx*(tail ? a.nsy2 : a.nsy), seg_rh = tail ? a.rh2 : a.rh;
-  const int nbx = ceil_div(nstrips, SPB);
-  int xb, bi, s;
-  decode_tile(tail ? blockIdx.x - nblk1 : blockIdx.x, nbx, tail ? a.b - a.b1 : a.b1, a.S, xb, bi, s);
-  const int strip = xb*SPB + sib;
-  if (tail) bi += a.b1;
-  if (strip >= nstrips) return;
-  const int live_waves = min(SPB, nstrips - xb*SPB)*NP;
-  const int sxi = strip % a.nsx, syi = strip/a.nsx;
-  const int h = a.h, w = a.w;
-  const int r0 = syi*seg_rh, r1 = min(r0 + seg_rh, h);
-  const int u = sxi*kBwdCols - 2 + lane;
-  const int uc = (u < 0) ? min(-u, w - 1) : ((u >= w) ? max(2*(w - 1) - u, 0) : u);
-  const bool interior = (lane >= 2) && (lane < 2 + kBwdCols) && (u < w);
-  const size_t hw = (size_t)h*w;
-  const size_t sb = ((size_t)s*a.b + bi)*hw;
-  float* const wave_lds = hist_lds + wid*kWaveFloats;
-  {
-    BwdPair<SSIM, ACC> cx{a};
-    cx.hist = wave_lds + lane;
-    cx.gacc = cx.hist + kPairHist*64;
-    cx.h = h; cx.w = w; cx.r0 = r0; cx.r1 = r1;
-    const bool col_ok = (u >= 0) && (u < w);
-    cx.interior = interior; cx.col_ok = col_ok;
-    cx.lane4 = (unsigned)uc*4u; cx.lane1 = (unsigned)uc;
-    reflect_weights_adj(min(max(u, 0), w - 1), w, cx.wla, cx.wra);
-    if (!col_ok) { cx.wla = 0.f; cx.wra = 0.f; }
-    const float uf = (float)uc;
-    const unsigned hw4 = (unsigned)hw*4u;
-    cx.w4 = (unsigned)w*4u;
-    const float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
-    cx.g_ssim = uniform(gscale*(SSIM ? kWSsim/3.f : 0.f));
-    cx.g_l1 = uniform(gscale*(SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f));
-    cx.xmax = (float)(w - 1); cx.ymax = (float)(h - 1); cx.wpf = (float)(w + 1);
-    cx.rs_pk = make_rsrc(a.packed, packed_image_floats(a.b, a.n, h, w)*4);
-    cx.rs_depth = make_rsrc(a.depth + sb, hw*4);
-    cx.rs_sel = make_rsrc(a.sel + sb, hw);
-    cx.rs_gd = make_rsrc(s == a.direct_scale ? a.g_direct + (size_t)bi*hw : a.g_depth + sb, hw*4);
-    const bool has_gin = a.g_in != nullptr;
-    cx.rs_gin = make_rsrc(has_gin ? a.g_in + sb : nullptr, has_gin ? hw*4 : 0);
-    const unsigned texel_bytes = (unsigned)(h + 1)*(unsigned)(w + 1)*12u;
-    cx.rowbytes = ((unsigned)w + 1u)*12u;
-    cx.so_y = (unsigned)(packed_texel_floats(a.b, a.n, h, w)*4) + (unsigned)bi*hw4*3u;
-    cx.so_ta = (unsigned)((packed_texel_floats(a.b, a.n, h, w) + packed_ypix_floats(a.b, h, w))*4) + (unsigned)bi*hw4*4u;
-    cx.so_tb = cx.so_ta + (unsigned)(packed_tpix_floats(a.b, h, w)*4);
-    const int i0 = 2*kw;                          // this wave's supports: i0, i0 + 1
-    cx.key0 = (unsigned)i0;
-    cx.add_gin = has_gin && i0 == 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      make_cam2(cx.cm[k], cx.hx0[k], cx.hy0[k], cx.hz0[k], a.T + ((size_t)(i0 + k)*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16,
-                a.wscale, a.hscale, uf);
-      cx.so_tex[k] = (unsigned)((i0 + k)*a.b + bi)*texel_bytes;
-    }
-    cx.run(r0 - 2);
-    const float ws = a.wscale, hs = a.hscale;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float* ps = cx.ps[k];
-      const float psum[kPoseSums] = {ps[0]*uf*ws, ps[1]*ws, ps[0]*ws, ps[2]*uf*hs, ps[3]*hs, ps[2]*hs, ps[4]*uf, ps[5], ps[4], ps[6]*ws, ps[7]*hs, ps[8]};
-      float mine = 0.f;
-#pragma unroll
-      for (int q = 0; q < kPoseSums; ++q) {
-        const float tot = wave_sum(psum[q]);
-        if (lane == q) mine = tot;
-      }
-      if (lane < kPoseSums) pose_lds[wid*kPoseArea + (i0 + k)*kPoseSums + lane] = mine;
-    }
-  }
-  // ---- epilogue chain (as k_recon_bwd)
-  unsigned o_strip = 0, o_block = 0;
-  if (lane == 0) {
-    if (ACC) o_strip = __hip_atomic_fetch_add(cnt + sib, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-    o_block = __hip_atomic_fetch_add(cnt + 4, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  o_strip = (unsigned)__builtin_amdgcn_readfirstlane((int)o_strip); o_block = (unsigned)__builtin_amdgcn_readfirstlane((int)o_block);
-  if (ACC && o_strip == (unsigned)NP - 1u) {
-    const float* base = hist_lds + (sib*NP)*kWaveFloats + kPairHist*64 + lane;
-    const rsrc_t rs_gd = make_rsrc(s == a.direct_scale ? a.g_direct + (size_t)bi*hw : a.g_depth + sb, hw*4);
-#pragma unroll 4
-    for (int r = 0; r < r1 - r0; ++r) {
-      float g = base[r*64];
-#pragma unroll
-      for (int k = 1; k < NP; ++k) g += base[k*kWaveFloats + r*64];
-      if (interior) bst(rs_gd, (unsigned)uc*4u, (unsigned)(r0 + r)*(unsigned)w*4u, g);
-    }
-  }
-  if (o_block != (unsigned)live_waves - 1u) return;
-  for (int e = lane; e < a.n*kPoseSums; e += 64) {
-    const int i = e/kPoseSums, k = e - i*kPoseSums;
-    float v = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < kPairWaves; ++wv) v += pose_lds[wv*kPoseArea + e];
-    float* pp = a.pose_partial + (((size_t)i*a.b + bi)*(size_t)a.pose_stride + (size_t)s*nbx + xb)*kPoseSums;
-    __hip_atomic_store((unsigned*)(pp + k), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (a.arrive == nullptr) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  unsigned last = 0;
-  if (lane == 0) {
-    const unsigned expected = (unsigned)nbx*(unsigned)a.S;
-    last = (__hip_atomic_fetch_add(a.arrive + bi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u) ? 1u : 0u;
-  }
-  if (!__builtin_amdgcn_readfirstlane((int)last)) return;
-  SMD_TAIL_ACQUIRE();
-  pose_finalize_wave(a, bi, a.S*nbx, reinterpret_cast<double*>(wave_lds));
-  if (lane == 0) __hip_atomic_store(a.arrive + bi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // The same epilogue as a launch of its own, for the un-fused ViewSynth backward (smd_unfused.hip), whose partials come from a
 // one-thread-per-pixel kernel: one block of four waves per sample.
@@ -1018,13 +656,18 @@ static void launch_bwd_t(dim3 grid, dim3 block, hipStream_t st, const ReconBwdAr
   else hipLaunchKernelGGL((k_recon_bwd<SSIM, SKIP, NS, ACC, false>), grid, block, 0, st, a);
 }
 
+#ifdef SMD_EXPERIMENTS
 template <bool SSIM, int NP>
 static void launch_bwd_pair_t(dim3 grid, hipStream_t st, const ReconBwdArgs& a) {
   note_variant(1, "smd::k_recon_bwd_pair<%s, %d>", SSIM ? "true" : "false", NP);
   hipLaunchKernelGGL((k_recon_bwd_pair<SSIM, NP>), grid, dim3(64*kPairWaves), 0, st, a);
 }
+#endif
 
 hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
+#ifndef SMD_EXPERIMENTS
+  if (a.pair) return hipErrorInvalidValue;
+#else
   if (a.pair) {   // two supports per wave: n = 2 or 4, min-reprojection, plain row loop (smd_api.hip decides)
     if (!(a.n == 2 || a.n == 4) || !(a.flags & SMD_USE_MIN) || a.rh > kAccRows || a.rh2 > kAccRows) return hipErrorInvalidValue;
     const int np = a.n/2, spbp = kPairWaves/np;
@@ -1034,6 +677,7 @@ hipError_t launch_recon_bwd(const ReconBwdArgs& a, hipStream_t st) {
     else { if (np == 1) launch_bwd_pair_t<false, 1>(gridp, st, a); else launch_bwd_pair_t<false, 2>(gridp, st, a); }
     return hipGetLastError();
   }
+#endif
   const int ns = a.wps, spb = kWavesPerBlock/ns;
   if (ns < 1 || ns > 4 || ns > a.n) return hipErrorInvalidValue;
   dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S, spb) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S, spb) : 0u)), block(64*ns*spb);

@@ -501,11 +501,13 @@ hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h,
   // carries the arrival counters of the in-launch second stage; without edge weighting: the two-launch form.
   const bool edges = (flags & SMD_USE_EDGES) && edge_w;
   unsigned* arrive = edges ? (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)) : nullptr;
-  // SMD_SMOOTH_CHAIN=0: the second stage as a launch of its own (k_smooth_finalize).  Measured at cfg 2 (rocprofv3, profiles/r04_smooth_ab.txt):
+  // SMD_SMOOTH_CHAIN=0 (experiments builds): the second stage as a launch of its own (k_smooth_finalize).  Measured at cfg 2 (rocprofv3, profiles/r04_smooth_ab.txt):
   // round 3's sweep (8-row units) 18.0 us with the in-launch chain against 7.1 + 6.7 us in two launches — the chain's five dependent round
   // trips at the end of a launch that is itself one generation of tiny waves cost 11 us; with 16-row units (half the blocks and partials)
   // 13.2 us with the chain against 7.4 + 7.4: the chain stays, now a launch cheaper AND faster.
-  if (getenv("SMD_SMOOTH_CHAIN") && atoi(getenv("SMD_SMOOTH_CHAIN")) == 0) arrive = nullptr;
+#ifdef SMD_EXPERIMENTS
+  { static const char* chain = getenv("SMD_SMOOTH_CHAIN"); if (chain && atoi(chain) == 0) arrive = nullptr; }
+#endif
   if (edges && !edges_ready) hipLaunchKernelGGL(k_smooth_edges, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, edge_w, (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)));
   double* contrib = (double*)(ws_sums + (size_t)sc.S*b*max_chunks*2);
   int main_blocks = 0;

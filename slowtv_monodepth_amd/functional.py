@@ -233,7 +233,7 @@ class _RowSkipTuner:
 
     def begin(self, dev):
         """-> (flag bits for this backward call, token for `end`)."""
-        if 'SMD_BWD_SKIP' in os.environ: return 0, None
+        if 'SMD_BWD_SKIP' in os.environ: return self._flag(os.environ['SMD_BWD_SKIP'] not in ('', '0')), None   # pinned: no timing (read here, per call; the library itself never reads the environment)
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing(): return self._flag(self.skip), None   # no timing events inside a HIP-graph capture: the choice made so far is what gets captured
         if self.pending: self._harvest()
         phase = self.calls % self.period - self.settle     # (the first calls of a process carry one-off costs)

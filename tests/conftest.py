@@ -91,6 +91,15 @@ def case_inputs(g: dict, device='cpu', dtype=torch.float32, requires_grad=True):
     return leaves, static
 
 
+@pytest.fixture
+def knobs():
+    """Pin launch-shape knobs of the library for one test (`smd_set_knob`), restored afterwards.  `knobs(name, value)` -> False if this
+    build lacks the knob (experiments-only)."""
+    from slowtv_monodepth_amd import _lib
+    yield _lib.set_knob
+    _lib.reset_knobs()
+
+
 @pytest.fixture(scope='session')
 def golden():
     cache = {}

@@ -1201,7 +1201,7 @@ def test_strip_boundary_shapes_match_oracle(F, b, h, w, n, S, mode):
 
 
 @pytest.mark.parametrize('b,h,w,n,S,b2,rh,rh2', [(3, 37, 70, 2, 2, 1, 12, 5), (5, 50, 130, 3, 1, 2, 16, 4), (4, 24, 61, 1, 3, 3, 8, 6)])
-def test_tapered_partition_gives_the_same_result(F, monkeypatch, b, h, w, n, S, b2, rh, rh2):
+def test_tapered_partition_gives_the_same_result(F, knobs, b, h, w, n, S, b2, rh, rh2):
     """The fused kernels cut the last samples of the dispatch order into shorter strips (load balance at the end of a launch).
     The partition must not change anything: same error map and selection bit for bit, same gradients up to the order of the
     per-strip partial sums."""
@@ -1213,9 +1213,9 @@ def test_tapered_partition_gives_the_same_result(F, monkeypatch, b, h, w, n, S, 
     noise = torch.randn(S*b, 1, h, w, generator=gen).cuda()
 
     def run(taper):
-        for k in ('SMD_FWD_RH', 'SMD_BWD_RH'): monkeypatch.setenv(k, str(rh))
-        for k in ('SMD_FWD_TAPER_B', 'SMD_BWD_TAPER_B'): monkeypatch.setenv(k, str(b2 if taper else 0))
-        for k in ('SMD_FWD_TAPER_RH', 'SMD_BWD_TAPER_RH'): monkeypatch.setenv(k, str(rh2))
+        for k in ('fwd_rh', 'bwd_rh'): knobs(k, rh)
+        for k in ('fwd_taper_b', 'bwd_taper_b'): knobs(k, b2 if taper else 0)
+        for k in ('fwd_taper_rh', 'bwd_taper_rh'): knobs(k, rh2)
         d = depth.clone().requires_grad_(True)
         T = F.pose_matrices(aa, t).unflatten(0, (n, b)).detach().requires_grad_(True)
         loss, err, sel, _ = F.image_recon_fused(d, imgs, supp, T, K, flags=F.recon_flags('ssim', True, True), noise=noise)
@@ -1329,10 +1329,10 @@ def test_k0_fused_path_at_non_integer_ratios_and_with_a_second_consumer_of_depth
 @pytest.mark.parametrize('b,h,w,n,lows,rh,b2', [(2, 33, 47, 2, [(33, 47), (16, 23), (8, 11), (4, 5)], 8, 0), (3, 50, 130, 1, [(50, 130), (25, 65), (12, 32), (6, 16)], 16, 1),
                                                  (5, 96, 200, 4, [(96, 200), (48, 100), (24, 50), (12, 25)], 16, 2), (2, 7, 66, 3, [(7, 66), (3, 33), (2, 16), (1, 8)], 4, 0),
                                                  (12, 192, 640, 2, [(192, 640), (96, 320), (48, 160), (24, 80)], 0, -1)])
-def test_shared_target_ring_equals_per_wave_loads(F, monkeypatch, b, h, w, n, lows, rh, b2):
+def test_shared_target_ring_equals_per_wave_loads(F, knobs, b, h, w, n, lows, rh, b2):
     """Round 3: with four scales the hot forward instantiation runs the four scales of a strip in one block and brings the target-side
     rows in once per block through an LDS ring (LDS-DMA + one barrier per four rows).  Only the way those rows reach the wave
-    changes: error map, selection and adopted depth must be bit-identical to the per-wave loads (`SMD_FWD_SHARE=0`), at image
+    changes: error map, selection and adopted depth must be bit-identical to the per-wave loads (knob `fwd_share` = 0), at image
     heights that are not multiples of four, strips shorter than an epoch, a tapered partition and the BASELINE size; the loss up to
     the order of the block partials."""
     gen = torch.Generator(device='cuda').manual_seed(h*w + n)
@@ -1342,10 +1342,10 @@ def test_shared_target_ring_equals_per_wave_loads(F, monkeypatch, b, h, w, n, lo
     d = [0.05 + 0.9*torch.rand(b, 1, hs, ws, device='cuda', generator=gen) for hs, ws in lows]
     flags = F.recon_flags('ssim', True, True)
     if rh:
-        monkeypatch.setenv('SMD_FWD_RH', str(rh)); monkeypatch.setenv('SMD_FWD_TAPER_B', str(b2)); monkeypatch.setenv('SMD_FWD_TAPER_RH', str(max(rh//2, 4)))
+        knobs('fwd_rh', rh); knobs('fwd_taper_b', b2); knobs('fwd_taper_rh', max(rh//2, 4))
 
     def run(share):
-        monkeypatch.setenv('SMD_FWD_SHARE', str(share))
+        knobs('fwd_share', share)
         loss, err, sel, _, dep = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=flags, min_depth=0.1, max_depth=100, seed=7, want_err=True)
         return loss, err, sel, dep
     l1, e1, s1, d1 = run(1)
@@ -1394,11 +1394,13 @@ def test_row_skip_tuner_times_both_row_loops_and_gradients_do_not_depend_on_the_
 
 
 @pytest.mark.parametrize('b,h,w,n', [(4, 96, 320, 2), (2, 50, 130, 2), (3, 96, 200, 4), (1, 7, 66, 2)])
-def test_two_supports_per_wave_backward_equals_one_support_per_wave(F, monkeypatch, b, h, w, n):
+def test_two_supports_per_wave_backward_equals_one_support_per_wave(F, monkeypatch, knobs, b, h, w, n):
     """Round 4 built the variant VERDICT r3 item 1b asked for — both supports of a strip in ONE backward wave, the SSIM partials evaluated once per
-    pixel for the support `sel` picked (`k_recon_bwd_pair`, `SMD_BWD_PAIR=1`).  It performs the same operations on the same operands as the
-    one-support-per-wave kernel, so at n = 2 every gradient must be BIT-equal (it is slower — `profiles/r04_pair_backward.txt` — and stays an experiment switch)."""
+    pixel for the support `sel` picked (`k_recon_bwd_pair`, knob `bwd_pair`).  It performs the same operations on the same operands as the
+    one-support-per-wave kernel, so at n = 2 every gradient must be BIT-equal.  It is slower (`profiles/r04_pair_backward.txt`) and since round 5
+    lives in `csrc/experiments/`: the product library does not contain it, so this test only runs against a `make EXPERIMENTS=1` build."""
     from slowtv_monodepth_amd import _lib
+    if not knobs('bwd_pair', 0): pytest.skip('k_recon_bwd_pair is not part of the product library (make EXPERIMENTS=1 builds it)')
     gen = torch.Generator(device='cuda').manual_seed(3)
     imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
     K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
@@ -1409,7 +1411,7 @@ def test_two_supports_per_wave_backward_equals_one_support_per_wave(F, monkeypat
     monkeypatch.setenv('SMD_BWD_SKIP', '0')
 
     def step(pair):
-        monkeypatch.setenv('SMD_BWD_PAIR', pair)
+        knobs('bwd_pair', int(pair))
         d = [v.clone().requires_grad_(True) for v in d0]; T = T0.clone().requires_grad_(True)
         loss, _, sel, _, _ = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=F.recon_flags('ssim', True, True), min_depth=0.1, max_depth=100, seed=2, want_err=False)
         loss.backward(); torch.cuda.synchronize()

@@ -384,5 +384,7 @@ def test_row_skip_tuner_schedule(monkeypatch):
     assert seen[:5] == [False, True, False, True, False] and all(seen[5:10]) and t.last is not None
     assert seen[10:15] == [True, True, False, True, False] and not any(seen[15:20])
     assert t.last == {'skipping_ms': 0.13, 'plain_ms': 0.12}
-    monkeypatch.setenv('SMD_BWD_SKIP', '2')
+    monkeypatch.setenv('SMD_BWD_SKIP', '2')      # pinned from the environment: no timing, the gated loop's flag on every call
+    assert t.begin('cuda:0') == (FLAGS['bwd_skip_rows'], None)
+    monkeypatch.setenv('SMD_BWD_SKIP', '0')
     assert t.begin('cuda:0') == (0, None)
