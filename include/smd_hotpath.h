@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 5
+#define SMD_ABI_VERSION 6
 
 #define SMD_OK 0
 #define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
@@ -150,6 +150,36 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
                              float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
                              const float* g_loss, const float* g_depth_up_in, float* const* g_disp, float* g_T, float* g_K, float* g_Kinv,
                              void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream);
+
+/* The whole `forward_loss` of the kbr configuration as ONE operator (round 5): `handlers.image_recon` on the K0-fused path +
+ * `handlers.disp_smooth` with `SmoothReg(use_edges=True)` + the weighted sum `sum_k w_k l_k` (src/core/trainer.py:383-392, 436-437,
+ * 462-464) — and, in the backward, the chain rule through `T_from_AAt` (+ `T.inverse()`) and `build_K` / `resize_K` down to the pose
+ * network's outputs (src/core/trainer.py:250-262).  Five launches for forward + backward where the separate operators need eleven:
+ *   forward:  the K0-fused reconstruction launch, with the smoothness sweep as guest blocks behind its own and the weighted sum formed
+ *             in-launch by whichever of the two final reducers arrives second -> loss3 = {total, l_recon, l_smooth};
+ *   backward: the fused reconstruction backward; the K0 adjoint's first launch, carrying as guests the pose epilogue — continued in the
+ *             same wave to g_aa, g_t (and g_fs, g_cs) — and the smoothness adjoint, which WRITES its share into g_disp[s] (adds, for a
+ *             level of the image's own size that the reconstruction backward already wrote); the K0 adjoint's second launch ADDS.
+ * flags: SMD_USE_MIN | SMD_USE_AUTOMASK | SMD_USE_EDGES (required) | SMD_PACKED_READY | SMD_EDGES_READY | SMD_NEED_K_GRAD |
+ *        SMD_BWD_SKIP_DEAD_ROWS.  In-kernel tie-break noise (`seed`), no error map, no warped images: the trainer's hot call.
+ * Returns SMD_E_UNSUPPORTED (nothing launched) for what it does not serve — loss_name 'l1', more than four supports, a smoothness term
+ * other than first-order edge-aware, fewer than two pyramid levels, a level taller than the image: the caller then uses the operators above.
+ *   scale_keys[s]: the `s` of `loss_s / 2**s` (src/core/handlers.py:279);  stats (S,b,2): per-image (mean, E) kept for the backward;
+ *   edge_weights: smd_disp_smooth_edge_weight_bytes() (filled here unless SMD_EDGES_READY);  w_recon / w_smooth: the frozen loss weights;
+ *   g_loss: device scalar dL/d total.  aa, t, invert (n*b rows, as given to smd_pose_fwd) with g_aa, g_t, and fs, cs with g_fs, g_cs
+ *   (needs SMD_NEED_K_GRAD), are optional (all NULL: stop at g_T / g_K / g_Kinv, which are always written).
+ * Same values as the separate operators: l_recon, l_smooth, sel, depth_up and every gradient bit for bit (tests/test_gpu_parity.py). */
+size_t smd_loss_path_workspace_bytes(const int* hs, const int* ws, int S, int b, int n, int h, int w);
+int smd_loss_path_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, float min_depth, float max_depth,
+                      const float* tgt, const float* supp, const float* T, const float* K, const float* K_inv, uint64_t seed,
+                      float* supp_packed, float* edge_weights, float* depth_up, uint8_t* sel, float* loss3, float* stats,
+                      void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, float w_recon, float w_smooth, void* stream);
+int smd_loss_path_bwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, float min_depth, float max_depth,
+                      const float* depth_up, float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
+                      const float* stats, const float* edge_weights, const float* g_loss, float w_recon, float w_smooth,
+                      const float* aa, const float* t, const uint8_t* invert, const float* fs, const float* cs,
+                      float* const* g_disp, float* g_T, float* g_K, float* g_Kinv, float* g_aa, float* g_t, float* g_fs, float* g_cs,
+                      void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Edge-aware disparity smoothness over all scales.  Replaces `handlers.disp_smooth(crit, disps, imgs)`

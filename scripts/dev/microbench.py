@@ -28,16 +28,26 @@ want_err = os.environ.get("MB_ERR", "0") == "1"   # 1: also write the per-pixel 
 fused_k0 = os.environ.get('MB_DISP', '1') == '1'   # 1: K0 fused into the reconstruction kernel (the product path); 0: separate K0 launch
 prep_mode = os.environ.get('MB_PREP', 'inline')   # inline | ahead (prepared frames, consumed right away) | cold (prepared, then 1 GiB of unrelated traffic before the forward)
 flush_src = torch.empty(1 << 28, device=dev) if prep_mode == 'cold' else None
+one_node = os.environ.get('MB_PATH', 'handlers') == 'node'   # node: the single-node loss path (functional.loss_path_fused) with the pose leaves; handlers: the separate operators
+for kv in filter(None, os.environ.get('MB_KNOBS', '').split(',')):   # e.g. MB_KNOBS=loss_path_guests=0,fwd_rh=12 (smd_set_knob)
+    k_, v_ = kv.split('='); assert _lib.set_knob(k_, int(v_)), f'knob {k_} is not in this build'
+aa = (0.01*torch.randn(n*b, 3, device=dev, generator=g)).requires_grad_(True); tt = (0.05*torch.randn(n*b, 3, device=dev, generator=g)).requires_grad_(True)
 def step():
     prepared = None
     if prep_mode != 'inline':
-        prepared = F.image_recon_prep(y['imgs'], y['supp_imgs'], flags=flags, pyramid=[d.shape[-2:] for d in disps] if fused_k0 else None)
+        prepared = F.image_recon_prep(y['imgs'], y['supp_imgs'], flags=flags, pyramid=[d.shape[-2:] for d in disps] if fused_k0 else None, smooth_edges=fused_k0)
         if flush_src is not None: flush_src.add_(1.0)     # reads + writes 1 GiB: evicts L2 and the 256 MB Infinity Cache
+    if one_node:
+        Ts = F.pose_matrices(aa, tt).unflatten(0, (n, b))
+        loss, *_ = F.loss_path_fused({s: d for s, d in enumerate(disps)}, y['imgs'], y['supp_imgs'], Ts, y['K'], pose=(aa, tt, None), flags=flags, min_depth=0.1, max_depth=100,
+                                     seed=1, prepared=prepared)
+        loss.backward()
+        return loss
     if fused_k0: loss, err, sel, _, _ = F.image_recon_fused_disp(disps, y['imgs'], y['supp_imgs'], T, y['K'], flags=flags, min_depth=0.1, max_depth=100, seed=1, want_err=want_err, prepared=prepared)
     else:
         depth_up, _ = F.disp_to_depth(disps, (h, w), 0.1, 100)
         loss, err, sel, _ = F.image_recon_fused(depth_up, y["imgs"], y["supp_imgs"], T, y["K"], flags=flags, seed=1, want_err=want_err)
-    lsm, _, _ = F.disp_smooth_fused({s: d for s, d in enumerate(disps)}, y['imgs'], use_edges=True, want_aux=False)
+    lsm, _, _ = F.disp_smooth_fused({s: d for s, d in enumerate(disps)}, y['imgs'], use_edges=True, want_aux=False, prepared=prepared)
     (loss + 0.001*lsm).backward()
     return loss
 for _ in range(3): step()

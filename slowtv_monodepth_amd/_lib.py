@@ -12,7 +12,7 @@ from pathlib import Path
 
 import torch  # noqa: F401  MUST precede the CDLL below: the library binds to the HIP runtime torch has already loaded
 
-__all__ = ['lib', 'call', 'set_knob', 'reset_knobs', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError']
+__all__ = ['lib', 'call', 'set_knob', 'reset_knobs', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError', 'Unsupported']
 
 _HERE = Path(__file__).resolve().parent
 lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
@@ -45,6 +45,9 @@ PROTOTYPES = {
     'smd_image_recon_disp_workspace_bytes': (_sz, [_vp, _vp, _i, _i, _i, _i, _i]),
     'smd_image_recon_disp_fwd': (_i, [_vp, _vp, _vp, _i, _f, _f] + [_vp]*6 + [_u64] + [_vp]*7 + [_sz] + [_i]*5 + [_vp]),
     'smd_image_recon_disp_bwd': (_i, [_vp, _vp, _i, _f, _f] + [_vp]*13 + [_sz] + [_i]*5 + [_vp]),
+    'smd_loss_path_workspace_bytes': (_sz, [_vp, _vp, _i, _i, _i, _i, _i]),
+    'smd_loss_path_fwd': (_i, [_vp]*4 + [_i, _f, _f] + [_vp]*5 + [_u64] + [_vp]*7 + [_sz] + [_i]*5 + [_f, _f, _vp]),
+    'smd_loss_path_bwd': (_i, [_vp]*4 + [_i, _f, _f] + [_vp]*9 + [_f, _f] + [_vp]*13 + [_sz] + [_i]*5 + [_vp]),
     'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_disp_smooth_edge_weight_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_gaussian_blur3x3': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -95,6 +98,10 @@ class HotpathError(RuntimeError):
     """A call into libsmd_hotpath.so returned a negative status."""
 
 
+class Unsupported(HotpathError):
+    """SMD_E_UNSUPPORTED: the entry point does not serve these arguments in this build (nothing was launched); the caller takes the general operators."""
+
+
 def _load() -> C.CDLL:
     if not lib_path.is_file():
         raise ImportError(
@@ -104,7 +111,7 @@ def _load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if handle.smd_abi_version() != 5: raise ImportError(f'ABI version mismatch in {lib_path}')
+    if handle.smd_abi_version() != 6: raise ImportError(f'ABI version mismatch in {lib_path}')
     return handle
 
 
@@ -118,6 +125,7 @@ def call(name: str, *args):
     if rc != 0:
         msg = lib.smd_last_error().decode()
         if rc == -1: raise ValueError(f'{name}: {msg}')
+        if rc == -4: raise Unsupported(f'{name}: {msg}')
         raise HotpathError(f'{name} failed ({rc}): {msg}')
 
 

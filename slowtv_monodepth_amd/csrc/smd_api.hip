@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "smd_kernels.h"
+#include "smd_smooth_dev.h"   // block counts of the smoothness sweep / adjoint (host-side inline helpers)
 
 namespace {
 
@@ -128,6 +129,9 @@ bool k0_fusable(const smd::ScaleSet& sc, int h, int flags) {
 }
 
 struct ReconWs { float* loss_partial; float* pose_partial; size_t bytes; };
+// What the fused loss path adds to the reconstruction forward: the smoothness sweep (as guest blocks of the main launch, or launched behind
+// it) and the in-launch weighted sum of the two losses.
+struct LossPathFwd { smd::SmoothFwdJob job; smd::LossCombine comb; bool guests; };
 
 ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
   ReconWs r;
@@ -271,7 +275,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
                           const float* tgt, const float* supp, const float* T, const float* K,
                           const float* K_inv, const float* noise, uint64_t seed, float* supp_packed, float* err, uint8_t* sel, float* loss,
                           float* warp0, void* workspace, size_t workspace_bytes,
-                          int b, int n, int S, int h, int w, int flags, void* stream) {
+                          int b, int n, int S, int h, int w, int flags, void* stream, const LossPathFwd* lp = nullptr) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
   if ((!depth && !sc) || !tgt || !supp || !T || !K || !K_inv || !supp_packed || !sel || !loss || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (smd_packed_supports_bytes(b, n, h, w) >= ((size_t)1 << 32)) return fail(SMD_E_INVALID, "the packed buffer (%zu bytes) must stay below 2^32", smd_packed_supports_bytes(b, n, h, w));
@@ -314,6 +318,10 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
   taper(a.b1, a.rh2, a.nsy2, b, h, pl, "fwd_taper_b", "fwd_taper_rh");
   if (a.rh2 > 58) { a.rh2 = 58; a.nsy2 = smd::ceil_div(h, a.rh2); }   // as plan(): one row-table entry per lane
+  if (lp) {
+    a.comb = lp->comb;
+    if (lp->guests) { a.sm = lp->job; a.guest_blocks = smd::smooth_main_blocks(a.sc, b); }
+  }
   a.lookahead = knob("fwd_ahead", 1) == 2 ? 2 : 1;
   a.share = (knob("fwd_share", 1) != 0 && a.S == 4 && a.rh % 4 == 0 && (a.b1 >= a.b || a.rh2 % 4 == 0)) ? 1 : 0;
   for (int i0 = 0; i0 < n; i0 += kMaxPerPass) {
@@ -324,6 +332,7 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
     if (a.last_pass) prof_mark(SMD_PROF_RECON_FWD, st, false);
     if (a.depth_out) { a.depth = a.depth_out; a.depth_out = nullptr; }   // later passes (n > 4) read the depth the first one wrote
   }
+  if (lp && !lp->guests) { if (int rc = check_launch(smd::launch_smooth_main(a.sc, b, lp->job, st), "loss_path smoothness sweep")) return rc; }
   prof_mark(SMD_PROF_RECON_FWD_ALL, st, false);   // the loss is reduced inside the last launch (recon_main_reduce)
   return SMD_OK;
 }
@@ -368,7 +377,7 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
                           const float* K_inv, const uint8_t* sel, const float* g_loss, const float* g_in, float k0_scale,
                           float* g_depth, float* g_T, float* g_K, float* g_Kinv, void* workspace, size_t workspace_bytes,
                           int b, int n, int S, int h, int w, int flags, void* stream, smd::PoseFinJob* guest = nullptr,
-                          float* g_direct = nullptr, int direct_scale = -1) {
+                          float* g_direct = nullptr, int direct_scale = -1, float g_scale = 1.f) {
   if (int rc = check_dims(b, n, S, h, w)) return rc;
   if (!depth || !supp_packed || !T || !K || !K_inv || !sel || !g_loss || !g_depth || !g_T || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if ((flags & SMD_NEED_K_GRAD) && (!g_K || !g_Kinv)) return fail(SMD_E_INVALID, "SMD_NEED_K_GRAD requires g_K and g_Kinv");
@@ -381,7 +390,7 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   memset(&a, 0, sizeof(a));
   a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv; a.sel = sel; a.g_loss = g_loss;
   a.g_depth = g_depth; a.pose_partial = ws.pose_partial;
-  a.g_in = g_in; a.k0_scale = k0_scale;
+  a.g_in = g_in; a.k0_scale = k0_scale; a.g_scale = g_scale;
   a.g_direct = g_direct; a.direct_scale = g_direct ? direct_scale : -1;
   a.arrive = packed_arrive(supp_packed, b, n, h, w) + 1;
   a.g_T = g_T; a.g_K = (flags & SMD_NEED_K_GRAD) ? g_K : nullptr; a.g_Kinv = (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr;
@@ -413,7 +422,7 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   if (guest) {   // the caller's next launch finalises the pose sums: no in-launch hand-off (the kernel skips it when `arrive` is null)
     a.arrive = nullptr;
     const int spb = smd::kWavesPerBlock/a.wps;
-    guest->a = a; guest->b1 = a.b1;
+    guest->a = a; guest->b1 = a.b1;   // (chain / sm of the job are the caller's: left as they are)
     guest->entries1 = S*smd::ceil_div(pl.nsx*pl.nsy, spb); guest->entries2 = S*smd::ceil_div(pl.nsx*a.nsy2, spb);
   }
   prof_mark(SMD_PROF_RECON_BWD_ALL, st, true);
@@ -470,6 +479,102 @@ int smd_image_recon_disp_bwd(const int* hs, const int* ws, int S, float min_dept
                               direct >= 0 ? g_disp[direct] : nullptr, direct)) return rc;
   return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth, k0_tmp, true, (hipStream_t)stream,
                                                     ride ? &guest : nullptr, direct), "disp_to_depth_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused loss path (round 5): `forward_loss` of the kbr configuration (src/core/trainer.py:383-392, 436-437, 462-464) as ONE operator.
+// Forward = the K0-fused reconstruction launch carrying the smoothness sweep as guest blocks and forming the weighted sum in-launch;
+// backward = the fused reconstruction backward, the K0 adjoint's first launch carrying the pose epilogue (now through to the pose network's
+// outputs) and the smoothness adjoint as guests, and the K0 adjoint's second launch adding into what the smoothness adjoint wrote.
+static const char* loss_path_unsupported(const smd::ScaleSet& sc, int n, int h, int w, int flags, int* direct) {
+  if (flags & SMD_LOSS_L1) return "loss_name 'l1'";
+  if ((flags & SMD_USE_LAPLACIAN) || !(flags & SMD_USE_EDGES)) return "a smoothness term other than SmoothReg(use_edges=True)";
+  int per_pass = knob("fwd_ni", 4);
+  if (per_pass < 1 || per_pass > 4) per_pass = 4;
+  if (n > per_pass) return "more supports than one forward pass holds";
+  if (!k0_fusable(sc, h, flags)) return "a pyramid level taller than the image";
+  if (sc.S < 2) return "a single pyramid level";
+  int ident = 0, d = -1;
+  for (int s = 0; s < sc.S; ++s) if (sc.hs[s] == h && sc.ws[s] == w) { ++ident; if (d < 0) d = s; }
+  if (ident > 1) return "two pyramid levels of the image's size";
+  if (ident == 1 && knob("bwd_direct_level", 1) == 0) return "knob bwd_direct_level = 0";
+  if (knob("bwd_guest_finalize", 1) == 0) return "knob bwd_guest_finalize = 0";
+  *direct = d;
+  return nullptr;
+}
+
+size_t smd_loss_path_workspace_bytes(const int* hs, const int* ws, int S, int b, int n, int h, int w) {
+  const size_t fwd = align256(smd_image_recon_workspace_bytes(b, n, S, h, w)) + smd_disp_smooth_workspace_bytes(hs, ws, S, b);
+  const size_t bwd = smd_image_recon_disp_workspace_bytes(hs, ws, S, b, n, h, w);
+  if (!smd_image_recon_workspace_bytes(b, n, S, h, w) || !smd_disp_smooth_workspace_bytes(hs, ws, S, b) || !bwd) return 0;
+  return fwd > bwd ? fwd : bwd;
+}
+
+int smd_loss_path_fwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, float min_depth, float max_depth,
+                      const float* tgt, const float* supp, const float* T, const float* K, const float* K_inv, uint64_t seed,
+                      float* supp_packed, float* edge_weights, float* depth_up, uint8_t* sel, float* loss3, float* stats,
+                      void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, float w_recon, float w_smooth, void* stream) {
+  if (!disp || !depth_up || !edge_weights || !loss3 || !stats || !workspace || !tgt) return fail(SMD_E_INVALID, "null pointer");
+  if ((min_depth > 0.f || max_depth > 0.f) && !(min_depth > 0.f)) return fail(SMD_E_INVALID, "Min depth must be greater than 0. (%g)", min_depth);
+  if (max_depth > 0.f && max_depth < min_depth) return fail(SMD_E_INVALID, "Max depth must be greater than min. (%g vs. %g)", max_depth, min_depth);
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, disp, nullptr, hs, ws, scale_keys, S)) return rc;
+  for (int s = 0; s < S; ++s) if (!disp[s]) return fail(SMD_E_INVALID, "null disparity pointer for scale %d", s);
+  int direct = -1;
+  if (const char* why = loss_path_unsupported(sc, n, h, w, flags, &direct)) return fail(SMD_E_UNSUPPORTED, "the fused loss path does not serve %s", why);
+  const size_t need = smd_loss_path_workspace_bytes(hs, ws, S, b, n, h, w);
+  if (!need || workspace_bytes < need) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  if (!(flags & SMD_EDGES_READY)) {   // frame-only half of the smoothness term inline (also zeroes the sweep's and the combination's counters)
+    if (int rc = check_launch(smd::launch_smooth_edges(sc, b, tgt, h, w, edge_weights, st), "disp_smooth_prep")) return rc;
+  }
+  const size_t base = align256(smd_image_recon_workspace_bytes(b, n, S, h, w));
+  LossPathFwd lp;
+  smd::smooth_fwd_job(sc, b, loss3 + 2, stats, (float*)((char*)workspace + base), edge_weights, &lp.job);
+  lp.comb.out3 = loss3; lp.comb.arrive = lp.job.arrive + (size_t)S*b + 1; lp.comb.w_rec = w_recon; lp.comb.w_sm = w_smooth;
+  lp.job.comb = lp.comb;
+  lp.guests = knob("loss_path_guests", 1) != 0;
+  const int rflags = flags & (SMD_USE_MIN | SMD_USE_AUTOMASK | SMD_PACKED_READY);
+  return recon_fwd_impl(nullptr, depth_up, &sc, min_depth, max_depth, tgt, supp, T, K, K_inv, nullptr, seed, supp_packed, nullptr, sel, loss3 + 1, nullptr,
+                        workspace, base, b, n, S, h, w, rflags, stream, &lp);
+}
+
+int smd_loss_path_bwd(const float* const* disp, const int* hs, const int* ws, const int* scale_keys, int S, float min_depth, float max_depth,
+                      const float* depth_up, float* supp_packed, const float* T, const float* K, const float* K_inv, const uint8_t* sel,
+                      const float* stats, const float* edge_weights, const float* g_loss, float w_recon, float w_smooth,
+                      const float* aa, const float* t, const uint8_t* invert, const float* fs, const float* cs,
+                      float* const* g_disp, float* g_T, float* g_K, float* g_Kinv, float* g_aa, float* g_t, float* g_fs, float* g_cs,
+                      void* workspace, size_t workspace_bytes, int b, int n, int h, int w, int flags, void* stream) {
+  if (!disp || !depth_up || !g_disp || !stats || !edge_weights || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if ((aa != nullptr) != (t != nullptr) || (aa != nullptr) != (g_aa != nullptr) || (aa != nullptr) != (g_t != nullptr)) return fail(SMD_E_INVALID, "aa, t, g_aa, g_t go together");
+  if ((fs != nullptr) != (cs != nullptr) || (fs != nullptr) != (g_fs != nullptr) || (fs != nullptr) != (g_cs != nullptr)) return fail(SMD_E_INVALID, "fs, cs, g_fs, g_cs go together");
+  if (fs && (!aa || !(flags & SMD_NEED_K_GRAD))) return fail(SMD_E_INVALID, "the intrinsics' chain rule needs the pose chain and SMD_NEED_K_GRAD");
+  smd::ScaleSet sc;
+  if (int rc = fill_scales(sc, disp, g_disp, hs, ws, scale_keys, S)) return rc;
+  for (int s = 0; s < S; ++s) if (!disp[s] || !g_disp[s]) return fail(SMD_E_INVALID, "null pointer for scale %d", s);
+  int direct = -1;
+  if (const char* why = loss_path_unsupported(sc, n, h, w, flags, &direct)) return fail(SMD_E_UNSUPPORTED, "the fused loss path does not serve %s", why);
+  const size_t need = smd_loss_path_workspace_bytes(hs, ws, S, b, n, h, w);
+  if (!need || workspace_bytes < need) return fail(SMD_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  const size_t base = align256(smd_image_recon_workspace_bytes(b, n, S, h, w));
+  float* g_depth = (float*)((char*)workspace + base);
+  float* k0_tmp = (float*)((char*)workspace + base + align256((size_t)S*b*h*w*sizeof(float)));
+  float a_scale = 1.f;
+  if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
+  const bool guests = knob("loss_path_guests", 1) != 0;
+  smd::PoseFinJob job;
+  memset(&job, 0, sizeof(job));
+  job.chain.aa = aa; job.chain.t = t; job.chain.invert = invert; job.chain.g_aa = g_aa; job.chain.g_t = g_t;
+  job.chain.fs = fs; job.chain.cs = cs; job.chain.g_fs = g_fs; job.chain.g_cs = g_cs; job.chain.h = h; job.chain.w = w;
+  job.sm.stats = stats; job.sm.edge_w = edge_weights; job.sm.g_loss = g_loss; job.sm.g_scale = w_smooth; job.sm.accumulate_scale = direct;
+  job.sm.blocks_per_sample = guests ? smd::smooth_bwd_blocks_per_sample(sc) : 0;
+  const int rflags = flags & (SMD_USE_MIN | SMD_USE_AUTOMASK | SMD_NEED_K_GRAD | SMD_BWD_SKIP_DEAD_ROWS);
+  if (int rc = recon_bwd_impl(depth_up, supp_packed, T, K, K_inv, sel, g_loss, nullptr, a_scale, g_depth, g_T, g_K, g_Kinv, workspace, base,
+                              b, n, S, h, w, rflags, stream, &job, direct >= 0 ? g_disp[direct] : nullptr, direct, w_recon)) return rc;
+  if (!guests) {   // the smoothness adjoint as a launch of its own, between the reconstruction backward (which wrote the direct level) and the K0 adjoint (which adds)
+    if (int rc = check_launch(smd::launch_smooth_bwd(sc, b, nullptr, h, w, SMD_USE_EDGES, stats, g_loss, edge_weights, (hipStream_t)stream, w_smooth, direct), "loss_path smoothness adjoint")) return rc;
+  }
+  return check_launch(smd::launch_disp_to_depth_bwd(sc, b, h, w, min_depth, max_depth, depth_up, g_depth, k0_tmp, true, (hipStream_t)stream, &job, direct, true), "loss_path K0 adjoint");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,6 +8,8 @@
 #include "smd_common.h"
 #include "smd_kernels.h"
 #include "smd_pose_fin.h"
+#include "smd_pose_dev.h"
+#include "smd_smooth_dev.h"
 
 namespace smd {
 
@@ -130,11 +132,27 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, 
     // two of the block's waves take the supports in turn (their round trips run side by side); static LDS counts against every
     // block of this launch, so no more than that
     __shared__ double scratch[fin_scratch_doubles(2)];
-    pose_finalize<true>(job.a, (int)blockIdx.y, (int)blockIdx.y < job.b1 ? job.entries1 : job.entries2, scratch, (int)(threadIdx.x >> 6), 2);
+    __shared__ float chain_lds[SMD_MAX_SUPPORTS*16 + 32];
+    const bool chain = job.chain.g_aa != nullptr;
+    pose_finalize<true>(job.a, (int)blockIdx.y, (int)blockIdx.y < job.b1 ? job.entries1 : job.entries2, scratch, (int)(threadIdx.x >> 6), 2, chain ? chain_lds : nullptr);
+    if (chain && (threadIdx.x >> 6) == 0) {
+      // Fused loss path: the chain rule runs on to the pose network's outputs in the same wave (the former smd_pose_bwd / smd_intrinsics_bwd
+      // launches): lane i < n takes support i's dL/dT from LDS through the Rodrigues adjoint, one more lane the intrinsics.
+      wave_lds_sync();
+      const int lane = threadIdx.x & 63, n = job.a.n, bi = (int)blockIdx.y;
+      if (lane < n) pose_bwd_one(job.chain.aa, job.chain.t, job.chain.invert, lane*job.a.b + bi, chain_lds + lane*16, job.chain.g_aa, job.chain.g_t);
+      else if (lane == n && job.chain.g_fs) intrinsics_bwd_one(job.chain.fs, job.chain.cs, bi, job.chain.h, job.chain.w, chain_lds + n*16, chain_lds + n*16 + 16, job.chain.g_fs, job.chain.g_cs);
+    }
     return;
   }
   // depth_up == nullptr: the incoming gradient already carries d depth / d disparity (the fused backward applied it)
   const int bx = (int)blockIdx.x - guest;
+  if (bx >= map.first_block[SMD_MAX_SCALES]) {   // fused loss path: the smoothness adjoint's blocks of this sample ride behind the resampling blocks
+    int s_, q;
+    smooth_bwd_decode(sc, bx - map.first_block[SMD_MAX_SCALES], s_, q);
+    smooth_bwd_block(sc, b, s_, (int)blockIdx.y, q, job.sm.stats, job.sm.g_loss, job.sm.g_scale, job.sm.edge_w, s_ == job.sm.accumulate_scale);
+    return;
+  }
   const int s = scale_of_block(map, sc.S, bx);
   const int blk = bx - map.first_block[s], bi = blockIdx.y;
   const int hs = sc.hs[s], ws = sc.ws[s];
@@ -188,7 +206,7 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_v(const ScaleSet sc, 
 }
 
 __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_h(const ScaleSet sc, const BwdMap map, int b, int h, int w, float a_scale,
-                                                             const float* __restrict__ tmp) {
+                                                             const float* __restrict__ tmp, int accumulate) {
   const int s = scale_of_block(map, sc.S, blockIdx.x);
   const int blk = blockIdx.x - map.first_block[s], bi = blockIdx.y;
   const int hs = sc.hs[s], ws = sc.ws[s];
@@ -208,7 +226,8 @@ __global__ __launch_bounds__(256) void k_disp_to_depth_bwd_h(const ScaleSet sc, 
     const float wx = ((x0 == jx) ? 1.f - lx : 0.f) + ((x1 == jx) ? lx : 0.f);
     acc = fmaf(wx, row[u], acc);
   }
-  sc.g[s][(size_t)bi*hs*ws + lp] = acc*a_scale;
+  float* out = sc.g[s] + (size_t)bi*hs*ws + lp;
+  *out = accumulate ? *out + acc*a_scale : acc*a_scale;   // accumulate: the smoothness adjoint already wrote its share (fused loss path)
 }
 
 size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, BwdMap* map) {
@@ -222,7 +241,7 @@ size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, Bwd
 
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
                                     const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st,
-                                    const PoseFinJob* job, int skip_scale) {
+                                    const PoseFinJob* job, int skip_scale, bool accumulate) {
   float a_scale = 1.f;
   if (min_depth > 0.f || max_depth > 0.f) a_scale = 1.f/min_depth - (max_depth > 0.f ? 1.f/max_depth : 0.f);
   if (premultiplied) { a_scale = 1.f; depth_up = nullptr; }
@@ -245,10 +264,11 @@ hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, flo
   m1.first_block[SMD_MAX_SCALES] = n1; m2.first_block[SMD_MAX_SCALES] = n2;
   PoseFinJob none;
   memset(&none, 0, sizeof(none));
-  if (n1 > 0) hipLaunchKernelGGL(k_disp_to_depth_bwd_v, dim3(n1 + (job ? 1 : 0), b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp,
+  const int sm_blocks = job ? job->sm.blocks_per_sample : 0;   // guest blocks of the smoothness adjoint (fused loss path)
+  if (n1 > 0) hipLaunchKernelGGL(k_disp_to_depth_bwd_v, dim3(n1 + (job ? 1 : 0) + sm_blocks, b), dim3(256), 0, st, sc, m1, b, h, w, a_scale, depth_up, g_depth_up, tmp,
                                  job ? *job : none);
   else if (job) return hipErrorInvalidValue;
-  if (resampled) hipLaunchKernelGGL(k_disp_to_depth_bwd_h, dim3(n2, b), dim3(256), 0, st, sc, m2, b, h, w, a_scale, tmp);
+  if (resampled) hipLaunchKernelGGL(k_disp_to_depth_bwd_h, dim3(n2, b), dim3(256), 0, st, sc, m2, b, h, w, a_scale, tmp, accumulate ? 1 : 0);
   return hipGetLastError();
 }
 

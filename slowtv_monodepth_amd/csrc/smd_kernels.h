@@ -62,6 +62,17 @@ __host__ __device__ inline size_t packed_rowtab_offset_floats(int b, int n, int 
 __host__ __device__ inline size_t packed_arrive_offset_floats(int b, int n, int h, int w) { return packed_rowtab_offset_floats(b, n, h, w) + (size_t)SMD_MAX_SCALES*(size_t)(h + 4)*4; }
 __host__ __device__ inline size_t packed_total_floats(int b, int n, int h, int w) { return packed_arrive_offset_floats(b, n, h, w) + (((size_t)b + 1 + 3) & ~(size_t)3); }
 
+// The fused loss path (round 5): total = w_rec*l_rec + w_sm*l_sm is formed in-launch by whichever final reducer arrives second.
+struct LossCombine { float* out3; unsigned* arrive; float w_rec, w_sm; };   // out3 = {total, l_rec, l_sm}; null: no combination
+// The smoothness sweep over the disparities (smd_smooth_dev.h: smooth_main_block), as a kernel of its own or as guest blocks of k_recon_main.
+struct SmoothFwdJob {
+  const float* edge_w;     // {wx, wy} per pixel of every level, or null (no edge weighting)
+  float* partial; int max_units; float* stats; float* loss;
+  unsigned* arrive;        // [S*b + 1] counters of the in-launch second stage (null: two-launch form)
+  double* contrib;         // [S*b]
+  LossCombine comb;
+};
+
 struct ReconPrepArgs {     // k_recon_prep: texel repack + target window sums + identity error, once per sample
   const float* tgt;        // (b,3,h,w)
   const float* supp;       // (n,b,3,h,w) planar
@@ -109,12 +120,18 @@ struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over suppo
   int first_pass, last_pass;
   int lookahead;           // 1 or 2 row steps between a tap gather and its first use (2: the hot K0-fused instantiation with N <= 2 only)
   int share;               // 1: a block is the FOUR scales of one strip and the target-side rows reach them through one LDS ring (S == 4, strip heights multiples of 4)
+  // Fused loss path (K0-fused single-pass instantiations only): blocks [main_blocks, main_blocks + guest_blocks) of the grid are GUEST blocks
+  // running the smoothness sweep over `sc` (sm); comb: the reconstruction loss also takes part in the in-launch weighted sum.
+  int main_blocks, guest_blocks;
+  SmoothFwdJob sm;
+  LossCombine comb;
 };
 
 struct ReconBwdArgs {
   const float* depth; const float* packed; const float* T; const float* K; const float* Kinv;
   const uint8_t* sel;
   const float* g_loss;    // device scalar
+  float g_scale;          // host-side factor of g_loss (the loss weight of the fused loss path; 1 otherwise)
   float* g_depth;         // (S,b,h,w)
   const float* g_in;      // (S,b,h,w) gradient reaching depth from other consumers, added on the last support pass, or null
   float k0_scale;         // K0 fused: != 0 -> g_depth receives dL/d(up-sampled disparity) = dL/d depth * (-depth^2 * k0_scale) (0 where the
@@ -189,10 +206,19 @@ hipError_t launch_disp_to_depth_fwd(const ScaleSet& sc, int b, int h, int w, flo
                                     float* depth_up, float* disp_up, hipStream_t st);
 struct BwdMap;
 size_t disp_to_depth_bwd_tmp_floats(const ScaleSet& sc, int b, int h, int w, BwdMap* map);
-struct PoseFinJob { ReconBwdArgs a; int entries1, entries2, b1; };   // the per-sample epilogue of the fused backward as guest work of the K0 adjoint
+// Guest work of the K0 adjoint's first launch: the per-sample epilogue of the fused backward (pose sums -> dL/dT, dL/dK, dL/dK^-1) and, in the
+// fused loss path (round 5), the chain rule on to the pose network's outputs (the former smd_pose_bwd / smd_intrinsics_bwd launches) and the
+// smoothness adjoint as extra blocks that write (or, for a level the reconstruction backward already wrote, add to) the level gradients.
+struct PoseChain {        // all null: stop at dL/dT, dL/dK, dL/dK^-1
+  const float* aa; const float* t; const uint8_t* invert; float* g_aa; float* g_t;   // (n*b,3) each; invert (n*b) or null
+  const float* fs; const float* cs; float* g_fs; float* g_cs;                        // (b,2) each or null
+  int h, w;
+};
+struct SmoothBwdJob { const float* stats; const float* edge_w; const float* g_loss; float g_scale; int blocks_per_sample; int accumulate_scale; };   // blocks_per_sample 0: none
+struct PoseFinJob { ReconBwdArgs a; int entries1, entries2, b1; PoseChain chain; SmoothBwdJob sm; };
 hipError_t launch_disp_to_depth_bwd(const ScaleSet& sc, int b, int h, int w, float min_depth, float max_depth,
                                     const float* depth_up, const float* g_depth_up, float* tmp, bool premultiplied, hipStream_t st,
-                                    const PoseFinJob* job = nullptr, int skip_scale = -1);
+                                    const PoseFinJob* job = nullptr, int skip_scale = -1, bool accumulate = false);
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, bool edges_ready, hipStream_t st);
@@ -200,7 +226,9 @@ hipError_t launch_blur3(const float* x, float* out, int planes, int h, int w, bo
 hipError_t launch_smooth_edges(const ScaleSet& sc, int b, const float* img, int h, int w, float* edge_w, hipStream_t st);   // frame-only: edge weights of every level + zeroed arrival counters
 size_t smooth_edge_bytes(const ScaleSet& sc, int b);
 hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
-                             const float* g_loss, const float* edge_w, hipStream_t st);
+                             const float* g_loss, const float* edge_w, hipStream_t st, float g_scale = 1.f, int accumulate_scale = -1);
+hipError_t launch_smooth_main(const ScaleSet& sc, int b, const SmoothFwdJob& job, hipStream_t st);   // the sweep alone (the fused loss path without guest blocks)
+void smooth_fwd_job(const ScaleSet& sc, int b, float* loss, float* stats, float* ws_sums, float* edge_w, SmoothFwdJob* job);   // carve the sweep's workspace / counters
 
 hipError_t launch_view_synth_fwd(const float* input, const float* depth, const float* T, const float* K, const float* Kinv,
                                  float* warp, float* depth_warp, uint8_t* mask_valid, int B, int C, int h, int w, hipStream_t st);

@@ -10,23 +10,9 @@
 //     the 3x3 block is inverted by its adjugate.
 #include "smd_common.h"
 #include "smd_kernels.h"
+#include "smd_pose_dev.h"
 
 namespace smd {
-
-__device__ __forceinline__ void rodrigues(const float a[3], float R[9], float& th, float& c, float n[3], float& s, float& k) {
-  th = sqrtf(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]);
-  c = fmaxf(th, kEps32);
-  n[0] = a[0]/c; n[1] = a[1]/c; n[2] = a[2]/c;
-  s = sinf(th); k = 1.f - cosf(th);
-  const float W[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float w2 = W[i*3]*W[j] + W[i*3 + 1]*W[3 + j] + W[i*3 + 2]*W[6 + j];
-      R[i*3 + j] = ((i == j) ? 1.f : 0.f) + s*W[i*3 + j] + k*w2;
-    }
-}
 
 __global__ void k_pose_fwd(const float* __restrict__ aa, const float* __restrict__ t, const uint8_t* __restrict__ invert, int N, float* __restrict__ T) {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
@@ -56,57 +42,7 @@ __global__ void k_pose_fwd(const float* __restrict__ aa, const float* __restrict
 __global__ void k_pose_bwd(const float* __restrict__ aa, const float* __restrict__ t, const uint8_t* __restrict__ invert, int N,
                            const float* __restrict__ g_T, float* __restrict__ g_aa, float* __restrict__ g_t) {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const float a[3] = {aa[i*3], aa[i*3 + 1], aa[i*3 + 2]}, tv[3] = {t[i*3], t[i*3 + 1], t[i*3 + 2]};
-  float R[9], th, c, n[3], s, k;
-  rodrigues(a, R, th, c, n, s, k);
-  const float* g = g_T + (size_t)i*16;
-  float G[9], gt[3];   // dL/dR, dL/dt
-  if (invert && invert[i]) {
-    const float u[3] = {g[3], g[7], g[11]};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) G[r*3 + q] = g[q*4 + r] - tv[r]*u[q];    // (G'_R)^T - t u^T
-      gt[r] = -(R[r*3]*u[0] + R[r*3 + 1]*u[1] + R[r*3 + 2]*u[2]);         // -R u
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) G[r*3 + q] = g[r*4 + q];
-      gt[r] = g[r*4 + 3];
-    }
-  }
-  const float W[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
-  float W2[9], gs = 0.f, gk = 0.f;
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      W2[r*3 + q] = W[r*3]*W[q] + W[r*3 + 1]*W[3 + q] + W[r*3 + 2]*W[6 + q];
-      gs += G[r*3 + q]*W[r*3 + q]; gk += G[r*3 + q]*W2[r*3 + q];
-    }
-  float gW[9];   // s G + k (G W^T + W^T G)
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      float gwt = 0.f, wtg = 0.f;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) { gwt += G[r*3 + m]*W[q*3 + m]; wtg += W[m*3 + r]*G[m*3 + q]; }
-      gW[r*3 + q] = s*G[r*3 + q] + k*(gwt + wtg);
-    }
-  const float gn[3] = {gW[7] - gW[5], gW[2] - gW[6], gW[3] - gW[1]};
-  const float inv_th = (th > 0.f) ? 1.f/th : 0.f;
-  const float gth = gs*cosf(th) + gk*sinf(th);
-  const float gna = gn[0]*a[0] + gn[1]*a[1] + gn[2]*a[2];
-  const float clip_pass = (th >= kEps32) ? 1.f : 0.f;
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    g_aa[i*3 + m] = gn[m]/c - clip_pass*gna/(c*c)*a[m]*inv_th + gth*a[m]*inv_th;
-    g_t[i*3 + m] = gt[m];
-  }
+  if (i < N) pose_bwd_one(aa, t, invert, i, g_T + (size_t)i*16, g_aa, g_t);
 }
 
 // mode 0: K (b,4,4) given -> Kinv;  mode 1: (fs, cs) normalised -> K resized to (h, w) and Kinv
@@ -136,12 +72,7 @@ __global__ void k_intrinsics_fwd(const float* __restrict__ fs, const float* __re
 __global__ void k_intrinsics_bwd(const float* __restrict__ fs, const float* __restrict__ cs, int b, int h, int w,
                                  const float* __restrict__ g_K, const float* __restrict__ g_Kinv, float* __restrict__ g_fs, float* __restrict__ g_cs) {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= b) return;
-  const float F = fs[i*2]*(float)w, G = fs[i*2 + 1]*(float)h, C = cs[i*2]*(float)w, D = cs[i*2 + 1]*(float)h;
-  const float* gk = g_K + (size_t)i*16; const float* gi = g_Kinv + (size_t)i*16;
-  const float gF = gk[0] - gi[0]/(F*F) + gi[2]*C/(F*F), gC = gk[2] - gi[2]/F;
-  const float gG = gk[5] - gi[5]/(G*G) + gi[6]*D/(G*G), gD = gk[6] - gi[6]/G;
-  g_fs[i*2] = gF*(float)w; g_fs[i*2 + 1] = gG*(float)h; g_cs[i*2] = gC*(float)w; g_cs[i*2 + 1] = gD*(float)h;
+  if (i < b) intrinsics_bwd_one(fs, cs, i, h, w, g_K + (size_t)i*16, g_Kinv + (size_t)i*16, g_fs, g_cs);
 }
 
 hipError_t launch_pose_fwd(const float* aa, const float* t, const uint8_t* invert, int N, float* T, hipStream_t st) {

@@ -37,11 +37,13 @@ __device__ __forceinline__ void wave_lds_sync() {   // LDS written by some lanes
 
 // MULTI: every wave of the block calls this (wave `wv` of `nwaves` sweeps supports wv, wv + nwaves, ...; block barriers);
 // otherwise ONE wave calls it with wv = 0, nwaves = 1.  scratch: fin_scratch_doubles(nwaves) doubles of LDS.
+// lds_out (optional, LDS): wave 0 also leaves dL/dT [n][16], dL/dK [16], dL/dK^-1 [16] there for a chain rule that continues in the same wave
+// (the fused loss path: smd_depth.hip).
 // Written to stay SMALL in registers (it is also guest code inside the K0 adjoint, whose occupancy it must not cost): the
 // sweep keeps four 16-byte loads in flight, and the 3x3 algebra is spread over the lanes one output element each, with the
 // intermediate matrices in LDS, instead of one lane holding ~50 doubles.
 template <bool MULTI>
-inline __device__ void pose_finalize(const ReconBwdArgs& a, int bi, int entries, double* scratch, int wv, int nwaves) {
+inline __device__ void pose_finalize(const ReconBwdArgs& a, int bi, int entries, double* scratch, int wv, int nwaves, float* lds_out = nullptr) {
   const int lane = threadIdx.x & 63;
   const int n = a.n, b = a.b;
   const unsigned F4 = (unsigned)entries*kPoseSums*4u;        // bytes per (support, sample); a multiple of 16
@@ -120,6 +122,7 @@ inline __device__ void pose_finalize(const ReconBwdArgs& a, int bi, int entries,
         if (r == 2) gt += gH[11];
       }
       a.g_T[((size_t)i*b + bi)*16 + e] = (float)gt;
+      if (lds_out) lds_out[i*16 + e] = (float)gt;
       if (e < 6) {                                                                    // dL/dK[r2][m2] share of this support
         const int r2 = e/3, m2 = e - r2*3;
         double v = gH[9 + r2]*(double)Tm[m2*4 + 3];
@@ -146,6 +149,7 @@ inline __device__ void pose_finalize(const ReconBwdArgs& a, int bi, int entries,
     }
     if (a.g_K) a.g_K[(size_t)bi*16 + lane] = (float)sK;
     if (a.g_Kinv) a.g_Kinv[(size_t)bi*16 + lane] = (float)sKi;
+    if (lds_out) { lds_out[n*16 + lane] = (float)sK; lds_out[n*16 + 16 + lane] = (float)sKi; }
   }
 }
 

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     cx.use_min = a.flags & SMD_USE_MIN;
     const unsigned hw4 = (unsigned)hw*4u;
     cx.w4 = (unsigned)w*4u;
-    float gscale = a.g_loss[0]/((float)a.S*(float)a.b*(float)h*(float)w);
+    float gscale = (a.g_loss[0]*a.g_scale)/((float)a.S*(float)a.b*(float)h*(float)w);
     if (!cx.use_min) gscale /= (float)a.n;
     cx.g_ssim = uniform(gscale*(SSIM ? kWSsim/3.f : 0.f));      // (columns outside the image never route: scan_sel)
     cx.g_l1 = uniform(gscale*(SSIM ? (1.f - kWSsim)/3.f : 1.f/3.f));

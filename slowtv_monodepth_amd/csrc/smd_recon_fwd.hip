@@ -27,6 +27,7 @@
 // Reference semantics: src/tools/geometry.py:285-391, src/losses/photometric.py:23-88, src/losses/reconstruction.py:43-126.
 #include "smd_common.h"
 #include "smd_kernels.h"
+#include "smd_smooth_dev.h"
 
 #ifndef SMD_FWD_PRIO
 #define SMD_FWD_PRIO 0   // experiment: s_setprio by remaining rows in the shared-ring forward (see step())
@@ -818,13 +819,13 @@ __device__ __forceinline__ void recon_main_reduce(const ReconMainArgs& a, MainTa
     for (int k = 0; k < kWavesPerBlock; ++k) bsum += tl.wsum[k];
     __hip_atomic_store((unsigned long long*)a.partial + blockIdx.x, __builtin_bit_cast(unsigned long long, bsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = (__hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
+    last = (__hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.main_blocks - 1u) ? 1u : 0u;
   }
   if (!__builtin_amdgcn_readfirstlane((int)last)) return;
   SMD_TAIL_ACQUIRE();
   // The sweep is pure latency (this wave runs alone at the very end of the launch): 16-byte agent-scope loads, sixteen of them
   // per lane issued before the first is used — one round trip per 2048 partials.  Beyond the last partial the buffer reads 0.
-  const unsigned bytes = gridDim.x*8u;
+  const unsigned bytes = (unsigned)a.main_blocks*8u;   // (the grid may carry guest blocks behind the main ones: they have no partial)
   const rsrc_t rs = make_rsrc(a.partial, bytes);
   typedef double d2 __attribute__((ext_vector_type(2)));
   double acc = 0.0;
@@ -838,8 +839,10 @@ __device__ __forceinline__ void recon_main_reduce(const ReconMainArgs& a, MainTa
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (lane == 0) {
-    a.loss[0] = (float)(acc*a.loss_scale);
+    const float l_rec = (float)(acc*a.loss_scale);
+    a.loss[0] = l_rec;
     __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this buffer
+    if (a.comb.out3) loss_combine_arrive(a.comb, 1, l_rec);   // fused loss path: the weighted sum with the smoothness term, by whoever is second
   }
 }
 
@@ -858,6 +861,12 @@ __global__ __launch_bounds__(64*kWavesPerBlock, ((N <= 2 && LA == 1) ? 4 : 3)) v
   if (reduce) {                       // the only block barrier, at the start, where every wave still is
     if (threadIdx.x == 0) tail.arrived = 0u;
     __syncthreads();
+  }
+  if (DISP && SINGLE && !AUX) {
+    // Fused loss path (round 5): the blocks behind the main ones are GUESTS running the smoothness sweep over the same disparity pyramid
+    // (smd_smooth_dev.h) — dispatched last, they fill the drain of this launch (its final fifth runs at one or two waves per SIMD) and their
+    // reduction chain ends long before the main blocks do.
+    if (a.guest_blocks != 0 && (int)blockIdx.x >= a.main_blocks) { smooth_main_block(a.sc, a.b, a.sm, (int)blockIdx.x - a.main_blocks); return; }
   }
   const float lane_sum = recon_main_body<N, SSIM, SINGLE, AUX, DISP, LA, SH>(a);
 #ifdef SMD_TRACE_WAVES
@@ -885,9 +894,19 @@ static void launch_main_t(dim3 grid, dim3 block, hipStream_t st, const ReconMain
   hipLaunchKernelGGL((k_recon_main<N, SSIM, SINGLE, AUX, DISP, LA, SH>), grid, block, 0, st, a);
 }
 
-hipError_t launch_recon_main(const ReconMainArgs& a, hipStream_t st) {
-  dim3 grid(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S) : 0u)), block(64*kWavesPerBlock);
+int recon_main_blocks(const ReconMainArgs& a) {
+  return (int)(recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S) + (a.b1 < a.b ? recon_grid_blocks(a.nsx*a.nsy2, a.b - a.b1, a.S) : 0u));
+}
+
+hipError_t launch_recon_main(const ReconMainArgs& a_in, hipStream_t st) {
+  ReconMainArgs a = a_in;
+  a.main_blocks = recon_main_blocks(a);
   const bool ssim = !(a.flags & SMD_LOSS_L1);
+  {  // guest blocks exist in the K0-fused single-pass instantiations only
+    const bool hot = ssim && a.first_pass && a.last_pass && a.warp0 == nullptr && a.noise == nullptr && a.depth_out != nullptr;
+    if (a.guest_blocks != 0 && !hot) return hipErrorInvalidValue;
+  }
+  dim3 grid((unsigned)(a.main_blocks + a.guest_blocks)), block(64*kWavesPerBlock);
   const bool single = a.first_pass && a.last_pass;
   const bool aux = a.warp0 != nullptr || a.noise != nullptr;
   const bool disp = a.depth_out != nullptr;     // K0 fused: only on the first pass over the supports, SSIM instantiations

@@ -9,9 +9,11 @@
 // in dhat, so sum_p (dE/ddhat_p) dhat_p = E and the mean-normalisation term of the adjoint needs only (mean, E):
 //   dL/dd_q = g_s/N * [ G_q / m  -  [mean >= eps] * E / (m * hs*ws) ],   G_q = dE/ddhat_q.
 #include <stdlib.h>
+#include <string.h>
 
 #include "smd_common.h"
 #include "smd_kernels.h"
+#include "smd_smooth_dev.h"
 
 namespace smd {
 
@@ -50,16 +52,6 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// Offset (in float2 units) of scale s in the per-pixel edge-weight buffer {exp(-|dI/dx|), exp(-|dI/dy|)}.
-__host__ __device__ inline size_t edge_offset(const ScaleSet& sc, int b, int s) {
-  size_t off = 0;
-  for (int k = 0; k < s; ++k) off += (size_t)b*sc.hs[k]*sc.ws[k];
-  return off;
-}
-
-// Offset (bytes) of the arrival counters behind the edge weights: [S*b] pairs + 1 (smd_disp_smooth_edge_weight_bytes).
-__host__ __device__ inline size_t edge_arrive_offset(const ScaleSet& sc, int b) { return (edge_offset(sc, b, sc.S)*sizeof(float2) + 255) & ~(size_t)255; }
-
 // Frame-only half (round 4): the edge weights {exp(-mean_c |dI/dx|), exp(-mean_c |dI/dy|)} of every pyramid level depend on the target
 // frames alone — `SmoothReg` resizes the image to each level and differentiates it (src/core/handlers.py:272-277, smooth.py:12-30,
 // 91-94) — so they are computed by a launch of their own that the trainer enqueues with the reconstruction's frame-only prep, under
@@ -71,7 +63,7 @@ __global__ __launch_bounds__(256) void k_smooth_edges(const ScaleSet sc, int b, 
                                                       unsigned* __restrict__ arrive) {
   const int s = sc.S - 1 - (int)blockIdx.z, bi = blockIdx.y;   // coarse scales first (few pixels, strided taps: the longest latency chains)
   if (arrive != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-    for (int e = threadIdx.x; e < sc.S*b + 1; e += 256) arrive[e] = 0u;
+    for (int e = threadIdx.x; e < sc.S*b + 2; e += 256) arrive[e] = 0u;   // pairs, pairs done, loss combination (fused loss path)
   const int lane = threadIdx.x & 63, unit = blockIdx.x*4 + (threadIdx.x >> 6);
   const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
   if (unit >= smooth_units_of(hs, ws)) return;
@@ -128,112 +120,8 @@ __global__ __launch_bounds__(256) void k_smooth_edges(const ScaleSet sc, int b, 
   }
 }
 
-// The sweep over the disparities: per wave, partial sums of the UN-normalised edge energy E' = sum w |d_p - d_q| and of d itself.
-// Because dhat = d / m with one m > 0 per image, E = E' / m: the mean is not needed inside the pixel loop, so the reference's
-// mean pass and its stencil pass collapse into one sweep.  A wave owns 63 columns + one halo lane and kSmoothRows rows: one
-// disparity load and one 8-byte weight load per row, all in flight together; `edge_w` null = no edge weighting (weights 1).
-//
-// `arrive` != null: the second stage runs inside this launch (round 3; the former k_smooth_finalize launch) as a chain of wave-level
-// hand-offs without a block barrier (cdna_hip_programming.md, Guideline 16): a wave publishes its partial write-through and
-// drains; the LAST wave of a block counts the block's arrival for its (scale, sample) pair; the wave that completes a pair
-// reduces it to (mean, E) -> stats and publishes the pair's share of the loss; the wave that completes the last pair adds
-// the shares up in a fixed order.  fp64, deterministic whichever waves end up doing it.
-//   arrive[0 .. S*b): arrival counters of the pairs, arrive[S*b]: pairs done (zeroed by k_smooth_edges, reset by their last arrivers)
-//   contrib: [S*b] doubles behind the partials in the workspace
-__global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const float* __restrict__ edge_w, float* partial, int max_units,
-                                                     float* stats, float* loss, unsigned* arrive, double* contrib) {
-  // 1-D grid of exactly the blocks that have work: for s = S-1 .. 0 (coarse scales first), for each sample, ceil(units_s / 4) blocks
-  int s = sc.S - 1, blk = (int)blockIdx.x;
-  for (; s > 0; --s) { const int nb = ceil_div(smooth_units_main(sc.hs[s], sc.ws[s]), 4)*b; if (blk < nb) break; blk -= nb; }
-  const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
-  const int units = smooth_units_main(hs, ws), bpi = ceil_div(units, 4);
-  const int bi = blk/bpi, bx = blk - bi*bpi;
-  const int lane = threadIdx.x & 63, unit = bx*4 + (threadIdx.x >> 6);
-  __shared__ unsigned waves_done;
-  if (arrive != nullptr) {            // the only block barrier: at the start, where every wave still is
-    if (threadIdx.x == 0) waves_done = 0u;
-    __syncthreads();
-  }
-  if (unit >= units) return;
-  {
-  const int nsx = (ws + kSmoothCols - 1)/kSmoothCols;
-  const int sxi = unit % nsx, syi = unit/nsx;
-  const int r0 = syi*kSmoothRowsMain, r1 = min(r0 + kSmoothRowsMain, hs);
-  const int u = sxi*kSmoothCols + lane, uc = min(u, ws - 1);        // lanes right of the image repeat its last column: |d - d| = 0
-  const bool live = lane < kSmoothCols && u < ws;
-  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
-  const float2* __restrict__ ew = edge_w ? (const float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
-  float dr_[kSmoothRowsMain + 1];
-  float2 wr_[kSmoothRowsMain];
-#pragma unroll
-  for (int k = 0; k <= kSmoothRowsMain; ++k) dr_[k] = d[(size_t)min(r0 + k, hs - 1)*ws + uc];   // the last image row pairs with itself
-#pragma unroll
-  for (int k = 0; k < kSmoothRowsMain; ++k) wr_[k] = ew ? ew[(size_t)min(r0 + k, hs - 1)*ws + uc] : make_float2(1.f, 1.f);
-  float accE = 0.f, accD = 0.f;
-#pragma unroll
-  for (int k = 0; k < kSmoothRowsMain; ++k) {
-    const float cur = dr_[k], right = lane_right(cur);
-    if (live && r0 + k < r1) {
-      accD += cur;
-      accE += fabsf(cur - right)*wr_[k].x + fabsf(cur - dr_[k + 1])*wr_[k].y;
-    }
-  }
-  const float totE = wave_sum(accE), totD = wave_sum(accD);
-  if (lane == 0) {   // published write-through (agent scope): the block that arrives last reads every partial in this launch
-    unsigned long long* pp = (unsigned long long*)partial + ((size_t)s*b + bi)*max_units + unit;
-    __hip_atomic_store(pp, ((unsigned long long)__builtin_bit_cast(unsigned, totD) << 32) | __builtin_bit_cast(unsigned, totE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  }
-  if (arrive == nullptr) return;      // two-launch form: k_smooth_finalize follows
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const int pair = s*b + bi, npairs = sc.S*b;
-  const unsigned live = (unsigned)min(4, units - bx*4);
-  unsigned flag = 0;
-  if (lane == 0) {
-    if (__hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == live - 1u)
-      flag = (__hip_atomic_fetch_add(arrive + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ceil_div(units, 4) - 1u) ? 1u : 0u;
-  }
-  if (!__builtin_amdgcn_readfirstlane((int)flag)) return;
-  SMD_TAIL_ACQUIRE();
-  {  // this wave completed the pair: (mean, E) and the pair's share of the loss
-    double e = 0.0, dsum = 0.0;
-    const unsigned long long* pp = (const unsigned long long*)partial + (size_t)pair*max_units;
-    auto ldp = [&](int c, double& ee, double& dd) {
-      const unsigned long long v = __hip_atomic_load(pp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ee += (double)__builtin_bit_cast(float, (unsigned)v); dd += (double)__builtin_bit_cast(float, (unsigned)(v >> 32));
-    };
-    int c = lane;
-    for (; c + 192 < units; c += 256) {   // four independent loads in flight; the order of the additions is fixed
-      double e0 = 0, d0 = 0, e1 = 0, d1 = 0, e2 = 0, d2 = 0, e3 = 0, d3 = 0;
-      ldp(c, e0, d0); ldp(c + 64, e1, d1); ldp(c + 128, e2, d2); ldp(c + 192, e3, d3);
-      e += (e0 + e1) + (e2 + e3); dsum += (d0 + d1) + (d2 + d3);
-    }
-    for (; c < units; c += 64) ldp(c, e, dsum);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); dsum += __shfl_xor(dsum, off, 64); }
-    const float mean = (float)(dsum/n);
-    const float E = (float)(e/(double)fmaxf(mean, kEps32));
-    flag = 0;
-    if (lane == 0) {
-      stats[(size_t)pair*2] = mean; stats[(size_t)pair*2 + 1] = E;
-      const double share = ldexp((double)E/((double)b*n), -sc.key[s]);   // 2^-key exactly, without the double-precision exp2 routine
-      __hip_atomic_store((unsigned long long*)contrib + pair, __builtin_bit_cast(unsigned long long, share), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(arrive + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the slot is free again
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      flag = (__hip_atomic_fetch_add(arrive + npairs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)npairs - 1u) ? 1u : 0u;
-    }
-  }
-  if (!__builtin_amdgcn_readfirstlane((int)flag)) return;
-  SMD_TAIL_ACQUIRE();
-  double total = 0.0;
-  for (int q = lane; q < npairs; q += 64) total += __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)contrib + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-  if (lane == 0) {
-    loss[0] = (float)(total/sc.S);
-    __hip_atomic_store(arrive + npairs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
+// The sweep over the disparities as a kernel of its own (body: smd_smooth_dev.h).
+__global__ __launch_bounds__(256) void k_smooth_main(const ScaleSet sc, int b, const SmoothFwdJob jb) { smooth_main_block(sc, b, jb, (int)blockIdx.x); }
 
 // Second stage as a launch of its own (used when the pyramid has more (scale, sample) pairs than arrival slots): per image mean m
 // and E = E'/max(m, eps) -> stats; loss = mean_s( 2^-key_s * sum_b E / (b*hs*ws) ).  One wave per pair, 16 waves, one block.
@@ -481,7 +369,21 @@ hipError_t launch_smooth_edges(const ScaleSet& sc, int b, const float* img, int 
   hipLaunchKernelGGL(k_smooth_edges, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, edge_w, (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)));
   return hipGetLastError();
 }
-size_t smooth_edge_bytes(const ScaleSet& sc, int b) { return edge_arrive_offset(sc, b) + ((((size_t)sc.S*b + 1)*sizeof(unsigned) + 255) & ~(size_t)255); }
+size_t smooth_edge_bytes(const ScaleSet& sc, int b) { return edge_arrive_offset(sc, b) + ((((size_t)sc.S*b + 2)*sizeof(unsigned) + 255) & ~(size_t)255); }
+
+// The sweep's partials [S*b][max_units] pairs + [S*b] doubles in `ws_sums` (smd_disp_smooth_workspace_bytes), its counters behind the edge weights.
+void smooth_fwd_job(const ScaleSet& sc, int b, float* loss, float* stats, float* ws_sums, float* edge_w, SmoothFwdJob* job) {
+  int max_chunks = 1;   // units (waves) of the largest scale; the partial sums of a (scale, sample) are strided by it
+  for (int s = 0; s < sc.S; ++s) max_chunks = max(max_chunks, smooth_units_of(sc.hs[s], sc.ws[s]));
+  memset(job, 0, sizeof(*job));
+  job->edge_w = edge_w; job->partial = ws_sums; job->max_units = max_chunks; job->stats = stats; job->loss = loss;
+  job->arrive = edge_w ? (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)) : nullptr;
+  job->contrib = (double*)(ws_sums + (size_t)sc.S*b*max_chunks*2);
+}
+hipError_t launch_smooth_main(const ScaleSet& sc, int b, const SmoothFwdJob& job, hipStream_t st) {
+  hipLaunchKernelGGL(k_smooth_main, dim3(smooth_main_blocks(sc, b)), dim3(256), 0, st, sc, b, job);
+  return hipGetLastError();
+}
 
 hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, float* loss, float* stats,
                              float* disp_grad, float* image_grad, float* ws_sums, float* edge_w, bool edges_ready, hipStream_t st) {
@@ -509,12 +411,11 @@ hipError_t launch_smooth_fwd(const ScaleSet& sc, int b, const float* img, int h,
   { static const char* chain = getenv("SMD_SMOOTH_CHAIN"); if (chain && atoi(chain) == 0) arrive = nullptr; }
 #endif
   if (edges && !edges_ready) hipLaunchKernelGGL(k_smooth_edges, dim3(ceil_div(max_chunks, 4), b, sc.S), dim3(256), 0, st, sc, b, img, h, w, edge_w, (unsigned*)((char*)edge_w + edge_arrive_offset(sc, b)));
-  double* contrib = (double*)(ws_sums + (size_t)sc.S*b*max_chunks*2);
-  int main_blocks = 0;
-  for (int s = 0; s < sc.S; ++s) main_blocks += ceil_div(smooth_units_main(sc.hs[s], sc.ws[s]), 4)*b;
-  hipLaunchKernelGGL(k_smooth_main, dim3(main_blocks), dim3(256), 0, st, sc, b, edges ? edge_w : nullptr, ws_sums, max_chunks,
-                     stats, loss, arrive, contrib);
-  if (!arrive) hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, max_chunks, stats, loss, 0);
+  SmoothFwdJob job;
+  smooth_fwd_job(sc, b, loss, stats, ws_sums, edges ? edge_w : nullptr, &job);
+  job.arrive = arrive;
+  hipLaunchKernelGGL(k_smooth_main, dim3(smooth_main_blocks(sc, b)), dim3(256), 0, st, sc, b, job);
+  if (!arrive) hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(1024), 0, st, sc, b, ws_sums, job.max_units, stats, loss, 0);
   if (disp_grad || image_grad)
     hipLaunchKernelGGL(k_smooth_aux, dim3(min(ceil_div(sc.hs[0]*sc.ws[0], 256), 480), b), dim3(256), 0, st, sc, b, img, h, w, stats, disp_grad, image_grad);
   return hipGetLastError();
@@ -589,61 +490,17 @@ __global__ __launch_bounds__(256) void k_smooth_bwd(const ScaleSet sc, int b, co
   }
 }
 
-// Streaming adjoint (round 4): a wave owns 62 columns (+ one halo lane on each side) and kSmoothRowsMain rows.  With
-//   t_x(v,u) = w_x(v,u) sg(dhat(v,u) - dhat(v,u+1))  (0 in the last column),   t_y(v,u) = w_y(v,u) sg(dhat(v,u) - dhat(v+1,u))  (0 in the last row)
-// the gradient of E' is G(v,u) = t_x(v,u) - t_x(v,u-1) + t_y(v,u) - t_y(v-1,u): per row ONE disparity load and ONE 8-byte weight load (all of a
-// unit's rows requested up front), the horizontal neighbours by DPP, the vertical ones from the previous / next row's registers — the
-// per-pixel form gathered 5 disparities and 3 weight pairs per pixel (12.7 -> ~9 us at cfg 2).  Same values: sg() of the same differences.
-constexpr int kSmoothBwdCols = 62;
-__host__ __device__ inline int smooth_units_bwd(int hs, int ws) { return ((ws + kSmoothBwdCols - 1)/kSmoothBwdCols)*((hs + kSmoothRowsMain - 1)/kSmoothRowsMain); }
-
-__global__ __launch_bounds__(256) void k_smooth_bwd_stream(const ScaleSet sc, int b, const float* __restrict__ stats, const float* __restrict__ g_loss,
-                                                           const float* __restrict__ edge_w) {
+// Streaming adjoint as a kernel of its own (body: smd_smooth_dev.h): 1-D grid, coarse scales first, ceil(units / 4) blocks per (scale, sample).
+__global__ __launch_bounds__(256) void k_smooth_bwd_stream(const ScaleSet sc, int b, const float* __restrict__ stats, const float* __restrict__ g_loss, float g_scale,
+                                                           const float* __restrict__ edge_w, int accumulate_scale) {
   int s = sc.S - 1, blk = (int)blockIdx.x;
   for (; s > 0; --s) { const int nb = ceil_div(smooth_units_bwd(sc.hs[s], sc.ws[s]), 4)*b; if (blk < nb) break; blk -= nb; }
-  const int hs = sc.hs[s], ws = sc.ws[s], n = hs*ws;
-  const int units = smooth_units_bwd(hs, ws), bpi = ceil_div(units, 4);
-  const int bi = blk/bpi, bx = blk - bi*bpi;
-  const int lane = threadIdx.x & 63, unit = bx*4 + (threadIdx.x >> 6);
-  if (unit >= units) return;
-  const int nsx = (ws + kSmoothBwdCols - 1)/kSmoothBwdCols;
-  const int sxi = unit % nsx, syi = unit/nsx;
-  const int r0 = syi*kSmoothRowsMain, r1 = min(r0 + kSmoothRowsMain, hs);
-  const int u = sxi*kSmoothBwdCols - 1 + lane, uc = min(max(u, 0), ws - 1);
-  const bool store = lane >= 1 && lane <= kSmoothBwdCols && u < ws;
-  const float* __restrict__ d = sc.p[s] + (size_t)bi*n;
-  float* __restrict__ gd = sc.g[s] + (size_t)bi*n;
-  const float2* __restrict__ ew = edge_w ? (const float2*)edge_w + edge_offset(sc, b, s) + (size_t)bi*n : nullptr;
-  const float mean = stats[((size_t)s*b + bi)*2], E = stats[((size_t)s*b + bi)*2 + 1];
-  const float m = fmaxf(mean, kEps32), inv_m = 1.f/m;
-  const float gs = g_loss[0]*exp2f(-(float)sc.key[s])/((float)sc.S*(float)b*(float)n);
-  const float mean_term = (mean >= kEps32) ? E*inv_m/(float)n : 0.f;
-  auto sg = [](float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); };
-  // rows r0-1 .. r0+R (clamped into the image; out-of-image terms are masked below)
-  float dr_[kSmoothRowsMain + 2];
-  float2 wr_[kSmoothRowsMain + 1];
-#pragma unroll
-  for (int k = 0; k < kSmoothRowsMain + 2; ++k) dr_[k] = d[(size_t)min(max(r0 - 1 + k, 0), hs - 1)*ws + uc]*inv_m;
-#pragma unroll
-  for (int k = 0; k < kSmoothRowsMain + 1; ++k) wr_[k] = ew ? ew[(size_t)min(max(r0 - 1 + k, 0), hs - 1)*ws + uc] : make_float2(1.f, 1.f);
-  const bool has_right = u >= 0 && u < ws - 1;           // t_x exists for columns 0 .. ws-2 (a halo lane left of the image holds none)
-  // t_y of the row above the unit
-  float ty_prev = (r0 > 0) ? wr_[0].y*sg(dr_[0] - dr_[1]) : 0.f;
-#pragma unroll
-  for (int k = 0; k < kSmoothRowsMain; ++k) {
-    const int v = r0 + k;
-    const float dc = dr_[k + 1], right = lane_right(dc);
-    const float tx = has_right ? wr_[k + 1].x*sg(dc - right) : 0.f;
-    const float tx_l = lane_left(tx);
-    const float ty = (v < hs - 1) ? wr_[k + 1].y*sg(dc - dr_[k + 2]) : 0.f;
-    const float G = (tx - tx_l) + (ty - ty_prev);
-    ty_prev = ty;
-    if (store && v < r1) gd[(size_t)v*ws + u] = gs*(G*inv_m - mean_term);
-  }
+  const int bpi = ceil_div(smooth_units_bwd(sc.hs[s], sc.ws[s]), 4);
+  smooth_bwd_block(sc, b, s, blk/bpi, blk % bpi, stats, g_loss, g_scale, edge_w, s == accumulate_scale);
 }
 
 hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h, int w, int flags, const float* stats,
-                             const float* g_loss, const float* edge_w, hipStream_t st) {
+                             const float* g_loss, const float* edge_w, hipStream_t st, float g_scale, int accumulate_scale) {
   if (flags & SMD_USE_LAPLACIAN) {
     int mu = 1;
     for (int s = 0; s < sc.S; ++s) mu = max(mu, ceil_div(sc.hs[s]*sc.ws[s], 256));
@@ -653,7 +510,7 @@ hipError_t launch_smooth_bwd(const ScaleSet& sc, int b, const float* img, int h,
   if (!(flags & SMD_USE_EDGES) || edge_w) {   // the streaming adjoint reads the cached weights (or none); the per-pixel form below re-derives them from the image
     int blocks = 0;
     for (int s = 0; s < sc.S; ++s) blocks += ceil_div(smooth_units_bwd(sc.hs[s], sc.ws[s]), 4)*b;
-    hipLaunchKernelGGL(k_smooth_bwd_stream, dim3(blocks), dim3(256), 0, st, sc, b, stats, g_loss, (flags & SMD_USE_EDGES) ? edge_w : nullptr);
+    hipLaunchKernelGGL(k_smooth_bwd_stream, dim3(blocks), dim3(256), 0, st, sc, b, stats, g_loss, g_scale, (flags & SMD_USE_EDGES) ? edge_w : nullptr, accumulate_scale);
     return hipGetLastError();
   }
   int max_chunks = 1;

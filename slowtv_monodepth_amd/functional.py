@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, SEL_MASKED, int_array, ptr_array
 from ._lib import call as _raw_call
 
-__all__ = ['crop_resize', 'disp_to_depth', 'image_recon_prep', 'PreparedFrames', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
+__all__ = ['loss_path_fused', 'crop_resize', 'disp_to_depth', 'image_recon_prep', 'PreparedFrames', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
            'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'layer_norm_cf', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
@@ -462,6 +462,107 @@ def disp_smooth_fused(disps: dict, imgs, *, use_edges: bool = False, want_aux: b
     keys = [int(k) for k in disps.keys()]
     flags = (FLAGS['use_edges'] if use_edges else 0) | (FLAGS['use_laplacian'] if use_laplacian else 0)
     return _DispSmooth.apply(imgs, flags, keys, want_aux, prepared, *disps.values())
+
+
+# ---------------------------------------------------------------------------------------------------
+class _LossPath(torch.autograd.Function):
+    """`forward_loss` of the kbr configuration as ONE autograd node (round 5): `handlers.image_recon` (K0 fused) + `handlers.disp_smooth`
+    (first-order, edge-aware) + the weighted sum (src/core/trainer.py:383-392, 436-437, 462-464), and in the backward the chain rule through
+    the pose / intrinsics prologue (:250-262) when its leaves are given.  `smd_loss_path_fwd/_bwd`: 1 + 3 launches."""
+
+    @staticmethod
+    def forward(ctx, tgt, supp, T, K, K_inv, aa, t, invert, fs, cs, seed, flags, min_depth, max_depth, keys, prepared, w_rec, w_sm, *disps):
+        b, _, h, w = tgt.shape
+        n, S = supp.shape[0], len(disps)
+        tgt_in, supp_in = tgt, supp
+        tgt = _check('imgs', tgt, (b, 3, h, w)); supp = _check('supp_imgs', supp, (n, b, 3, h, w)); T = _check('Ts', T, (n, b, 4, 4))
+        K = _check('Ks', K, (b, 4, 4)); K_inv = _check('K_inv', K_inv, (b, 4, 4))
+        disps = [_check(f'disp[{i}]', d) for i, d in enumerate(disps)]
+        for d in disps:
+            if d.ndim != 4 or d.shape[0] != b or d.shape[1] != 1: raise ValueError(f'disparities must be (b,1,hs,ws), got {tuple(d.shape)}')
+        if aa is not None:
+            aa = _check('aa', aa, (n*b, 3)); t = _check('t', t, (n*b, 3))
+            if invert is not None and (invert.dtype != torch.uint8 or tuple(invert.shape) != (n*b,)): raise ValueError('invert must be uint8 (n*b,)')
+        if fs is not None: fs = _check('fs', fs, (b, 2)); cs = _check('cs', cs, (b, 2))
+        hs, ws = [d.shape[2] for d in disps], [d.shape[3] for d in disps]
+        hs_a, ws_a, keys_a = int_array(hs), int_array(ws), int_array(keys)
+        dev = tgt.device
+        depth_up = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.float32)
+        sel = torch.empty((S, b, 1, h, w), device=dev, dtype=torch.uint8)
+        loss3 = torch.empty(3, device=dev, dtype=torch.float32)
+        stats = torch.empty((S, b, 2), device=dev, dtype=torch.float32)
+        nbytes = _lib.lib.smd_loss_path_workspace_bytes(hs_a, ws_a, S, b, n, h, w)
+        wsp = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+        packed, cflags = _packed_for(prepared, tgt_in, supp_in, flags, hs, ws, b, n, h, w, dev)
+        cflags |= FLAGS['use_edges']
+        ew = prepared.edges_for(tgt_in, hs, ws) if prepared is not None else None
+        if ew is not None:
+            ew.record_stream(torch.cuda.current_stream(dev))     # (the wait for `prepared.event` happened in _packed_for)
+            cflags |= FLAGS['edges_ready']
+        else: ew = torch.empty(_lib.lib.smd_disp_smooth_edge_weight_bytes(hs_a, ws_a, S, b), device=dev, dtype=torch.uint8)
+        call('smd_loss_path_fwd', ptr_array([d.data_ptr() for d in disps]), hs_a, ws_a, keys_a, S, float(min_depth or 0), float(max_depth or 0),
+             tgt.data_ptr(), supp.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(), int(seed) & (2**64 - 1), packed.data_ptr(), ew.data_ptr(),
+             depth_up.data_ptr(), sel.data_ptr(), loss3.data_ptr(), stats.data_ptr(), wsp.data_ptr(), nbytes, b, n, h, w, cflags, float(w_rec), float(w_sm), _stream())
+        ctx.save_for_backward(depth_up, packed, T, K, K_inv, sel, stats, ew, aa, t, invert, fs, cs, *disps)
+        ctx.set_materialize_grads(False)
+        ctx.meta = (b, n, S, h, w, int(flags), hs, ws, list(keys), float(min_depth or 0), float(max_depth or 0), float(w_rec), float(w_sm))
+        ctx.need_k = bool(fs is not None or ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        total, l_rec, l_sm = loss3[0], loss3[1], loss3[2]
+        ctx.mark_non_differentiable(l_rec, l_sm, sel)
+        return total, l_rec, l_sm, sel, depth_up
+
+    @staticmethod
+    def backward(ctx, g_loss, _g1, _g2, _gs, g_depth_up):
+        depth_up, packed, T, K, K_inv, sel, stats, ew, aa, t, invert, fs, cs, *disps = ctx.saved_tensors
+        b, n, S, h, w, flags, hs, ws, keys, mn, mx, w_rec, w_sm = ctx.meta
+        dev = _on(depth_up)
+        if g_depth_up is not None: raise NotImplementedError('loss_path_fused: `depth_up` has another differentiable consumer; use image_recon_fused_disp + disp_smooth_fused')
+        g_loss = (g_loss if g_loss is not None else torch.zeros((), device=dev)).to(torch.float32).contiguous()
+        g_disps = [torch.empty((b, 1, hs[s], ws[s]), device=dev, dtype=torch.float32) for s in range(S)]
+        g_T = torch.empty((n, b, 4, 4), device=dev, dtype=torch.float32)
+        g_K = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
+        g_Ki = torch.empty((b, 4, 4), device=dev, dtype=torch.float32) if ctx.need_k else None
+        g_aa = torch.empty_like(aa) if aa is not None else None
+        g_t = torch.empty_like(t) if aa is not None else None
+        g_fs = torch.empty_like(fs) if fs is not None else None
+        g_cs = torch.empty_like(cs) if fs is not None else None
+        cflags = flags | FLAGS['use_edges'] | (FLAGS['need_k_grad'] if ctx.need_k else 0)
+        hs_a, ws_a, keys_a = int_array(hs), int_array(ws), int_array(keys)
+        nbytes = _lib.lib.smd_loss_path_workspace_bytes(hs_a, ws_a, S, b, n, h, w)
+        wsp = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+        tuner = row_skip_tuner(dev); tflag, token = tuner.begin(dev)
+        P = lambda x: x.data_ptr() if x is not None else None
+        call('smd_loss_path_bwd', ptr_array([d.data_ptr() for d in disps]), hs_a, ws_a, keys_a, S, mn, mx, depth_up.data_ptr(), packed.data_ptr(), T.data_ptr(),
+             K.data_ptr(), K_inv.data_ptr(), sel.data_ptr(), stats.data_ptr(), ew.data_ptr(), g_loss.data_ptr(), w_rec, w_sm,
+             P(aa), P(t), P(invert), P(fs), P(cs), ptr_array([g.data_ptr() for g in g_disps]), g_T.data_ptr(), P(g_K), P(g_Ki), P(g_aa), P(g_t), P(g_fs), P(g_cs),
+             wsp.data_ptr(), nbytes, b, n, h, w, cflags | tflag, _stream())
+        tuner.end(token)
+        need = ctx.needs_input_grad
+        return (None, None, (g_T if need[2] else None), (g_K if need[3] else None), (g_Ki if need[4] else None), g_aa, g_t, None, g_fs, g_cs,
+                None, None, None, None, None, None, None, None, *g_disps)
+
+
+def loss_path_fused(disps: dict, imgs, supp_imgs, Ts, Ks, K_inv=None, *, pose=None, intrinsics=None, flags: int, min_depth=None, max_depth=None,
+                    seed: int = 0, w_recon: float = 1.0, w_smooth: float = 0.001, prepared: PreparedFrames | None = None):
+    """`forward_loss` with `img_recon` + `disp_smooth(use_edges=True)` as one operator:
+        -> (loss = w_recon*l_recon + w_smooth*l_smooth, l_recon, l_smooth, sel (S,b,1,h,w) uint8, depth_up (S,b,1,h,w)).
+
+    disps {key: (b,1,hs,ws)} sigmoid disparities (key = the `s` of `loss_s / 2**s`); Ts (n,b,4,4), Ks (b,4,4) [, K_inv].
+    `pose=(aa, t, invert)`: the (n*b,3) leaves `Ts` was built from with `pose_matrices` — then `Ts` is taken as a value and the backward hands the
+    gradients to `aa` and `t` directly (no `pose_matrices` backward launch); likewise `intrinsics=(fs, cs)` for `Ks`, `K_inv` from `intrinsics`.
+    Raises `_lib.Unsupported` for what the operator does not serve (see include/smd_hotpath.h); `depth_up` must not have another
+    differentiable consumer."""
+    if min_depth is not None and min_depth <= 0: raise ValueError(f'Min depth must be greater than 0. ({min_depth})')
+    if max_depth and min_depth and max_depth < min_depth: raise ValueError(f'Max depth must be greater than min. ({max_depth} vs. {min_depth})')
+    aa, t, inv = pose if pose is not None else (None, None, None)
+    fs, cs = intrinsics if intrinsics is not None else (None, None)
+    if pose is not None: Ts = Ts.detach()
+    if intrinsics is not None:
+        if K_inv is None: raise ValueError('intrinsics=(fs, cs) goes with the K, K_inv that `functional.intrinsics(fs, cs, size)` returned')
+        Ks, K_inv = Ks.detach(), K_inv.detach()
+    if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else inv_intrinsics(Ks)
+    keys = [int(k) for k in disps.keys()]
+    return _LossPath.apply(imgs, supp_imgs, Ts, Ks, K_inv, aa, t, inv, fs, cs, seed, flags, min_depth, max_depth, keys, prepared, w_recon, w_smooth, *disps.values())
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -59,16 +59,20 @@ class HipLossBackend:
         return F.image_recon_prep(imgs, supp_imgs, flags=F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask), pyramid=pyramid, stream=stream,
                                   smooth_edges=smooth_edges)
 
+    def invert_mask(self, invert, device):
+        """python bool list -> cached uint8 device tensor (None if no pose is inverted): the same flags every step, so the device copy is kept
+        (and no host-to-device copy happens inside a HIP-graph capture)."""
+        if not any(invert): return None
+        key = (tuple(invert), device)
+        cache = self.__dict__.setdefault('_invert_masks', {})
+        inv = cache.get(key)
+        if inv is None: inv = cache[key] = torch.tensor(list(invert), dtype=torch.uint8).to(device)
+        return inv
+
     def pose_matrices(self, aa, t, invert):
         """(N,3),(N,3) + python bool list -> (N,4,4); one launch for Rodrigues + the backward-in-time inverses."""
         from . import functional as F
-        inv = None
-        if any(invert):   # the same flags every step: keep the device copy (and no host-to-device copy inside a HIP-graph capture)
-            key = (tuple(invert), aa.device)
-            cache = self.__dict__.setdefault('_invert_masks', {})
-            inv = cache.get(key)
-            if inv is None: inv = cache[key] = torch.tensor(invert, dtype=torch.uint8).to(aa.device)
-        return F.pose_matrices(aa.float(), t.float(), inv)
+        return F.pose_matrices(aa.float(), t.float(), self.invert_mask(invert, aa.device))
 
     def intrinsics(self, fs, cs, size):
         from . import functional as F
@@ -77,6 +81,27 @@ class HipLossBackend:
     def disp_smooth(self, crit, disps, imgs, want_aux=True, prepared=None):
         from . import handlers
         return handlers.disp_smooth(crit, {k: d.float() for k, d in disps.items()}, imgs, want_aux=want_aux, prepared=prepared)
+
+    def loss_path(self, crit, reg, depths, disps, imgs, supp_imgs, Ts, Ks, K_inv, w_recon, w_smooth, pose=None, intrinsics=None, prepared=None):
+        """`img_recon` + `disp_smooth` + their weighted sum as ONE autograd node (`functional.loss_path_fused`: 1 launch forward, 3 backward).
+        -> (loss, l_recon, l_smooth), or None when the operator does not serve this configuration (the caller then runs the two handlers)."""
+        from . import functional as F
+        from ._lib import Unsupported
+        from .handlers import LazyDepths
+        if not (isinstance(depths, LazyDepths) and depths.pending and imgs.is_cuda and imgs.shape[1] == 3 and imgs.dtype == torch.float32): return None
+        if crit.loss_name != 'ssim' or getattr(crit, 'mask_name', None): return None
+        if not reg.use_edges or getattr(reg, 'use_laplacian', False) or getattr(reg, 'use_blur', False): return None
+        flags = F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask)
+        dl = [d.float() for d in depths.disps]
+        if prepared is not None and not prepared.matches(imgs, supp_imgs, flags, [d.shape[-2] for d in dl], [d.shape[-1] for d in dl]): prepared = None
+        try:
+            loss, l_rec, l_sm, _sel, depth_up = F.loss_path_fused(dict(zip(depths.keys_, dl)), imgs, supp_imgs, Ts.float(), Ks.float(), K_inv, pose=pose, intrinsics=intrinsics,
+                                                                  flags=flags, min_depth=depths.min_depth, max_depth=depths.max_depth, seed=crit.next_seed(),
+                                                                  w_recon=w_recon, w_smooth=w_smooth, prepared=prepared)
+        except Unsupported:
+            return None
+        depths.adopt(depth_up.detach())    # `fwd['depth_up']` for later readers (metrics, logging); no differentiable consumer may follow
+        return loss, l_rec, l_sm
 
 
 class EventTimer:
@@ -118,6 +143,7 @@ class MonoDepthModule(nn.Module):
         self.nets = parsers.get_net(cfg['net'])
         self.losses, self.weights = parsers.get_loss(copy.deepcopy(cfg['loss']))
         self.backend = loss_backend or HipLossBackend()
+        self._w = {k: float(v) for k, v in self.weights.items()}   # the frozen loss weights as host numbers (read once, here, while they are on the CPU)
         # Losses whose inputs only networks outside this package produce (the autoencoder network and the
         # virtual-stereo decoder head are out of scope; their handlers and criteria exist and are parity-tested on their own):
         # refuse at construction instead of failing with a KeyError in the middle of the first step.
@@ -191,6 +217,7 @@ class MonoDepthModule(nn.Module):
                             if self._K_inv is not None: self._K_inv.record_stream(main)
                 if side is not None:
                     for v in produced.values(): v.record_stream(main)
+                    for v in (getattr(self, '_pose_leaves', None) or ())[:2]: v.record_stream(main)   # read by the loss path's backward on the main stream
                 fwd.update(produced)
             else:
                 raise KeyError(f'Unrecognized key: {key}.')
@@ -209,7 +236,9 @@ class MonoDepthModule(nn.Module):
         pose = {k: v.float() for k, v in pose.items()}
         idxs = [i for i in idxs_all if i != 0]
         flags = [bool(inv(i)) for i in idxs for _ in range(sh[1])]
-        Ts = self.backend.pose_matrices(pose['R'][:, 0], pose['t'][:, 0], flags).unflatten(0, sh)
+        aa, tr = pose['R'][:, 0], pose['t'][:, 0]
+        Ts = self.backend.pose_matrices(aa, tr, flags).unflatten(0, sh)
+        self._pose_leaves = (aa, tr, flags, idxs)   # for the fused loss path: its backward hands the gradients to the network's outputs directly
         for i, T in zip(idxs, Ts): out[f'T_{i}'] = T
         if 'fs' in pose:
             out['fs'], out['cs'] = pose['fs'].unflatten(0, sh), pose['cs'].unflatten(0, sh)
@@ -228,6 +257,8 @@ class MonoDepthModule(nn.Module):
     def forward_loss(self, fwd: dict, x: dict, y: dict):
         """Weighted sum of the configured losses (src/core/trainer.py:350-472); `loss_dict['loss_<k>']` per loss."""
         loss, loss_dict = 0., {}
+        fused = self._forward_loss_fused(fwd, x, y)
+        if fused is not None: return fused
         for k, crit in self.losses.items():
             with self.timer(f'Loss-{k}'):
                 if k == 'img_recon':
@@ -266,6 +297,28 @@ class MonoDepthModule(nn.Module):
             loss_dict.update(ld)
         return loss, loss_dict
 
+    def _forward_loss_fused(self, fwd: dict, x: dict, y: dict):
+        """The kbr loss configuration — `img_recon` + `disp_smooth`, nothing else, no image logging — through ONE autograd node
+        (`HipLossBackend.loss_path`).  None: not that configuration / not served; `forward_loss` then runs the handlers one by one."""
+        fn = getattr(self.backend, 'loss_path', None)
+        if fn is None or self.want_aux or set(self.losses.keys()) != {'img_recon', 'disp_smooth'} or fwd.get('mask_up') is not None: return None
+        crit, reg = self.losses['img_recon'], self.losses['disp_smooth']
+        learned = 'K' in fwd
+        K_inv = fwd.get('K_inv') if learned else getattr(self, '_K_inv', None)
+        if K_inv is None and not learned and hasattr(self.backend, 'inv_intrinsics'): K_inv = self.backend.inv_intrinsics(y['K'])
+        pose, leaves = None, getattr(self, '_pose_leaves', None)
+        if leaves is not None and [int(i) for i in x['supp_idxs']] == list(leaves[3]):   # every support's pose is predicted (no stereo frame): Ts is exactly pose_matrices(aa, t)
+            inv = self.backend.invert_mask(leaves[2], leaves[0].device) if hasattr(self.backend, 'invert_mask') else None
+            pose = (leaves[0].float(), leaves[1].float(), inv)
+        intr = (fwd['fs'][0].float(), fwd['cs'][0].float()) if (learned and 'fs' in fwd and K_inv is not None) else None
+        with self.timer('Loss-img_recon'):
+            out = fn(crit, reg, fwd['depth_up'], fwd['disp'], y['imgs'], y['supp_imgs'], fwd['Ts'], fwd.get('K', y['K']), K_inv,
+                     self._w['img_recon'], self._w['disp_smooth'], pose=pose, intrinsics=intr, prepared=self._prepared)
+        if out is None: return None
+        loss, l_rec, l_sm = out
+        ld = {'loss_img_recon': l_rec, 'loss_disp_smooth': l_sm}
+        return loss, {f'loss_{k}': ld[f'loss_{k}'] for k in self.losses}
+
     def step(self, batch, mode: str = 'train'):
         """One forward pass + losses (src/core/trainer.py:115-190) -> (loss, loss_dict, fwd)."""
         if mode == 'train':   # `training_step`: `batch = self.ar_aug(batch)` on every step (trainer.py:106) — at p = 0 it only draws `random.random()`
@@ -274,7 +327,7 @@ class MonoDepthModule(nn.Module):
         x, y, m = batch
         self.synth = ViewSynth(x['imgs'].shape[-2:])
         self._prepared = self._prepare_frames(y) if self.prep_ahead == 'own' else None
-        self._y, self._K_inv = y, None
+        self._y, self._K_inv, self._pose_leaves = y, None, None
         try:
             with self.timer('Total'):
                 with self.timer('Forward'): fwd = self.forward(x)
@@ -283,7 +336,7 @@ class MonoDepthModule(nn.Module):
         finally:
             # the prep-ahead state belongs to THIS step: a later `module.forward(x)` (validation, inference) must neither launch the
             # prep for the previous batch nor keep that batch (and its 150 MB packed buffer) alive
-            self._y = self._prepared = self._K_inv = None
+            self._y = self._prepared = self._K_inv = self._pose_leaves = None
         return loss, loss_dict, fwd
 
     def _prepare_frames(self, y: dict, stream=None):

@@ -1591,3 +1591,97 @@ def test_aspect_ratio_aug_on_a_training_batch(F):
     loss, ld, fwd = m.step(batch, mode='train')
     loss.backward()
     assert torch.isfinite(loss).item() and len(batch[2]['augs']) == 2 and tuple(batch[0]['imgs'].shape[-2:]) == (96, 192)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Round 5: the whole loss path as ONE autograd node (smd_loss_path_fwd / _bwd)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('b,h,w,n,lows,learn_k,use_min,automask,prep', [
+    (3, 50, 130, 2, [(50, 130), (25, 65), (12, 32), (6, 16)], False, True, True, False),
+    (12, 192, 640, 2, [(192, 640), (96, 320), (48, 160), (24, 80)], False, True, True, True),      # cfg 2, frames prepared ahead
+    (2, 96, 200, 4, [(96, 200), (48, 100), (24, 50), (12, 25)], True, True, True, True),            # four supports, learned intrinsics
+    (2, 33, 47, 3, [(33, 47), (16, 23), (8, 11)], True, False, False, False),                       # mean over the supports, three levels
+    (1, 64, 300, 1, [(32, 150), (16, 75), (4, 19)], False, True, False, False),                     # no level of the image's size, one support
+    (2, 384, 640, 2, [(384, 640), (192, 320), (96, 160), (48, 80)], False, True, True, True)])      # cfg 4 / 5 size
+@pytest.mark.parametrize('guests', [1, 0])
+def test_single_node_loss_path_equals_the_two_handlers(F, knobs, b, h, w, n, lows, learn_k, use_min, automask, prep, guests):
+    """`functional.loss_path_fused` (one autograd node: the reconstruction launch carrying the smoothness sweep as guest blocks and forming the
+    weighted sum in-launch; the backward's pose epilogue continued to the pose network's outputs, the smoothness adjoint as guest blocks of
+    the K0 adjoint, which adds) against the separate operators it replaces — `pose_matrices` / `intrinsics`, `image_recon_fused_disp`,
+    `disp_smooth_fused`, `w_rec*l_rec + w_sm*l_sm` in eager mode and autograd's gradient additions.  Same kernels on the same operands:
+    l_rec, l_sm, the total, `sel`, `depth_up` and the disparity gradients must be BIT-equal; the pose / intrinsics leaves, whose adjoint is
+    compiled into another kernel (fp contraction may differ), to 1e-6 of the tensor's max.  `guests` = 0 (knob `loss_path_guests`) runs
+    the guest work as launches of its own: same bits again."""
+    from slowtv_monodepth_amd._lib import FLAGS
+    knobs('loss_path_guests', guests)
+    gen = torch.Generator(device='cuda').manual_seed(h*w + n)
+    imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
+    supp = (imgs[None] + 0.15*torch.randn(n, b, 3, h, w, device='cuda', generator=gen)).clamp(0, 1)
+    d0 = [0.05 + 0.9*torch.rand(b, 1, hs, ws, device='cuda', generator=gen) for hs, ws in lows]
+    keys = list(range(len(lows)))
+    aa0 = 0.01*torch.randn(n*b, 3, device='cuda', generator=gen); t0 = 0.05*torch.randn(n*b, 3, device='cuda', generator=gen)
+    inv = torch.tensor([i % 2 == 0 for i in range(n) for _ in range(b)], dtype=torch.uint8, device='cuda')
+    fs0 = torch.tensor([0.58, 1.92], device='cuda')[None].repeat(b, 1)*(1 + 0.05*torch.randn(b, 2, device='cuda', generator=gen))
+    cs0 = 0.5 + 0.03*torch.randn(b, 2, device='cuda', generator=gen)
+    K0 = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    flags = F.recon_flags('ssim', use_min, automask)
+    w_rec, w_sm = torch.tensor(1.0, device='cuda'), torch.tensor(0.001, device='cuda')
+    g_out = torch.tensor(0.5, device='cuda')            # an accumulation micro-step's 1/k
+
+    def leaves():
+        L = dict(d=[v.clone().requires_grad_(True) for v in d0], aa=aa0.clone().requires_grad_(True), t=t0.clone().requires_grad_(True))
+        if learn_k: L.update(fs=fs0.clone().requires_grad_(True), cs=cs0.clone().requires_grad_(True))
+        return L
+
+    def prepared():
+        return F.image_recon_prep(imgs, supp, flags=flags, pyramid=lows, smooth_edges=True) if prep else None
+
+    def two_nodes():
+        L = leaves()
+        Ts = F.pose_matrices(L['aa'], L['t'], inv).unflatten(0, (n, b))
+        K, K_inv = F.intrinsics(L['fs'], L['cs'], (h, w)) if learn_k else (K0, None)
+        pr = prepared()
+        l_rec, _, sel, _, dep = F.image_recon_fused_disp(L['d'], imgs, supp, Ts, K, K_inv, flags=flags, min_depth=0.1, max_depth=100, seed=11, want_err=False, prepared=pr)
+        l_sm, _, _ = F.disp_smooth_fused(dict(zip(keys, L['d'])), imgs, use_edges=True, want_aux=False, prepared=pr)
+        loss = 0. + w_rec*l_rec
+        loss = loss + w_sm*l_sm
+        loss.backward(g_out)
+        return loss.detach(), l_rec.detach(), l_sm.detach(), sel, dep.detach(), L
+
+    def one_node():
+        L = leaves()
+        Ts = F.pose_matrices(L['aa'], L['t'], inv).unflatten(0, (n, b))
+        K, K_inv = F.intrinsics(L['fs'], L['cs'], (h, w)) if learn_k else (K0, None)
+        loss, l_rec, l_sm, sel, dep = F.loss_path_fused(dict(zip(keys, L['d'])), imgs, supp, Ts, K, K_inv, pose=(L['aa'], L['t'], inv),
+                                                        intrinsics=(L['fs'], L['cs']) if learn_k else None, flags=flags, min_depth=0.1, max_depth=100, seed=11,
+                                                        w_recon=1.0, w_smooth=float(w_sm), prepared=prepared())
+        loss.backward(g_out)
+        return loss.detach(), l_rec, l_sm, sel, dep.detach(), L
+
+    monkey_skip = pytest.MonkeyPatch()
+    monkey_skip.setenv('SMD_BWD_SKIP', '0')      # one row loop for both (the tuner would otherwise time its two loops on different calls)
+    try:
+        la, ra, sa, sel_a, dep_a, A = two_nodes()
+        lb, rb, sb, sel_b, dep_b, B = one_node()
+        torch.cuda.synchronize()
+    finally: monkey_skip.undo()
+    assert torch.equal(sel_a, sel_b) and torch.equal(dep_a, dep_b)
+    assert torch.equal(ra, rb) and torch.equal(sa, sb), (ra.item(), rb.item(), sa.item(), sb.item())
+    assert torch.equal(la, lb), (la.item(), lb.item())
+    for k, (x, y) in enumerate(zip(A['d'], B['d'])): assert torch.equal(x.grad, y.grad), f'd loss / d disp[{k}]: max diff {(x.grad - y.grad).abs().max().item():.3e}'
+    for k in ('aa', 't') + (('fs', 'cs') if learn_k else ()):
+        assert rel_to_max(B[k].grad, A[k].grad) <= 1e-6, (k, rel_to_max(B[k].grad, A[k].grad))
+    assert torch.isfinite(lb) and all(torch.isfinite(x.grad).all() for x in B['d'])
+
+
+def test_single_node_loss_path_declines_what_it_does_not_serve(F):
+    """SMD_E_UNSUPPORTED -> `_lib.Unsupported`, nothing launched: pure-L1 error, a single pyramid level."""
+    from slowtv_monodepth_amd._lib import Unsupported
+    b, h, w, n = 1, 16, 70, 2
+    imgs = torch.rand(b, 3, h, w, device='cuda'); supp = torch.rand(n, b, 3, h, w, device='cuda')
+    T = torch.eye(4, device='cuda').repeat(n, b, 1, 1); K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None]
+    d = {0: torch.rand(b, 1, h, w, device='cuda') + 0.1, 1: torch.rand(b, 1, h//2, w//2, device='cuda') + 0.1}
+    with pytest.raises(Unsupported): F.loss_path_fused(d, imgs, supp, T, K, flags=F.recon_flags('l1', True, True), min_depth=0.1, max_depth=100)
+    with pytest.raises(Unsupported): F.loss_path_fused({0: d[0]}, imgs, supp, T, K, flags=F.recon_flags('ssim', True, True), min_depth=0.1, max_depth=100)
+    loss, *_ = F.loss_path_fused(d, imgs, supp, T, K, flags=F.recon_flags('ssim', True, True), min_depth=0.1, max_depth=100)
+    assert torch.isfinite(loss)

@@ -148,7 +148,7 @@ def test_two_steps_in_flight_with_prep_ahead_equal_inline_prep(F, monkeypatch, s
     batches = [make_batch(12, 192, 640, (-1, 1), seed=42 + k, device='cuda') for k in range(2)]
 
     from slowtv_monodepth_amd import functional as Fm
-    real_prep, real_fused = Fm.image_recon_prep, Fm.image_recon_fused_disp
+    real_prep, real_fused, real_path = Fm.image_recon_prep, Fm.image_recon_fused_disp, Fm.loss_path_fused
     calls = {}
 
     def spy_prep(*a, **kw):
@@ -158,7 +158,10 @@ def test_two_steps_in_flight_with_prep_ahead_equal_inline_prep(F, monkeypatch, s
     def spy_fused(*a, **kw):
         calls['prepared'] = calls.get('prepared', []) + [kw.get('prepared') is not None]
         return real_fused(*a, **kw)
-    monkeypatch.setattr(Fm, 'image_recon_prep', spy_prep); monkeypatch.setattr(Fm, 'image_recon_fused_disp', spy_fused)
+    def spy_path(*a, **kw):      # the single-node loss path the trainer takes for this configuration (round 5)
+        calls['prepared'] = calls.get('prepared', []) + [kw.get('prepared') is not None]
+        return real_path(*a, **kw)
+    monkeypatch.setattr(Fm, 'image_recon_prep', spy_prep); monkeypatch.setattr(Fm, 'image_recon_fused_disp', spy_fused); monkeypatch.setattr(Fm, 'loss_path_fused', spy_path)
 
     def run(prep_ahead):
         calls.clear()
@@ -168,7 +171,8 @@ def test_two_steps_in_flight_with_prep_ahead_equal_inline_prep(F, monkeypatch, s
         for batch in batches:                      # no optimizer step: the second step's gradients must not depend on float order of an update
             for p in m.parameters(): p.grad = None
             loss, ld, fwd = m.step(batch)
-            outs = [fwd['disp'][s] for s in sorted(fwd['disp'])] + [fwd['Ts']]   # what the loss path hands back to the networks
+            outs = [fwd['disp'][s] for s in sorted(fwd['disp'])]   # what the loss path hands back to the depth network (the pose side is covered by the parameter gradients:
+                                                                   # the single-node loss path differentiates through to the pose network's outputs, `fwd['Ts']` gets no gradient)
             for o in outs: o.retain_grad()
             loss.backward()
             losses.append(loss.detach())           # no .item(): nothing here waits for the device

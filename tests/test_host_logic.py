@@ -31,7 +31,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), f'{name} declared in include/smd_hotpath.h but not exported by {_lib.lib_path}'
         assert name in _lib.PROTOTYPES, f'{name} has no ctypes prototype'
     assert set(_lib.PROTOTYPES) <= declared
-    assert _lib.lib.smd_abi_version() == 5
+    assert _lib.lib.smd_abi_version() == 6
+    # launch-shape knobs (the parity tests' pins): known name, unknown name, experiments-only name in the product build; and nothing reads the environment
+    assert _lib.set_knob('fwd_rh', 12) is True and _lib.set_knob('bwd_pair', 1) is False
+    with pytest.raises(ValueError): _lib.set_knob('no_such_knob', 1)
+    _lib.reset_knobs()
+    import subprocess
+    syms = subprocess.run(['nm', '-D', '--undefined-only', str(_lib.lib_path)], capture_output=True, text=True).stdout
+    assert 'getenv' not in syms, 'the product library must not read the environment (knobs: smd_set_knob; experiments: make EXPERIMENTS=1)'
     assert _lib.lib.smd_image_recon_workspace_bytes(12, 2, 4, 192, 640) > 2*12*4*12*4   # at least the pose partials
     assert _lib.lib.smd_image_recon_workspace_bytes(0, 2, 4, 192, 640) == 0
     # image part (texels + target pixels + two window-term planes) + the tail: K0 row table for SMD_MAX_SCALES pyramid levels + 1 + b arrival counters (padded to 16 B)
