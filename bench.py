@@ -150,6 +150,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='capture one whole training step (networks, loss path, backward, optimizer) into a HIP graph after the warm-up and time its '
                                                           'replays: what the host has to enqueue per step drops from ~1000 launches to one (multi-GPU readiness: eight ranks\' Python '
                                                           'threads); the library\'s event profile is off in this mode, so the roofline fields are null')
+    ap.add_argument('--knob', action='append', default=[], metavar='NAME=VALUE', help='pin a launch-shape knob of the library (smd_set_knob) for an A/B run, e.g. --knob bwd_live=0; recorded in config.knobs')
     ap.add_argument('--precision', default=None, choices=['32', 'bf16'], help='override the network autocast precision of the workload (the loss path is always fp32)')
     args = ap.parse_args()
 
@@ -158,6 +159,9 @@ def main():
     from slowtv_monodepth_amd.train import StepModule, init_distributed, train_steps, wrap_ddp
     from slowtv_monodepth_amd.trainer import MonoDepthModule
 
+    for kv in args.knob:
+        k_, v_ = kv.split('=')
+        if not _lib.set_knob(k_, int(v_)): raise SystemExit(f'bench.py: knob {k_} is not in this build of the library')
     t_start = time.perf_counter()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # not under a launcher: start one rank per GPU ourselves (one process per GPU, RCCL process group)
@@ -310,6 +314,16 @@ def main():
         tuner = _F.row_skip_tuner(torch.cuda.current_device())
         skipping = (int(os.environ['SMD_BWD_SKIP']) >= 1) if 'SMD_BWD_SKIP' in os.environ else tuner.skip
         k_fwd, k_bwd = kernel_variants
+        # What the selection maps of the LAST step looked like (outside the timed region): the share of auto-masked pixels and of pixels routed to each
+        # support.  The backward's cost depends on it (a support nobody selects in a strip costs its wave nothing: the liveness table) — a bench whose
+        # masks have collapsed (cfg 4 with randomly initialised learned intrinsics: > 99 % auto-masked from the second step on) times the all-masked floor.
+        sel_stats = None
+        sel = getattr(module.backend, 'last_sel', None)
+        if sel is not None:
+            sel_stats = {'automasked_share': round((sel == 255).float().mean().item(), 4),
+                         'routed_share_per_support': [round((sel == i).float().mean().item(), 4) for i in range(n)],
+                         'dead_wave_share_per_support': {'as_the_liveness_table_sees_it': [round(v, 4) for v in _F.dead_wave_shares(sel, True, n, table_rh=16).tolist()],
+                                                         'exact_footprint': [round(v, 4) for v in _F.dead_wave_shares(sel, True, n).tolist()]}}
         out = {
             'metric': BASELINE_METRIC,
             'value': round(wl['b']*world*args.steps/elapsed, 2), 'unit': 'images/s',
@@ -321,11 +335,15 @@ def main():
                        'global_batch': wl['b']*world, 'per_gpu_batch': wl['b'], 'parallelism': f'dp{world}',
                        'loss_dtype': 'f32', 'channels_last': args.channels_last, 'two_stream_nets': os.environ.get('SMD_OVERLAP_NETS', '1') != '0', 'final_loss': round(last_loss, 6),
                        'rccl_ranks': rccl_ranks, 'dp_impl': (os.environ.get('SMD_DP_IMPL', 'flat') if rccl_ranks > 1 or os.environ.get('SMD_FORCE_DDP') == '1' else None),
-                       'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3), 'host_cpu_ms_per_step': round(host_cpu/args.steps*1e3, 3), 'hip_graph': graph_note},
+                       'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3), 'host_cpu_ms_per_step': round(host_cpu/args.steps*1e3, 3), 'hip_graph': graph_note,
+                       'prep_ahead': module.prep_ahead if not args.graph else 'False (forced by --graph: the prep-ahead hand-off across streams crashes hipStreamEndCapture on this stack; the default bench runs prep_ahead=pose)',
+                       'loss_path': getattr(module.backend, 'last_path', None), 'knobs': args.knob or None,
+                       'automasked_share': sel_stats['automasked_share'] if sel_stats else None, 'routed_share_per_support': sel_stats['routed_share_per_support'] if sel_stats else None,
+                       'dead_wave_share_per_support': sel_stats['dead_wave_share_per_support'] if sel_stats else None},
             'roofline': {'kernel': f'{k_fwd} (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; the instantiation the library reports for the last forward launch, name as rocprofv3 prints it)', 'bound': 'hbm',
                          'achieved': round(B_fwd/(f_ms*1e-3)/1e9, 1) if f_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(B_fwd/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if f_ms else None, 'traffic': traffic, 'traffic_source': traffic_source,
-                         'whole_forward_ms': round(fa_ms, 5), 'whole_forward_launches': 'the forward entry point on the critical path: k_recon_main (all 4 scales; the loss is reduced inside it by the last block)',
+                         'whole_forward_ms': round(fa_ms, 5), 'whole_forward_launches': 'the forward entry point on the critical path: k_recon_main (all 4 scales; the loss is reduced inside it by the last block; in the single-node loss path the smoothness sweep rides in the same launch as guest blocks and the weighted sum is formed in-launch)',
                          'prep_ms': round(p_ms, 5), 'prep_launch': 'k_recon_prep (frame-only: texel repack, target window sums, identity error), enqueued on the pose network\'s side stream behind that network, i.e. under the depth network (trainer.prep_ahead)',
                          'whole_forward_frac': round(B_fwd/(fa_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
                          'forward_incl_prep_frac': round(B_fwd/((fa_ms + p_ms)*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fa_ms else None,
@@ -335,12 +353,13 @@ def main():
                          'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
             'roofline_bwd': {'kernel': f'{k_bwd} (fused adjoint, one wave per (strip, support); the pose / intrinsics epilogue rides in the K0-adjoint launch that follows; the instantiation the library reports for the last backward launch)', 'bound': 'hbm',
                              'row_loop': {'dead_row_skipping': skipping, 'timed': tuner.last,
-                                          'chosen_by': 'SMD_BWD_SKIP' if 'SMD_BWD_SKIP' in os.environ else 'functional.row_skip_tuner: four early backward calls of every 128 alternate between the two row loops (same gradients bit for bit) with HIP events around the entry point; skipping is kept if it is more than 3 % faster (profiles/r04_skip_regimes.txt)'},
+                                          'chosen_by': 'SMD_BWD_SKIP' if 'SMD_BWD_SKIP' in os.environ else 'functional.row_skip_tuner: four early backward calls of every period (16 calls, doubling up to 256 while the timings confirm the choice) alternate between the two row loops (same gradients bit for bit) with HIP events around the entry point; skipping is kept if it is more than 3 % faster (profiles/r04_skip_regimes.txt)',
+                                          'liveness_table': 'on: a backward wave whose (strip, support) no pixel selects parks zeros instead of running its row loop (the forward records, per strip and support, the columns with such a pixel)' if not any(k.startswith('bwd_live=0') for k in args.knob) else 'off (--knob bwd_live=0)'},
                              'achieved': round(B_bwd/(b_ms*1e-3)/1e9, 1) if b_ms else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                              'frac': round(B_bwd/(b_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4) if b_ms else None,
                              'algorithmic_bytes': B_bwd, 'avg_kernel_ms': round(b_ms, 5), 'launches_timed': len(bwd_ms),
                              'traffic': (tj.get(args.workload, {}).get('recon_bwd_bytes') if tf.is_file() else None),
-                             'whole_backward_ms': round(ba_ms, 5), 'whole_backward_launches': 'k_recon_bwd alone (events around smd_image_recon_bwd\'s launches; the K0 adjoint, which also carries the pose epilogue, follows outside this pair)'},
+                             'whole_backward_ms': round(ba_ms, 5), 'whole_backward_launches': 'k_recon_bwd alone (events around the fused backward\'s launch; the K0 adjoint — two launches, the first also carrying the pose epilogue through to the pose network\'s outputs and the smoothness adjoint as guest blocks — follows outside this pair)'},
         }
         note(f'timed region done: {out["value"]} img/s')
         if world == 1 and not args.no_cpu_baseline:

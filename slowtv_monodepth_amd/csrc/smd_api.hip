@@ -43,12 +43,13 @@ int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil
 //   and fwd_taper_rh / bwd_taper_rh their height; fwd_ni supports per forward launch (1..4); fwd_share (default 1: with four scales a block
 //   of the hot forward is the four scales of one strip and the target-side rows reach it through an LDS ring); bwd_skip (0 / 2: the
 //   backward's row loop, overriding the SMD_BWD_SKIP_DEAD_ROWS flag of the call); bwd_wps (waves per strip of the backward);
-//   bwd_guest_finalize; bwd_direct_level; loss_path_guests (0: the fused loss path launches its guest work as kernels of their own).
+//   bwd_guest_finalize; bwd_direct_level; loss_path_guests (0: the fused loss path launches its guest work as kernels of their own);
+//   bwd_live (0: the backward ignores the forward's liveness table and runs every wave's row loop).
 //   Experiments builds only: fwd_ahead (2: tap gathers two rows ahead, measured slower), bwd_pair (two supports per wave, dropped), smooth_chain.
 struct KnobDef { const char* name; bool experiment; };
 constexpr KnobDef kKnobs[] = {{"fwd_rh", false}, {"bwd_rh", false}, {"fwd_taper_b", false}, {"bwd_taper_b", false}, {"fwd_taper_rh", false},
                               {"bwd_taper_rh", false}, {"fwd_ni", false}, {"fwd_share", false}, {"bwd_skip", false}, {"bwd_wps", false},
-                              {"bwd_guest_finalize", false}, {"bwd_direct_level", false}, {"loss_path_guests", false},
+                              {"bwd_guest_finalize", false}, {"bwd_direct_level", false}, {"loss_path_guests", false}, {"bwd_live", false},
                               {"fwd_ahead", true}, {"bwd_pair", true}, {"smooth_chain", true}};
 constexpr int kNumKnobs = sizeof(kKnobs)/sizeof(kKnobs[0]);
 constexpr int kKnobUnset = INT_MIN;
@@ -107,6 +108,14 @@ void taper(int& b1, int& rh2, int& nsy2, int b, int h, const StripPlan& pl, cons
   b1 = b - b2; rh2 = r2; nsy2 = smd::ceil_div(h, r2);
 }
 
+// The forward's partition (shared with the backward, which reads the liveness table the forward indexed by ITS strips).
+StripPlan fwd_partition(int b, int S, int h, int w, int& b1, int& rh2, int& nsy2) {
+  const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
+  taper(b1, rh2, nsy2, b, h, pl, "fwd_taper_b", "fwd_taper_rh");
+  if (rh2 > 58) { rh2 = 58; nsy2 = smd::ceil_div(h, rh2); }   // as plan(): one row-table entry per lane
+  return pl;
+}
+
 // ---- optional event-pair recording around the dominant kernels (bench.py roofline measurement) ----
 struct ProfSlot { hipEvent_t* ev = nullptr; int cap = 0, used = 0; };
 ProfSlot g_prof[5];   // SMD_PROF_*: dominant forward kernel, dominant backward kernel, whole forward entry point, whole backward entry point, prep launches
@@ -143,6 +152,7 @@ ReconWs carve_recon(void* base, int b, int n, int S, int h, int w) {
   return r;
 }
 
+unsigned* packed_live(float* packed, int b, int n, int h, int w) { return (unsigned*)(packed + smd::packed_live_offset_floats(b, n, h, w)); }
 uint4* packed_rowtab(float* packed, int b, int n, int h, int w) { return (uint4*)(packed + smd::packed_rowtab_offset_floats(b, n, h, w)); }
 unsigned* packed_arrive(float* packed, int b, int n, int h, int w) { return (unsigned*)(packed + smd::packed_arrive_offset_floats(b, n, h, w)); }
 
@@ -310,14 +320,13 @@ static int recon_fwd_impl(const float* depth, float* depth_out, const smd::Scale
   a.depth = depth; a.packed = supp_packed; a.T = T; a.K = K; a.Kinv = K_inv;
   a.noise = noise; a.err = err; a.sel = sel; a.partial = ws.loss_partial; a.warp0 = warp0;
   a.arrive = packed_arrive(supp_packed, b, n, h, w); a.loss = loss; a.loss_scale = 1.0/((double)S*b*h*w);
+  a.live = packed_live(supp_packed, b, n, h, w);
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));
   a.inv_n = (float)(1.0/(double)n);
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-  const StripPlan pl = plan(b, S, h, w, smd::kFwdCols);
+  const StripPlan pl = fwd_partition(b, S, h, w, a.b1, a.rh2, a.nsy2);
   a.rh = pl.rh; a.nsx = pl.nsx; a.nsy = pl.nsy;
-  taper(a.b1, a.rh2, a.nsy2, b, h, pl, "fwd_taper_b", "fwd_taper_rh");
-  if (a.rh2 > 58) { a.rh2 = 58; a.nsy2 = smd::ceil_div(h, a.rh2); }   // as plan(): one row-table entry per lane
   if (lp) {
     a.comb = lp->comb;
     if (lp->guests) { a.sm = lp->job; a.guest_blocks = smd::smooth_main_blocks(a.sc, b); }
@@ -393,6 +402,8 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   a.g_in = g_in; a.k0_scale = k0_scale; a.g_scale = g_scale;
   a.g_direct = g_direct; a.direct_scale = g_direct ? direct_scale : -1;
   a.arrive = packed_arrive(supp_packed, b, n, h, w) + 1;
+  a.live = (n <= smd::kLiveSupports && knob("bwd_live", 1) != 0) ? packed_live(supp_packed, b, n, h, w) : nullptr;   // (written by the forward on this buffer)
+  { int fnsy2; const StripPlan fp = fwd_partition(b, S, h, w, a.fwd_b1, a.fwd_rh2, fnsy2); a.fwd_rh = fp.rh; }             // (same knobs as the forward call that filled it)
   a.g_T = g_T; a.g_K = (flags & SMD_NEED_K_GRAD) ? g_K : nullptr; a.g_Kinv = (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
   a.wscale = (float)((double)w/(double)(w - 1)); a.hscale = (float)((double)h/(double)(h - 1));

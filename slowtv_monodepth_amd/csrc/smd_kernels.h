@@ -60,7 +60,18 @@ __host__ __device__ inline size_t packed_image_floats(int b, int n, int h, int w
 }
 __host__ __device__ inline size_t packed_rowtab_offset_floats(int b, int n, int h, int w) { return (packed_image_floats(b, n, h, w) + 3) & ~(size_t)3; }   // 16-byte aligned
 __host__ __device__ inline size_t packed_arrive_offset_floats(int b, int n, int h, int w) { return packed_rowtab_offset_floats(b, n, h, w) + (size_t)SMD_MAX_SCALES*(size_t)(h + 4)*4; }
-__host__ __device__ inline size_t packed_total_floats(int b, int n, int h, int w) { return packed_arrive_offset_floats(b, n, h, w) + (((size_t)b + 1 + 3) & ~(size_t)3); }
+// ... and (round 5) the LIVENESS table the forward leaves for the backward: which columns of each forward strip have, in ANY of the strip's rows,
+// a pixel whose final selection is support k — one 64-bit lane mask per (scale, sample, forward strip, k < 4): bit l <-> column 62*sx - 1 + l.
+// A backward wave (one support of one strip) whose 3x3-dilated footprint overlaps no such column has nothing to do: every gradient it would
+// compute is an exact zero.  Entry layout: live_rh [b] ints (rows per forward strip of each sample: the tapered partition differs per sample),
+// then masks [SMD_MAX_SCALES][b][live_max_strips][4] uint64.  Every entry is owned by one forward wave, which stores it unconditionally on the
+// launch's last pass: no zero-fill, no atomics.
+constexpr int kLiveSupports = 4;
+__host__ __device__ inline size_t live_max_strips(int h, int w) { return (size_t)((w + kFwdCols - 1)/kFwdCols)*(size_t)((h + 3)/4); }   // strips of >= 4 rows
+__host__ __device__ inline size_t packed_live_offset_floats(int b, int n, int h, int w) { return (packed_arrive_offset_floats(b, n, h, w) + (((size_t)b + 1 + 3) & ~(size_t)3) + 63) & ~(size_t)63; }   // 256-byte aligned
+__host__ __device__ inline size_t live_header_floats(int b) { return ((size_t)b + 63) & ~(size_t)63; }
+__host__ __device__ inline size_t live_table_floats(int b, int h, int w) { return live_header_floats(b) + (size_t)SMD_MAX_SCALES*b*live_max_strips(h, w)*kLiveSupports*2; }
+__host__ __device__ inline size_t packed_total_floats(int b, int n, int h, int w) { return packed_live_offset_floats(b, n, h, w) + live_table_floats(b, h, w); }
 
 // The fused loss path (round 5): total = w_rec*l_rec + w_sm*l_sm is formed in-launch by whichever final reducer arrives second.
 struct LossCombine { float* out3; unsigned* arrive; float w_rec, w_sm; };   // out3 = {total, l_rec, l_sm}; null: no combination
@@ -125,6 +136,7 @@ struct ReconMainArgs {     // k_recon_main: warp + SSIM/L1 + min/mean over suppo
   int main_blocks, guest_blocks;
   SmoothFwdJob sm;
   LossCombine comb;
+  unsigned* live;          // the liveness table in the tail of `packed` (written on the last pass), or null
 };
 
 struct ReconBwdArgs {
@@ -149,6 +161,8 @@ struct ReconBwdArgs {
   float wscale, hscale;
   int skip_level;         // 0..2, see k_recon_bwd
   int pair;               // 1: two supports per wave (k_recon_bwd_pair; n = 2 or 4, min-reprojection, plain row loop)
+  const unsigned* live;   // the forward's liveness table (smd_kernels.h: packed_live_offset_floats), or null: every wave runs its row loop
+  int fwd_rh, fwd_b1, fwd_rh2;   // ... and the forward's partition: rows per forward strip of the first fwd_b1 samples / of the rest (the table is indexed by forward strips)
   float* g_direct;        // K0 fused: rows of scale `direct_scale` (a pyramid level that already has the image size: its K0 adjoint is the
   int direct_scale;       //   identity) go straight to that level's gradient tensor (b,h,w) instead of g_depth; -1: none
 };

@@ -459,6 +459,49 @@ constexpr int kAccRows = 16;   // tallest strip of the multi-support instantiati
 #ifdef SMD_TRACE_WAVES
 __device__ unsigned long long g_wave_trace_bwd[1 << 16][3];
 #endif
+// Does any pixel within one row / column of the strip (rows r0 .. r1-1, columns c0 .. c0+59) select `key`?  Conservative in the rows (a forward strip's
+// mask covers all of its rows), exact in the columns.  Wave-uniform: scalar loads and scalar arithmetic only.  Two halves, so that the loads can be
+// in flight across the block's start-up barrier: issue() requests the (at most 3 x 3) forward-strip entries the footprint overlaps — every entry
+// before the first is looked at, indices beyond the footprint repeating its last strip: ONE round trip — and live() combines them.
+struct LiveProbe {
+  unsigned long long m[9];
+  int clo, chi, fx0, fx1;
+  bool wide;              // a footprint of more than 3 x 3 forward strips (strips of 4 rows against a tall backward strip: knob settings only): no skipping
+  __device__ __forceinline__ void issue(const ReconBwdArgs& a, int s, int bi, int key, int r0, int r1, int c0) {
+    const int frh = bi < a.fwd_b1 ? a.fwd_rh : a.fwd_rh2;            // rows per forward strip of this sample (the forward's partition: launch arguments, no dependent load)
+    const int fnsx = ceil_div(a.w, kFwdCols);
+    const int rlo = max(r0 - 1, 0), rhi = min(r1, a.h - 1);
+    clo = max(c0 - 1, 0); chi = min(c0 + kBwdCols, a.w - 1);
+    const int fy0 = rlo/frh, fy1 = rhi/frh;
+    fx0 = clo/kFwdCols; fx1 = chi/kFwdCols;
+    wide = key >= kLiveSupports || fy1 - fy0 > 2 || fx1 - fx0 > 2;
+    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(a.live + live_header_floats(a.b))
+                                    + ((size_t)s*a.b + bi)*live_max_strips(a.h, a.w)*kLiveSupports + min(key, kLiveSupports - 1);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) m[dy*3 + dx] = tab[((size_t)min(fy0 + dy, fy1)*fnsx + min(fx0 + dx, fx1))*kLiveSupports];
+  }
+  __device__ __forceinline__ bool live() const {
+    if (wide) return true;
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      // forward lane l of strip fx holds column 62 fx - 1 + l: the lanes of columns max(clo, 62 fx - 1) .. min(chi, 62 fx + 62)
+      const int fx = min(fx0 + dx, fx1);
+      const int l0 = max(clo - (fx*kFwdCols - 1), 0), l1 = min(chi - (fx*kFwdCols - 1), 63);
+      const unsigned long long rg = (l1 >= 63 ? ~0ull : ((1ull << (l1 + 1)) - 1ull)) & ~((1ull << l0) - 1ull);
+      any |= (m[dx] | m[3 + dx] | m[6 + dx]) & rg;
+    }
+    return any != 0ull;
+  }
+};
+__device__ __forceinline__ bool strip_is_live(const ReconBwdArgs& a, int s, int bi, int key, int r0, int r1, int c0) {
+  LiveProbe p;
+  p.issue(a, s, bi, key, r0, r1, c0);
+  return p.live();
+}
+
 template <bool SSIM, int SKIP, int NS, bool ACC, bool XTRA>
 __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconBwdArgs a) {
 #ifdef SMD_TRACE_WAVES
@@ -477,12 +520,14 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   __shared__ __attribute__((aligned(16))) float hist_lds[kLdsFloats];
   float* const pose_lds = hist_lds + SPB*NS*kWaveFloats;
   unsigned* const cnt = reinterpret_cast<unsigned*>(pose_lds + SPB*NS*kPoseArea);   // [0 .. SPB): waves of a strip done; [4]: waves of the block done
-  for (int e = threadIdx.x; e < SPB*NS*kPoseArea; e += 64*SPB*NS) pose_lds[e] = 0.f;
-  if (threadIdx.x < 8) cnt[threadIdx.x] = 0u;
-  __syncthreads();                                           // the only block barrier: at the start, where every wave still is
   const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int sib = wid/NS, kw = wid - sib*NS;               // strip within the block, first support of this wave
+  // Which support a wave of the block takes ROTATES with the block index (round 5).  The hardware places wave j of a workgroup on SIMD j mod 4, so
+  // with "wave j = support j" every wave of support k in the launch shared a SIMD with the other waves of support k.  `wid` below is the wave's
+  // LOGICAL index (strip, support): LDS regions, the order of the cross-support sum and of the pose sums all follow it, so the results are the same
+  // bits as without the rotation.  (blockIdx >> 3: workgroup p runs on XCD p mod 8, so the blocks that share a CU differ in p >> 3.)
+  const int wid_hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sib = wid_hw/NS, kw = (wid_hw - sib*NS + (int)((blockIdx.x >> 3) % (unsigned)NS)) % NS;   // strip within the block, first support of this wave
+  const int wid = sib*NS + kw;
   // segment of the (possibly tapered) partition this block belongs to (smd_kernels.h: ReconMainArgs::b1)
   const unsigned nblk1 = recon_grid_blocks(a.nsx*a.nsy, a.b1, a.S, SPB);
   const bool tail = blockIdx.x >= nblk1;
@@ -492,10 +537,20 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   decode_tile(tail ? blockIdx.x - nblk1 : blockIdx.x, nbx, tail ? a.b - a.b1 : a.b1, a.S, xb, bi, s);
   const int strip = xb*SPB + sib;
   if (tail) bi += a.b1;
+  const int sxi = strip % a.nsx, syi = strip/a.nsx;
+  // Liveness of this wave's first support (round 5), asked BEFORE the block's start-up barrier so that the scalar loads of the table entries are in
+  // flight while the block zeroes its LDS: a check placed in front of the row loop cost every wave two dependent round trips (+5 % at cfg 2, where
+  // nothing is dead).
+  const bool probe_on = ACC && a.live != nullptr && a.g_in == nullptr && strip < nstrips;
+  LiveProbe probe;
+  if (probe_on) probe.issue(a, s, bi, (a.flags & SMD_USE_MIN) ? kw : 0, syi*seg_rh, min(syi*seg_rh + seg_rh, a.h), sxi*kBwdCols);
+  for (int e = threadIdx.x; e < SPB*NS*kPoseArea; e += 64*SPB*NS) pose_lds[e] = 0.f;
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0u;
+  __syncthreads();                                           // the only block barrier: at the start, where every wave still is
+  const bool first_live = probe_on ? probe.live() : true;
   constexpr int nw = NS;                                   // waves that work on a strip
   if (strip >= nstrips) return;                // nothing to do (the chain below counts live waves only)
   const int live_waves = min(SPB, nstrips - xb*SPB)*nw;
-  const int sxi = strip % a.nsx, syi = strip/a.nsx;
   const int h = a.h, w = a.w;
   const int r0 = syi*seg_rh, r1 = min(r0 + seg_rh, h);
   const int u = sxi*kBwdCols - 2 + lane;
@@ -547,12 +602,19 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     cx.pb0 = peel ? r0 - 1 : max(r0 - 1, 0); cx.pb1 = peel ? r1 : min(r1, h - 1);   // centre rows whose coefficients are needed
 
     for (int i = kw; i < a.n; i += NS) {
+      cx.add_gin = has_gin && i == 0;
+      cx.acc_prev = i != kw;
+      // Liveness (round 5): the forward left, per forward strip and support, the columns in which some row selects that support.  If no such
+      // column lies within one pixel of this strip's rows r0-1 .. r1 and columns c0-1 .. c0+60, every gradient this wave would compute for support
+      // i is an exact zero (the plain row loop multiplies by the routing mask) — park zeros and go on.  Wave-uniform, a few scalar loads.
+      if (ACC && a.live != nullptr && !cx.add_gin && !(i == kw ? first_live : strip_is_live(a, s, bi, cx.use_min ? i : 0, r0, r1, sxi*kBwdCols))) {
+        if (!cx.acc_prev) for (int r = 0; r < r1 - r0; ++r) cx.gacc[r*64] = 0.f;
+        continue;     // (its pose sums stay the zeros the block started with)
+      }
       make_cam2(cx.cm, cx.hx0, cx.hy0, cx.hz0, a.T + ((size_t)i*a.b + bi)*16, a.K + (size_t)bi*16, a.Kinv + (size_t)bi*16,
                 a.wscale, a.hscale, uf);
       cx.so_tex = (unsigned)(i*a.b + bi)*texel_bytes;
       cx.sel_key = cx.use_min ? (unsigned)i : (unsigned)SMD_SEL_MASKED;
-      cx.add_gin = has_gin && i == 0;
-      cx.acc_prev = i != kw;
       cx.run(jstart);
 
       // per-wave pose sums: d/d(H[0..8], a0, a1, tz) of the UN-scaled homography (rows 0/1 of the folded one carry the grid

@@ -358,6 +358,9 @@ struct MainCtx {
   const float* nz_sb;               // noise of this (scale, sample) (AUX)
   rsrc_t rs_pk, rs_depth, rs_err, rs_sel;
   float lsum;
+  // liveness of this strip for the backward (smd_kernels.h): lanes (= columns) in which some row's FINAL selection is support k; wave-uniform
+  static constexpr int NT = SINGLE ? (N < kLiveSupports ? N : kLiveSupports) : kLiveSupports;
+  unsigned long long livem[NT];
   float Px[N][3], Pxx[N][3], Pxy[N][3];
   MainPend<N> P[LA];
   f3 py;                   // target row in flight
@@ -630,6 +633,8 @@ struct MainCtx {
         if (has_err) bst(rs_err, st4, cro, e);      // the error map is an optional output (logging / tests): one store less per row
         bst8(rs_sel, st1, cro1, (unsigned)bsel);
 #endif
+#pragma unroll
+        for (int k = 0; k < NT; ++k) livem[k] |= __ballot(bsel == k);   // one v_cmp + one scalar or per support (halo lanes included: they hold real neighbours)
         lsum += interior ? e : 0.f;
       }
     }
@@ -749,6 +754,8 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
   cx.rs_err = make_rsrc(cx.has_err ? a.err + sb : nullptr, cx.has_err ? hw*4 : 0);
   cx.rs_sel = make_rsrc(a.sel + sb, hw);
   cx.lsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < Ctx::NT; ++k) cx.livem[k] = 0ull;
 #if SMD_FWD_PRIO == 1
   if (SH) __builtin_amdgcn_s_setprio(3);
 #endif
@@ -789,6 +796,14 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
         for (int c = 0; c < 3; ++c) XA[k][c] = XB[k][c];
     }
     cx.template step<true, true, SB>(a.h, XA, XB, YA, YB);
+  }
+  if (a.live != nullptr && (SINGLE || a.last_pass)) {   // this strip's entry of the liveness table: lane k stores support k's column mask (zeros beyond NT)
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int k = 0; k < Ctx::NT; ++k) mine = (lane == k) ? cx.livem[k] : mine;
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(a.live + live_header_floats(a.b));
+    if (lane < kLiveSupports) tab[(((size_t)s_*a.b + bi_)*live_max_strips(a.h, a.w) + (size_t)strip)*kLiveSupports + lane] = mine;
+    if (strip == 0 && s_ == 0 && lane == 0) a.live[bi_] = (unsigned)seg_rh;   // rows per forward strip of this sample
   }
 
   return cx.lsum;

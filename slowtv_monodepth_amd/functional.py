@@ -198,6 +198,29 @@ def dead_tile_shares(sel: torch.Tensor, use_min: bool, n: int = 1, cols: int = 6
     return torch.stack([dead(s4 == i) for i in range(max(int(n), 1))])
 
 
+def dead_wave_shares(sel: torch.Tensor, use_min: bool, n: int = 1, rh: int = 16, cols: int = 60, table_rh: int | None = None) -> torch.Tensor:
+    """(n,): per support, the share of the fused backward's (strip of `rh` rows x `cols` columns, support) waves in whose footprint — the strip
+    dilated by one pixel: rows r0-1 .. r1, columns c0-1 .. c0+cols — NO pixel routes gradient to that support: the waves that park zeros instead
+    of running their row loop.  `table_rh`: rows are rounded out to whole forward strips of that many rows, which is what the forward's
+    liveness table resolves (smd_kernels.h); None: the exact footprint.  sel: (S,b,1,h,w)|(S,b,h,w) uint8 (host-side diagnostic, used by bench.py)."""
+    S = sel.shape[0]
+    s4 = sel.reshape(S, -1, sel.shape[-2], sel.shape[-1])
+    h, w = s4.shape[-2:]
+    out = []
+    for k in range(max(int(n), 1)):
+        live = (s4 == k) if use_min else (s4 != SEL_MASKED)
+        dead, tot = 0, 0
+        for r0 in range(0, h, rh):
+            lo, hi = max(r0 - 1, 0), min(r0 + rh, h - 1)
+            if table_rh: lo, hi = (lo//table_rh)*table_rh, min((hi//table_rh + 1)*table_rh - 1, h - 1)
+            rows = live[:, :, lo:hi + 1].any(2)                       # (S,B,w)
+            for c0 in range(0, w, cols):
+                d = ~rows[:, :, max(c0 - 1, 0): min(c0 + cols, w - 1) + 1].any(2)
+                dead += int(d.sum()); tot += d.numel()
+        out.append(dead/max(tot, 1))
+    return torch.tensor(out)
+
+
 class _RowSkipTuner:
     """Chooses between the two row loops of the fused backward by timing them on the live data, without ever stalling the stream.
 
@@ -206,15 +229,19 @@ class _RowSkipTuner:
     row of a wave's window has a live pixel (the masks of a training run at 192x640 from the second step on: 110 vs 135 us), the
     gated loop wins once 75-80 % of the (row, 60-column window) units are dead and takes less than half the time when the automask
     takes everything (52 vs 117 us; 384x640 with randomly initialised learned intrinsics: 110-120 vs 247 us) — and the share of
-    masked pixels alone does not predict the sign.  So it is measured: after `settle` calls, `2*trials` backward calls of every `period` alternate between the two
+    masked pixels alone does not predict the sign.  So it is measured: after `settle` calls, `2*trials` backward calls of every period alternate between the two
     loops with a pair of HIP events around the entry point; later calls harvest the pairs that have completed (`Event.query`, no
-    wait), and skipping is used from then on if its fastest trial beats the plain loop's by more than 3 %.  `SMD_BWD_SKIP` in the
+    wait), and skipping is used from then on if its fastest trial beats the plain loop's by more than 3 %.  The period between two timings adapts (below).  `SMD_BWD_SKIP` in the
     environment pins the choice (a profiler perturbs the timing: `scripts/round_profiles.sh` pins what the un-traced run chose; pin it
     as well when capturing the step into a HIP graph — timing events cannot be recorded during capture)."""
-    period, settle, trials, margin = 128, 1, 2, 0.97   # (the masks of a young network change within a few optimiser steps: re-timed often)
+    # The re-timing period adapts (round 5): the masks of a young network change within a few optimiser steps (profiles/r04_mask_runs.txt), those of
+    # a trained one hardly at all — a period starts at `period_min` calls, doubles each time the timing confirms the previous choice (up to
+    # `period_max`) and falls back to `period_min` when the choice flips.
+    period_min, period_max, settle, trials, margin = 16, 256, 1, 2, 0.97
 
     def __init__(self):
         self.calls, self.skip, self.pending, self.samples, self.last = 0, False, [], {True: [], False: []}, None
+        self.period, self.decided = self.period_min, 0
 
     def _flag(self, skip: bool) -> int:
         return FLAGS['bwd_skip_rows'] if skip else 0
@@ -227,8 +254,10 @@ class _RowSkipTuner:
         self.pending = still
         if len(self.samples[True]) >= self.trials and len(self.samples[False]) >= self.trials:
             t_skip, t_plain = min(self.samples[True]), min(self.samples[False])
-            self.skip = t_skip < self.margin*t_plain
-            self.last = {'skipping_ms': round(t_skip, 5), 'plain_ms': round(t_plain, 5)}
+            choice = t_skip < self.margin*t_plain
+            self.period = min(2*self.period, self.period_max) if (self.decided and choice == self.skip) else self.period_min
+            self.skip, self.decided = choice, self.decided + 1
+            self.last = {'skipping_ms': round(t_skip, 5), 'plain_ms': round(t_plain, 5), 'next_period': self.period}
             self.samples = {True: [], False: []}
 
     def begin(self, dev):
@@ -236,7 +265,8 @@ class _RowSkipTuner:
         if 'SMD_BWD_SKIP' in os.environ: return self._flag(os.environ['SMD_BWD_SKIP'] not in ('', '0')), None   # pinned: no timing (read here, per call; the library itself never reads the environment)
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing(): return self._flag(self.skip), None   # no timing events inside a HIP-graph capture: the choice made so far is what gets captured
         if self.pending: self._harvest()
-        phase = self.calls % self.period - self.settle     # (the first calls of a process carry one-off costs)
+        if self.calls >= self.period: self.calls = 0       # a new period (its length may have changed at the last harvest)
+        phase = self.calls - self.settle                   # (the first calls of a process carry one-off costs)
         self.calls += 1
         if 0 <= phase < 2*self.trials:
             mode = phase % 2 == 0

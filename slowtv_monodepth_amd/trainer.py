@@ -35,6 +35,7 @@ class HipLossBackend:
 
     def image_recon(self, crit, synth, depths, masks, imgs, supp_imgs, Ts, Ks, want_warp=True, K_inv=None, prepared=None):
         from . import handlers
+        self.last_sel, self.last_path = None, 'handlers: image_recon + disp_smooth as separate autograd nodes'
         return handlers.image_recon(crit, synth, depths, masks, imgs, supp_imgs, Ts.float(), Ks.float(), K_inv=K_inv, want_warp=want_warp, prepared=prepared)
 
     def inv_intrinsics(self, K):
@@ -100,6 +101,7 @@ class HipLossBackend:
                                                                   w_recon=w_recon, w_smooth=w_smooth, prepared=prepared)
         except Unsupported:
             return None
+        self.last_sel, self.last_path = _sel, 'single node: smd_loss_path_fwd (1 launch) / smd_loss_path_bwd (3 launches)'   # (references only: what bench.py reports about the last step)
         depths.adopt(depth_up.detach())    # `fwd['depth_up']` for later readers (metrics, logging); no differentiable consumer may follow
         return loss, l_rec, l_sm
 

@@ -42,13 +42,15 @@ def oracle_run(g, leaves, Ts, K, static):
     return loss, out
 
 
-def impose_reference_routing(g, sel):
+def impose_reference_routing(g, sel, knobs):
     """Compact (BASELINE-resolution) fixtures, between forward and backward: overwrite the kernel's decision map (`sel`, the tensor its
     backward reads) with the REFERENCE's (`out_sel_all`), so that the gradients that follow are compared under identical routing.
     Among 0.5-1 M pixels a few dozen have two candidate errors within the error map's fp32 noise (observed gap <= 5e-5; the synthetic
     frames are integer shifts of one 8-bit scene, which makes near-ties common) and rounding decides them; each re-routes the gradient of
     its 3x3 window by percents.  -> the kernel's own map (for the flip count / tie proof).  (`.data`: the forward saved `sel` for its
-    backward; this is a test aid, nothing in the product writes to it.)"""
+    backward; this is a test aid, nothing in the product writes to it.  The forward's liveness table describes the map it wrote itself, so the
+    backward is told to ignore it: knob `bwd_live` = 0.)"""
+    knobs('bwd_live', 0)
     own = sel.clone()
     sel.data.copy_(g['out_sel_all'].reshape(sel.shape).to(sel.device))
     return own
@@ -111,7 +113,7 @@ def judge_against_reference_at_baseline_size(g, name, grads, sel_own):
 
 
 @pytest.mark.parametrize('name', TRAIN_CASES)
-def test_fused_path_matches_oracle_and_reference(F, golden, name):
+def test_fused_path_matches_oracle_and_reference(F, golden, knobs, name):
     g = golden(name)
     dev = 'cuda'
     compact = bool(g.get('meta_compact'))
@@ -139,7 +141,7 @@ def test_fused_path_matches_oracle_and_reference(F, golden, name):
         l_sm, dgrad, igrad = F.disp_smooth_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'],
                                                  use_edges=bool(g['meta_use_edges']))
         loss = loss + g['meta_w_smooth']*l_sm
-    if compact: sel_own = impose_reference_routing(g, sel)
+    if compact: sel_own = impose_reference_routing(g, sel, knobs)
     loss.backward()
     torch.cuda.synchronize()
 
@@ -702,7 +704,7 @@ def test_whole_chain_from_network_outputs_matches_reference_gradients(F, golden,
 
 
 @pytest.mark.parametrize('name', TRAIN_CASES_BASELINE)
-def test_whole_chain_at_baseline_resolution_matches_reference(F, golden, name):
+def test_whole_chain_at_baseline_resolution_matches_reference(F, golden, knobs, name):
     """The trainer's operators at the resolutions BASELINE.json quotes, from the networks' outputs (aa, t, (fs, cs), the disparity pyramid)
     through `pose_matrices` / `intrinsics`, the K0-FUSED reconstruction (the kernel pair `bench.py` times, here with the recorded
     tie-break tensor instead of the in-kernel draw) and the smoothness sweep, to the loss and the gradient of every network output —
@@ -724,7 +726,7 @@ def test_whole_chain_at_baseline_resolution_matches_reference(F, golden, name):
                                                             min_depth=g['meta_min_depth'] or None, max_depth=g['meta_max_depth'] or None, noise=static['noise'])
     l_sm, _, _ = F.disp_smooth_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'], use_edges=bool(g['meta_use_edges']), want_aux=False)
     loss = l_rec + g['meta_w_smooth']*l_sm
-    sel_own = impose_reference_routing(g, sel)
+    sel_own = impose_reference_routing(g, sel, knobs)
     loss.backward()
     torch.testing.assert_close(loss.detach().cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
     torch.testing.assert_close(l_rec.detach().cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
@@ -1258,7 +1260,7 @@ def test_k0_and_smoothness_at_non_integer_ratios(F, b, h, w, lows, use_edges):
 # K0 fused into the reconstruction kernel: disparity pyramid in, loss + depth stack out
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('name', TRAIN_CASES)
-def test_k0_fused_path_matches_reference_fixtures(F, golden, name):
+def test_k0_fused_path_matches_reference_fixtures(F, golden, knobs, name):
     """`image_recon_fused_disp` on the reference's recorded cases: the depth stack it writes against `out_depth_up_*`, the loss
     against `out_loss_img_recon`, and the gradients w.r.t. every disparity scale against the reference's own autograd."""
     g = golden(name)
@@ -1278,7 +1280,7 @@ def test_k0_fused_path_matches_reference_fixtures(F, golden, name):
     if g['meta_w_smooth'] >= 0:
         l_sm, _, _ = F.disp_smooth_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'], use_edges=bool(g['meta_use_edges']), want_aux=False)
         loss = loss + g['meta_w_smooth']*l_sm
-    if g.get('meta_compact'): sel_own = impose_reference_routing(g, sel)
+    if g.get('meta_compact'): sel_own = impose_reference_routing(g, sel, knobs)
     loss.backward()
     if g.get('meta_compact'):
         report, ok = judge_against_reference_at_baseline_size(g, name, {f'disp_{s}': leaves[f'disp_{s}'].grad for s in scales}, sel_own)
@@ -1685,3 +1687,44 @@ def test_single_node_loss_path_declines_what_it_does_not_serve(F):
     with pytest.raises(Unsupported): F.loss_path_fused({0: d[0]}, imgs, supp, T, K, flags=F.recon_flags('ssim', True, True), min_depth=0.1, max_depth=100)
     loss, *_ = F.loss_path_fused(d, imgs, supp, T, K, flags=F.recon_flags('ssim', True, True), min_depth=0.1, max_depth=100)
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize('b,h,w,n,lows,use_min,rows', [(3, 96, 320, 4, [(96, 320), (48, 160), (24, 80), (12, 40)], True, 'bands'), (2, 50, 130, 2, [(50, 130), (25, 65)], True, 'bands'),
+                                                       (2, 64, 200, 3, [(64, 200), (32, 100), (16, 50)], False, 'bands'), (2, 40, 70, 4, [(40, 70), (20, 35)], True, 'dead')])
+@pytest.mark.parametrize('skip', ['0', '2'])
+def test_backward_liveness_table_skips_only_exact_zeros(F, knobs, monkeypatch, b, h, w, n, lows, use_min, rows, skip):
+    """Round 5: the forward leaves, per forward strip and support, the columns in which some row's final selection is that support; a backward
+    wave (one support of one strip) whose 3x3-dilated footprint overlaps none of them parks zeros instead of running its row loop.  Every gradient
+    must be BIT-equal to the run that ignores the table (knob `bwd_live` = 0) — on frames built so that whole supports are dead in whole
+    bands of the image (their frames are unrelated noise there), that one support is dead everywhere, and with the automask taking regions."""
+    monkeypatch.setenv('SMD_BWD_SKIP', skip)
+    gen = torch.Generator(device='cuda').manual_seed(h + w + n)
+    imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
+    supp = torch.rand(n, b, 3, h, w, device='cuda', generator=gen)                    # unrelated: never the best candidate where another one is close
+    if rows == 'bands':
+        for i in range(n):      # support i resembles the target in the i-th horizontal band only (and in a vertical stripe for the last one)
+            r0, r1 = i*h//n, (i + 1)*h//n
+            supp[i, :, :, r0:r1] = (imgs[:, :, r0:r1] + 0.02*torch.randn(b, 3, r1 - r0, w, device='cuda', generator=gen)).clamp(0, 1)
+        supp[n - 1, :, :, :, w//3: w//3 + 9] = imgs[:, :, :, w//3: w//3 + 9]
+    else:
+        supp[0] = (imgs + 0.02*torch.randn(b, 3, h, w, device='cuda', generator=gen)).clamp(0, 1)    # support 0 wins everywhere (or the automask does): 1 .. n-1 are dead
+    imgs[:, :, : h//5, : w//4] = 1.0; supp[:, :, :, : h//5 + 2, : w//4 + 2] = 1.0      # a saturated corner: exact ties, auto-masked
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    T0 = torch.eye(4, device='cuda').repeat(n, b, 1, 1); T0[..., :3, 3] = 0.002*torch.randn(n, b, 3, device='cuda', generator=gen)
+    d0 = [0.05 + 0.9*torch.rand(b, 1, hs, ws, device='cuda', generator=gen) for hs, ws in lows]
+    automask = rows == 'dead'      # (bands: min-reprojection alone routes each band to its support; with the automask on, the un-warped frames win nearly everywhere)
+    flags = F.recon_flags('ssim', use_min, automask)
+
+    def run(live):
+        knobs('bwd_live', live)
+        d = [v.clone().requires_grad_(True) for v in d0]; T = T0.clone().requires_grad_(True)
+        loss, _, sel, _, _ = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=flags, min_depth=0.1, max_depth=100, seed=5, want_err=False)
+        loss.backward(); torch.cuda.synchronize()
+        return sel, [v.grad for v in d] + [T.grad]
+    sel, g1 = run(1)
+    _, g0 = run(0)
+    for k, (x, y) in enumerate(zip(g1, g0)): assert torch.equal(x, y), f'gradient #{k} differs with the liveness table (max {(x - y).abs().max().item():.3e})'
+    shares = [(sel == i).float().mean().item() for i in range(n)] + [(sel == 255).float().mean().item()]
+    assert all(torch.isfinite(x).all() for x in g1), shares
+    if use_min and rows == 'bands': assert all(0.1 < v < 0.9 for v in shares[:n]), shares        # every support is live in its band and dead elsewhere
+    if rows == 'dead': assert shares[-1] > 0.01 and max(shares[1:n]) < 0.02, shares               # supports 1 .. n-1 are (nearly) dead everywhere; the automask takes a region

@@ -41,8 +41,10 @@ def test_library_exports_every_declared_symbol():
     assert 'getenv' not in syms, 'the product library must not read the environment (knobs: smd_set_knob; experiments: make EXPERIMENTS=1)'
     assert _lib.lib.smd_image_recon_workspace_bytes(12, 2, 4, 192, 640) > 2*12*4*12*4   # at least the pose partials
     assert _lib.lib.smd_image_recon_workspace_bytes(0, 2, 4, 192, 640) == 0
-    # image part (texels + target pixels + two window-term planes) + the tail: K0 row table for SMD_MAX_SCALES pyramid levels + 1 + b arrival counters (padded to 16 B)
-    assert _lib.lib.smd_packed_supports_bytes(12, 2, 192, 640) == 2*12*193*641*12 + 12*192*640*(12 + 32) + 8*(192 + 4)*16 + 16*4
+    # image part (texels + target pixels + two window-term planes) + the tail: K0 row table for SMD_MAX_SCALES pyramid levels + 1 + b arrival counters (padded to 16 B),
+    # padded to 256 B, + the liveness table the forward leaves for the backward: b ints (padded to 256 B) + SMD_MAX_SCALES x b x (strips of >= 4 rows) x 4 supports x 8 B
+    head = 2*12*193*641*12 + 12*192*640*(12 + 32) + 8*(192 + 4)*16 + 16*4
+    assert _lib.lib.smd_packed_supports_bytes(12, 2, 192, 640) == (head + 255)//256*256 + 256 + 8*12*(11*48)*4*8
 
 
 def test_abi_rejects_bad_arguments_without_touching_the_gpu():
@@ -381,7 +383,7 @@ def test_row_skip_tuner_schedule(monkeypatch):
         def elapsed_time(self, other): return FakeEvent.times.pop(0)
     monkeypatch.setattr(torch.cuda, 'Event', FakeEvent); monkeypatch.setattr(torch.cuda, 'current_stream', lambda dev=None: None)
     monkeypatch.delenv('SMD_BWD_SKIP', raising=False)
-    t = F._RowSkipTuner(); t.period, t.settle, t.trials = 10, 1, 2
+    t = F._RowSkipTuner(); t.period = t.period_min = t.period_max = 10; t.settle, t.trials = 1, 2
     FakeEvent.times = [0.100, 0.120, 0.101, 0.119,    # period 1: skipping 0.100 / 0.101, plain 0.120 / 0.119 -> skipping
                        0.130, 0.120, 0.131, 0.121]    # period 2: the other way round -> plain
     seen = []
@@ -390,7 +392,15 @@ def test_row_skip_tuner_schedule(monkeypatch):
         seen.append(flag != 0)
     assert seen[:5] == [False, True, False, True, False] and all(seen[5:10]) and t.last is not None
     assert seen[10:15] == [True, True, False, True, False] and not any(seen[15:20])
-    assert t.last == {'skipping_ms': 0.13, 'plain_ms': 0.12}
+    assert t.last == {'skipping_ms': 0.13, 'plain_ms': 0.12, 'next_period': 10}
+    # the period adapts: it doubles while the timings confirm the choice and falls back to the minimum when the choice flips
+    a = F._RowSkipTuner(); a.period = a.period_min = 8; a.period_max = 32; a.settle, a.trials = 0, 1
+    FakeEvent.times = [0.1, 0.2]*3 + [0.2, 0.1] + [0.2, 0.1]    # skipping x3, then plain x2
+    periods = []
+    for _ in range(8 + 8 + 16 + 32 + 8 + 4):
+        flag, token = a.begin('cuda:0'); a.end(token)
+        periods.append(a.period)
+    assert periods[2] == 8 and periods[8 + 2] == 16 and periods[8 + 16 + 2] == 32 and periods[8 + 16 + 32 + 2] == 8 and periods[-1] == 16, periods[::4]
     monkeypatch.setenv('SMD_BWD_SKIP', '2')      # pinned from the environment: no timing, the gated loop's flag on every call
     assert t.begin('cuda:0') == (FLAGS['bwd_skip_rows'], None)
     monkeypatch.setenv('SMD_BWD_SKIP', '0')
