@@ -424,7 +424,10 @@ struct MainCtx {
     const float dep = (d > 0.f) ? __builtin_amdgcn_rcpf(fmaxf(d, kEps32)) : 0.f;
     // each row is interior to one strip.  No control flow around the store (a divergent `if` ends the row step's basic block twice): a lane or a
     // row that must not write is sent out of the buffer's range, where the bounds check drops it
-    bst(rs_dout, interior ? lane4 : 0xffffffffu, (row >= r0 && row < r1) ? (unsigned)row*w4 : 0xf0000000u, dep);
+    // (a lane / row that must not write gets an offset the bounds check drops.  0x80000000, not 0xffffffff: the hardware adds the vector and the
+    // scalar offset, and whether that sum wraps in 32 bits is not something the probes cover — this sentinel cannot wrap into range: every plane
+    // addressed here is far below 2 GiB, and even 0x80000000 + 0xf0000000 lands at 0x70000000, beyond any of them)
+    bst(rs_dout, interior ? lane4 : 0x80000000u, (row >= r0 && row < r1) ? (unsigned)row*w4 : 0xf0000000u, dep);
     return dep;
   }
 
@@ -609,7 +612,7 @@ struct MainCtx {
       // every lane runs this (the halo lanes' values are finite and go nowhere): only the stores and the loss sum look at `interior`, through
       // an out-of-range lane offset / a select — no exec-mask region in the row step except the rare tie-break one
       const unsigned lane1 = lane4 >> 2, cro = (unsigned)v*w4, cro1 = (unsigned)v*(unsigned)w;
-      const unsigned st4 = interior ? lane4 : 0xffffffffu, st1 = interior ? lane1 : 0xffffffffu;
+      const unsigned st4 = interior ? lane4 : 0x80000000u, st1 = interior ? lane1 : 0x80000000u;   // (0x80000000 + row offset cannot wrap into range: see the depth store)
       if (!SINGLE && !a.first_pass) {
         const float prev = bld(rs_err, lane4, cro);
         if (use_min) { if (!(best < prev)) { best = prev; bsel = (int)bld8(rs_sel, lane1, cro1); } }

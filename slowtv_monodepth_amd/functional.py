@@ -1153,9 +1153,9 @@ def disp_smooth_blurred(disps: dict, imgs, *, use_edges: bool = False, want_aux:
         img_s = imgs if (hs, ws) == (H, W) else crop_resize([imgs], (H, W), (hs, ws))[0][0]
         bd = gaussian_blur3x3(d)
         x = bd + (d.mean(dim=(2, 3), keepdim=True) - bd.mean(dim=(2, 3), keepdim=True))
-        l, dg, ig = disp_smooth_fused({k: x}, gaussian_blur3x3(img_s), use_edges=use_edges, want_aux=want_aux and i == 0)
+        l, dg, ig = disp_smooth_fused({k: x}, gaussian_blur3x3(img_s), use_edges=use_edges, want_aux=want_aux and k == 0)
         total = total + l
-        if i == 0: aux = (dg, ig)
+        if k == 0: aux = (dg, ig)      # the reference returns the maps of scale KEY 0 (`ls[0][1]`, src/core/handlers.py:280), wherever it sits in the dict
     return total/len(keys), aux[0], aux[1]
 
 

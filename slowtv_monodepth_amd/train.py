@@ -229,6 +229,35 @@ def dataset_supp_idxs(cfg: dict) -> list:
     return [-1, 1]
 
 
+def restore_training_state(ckpt: dict, opt, sched, verbose: bool = True) -> int:
+    """`--resume`: optimizer + scheduler state and the epoch to continue from.  -> first epoch to run.
+
+    Optimizer and scheduler go together: either BOTH states are restored, or neither — then the moments start from zero and the fresh scheduler is
+    stepped forward to the resumed epoch, so that the learning rate is the one the schedule prescribes there (a StepLR past its decay point would
+    otherwise train at the initial rate while the epoch counter says otherwise).  A reference checkpoint carries timm's parameter-group layout,
+    which this package's optimizer refuses: that is the case this serves."""
+    import copy
+    first_epoch = int(ckpt.get('epoch', -1)) + 1
+    opt_backup = copy.deepcopy(opt.state_dict())
+    sched_backup = copy.deepcopy(sched.state_dict()) if sched is not None else None
+    try:
+        if not ckpt.get('optimizer_states'): raise KeyError('no optimizer state in the checkpoint')
+        opt.load_state_dict(ckpt['optimizer_states'][0])
+        if sched is not None:
+            if not ckpt.get('lr_schedulers'): raise KeyError('no scheduler state in the checkpoint')
+            sched.load_state_dict(ckpt['lr_schedulers'][0])
+    except (ValueError, KeyError) as e:
+        opt.load_state_dict(opt_backup)
+        if sched is not None:
+            sched.load_state_dict(sched_backup)
+            for _ in range(first_epoch): sched.step()
+        if verbose:
+            lrs = [round(g['lr'], 10) for g in opt.param_groups]
+            print(f'--resume: optimizer / scheduler state not restored ({e}); weights only — optimizer moments start from zero, the scheduler was '
+                  f'stepped to epoch {first_epoch} (learning rates {lrs})', flush=True)
+    return first_epoch
+
+
 def main(argv=None):
     p = argparse.ArgumentParser(description='Monocular depth trainer (MI355X hot path).')
     p.add_argument('--cfg-files', '-c', type=Path, nargs='*', required=True, help='YAML configs (default, override...).')
@@ -268,16 +297,12 @@ def main(argv=None):
     first_epoch = 0
     if args.resume is not None:
         from .networks.checkpoint import load_reference_checkpoint
+        import pickle
         try: ckpt = torch.load(args.resume, map_location='cpu', weights_only=True)
-        except Exception:   # a Lightning checkpoint pickles hyper-parameter objects: fall back to the full unpickler for a file the user named
-            ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)
+        except pickle.UnpicklingError:   # a Lightning checkpoint pickles hyper-parameter objects the allow-list refuses: the full unpickler, for a file the user named
+            ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)   # (a corrupt / missing file raises something else and is not retried)
         load_reference_checkpoint(module, ckpt)
-        try:   # a reference checkpoint carries timm's parameter-group layout: continue weights-only rather than refuse it
-            if ckpt.get('optimizer_states'): opt.load_state_dict(ckpt['optimizer_states'][0])
-            if sched is not None and ckpt.get('lr_schedulers'): sched.load_state_dict(ckpt['lr_schedulers'][0])
-        except (ValueError, KeyError) as e:
-            if rank == 0: print(f'--resume: optimizer / scheduler state not restored ({e}); continuing with the weights only', flush=True)
-        first_epoch = int(ckpt.get('epoch', -1)) + 1
+        first_epoch = restore_training_state(ckpt, opt, sched, verbose=rank == 0)
         if rank == 0: print(f'resumed from {args.resume}: epoch {first_epoch}, global step {ckpt.get("global_step", 0)}', flush=True)
     for epoch in range(first_epoch, tcfg.get('max_epochs', 1)):
         t0 = time.time()

@@ -353,7 +353,8 @@ class MonoDepthModule(nn.Module):
         h, w = y['imgs'].shape[-2:]
         pyramid = None if self.want_aux else [(max(h >> s, 1), max(w >> s, 1)) for s in self.scales]   # want_aux: depth comes from the K0 launch
         reg = self.losses['disp_smooth'] if 'disp_smooth' in self.losses else None                    # its edge weights are frame-only too
-        edges = bool(pyramid) and reg is not None and getattr(reg, 'use_edges', False) and not getattr(reg, 'use_laplacian', False)
+        edges = (bool(pyramid) and reg is not None and getattr(reg, 'use_edges', False) and not getattr(reg, 'use_laplacian', False)
+                 and not getattr(reg, 'use_blur', False))    # (the blurred form computes its weights from the blurred image: nothing would read these)
         return fn(crit, y['imgs'], y['supp_imgs'], pyramid, st, **({'smooth_edges': True} if edges else {}))
 
     # ------------------------------------------------------------------------------------------------

@@ -332,6 +332,31 @@ def test_checkpoint_has_the_fields_lightning_restores_and_resume_round_trips(tmp
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()): assert k1 == k2 and torch.equal(v1, v2)
 
 
+def test_resume_restores_optimizer_and_scheduler_together_or_fast_forwards_the_schedule():
+    """`train.restore_training_state`: a checkpoint whose optimizer state does not fit (a reference checkpoint: timm's parameter groups)
+    must not leave the epoch counter at N with a scheduler at epoch 0 — the fresh scheduler is stepped to N; a fitting checkpoint restores both."""
+    import warnings
+    from slowtv_monodepth_amd.train import restore_training_state
+    def fresh():
+        p = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))]
+        opt = torch.optim.AdamW([{'params': [p[0]]}, {'params': [p[1]]}], lr=1e-3)
+        return opt, torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        opt, sched = fresh()
+        for _ in range(5): sched.step()
+        good = {'epoch': 4, 'optimizer_states': [opt.state_dict()], 'lr_schedulers': [sched.state_dict()]}
+        o2, s2 = fresh()
+        assert restore_training_state(good, o2, s2, verbose=False) == 5 and s2.last_epoch == 5 and abs(o2.param_groups[0]['lr'] - 1e-5) < 1e-12
+        other = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0)      # one parameter group instead of two: load_state_dict raises ValueError
+        bad = {'epoch': 4, 'optimizer_states': [other.state_dict()], 'lr_schedulers': [sched.state_dict()]}
+        o3, s3 = fresh()
+        assert restore_training_state(bad, o3, s3, verbose=False) == 5
+        assert s3.last_epoch == 5 and abs(o3.param_groups[0]['lr'] - 1e-5) < 1e-12 and len(o3.state) == 0     # schedule at epoch 5, moments fresh
+        o4, s4 = fresh()
+        assert restore_training_state({'epoch': 1}, o4, s4, verbose=False) == 2 and abs(o4.param_groups[1]['lr'] - 1e-4) < 1e-12
+
+
 def test_trainer_applies_the_aspect_ratio_augmentation_in_training_mode_only():
     """src/core/trainer.py:54-60, 106: `training_step` augments the batch, `validation_step` does not (host logic, CPU operator)."""
     import random
