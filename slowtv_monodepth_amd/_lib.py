@@ -47,7 +47,7 @@ PROTOTYPES = {
     'smd_image_recon_disp_bwd': (_i, [_vp, _vp, _i, _f, _f] + [_vp]*13 + [_sz] + [_i]*5 + [_vp]),
     'smd_loss_path_workspace_bytes': (_sz, [_vp, _vp, _i, _i, _i, _i, _i]),
     'smd_loss_path_fwd': (_i, [_vp]*4 + [_i, _f, _f] + [_vp]*5 + [_u64] + [_vp]*7 + [_sz] + [_i]*5 + [_f, _f, _vp]),
-    'smd_loss_path_bwd': (_i, [_vp]*4 + [_i, _f, _f] + [_vp]*9 + [_f, _f] + [_vp]*13 + [_sz] + [_i]*5 + [_vp]),
+    'smd_loss_path_bwd': (_i, [_vp]*4 + [_i, _f, _f] + [_vp]*9 + [_f, _f] + [_vp]*14 + [_sz] + [_i]*5 + [_vp]),
     'smd_disp_smooth_workspace_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_disp_smooth_edge_weight_bytes': (_sz, [_vp, _vp, _i, _i]),
     'smd_gaussian_blur3x3': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -31,6 +31,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), f'{name} declared in include/smd_hotpath.h but not exported by {_lib.lib_path}'
         assert name in _lib.PROTOTYPES, f'{name} has no ctypes prototype'
     assert set(_lib.PROTOTYPES) <= declared
+    # every ctypes prototype has exactly the header's parameter count, and pointer / integer / float kinds in the same places (ctypes accepts MORE
+    # arguments than `argtypes` lists and passes the surplus as 32-bit ints: a prototype one pointer short once truncated the stream handle)
+    import ctypes as C
+    code = re.sub(r'/\*.*?\*/', ' ', header, flags=re.S)
+    for name, params in re.findall(r'\b(smd_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', code, flags=re.S):
+        params = [q.strip() for q in params.replace('\n', ' ').split(',')]
+        if params == ['void']: params = []
+        kinds = ['p' if '*' in q else ('f' if re.match(r'(const\s+)?float\b', q) else 'i') for q in params]
+        proto = _lib.PROTOTYPES[name][1]
+        got = ['p' if t in (C.c_void_p, C.c_char_p) else ('f' if t is C.c_float else 'i') for t in proto]
+        assert got == kinds, f'{name}: ctypes prototype {got} does not match the header {kinds}'
     assert _lib.lib.smd_abi_version() == 6
     # launch-shape knobs (the parity tests' pins): known name, unknown name, experiments-only name in the product build; and nothing reads the environment
     assert _lib.set_knob('fwd_rh', 12) is True and _lib.set_knob('bwd_pair', 1) is False
