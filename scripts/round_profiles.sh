@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/rNN_* is regenerated from, in one GPU call (GPU box): kernel-trace summaries of the bench at cfg 2/4/5, the PMC
 # traffic passes, and the one-rank RCCL lines.  usage: scripts/round_profiles.sh r03      (outputs under gpurun_out/)
-tag=${1:-r04}
+tag=${1:-r05}
 cd "$GRAFT_REPO_ROOT"
 # The backward picks its row loop by timing both on the live data (functional.row_skip_tuner); a profiler perturbs that timing, so the
 # traced and counter runs are pinned (SMD_BWD_SKIP) to what the un-traced bench of the same workload chose.

@@ -460,46 +460,25 @@ constexpr int kAccRows = 16;   // tallest strip of the multi-support instantiati
 __device__ unsigned long long g_wave_trace_bwd[1 << 16][3];
 #endif
 // Does any pixel within one row / column of the strip (rows r0 .. r1-1, columns c0 .. c0+59) select `key`?  Conservative in the rows (a forward strip's
-// mask covers all of its rows), exact in the columns.  Wave-uniform: scalar loads and scalar arithmetic only.  Two halves, so that the loads can be
-// in flight across the block's start-up barrier: issue() requests the (at most 3 x 3) forward-strip entries the footprint overlaps — every entry
-// before the first is looked at, indices beyond the footprint repeating its last strip: ONE round trip — and live() combines them.
-struct LiveProbe {
-  unsigned long long m[9];
-  int clo, chi, fx0, fx1;
-  bool wide;              // a footprint of more than 3 x 3 forward strips (strips of 4 rows against a tall backward strip: knob settings only): no skipping
-  __device__ __forceinline__ void issue(const ReconBwdArgs& a, int s, int bi, int key, int r0, int r1, int c0) {
-    const int frh = bi < a.fwd_b1 ? a.fwd_rh : a.fwd_rh2;            // rows per forward strip of this sample (the forward's partition: launch arguments, no dependent load)
-    const int fnsx = ceil_div(a.w, kFwdCols);
-    const int rlo = max(r0 - 1, 0), rhi = min(r1, a.h - 1);
-    clo = max(c0 - 1, 0); chi = min(c0 + kBwdCols, a.w - 1);
-    const int fy0 = rlo/frh, fy1 = rhi/frh;
-    fx0 = clo/kFwdCols; fx1 = chi/kFwdCols;
-    wide = key >= kLiveSupports || fy1 - fy0 > 2 || fx1 - fx0 > 2;
-    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(a.live + live_header_floats(a.b))
-                                    + ((size_t)s*a.b + bi)*live_max_strips(a.h, a.w)*kLiveSupports + min(key, kLiveSupports - 1);
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) m[dy*3 + dx] = tab[((size_t)min(fy0 + dy, fy1)*fnsx + min(fx0 + dx, fx1))*kLiveSupports];
-  }
-  __device__ __forceinline__ bool live() const {
-    if (wide) return true;
-    unsigned long long any = 0ull;
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      // forward lane l of strip fx holds column 62 fx - 1 + l: the lanes of columns max(clo, 62 fx - 1) .. min(chi, 62 fx + 62)
-      const int fx = min(fx0 + dx, fx1);
-      const int l0 = max(clo - (fx*kFwdCols - 1), 0), l1 = min(chi - (fx*kFwdCols - 1), 63);
-      const unsigned long long rg = (l1 >= 63 ? ~0ull : ((1ull << (l1 + 1)) - 1ull)) & ~((1ull << l0) - 1ull);
-      any |= (m[dx] | m[3 + dx] | m[6 + dx]) & rg;
-    }
-    return any != 0ull;
-  }
-};
-__device__ __forceinline__ bool strip_is_live(const ReconBwdArgs& a, int s, int bi, int key, int r0, int r1, int c0) {
-  LiveProbe p;
-  p.issue(a, s, bi, key, r0, r1, c0);
-  return p.live();
+// mask covers all of its rows), exact in the columns.  The footprint overlaps at most 3 x 3 forward strips in every partition the heuristics choose:
+// lane l < 9 fetches entry (l / 3, l mod 3) — indices beyond the footprint repeat its last strip — masks it with the lanes of its columns, and one
+// ballot answers for the wave: ONE vector load, one round trip, a handful of short-lived VGPRs.  (Done on the scalar unit — nine s_loads and their
+// 64-bit masks — it pushed the kernel over its SGPR budget: spills through VGPRs into scratch, +56 MB of HBM writes per launch in round 5's first PMC pass.)
+__device__ __forceinline__ bool strip_is_live(const ReconBwdArgs& a, int s, int bi, int key, int r0, int r1, int c0, int lane) {
+  const int frh = bi < a.fwd_b1 ? a.fwd_rh : a.fwd_rh2;            // rows per forward strip of this sample (the forward's partition: launch arguments, no dependent load)
+  const int fnsx = ceil_div(a.w, kFwdCols);
+  const int rlo = max(r0 - 1, 0), rhi = min(r1, a.h - 1), clo = max(c0 - 1, 0), chi = min(c0 + kBwdCols, a.w - 1);
+  const int fy0 = rlo/frh, fy1 = rhi/frh, fx0 = clo/kFwdCols, fx1 = chi/kFwdCols;
+  if (key >= kLiveSupports || fy1 - fy0 > 2 || fx1 - fx0 > 2) return true;   // (strips of 4 rows against a tall backward strip: knob settings only)
+  const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(a.live + live_header_floats(a.b))
+                                  + ((size_t)s*a.b + bi)*live_max_strips(a.h, a.w)*kLiveSupports + key;
+  const int q = min(lane, 8), dy = q/3, dx = q - dy*3;
+  const int fy = min(fy0 + dy, fy1), fx = min(fx0 + dx, fx1);
+  const unsigned long long m = tab[((size_t)fy*fnsx + fx)*kLiveSupports];
+  // forward lane l of strip fx holds column 62 fx - 1 + l: the lanes of columns max(clo, 62 fx - 1) .. min(chi, 62 fx + 62)
+  const int l0 = max(clo - (fx*kFwdCols - 1), 0), l1 = min(chi - (fx*kFwdCols - 1), 63);
+  const unsigned long long range = (l1 >= 63 ? ~0ull : ((1ull << (l1 + 1)) - 1ull)) & ~((1ull << l0) - 1ull);
+  return __ballot((m & range) != 0ull) != 0ull;
 }
 
 template <bool SSIM, int SKIP, int NS, bool ACC, bool XTRA>
@@ -541,13 +520,15 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   // Liveness of this wave's first support (round 5), asked BEFORE the block's start-up barrier so that the scalar loads of the table entries are in
   // flight while the block zeroes its LDS: a check placed in front of the row loop cost every wave two dependent round trips (+5 % at cfg 2, where
   // nothing is dead).
-  const bool probe_on = ACC && a.live != nullptr && a.g_in == nullptr && strip < nstrips;
-  LiveProbe probe;
-  if (probe_on) probe.issue(a, s, bi, (a.flags & SMD_USE_MIN) ? kw : 0, syi*seg_rh, min(syi*seg_rh + seg_rh, a.h), sxi*kBwdCols);
+  // Plain loop only: the gated loop finds a dead strip with its own scan of `sel` (its prologue and the zero fill are all it then runs), and it sits at
+  // its register limit — the probe cost it three spilled dwords per lane for 5 % where nearly everything is masked.
+  constexpr bool kProbe = SKIP == 0;
+  bool first_live = true;
+  if (kProbe && ACC && a.live != nullptr && a.g_in == nullptr && strip < nstrips)
+    first_live = strip_is_live(a, s, bi, (a.flags & SMD_USE_MIN) ? kw : 0, syi*seg_rh, min(syi*seg_rh + seg_rh, a.h), sxi*kBwdCols, lane);
   for (int e = threadIdx.x; e < SPB*NS*kPoseArea; e += 64*SPB*NS) pose_lds[e] = 0.f;
   if (threadIdx.x < 8) cnt[threadIdx.x] = 0u;
   __syncthreads();                                           // the only block barrier: at the start, where every wave still is
-  const bool first_live = probe_on ? probe.live() : true;
   constexpr int nw = NS;                                   // waves that work on a strip
   if (strip >= nstrips) return;                // nothing to do (the chain below counts live waves only)
   const int live_waves = min(SPB, nstrips - xb*SPB)*nw;
@@ -607,7 +588,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
       // Liveness (round 5): the forward left, per forward strip and support, the columns in which some row selects that support.  If no such
       // column lies within one pixel of this strip's rows r0-1 .. r1 and columns c0-1 .. c0+60, every gradient this wave would compute for support
       // i is an exact zero (the plain row loop multiplies by the routing mask) — park zeros and go on.  Wave-uniform, a few scalar loads.
-      if (ACC && a.live != nullptr && !cx.add_gin && !(i == kw ? first_live : strip_is_live(a, s, bi, cx.use_min ? i : 0, r0, r1, sxi*kBwdCols))) {
+      if (kProbe && ACC && a.live != nullptr && !cx.add_gin && !(i == kw ? first_live : strip_is_live(a, s, bi, cx.use_min ? i : 0, r0, r1, sxi*kBwdCols, lane))) {
         if (!cx.acc_prev) for (int r = 0; r < r1 - r0; ++r) cx.gacc[r*64] = 0.f;
         continue;     // (its pose sums stay the zeros the block started with)
       }
