@@ -350,6 +350,11 @@ def main():
                          'algorithmic_bytes': B_fwd, 'avg_kernel_ms': round(f_ms, 5), 'launches_timed': len(fwd_ms),
                          'avg_kernel_ms_inline_prep': round(avg(fwd_inline_ms), 5) if fwd_inline_ms else None,
                          'frac_inline_prep': round(B_fwd/(avg(fwd_inline_ms)*1e-3)/1e9/HBM_PEAK_GBPS, 4) if fwd_inline_ms else None,
+                         # since round 5 the launch also carries the smoothness sweep as guest blocks (single-node loss path): `frac` stays on the reconstruction's
+                         # bytes alone (comparable with earlier rounds and with BASELINE's "fused warp+SSIM+min-reproj kernel"); this is the launch's whole algorithmic work
+                         'frac_incl_guest_smoothness_sweep': (round((B_fwd + wl['b']*wl['h']*wl['w']*17.3125)/(f_ms*1e-3)/1e9/HBM_PEAK_GBPS, 4)
+                                                              if (f_ms and str(getattr(module.backend, 'last_path', '')).startswith('single node')) else None),
+                         'guest_note': 'the forward launch also runs the smoothness sweep of handlers.disp_smooth (25.5 MB algorithmic at cfg 2: b*h*w*17.3125, SURVEY.md §8d) as guest blocks behind its own; its duration includes them',
                          'peak_measured_copy': round(copy_gbps, 1), 'peak_measured_read': round(read_gbps, 1), 'frac_of_measured_copy': round(B_fwd/(f_ms*1e-3)/1e9/copy_gbps, 4) if f_ms else None},
             'roofline_bwd': {'kernel': f'{k_bwd} (fused adjoint, one wave per (strip, support); the pose / intrinsics epilogue rides in the K0-adjoint launch that follows; the instantiation the library reports for the last backward launch)', 'bound': 'hbm',
                              'row_loop': {'dead_row_skipping': skipping, 'timed': tuner.last,
