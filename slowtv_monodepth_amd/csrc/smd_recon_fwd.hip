@@ -806,7 +806,6 @@ __device__ __forceinline__ float recon_main_body(const ReconMainArgs& a) {   // 
     for (int k = 0; k < Ctx::NT; ++k) mine = (lane == k) ? cx.livem[k] : mine;
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(a.live + live_header_floats(a.b));
     if (lane < kLiveSupports) tab[(((size_t)s_*a.b + bi_)*live_max_strips(a.h, a.w) + (size_t)strip)*kLiveSupports + lane] = mine;
-    if (strip == 0 && s_ == 0 && lane == 0) a.live[bi_] = (unsigned)seg_rh;   // rows per forward strip of this sample
   }
 
   return cx.lsum;

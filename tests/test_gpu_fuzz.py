@@ -100,6 +100,66 @@ def test_random_shapes_and_options_match_the_oracle(seed):
     assert e < tol, f'{what}: d loss / d T off by {e:.3e} (rel. to max)'
 
 
+@pytest.mark.parametrize('seed', _more(32))
+def test_random_shapes_single_node_loss_path_equals_the_separate_operators(seed):
+    """Round 5: the trainer's hot call is the single-node loss path (`functional.loss_path_fused`: guest blocks in the drain of the forward launch and
+    beside the K0 adjoint, the weighted sum formed in-launch, the pose chain rule in the epilogue's wave).  Random batch / image / pyramid sizes, one
+    to four supports, inverted poses, learned intrinsics or not: bit-equal to `pose_matrices` + `image_recon_fused_disp` + `disp_smooth_fused` + the
+    eager weighted sum wherever the operator serves the draw (it declines single-level pyramids, a level taller than the image and two
+    full-resolution levels: then `Unsupported` must be raised and nothing else)."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as F
+    from slowtv_monodepth_amd._lib import Unsupported
+    r = random.Random(7000 + seed)
+    b = r.choice([1, 2, 3, 5])
+    h = r.choice([r.randint(2, 12), r.randint(13, 40), r.randint(41, 100)])
+    w = r.choice([r.randint(2, 20), r.randint(55, 70), r.randint(110, 135), r.randint(21, 260)])
+    n = r.choice([1, 2, 2, 3, 4])
+    S = r.choice([1, 2, 3, 4, 4, 4])
+    if r.random() < 0.6: lows = [(max(h >> s, 1), max(w >> s, 1)) for s in range(S)]
+    else: lows = [(r.randint(1, h), r.randint(1, w)) for _ in range(S)]
+    keys = list(range(S)) if r.random() < 0.7 else sorted(r.sample(range(6), S))
+    use_min, automask, learn_k = r.random() < 0.7, r.random() < 0.7, r.random() < 0.4
+    gen = torch.Generator(device='cuda').manual_seed(seed)
+    imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
+    supp = 0.5*imgs[None] + 0.5*torch.rand(n, b, 3, h, w, device='cuda', generator=gen)
+    d0 = [0.05 + 0.9*torch.rand(b, 1, hs, ws, device='cuda', generator=gen) for hs, ws in lows]
+    aa0, t0 = 0.02*torch.randn(n*b, 3, device='cuda', generator=gen), 0.1*torch.randn(n*b, 3, device='cuda', generator=gen)
+    inv = torch.tensor([r.random() < 0.5 for _ in range(n) for _ in range(b)], dtype=torch.uint8, device='cuda') if r.random() < 0.7 else None
+    fs0 = torch.tensor([0.58, 1.92], device='cuda')[None].repeat(b, 1)*(1 + 0.05*torch.randn(b, 2, device='cuda', generator=gen)); cs0 = 0.5 + 0.03*torch.randn(b, 2, device='cuda', generator=gen)
+    K0 = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    flags = F.recon_flags('ssim', use_min, automask)
+    w_sm = torch.tensor(r.choice([0.001, 0.1, 1.0]), device='cuda')
+    what = f'seed {seed}: b={b} {h}x{w} n={n} pyramid {lows} keys {keys} min={use_min} automask={automask} learnK={learn_k}'
+    os.environ['SMD_BWD_SKIP'] = '0'
+    try:
+        def run(one_node):
+            L = dict(d=[v.clone().requires_grad_(True) for v in d0], aa=aa0.clone().requires_grad_(True), t=t0.clone().requires_grad_(True))
+            if learn_k: L.update(fs=fs0.clone().requires_grad_(True), cs=cs0.clone().requires_grad_(True))
+            Ts = F.pose_matrices(L['aa'], L['t'], inv).unflatten(0, (n, b))
+            K, K_inv = F.intrinsics(L['fs'], L['cs'], (h, w)) if learn_k else (K0, None)
+            if one_node:
+                loss, l_rec, l_sm, sel, dep = F.loss_path_fused(dict(zip(keys, L['d'])), imgs, supp, Ts, K, K_inv, pose=(L['aa'], L['t'], inv),
+                                                                intrinsics=(L['fs'], L['cs']) if learn_k else None, flags=flags, min_depth=0.1, max_depth=100, seed=seed,
+                                                                w_recon=1.0, w_smooth=float(w_sm))
+            else:
+                l_rec, _, sel, _, dep = F.image_recon_fused_disp(L['d'], imgs, supp, Ts, K, K_inv, flags=flags, min_depth=0.1, max_depth=100, seed=seed, want_err=False)
+                l_sm, _, _ = F.disp_smooth_fused(dict(zip(keys, L['d'])), imgs, use_edges=True, want_aux=False)
+                loss = (0. + torch.tensor(1.0, device='cuda')*l_rec) + w_sm*l_sm
+            loss.backward()
+            return loss.detach(), l_rec.detach(), l_sm.detach(), sel, dep.detach(), L
+        supported = S >= 2 and all(hs <= h for hs, _ in lows) and sum((hs, ws) == (h, w) for hs, ws in lows) <= 1
+        if not supported:
+            with pytest.raises(Unsupported): run(True)
+            return
+        a, bb = run(False), run(True)
+        torch.cuda.synchronize()
+    finally: del os.environ['SMD_BWD_SKIP']
+    for k, name in enumerate(('loss', 'l_rec', 'l_sm', 'sel', 'depth_up')): assert torch.equal(a[k], bb[k]), f'{what}: {name} differs'
+    for k, (x, y) in enumerate(zip(a[5]['d'], bb[5]['d'])): assert torch.equal(x.grad, y.grad), f'{what}: d loss / d disp[{k}] differs by {(x.grad - y.grad).abs().max().item():.3e}'
+    for k in ('aa', 't') + (('fs', 'cs') if learn_k else ()): assert rel_to_max(bb[5][k].grad, a[5][k].grad) <= 2e-6, f'{what}: d loss / d {k}: {rel_to_max(bb[5][k].grad, a[5][k].grad):.2e}'
+
+
 @pytest.mark.parametrize('seed', _more(12))
 def test_random_smoothness_options_match_the_oracle(seed):
     """`handlers.disp_smooth` over random image / pyramid sizes with `use_edges` and `use_laplacian` drawn at random (the first-order form is
