@@ -63,7 +63,8 @@ __host__ __device__ inline size_t packed_arrive_offset_floats(int b, int n, int 
 // ... and (round 5) the LIVENESS table the forward leaves for the backward: which columns of each forward strip have, in ANY of the strip's rows,
 // a pixel whose final selection is support k — one 64-bit lane mask per (scale, sample, forward strip, k < 4): bit l <-> column 62*sx - 1 + l.
 // A backward wave (one support of one strip) whose 3x3-dilated footprint overlaps no such column has nothing to do: every gradient it would
-// compute is an exact zero.  Entry layout: live_rh [b] ints (rows per forward strip of each sample: the tapered partition differs per sample),
+// compute is an exact zero.  Entry layout: a reserved header of live_header_floats(b) words (the backward gets the forward's partition — rows per forward strip of each
+// sample: the tapered partition differs per sample — as launch arguments fwd_rh / fwd_b1 / fwd_rh2, not from memory),
 // then masks [SMD_MAX_SCALES][b][live_max_strips][4] uint64.  Every entry is owned by one forward wave, which stores it unconditionally on the
 // launch's last pass: no zero-fill, no atomics.
 constexpr int kLiveSupports = 4;
