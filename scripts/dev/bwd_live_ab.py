@@ -12,6 +12,8 @@ from slowtv_monodepth_amd.train import StepModule, train_steps
 from slowtv_monodepth_amd.trainer import MonoDepthModule
 name = sys.argv[1] if len(sys.argv) > 1 else 'cfg5'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+for kv in filter(None, os.environ.get('MB_KNOBS', '').split(',')):   # e.g. MB_KNOBS=bwd_wps=1 (smd_set_knob), applied to every variant
+    k_, v_ = kv.split('='); assert _lib.set_knob(k_, int(v_)), f'knob {k_} is not in this build'
 wl = dict(bench.WORKLOADS[name])
 torch.manual_seed(42)
 module = MonoDepthModule(bench.make_cfg(wl)).cuda()

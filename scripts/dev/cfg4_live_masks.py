@@ -3,7 +3,7 @@
 The bench's cfg 4 collapses: with randomly initialised learned intrinsics > 99 % of the pixels are auto-masked from the second optimiser step on, so what
 it times is the all-masked floor of the backward.  Here the same operator runs on frames / disparities / poses whose masks are alive — the generator of the
 BASELINE-resolution reference fixtures (tests/golden/exact_inputs.py + the motion of make_golden.py: a camera translation that roughly explains the frames'
-shifts), 12 samples — with both row loops pinned, interleaved.  usage: cfg4_live_masks.py [n_supports]"""
+shifts), 12 samples — with both row loops pinned, interleaved.  usage: cfg4_live_masks.py [n_supports] [batch] [height]"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
@@ -11,7 +11,9 @@ import torch
 from exact_inputs import frame_shifts, make_inputs_exact
 from slowtv_monodepth_amd import functional as F, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-b, h, w, scales = 12, 384, 640, [0, 1, 2, 3]
+for kv in filter(None, os.environ.get('MB_KNOBS', '').split(',')):   # e.g. MB_KNOBS=bwd_wps=1 (smd_set_knob)
+    k_, v_ = kv.split('='); assert _lib.set_knob(k_, int(v_)), f'knob {k_} is not in this build'
+b, h, w, scales = (int(sys.argv[2]) if len(sys.argv) > 2 else 12), (int(sys.argv[3]) if len(sys.argv) > 3 else 384), 640, [0, 1, 2, 3]
 inp = make_inputs_exact(2025, b, h, w, n, scales)
 g = torch.Generator().manual_seed(2026)
 sh = torch.tensor(frame_shifts(n), dtype=torch.float32)
@@ -30,7 +32,7 @@ def once():
     out[0].backward()
     return out
 sel = once()[3]
-print(f'384x640 b=12 n={n}, learned K, live masks: automasked {(sel == 255).float().mean().item():.3f} routed {[round((sel == i).float().mean().item(), 3) for i in range(n)]} '
+print(f'{h}x640 b={b} n={n}, learned K, live masks: automasked {(sel == 255).float().mean().item():.3f} routed {[round((sel == i).float().mean().item(), 3) for i in range(n)]} '
       f'dead waves (table) {[round(v, 3) for v in F.dead_wave_shares(sel, True, n, table_rh=16).tolist()]}')
 iters, rounds = 5, 6
 times = {v: ([], []) for v in ('0', '2')}

@@ -420,7 +420,14 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   // so its tail is a fraction of a unit) and the waves of a strip share the target-side rows through one L1; 1: a wave takes every
   // support of its strip in turn.  cfg 2, rocprofv3: 113 vs 115 us on coherent masks, 187 vs 212 us on incoherent inputs, 140 vs
   // 145 us in the bench (profiles/r03_ab_kernel_times.txt).
-  a.wps = knob("bwd_wps", n < 4 ? n : 4);
+  // Round 5: ONE wave per strip, taking the supports in turn, once the launch has at least three generations of such waves (strips x scales x
+  // samples >= 3 x 4096 slots: 384x640 at b = 12, 192x640 at b = 24).  With every support live the two shapes cost the same there (441.7 vs 445.5 us
+  // at four supports, 243.2 vs 243.1 at two; 10 % in favour of one wave per support in launches half that size: r05_bwd_wps_sweep.txt); but a wave
+  // that takes its supports in turn simply passes over the ones the liveness table calls dead, so its time follows the LIVE supports — whereas a
+  // dead support's own wave frees an issue slot, not a place for another block (LDS-resident until the block's slowest wave ends).  cfg 5 on
+  // the masks of a training run: 404 -> 362 us; three supports all live: 362 -> 346 (four waves' slots hold 4 strips instead of 1 1/3).
+  const long units1 = (long)pl.nsx*pl.nsy*S*b;
+  a.wps = knob("bwd_wps", (n >= 2 && units1 >= 3L*4096) ? 1 : (n < 4 ? n : 4));
   if (a.wps < 1) a.wps = 1;
   if (a.wps > 4) a.wps = 4;
   if (a.wps > n) a.wps = n;

@@ -1728,3 +1728,37 @@ def test_backward_liveness_table_skips_only_exact_zeros(F, knobs, monkeypatch, b
     assert all(torch.isfinite(x).all() for x in g1), shares
     if use_min and rows == 'bands': assert all(0.1 < v < 0.9 for v in shares[:n]), shares        # every support is live in its band and dead elsewhere
     if rows == 'dead': assert shares[-1] > 0.01 and max(shares[1:n]) < 0.02, shares               # supports 1 .. n-1 are (nearly) dead everywhere; the automask takes a region
+
+
+@pytest.mark.parametrize('b,h,w,n,lows', [(3, 96, 320, 4, [(96, 320), (48, 160), (24, 80), (12, 40)]), (2, 50, 130, 2, [(50, 130), (25, 65)]),
+                                          (2, 64, 200, 3, [(64, 200), (32, 100), (16, 50)]), (12, 192, 640, 2, [(192, 640), (96, 320), (48, 160), (24, 80)])])
+@pytest.mark.parametrize('skip', ['0', '2'])
+def test_one_wave_per_strip_equals_one_wave_per_support(F, knobs, monkeypatch, b, h, w, n, lows, skip):
+    """Round 5: in launches of three or more generations the backward runs ONE wave per strip that takes the supports in turn (and passes over the
+    ones the liveness table calls dead) instead of one wave per (strip, support).  Same operations on the same operands, the supports' shares of
+    dL/d depth added in the same order: every disparity gradient BIT-equal between knob `bwd_wps` = 1 and = min(n, 4), with dead supports in bands of
+    the image (the pose gradient to 1e-6: its fp32 per-block partial sums group other strips)."""
+    monkeypatch.setenv('SMD_BWD_SKIP', skip)
+    gen = torch.Generator(device='cuda').manual_seed(h + w + n)
+    imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
+    supp = torch.rand(n, b, 3, h, w, device='cuda', generator=gen)
+    for i in range(n):
+        r0, r1 = i*h//n, (i + 1)*h//n
+        supp[i, :, :, r0:r1] = (imgs[:, :, r0:r1] + 0.02*torch.randn(b, 3, r1 - r0, w, device='cuda', generator=gen)).clamp(0, 1)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    T0 = torch.eye(4, device='cuda').repeat(n, b, 1, 1); T0[..., :3, 3] = 0.002*torch.randn(n, b, 3, device='cuda', generator=gen)
+    d0 = [0.05 + 0.9*torch.rand(b, 1, hs, ws, device='cuda', generator=gen) for hs, ws in lows]
+    flags = F.recon_flags('ssim', True, False)
+
+    def run(wps):
+        knobs('bwd_wps', wps)
+        d = [v.clone().requires_grad_(True) for v in d0]; T = T0.clone().requires_grad_(True)
+        loss, _, sel, _, _ = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=flags, min_depth=0.1, max_depth=100, seed=5, want_err=False)
+        loss.backward(); torch.cuda.synchronize()
+        from slowtv_monodepth_amd import _lib
+        return [v.grad for v in d] + [T.grad], _lib.lib.smd_last_kernel_variant(1).decode()
+    g1, k1 = run(1); gn, kn = run(min(n, 4))
+    assert f', 1, true' in k1 and f', {min(n, 4)}, true' in kn, (k1, kn)
+    for k, (x, y) in enumerate(zip(g1[:-1], gn[:-1])): assert torch.equal(x, y), f'd loss / d disp[{k}]: one wave per strip differs from one wave per support (max {(x - y).abs().max().item():.3e})'
+    # dL/dT: a block's pose sums are added in fp32 over its waves before the fp64 sum over the blocks, and a block is now four strips instead of one
+    assert rel_to_max(g1[-1], gn[-1]) <= 1e-6
