@@ -1731,7 +1731,8 @@ def test_backward_liveness_table_skips_only_exact_zeros(F, knobs, monkeypatch, b
 
 
 @pytest.mark.parametrize('b,h,w,n,lows', [(3, 96, 320, 4, [(96, 320), (48, 160), (24, 80), (12, 40)]), (2, 50, 130, 2, [(50, 130), (25, 65)]),
-                                          (2, 64, 200, 3, [(64, 200), (32, 100), (16, 50)]), (12, 192, 640, 2, [(192, 640), (96, 320), (48, 160), (24, 80)])])
+                                          (2, 64, 200, 3, [(64, 200), (32, 100), (16, 50)]), (12, 192, 640, 2, [(192, 640), (96, 320), (48, 160), (24, 80)]),
+                                          (12, 384, 640, 4, [(384, 640), (192, 320), (96, 160), (48, 80)])])       # cfg 5's size: what the heuristic itself picks there is checked too
 @pytest.mark.parametrize('skip', ['0', '2'])
 def test_one_wave_per_strip_equals_one_wave_per_support(F, knobs, monkeypatch, b, h, w, n, lows, skip):
     """Round 5: in launches of three or more generations the backward runs ONE wave per strip that takes the supports in turn (and passes over the
@@ -1757,8 +1758,20 @@ def test_one_wave_per_strip_equals_one_wave_per_support(F, knobs, monkeypatch, b
         loss.backward(); torch.cuda.synchronize()
         from slowtv_monodepth_amd import _lib
         return [v.grad for v in d] + [T.grad], _lib.lib.smd_last_kernel_variant(1).decode()
+    def run_default():
+        d = [v.clone().requires_grad_(True) for v in d0]; T = T0.clone().requires_grad_(True)
+        loss, *_ = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=flags, min_depth=0.1, max_depth=100, seed=5, want_err=False)
+        loss.backward(); torch.cuda.synchronize()
+        from slowtv_monodepth_amd import _lib
+        return [v.grad for v in d] + [T.grad], _lib.lib.smd_last_kernel_variant(1).decode()
     g1, k1 = run(1); gn, kn = run(min(n, 4))
     assert f', 1, true' in k1 and f', {min(n, 4)}, true' in kn, (k1, kn)
     for k, (x, y) in enumerate(zip(g1[:-1], gn[:-1])): assert torch.equal(x, y), f'd loss / d disp[{k}]: one wave per strip differs from one wave per support (max {(x - y).abs().max().item():.3e})'
     # dL/dT: a block's pose sums are added in fp32 over its waves before the fp64 sum over the blocks, and a block is now four strips instead of one
     assert rel_to_max(g1[-1], gn[-1]) <= 1e-6
+    if b*h*w >= 12*384*640:      # three or more generations of strip waves: the library's own choice is one wave per strip (smd_api.hip)
+        from slowtv_monodepth_amd import _lib
+        _lib.reset_knobs()
+        gd, kd = run_default()
+        assert ', 1, true' in kd, kd
+        assert all(torch.equal(x, y) for x, y in zip(gd, g1))
