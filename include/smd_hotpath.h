@@ -66,7 +66,7 @@ int smd_abi_version(void);
  * same results: rows per strip, the tapered partition, shared LDS ring vs. per-wave loads in the forward, the backward's two row loops,
  * guest work vs. launches of their own.  They exist so that the parity tests can pin both sides of each such choice and compare; the
  * library never reads the environment.  Names: fwd_rh bwd_rh fwd_taper_b bwd_taper_b fwd_taper_rh bwd_taper_rh fwd_ni fwd_share bwd_skip
- * bwd_wps bwd_guest_finalize bwd_direct_level loss_path_guests bwd_live (and, in -DSMD_EXPERIMENTS builds only: fwd_ahead bwd_pair smooth_chain).
+ * bwd_wps bwd_guest_finalize bwd_direct_level loss_path_guests bwd_live bwd_scales_block (and, in -DSMD_EXPERIMENTS builds only: fwd_ahead bwd_pair smooth_chain).
  * smd_set_knob: 0, SMD_E_INVALID for an unknown name, SMD_E_UNSUPPORTED for an experiments-only knob in the product build. */
 int smd_set_knob(const char* name, int value);
 void smd_reset_knobs(void);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the fused backward on the selection maps of a REAL training run, same inputs for every variant (GPU box).
 Trains the bench's model for `steps` optimiser steps, captures the arguments of the last `loss_path_fused` call, then times forward + backward of
-that call alone under: liveness table on / off (knob bwd_live) x plain / gated row loop (SMD_BWD_SKIP).  usage: bwd_live_ab.py [cfg5|cfg4|cfg2] [steps]"""
+that call alone under: liveness table on / off (knob bwd_live; AB_KNOB=<name> varies another 0/1 knob instead) x plain / gated row loop (SMD_BWD_SKIP).
+usage: bwd_live_ab.py [cfg5|cfg4|cfg2] [steps]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -42,13 +43,14 @@ def once():
 sel = once()[3]
 print(f'{name} after {steps} steps: automasked {(sel == 255).float().mean().item():.3f} routed {[round((sel == i).float().mean().item(), 4) for i in range(n)]} '
       f'dead waves (table) {[round(v, 3) for v in F.dead_wave_shares(sel, True, n, table_rh=16).tolist()]} (exact) {[round(v, 3) for v in F.dead_wave_shares(sel, True, n).tolist()]}')
+ab_knob = os.environ.get('AB_KNOB', 'bwd_live')
 iters, rounds = 5, 6          # the variants are INTERLEAVED (a box's clocks drift over the first seconds: whatever is timed first looks slower)
 variants = [(skip, live) for skip in ('0', '2') for live in (1, 0)]
 times = {v: ([], []) for v in variants}
 for _ in range(3): once()
 for r in range(rounds):
     for v in (variants if r % 2 == 0 else variants[::-1]):
-        os.environ['SMD_BWD_SKIP'] = v[0]; _lib.set_knob('bwd_live', v[1])
+        os.environ['SMD_BWD_SKIP'] = v[0]; _lib.set_knob(ab_knob, v[1])
         once(); torch.cuda.synchronize()
         for k in (0, 1): _lib.lib.smd_profile_enable(k, iters)
         for _ in range(iters): once()
@@ -59,4 +61,4 @@ for r in range(rounds):
             _lib.lib.smd_profile_enable(k, 0)
 med = lambda x: sorted(x)[len(x)//2]
 for v in variants:
-    print(f'  row loop {"gated" if v[0] == "2" else "plain"}, liveness table {"on " if v[1] else "off"}: forward {med(times[v][0]):.1f} us, backward {med(times[v][1]):.1f} us (min {min(times[v][1]):.1f}, {len(times[v][1])} launches)')
+    print(f'  row loop {"gated" if v[0] == "2" else "plain"}, {ab_knob} {v[1]}: forward {med(times[v][0]):.1f} us, backward {med(times[v][1]):.1f} us (min {min(times[v][1]):.1f}, {len(times[v][1])} launches)')

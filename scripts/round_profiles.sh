@@ -16,7 +16,7 @@ for wl in cfg2 cfg4 cfg5; do
     # (round 4: under `rocprofv3 --pmc` the bf16 ConvNeXt workload dies inside MIOpen's convolution backward; the loss path alone — same kernels, same
     # shapes, scripts/dev/microbench.py inputs — is counted instead, and the summary says so)
     echo "$wl: counter passes over bench.py failed; counting the loss path alone (scripts/dev/microbench.py $wl)" | tee gpurun_out/pmc_fallback_$wl.txt
-    SMD_BWD_SKIP=$skip PMC_TIMEOUT=300 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" bash scripts/pmc.sh ${tag}_bench_$wl python scripts/dev/microbench.py $wl 5 > /dev/null
+    SMD_BWD_SKIP=$skip PMC_TIMEOUT=300 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" bash scripts/pmc.sh ${tag}_bench_$wl python $GRAFT_REPO_ROOT/scripts/dev/microbench.py $wl 5 > /dev/null
     sed -i "1i (counter passes over scripts/dev/microbench.py $wl 5: bench.py --workload $wl crashes inside MIOpen under rocprofv3 --pmc)" gpurun_out/pmc_${tag}_bench_$wl/summary.txt
   fi
 done

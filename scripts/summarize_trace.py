@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 kernel_trace.csv: per-kernel count / avg / min / max duration (us), VGPRs, LDS, grid.
 
-usage: summarize_trace.py kernel_trace.csv [--steady MARKER N]
+usage: summarize_trace.py kernel_trace.csv [--steady MARKER N | --timeline FIRST LAST [PAD]]
+  --timeline FIRST LAST [PAD]   the dispatch sequence of the LAST training step from the launch whose name contains FIRST to the one whose name contains
+                      LAST, PAD (default 3) dispatches either side: start offset, duration, gap to the previous dispatch's end, stream (queue) —
+                      what actually sits on the critical path between the networks' forward and their backward.
   --steady MARKER N   keep only the dispatches of the last N training steps, delimited by the launches of the kernel whose
                       name contains MARKER (one launch per step), so that MIOpen's first-use solver search during warm-up
                       does not drown the steady state.  Totals are then also printed per step.
@@ -10,6 +13,22 @@ import csv, sys, collections
 args = sys.argv[1:]
 rows = list(csv.DictReader(open(args[0])))
 steps = None
+if len(args) >= 4 and args[1] == '--timeline':
+    first, last, pad = args[2], args[3], int(args[4]) if len(args) > 4 else 3
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    i1 = max(i for i, r in enumerate(rows) if last in r['Kernel_Name'])
+    i0 = max(i for i, r in enumerate(rows[:i1]) if first in r['Kernel_Name'])
+    sel = rows[max(i0 - pad, 0):i1 + pad + 1]
+    t0, prev_end = int(rows[i0]['Start_Timestamp']), None
+    print(f'{"start_us":>10s} {"dur_us":>9s} {"gap_us":>8s} {"queue":>6s}  kernel   (t = 0: start of the first "{first}" launch of the last step)')
+    for r in sel:
+        st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        gap = '' if prev_end is None else f'{(st - prev_end)/1e3:8.2f}'
+        print(f'{(st - t0)/1e3:10.2f} {(en - st)/1e3:9.2f} {gap:>8s} {r.get("Queue_Id", ""):>6s}  {r["Kernel_Name"][:110]}')
+        prev_end = en if prev_end is None else max(prev_end, en)
+    span = (int(rows[i1]['End_Timestamp']) - t0)/1e3
+    print(f'span from the start of "{first}" to the end of "{last}": {span:.2f} us')
+    sys.exit(0)
 if len(args) >= 4 and args[1] == '--steady':
     marker, n = args[2], int(args[3])
     rows.sort(key=lambda r: int(r['Start_Timestamp']))

@@ -44,12 +44,13 @@ int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil
 //   of the hot forward is the four scales of one strip and the target-side rows reach it through an LDS ring); bwd_skip (0 / 2: the
 //   backward's row loop, overriding the SMD_BWD_SKIP_DEAD_ROWS flag of the call); bwd_wps (waves per strip of the backward);
 //   bwd_guest_finalize; bwd_direct_level; loss_path_guests (0: the fused loss path launches its guest work as kernels of their own);
-//   bwd_live (0: the backward ignores the forward's liveness table and runs every wave's row loop).
+//   bwd_live (0: the backward ignores the forward's liveness table and runs every wave's row loop); bwd_scales_block (0: with one wave per strip a
+//   block stays four strips of one scale instead of the four scales of one strip).
 //   Experiments builds only: fwd_ahead (2: tap gathers two rows ahead, measured slower), bwd_pair (two supports per wave, dropped), smooth_chain.
 struct KnobDef { const char* name; bool experiment; };
 constexpr KnobDef kKnobs[] = {{"fwd_rh", false}, {"bwd_rh", false}, {"fwd_taper_b", false}, {"bwd_taper_b", false}, {"fwd_taper_rh", false},
                               {"bwd_taper_rh", false}, {"fwd_ni", false}, {"fwd_share", false}, {"bwd_skip", false}, {"bwd_wps", false},
-                              {"bwd_guest_finalize", false}, {"bwd_direct_level", false}, {"loss_path_guests", false}, {"bwd_live", false},
+                              {"bwd_guest_finalize", false}, {"bwd_direct_level", false}, {"loss_path_guests", false}, {"bwd_live", false}, {"bwd_scales_block", false},
                               {"fwd_ahead", true}, {"bwd_pair", true}, {"smooth_chain", true}};
 constexpr int kNumKnobs = sizeof(kKnobs)/sizeof(kKnobs[0]);
 constexpr int kKnobUnset = INT_MIN;
@@ -431,6 +432,10 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   if (a.wps < 1) a.wps = 1;
   if (a.wps > 4) a.wps = 4;
   if (a.wps > n) a.wps = n;
+  // four scales and two or four strips per block: blocks of the scales of a strip instead (k_recon_bwd) — every block must then have its strip
+  const int spb = smd::kWavesPerBlock/a.wps;
+  a.scales_block = (n > 1 && S == 4 && smd::kWavesPerBlock == 4 && (spb == 2 || spb == 4) && (pl.nsx*pl.nsy) % spb == 0
+                    && (a.b1 >= b || (pl.nsx*a.nsy2) % spb == 0) && knob("bwd_scales_block", 1) != 0) ? 1 : 0;
 #ifdef SMD_EXPERIMENTS
   // Two supports per wave (knob bwd_pair; experiment of round 4): the strips of a block must be those of the one-support-per-wave kernel
   // with wps = n, so that the K0-adjoint guest epilogue finds the same per-block pose entries.

@@ -159,6 +159,7 @@ struct ReconBwdArgs {
   int b1, rh2, nsy2;      // tapered partition, as in ReconMainArgs
   int pose_stride;        // entries reserved per (support, sample) in pose_partial: S*nsx*max(nsy, nsy2)
   int wps;                // waves per strip (1 .. min(n, 4)): the supports of a strip are split over this many waves of one block
+  int scales_block;       // wps == 1, S == 4: a block is the four SCALES of one strip (they read the same target-side rows and gather near the same texels) instead of four strips of one scale
   float wscale, hscale;
   int skip_level;         // 0..2, see k_recon_bwd
   int pair;               // 1: two supports per wave (k_recon_bwd_pair; n = 2 or 4, min-reprojection, plain row loop)

@@ -514,7 +514,14 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   const int nbx = ceil_div(nstrips, SPB);
   int xb, bi, s;
   decode_tile(tail ? blockIdx.x - nblk1 : blockIdx.x, nbx, tail ? a.b - a.b1 : a.b1, a.S, xb, bi, s);
-  const int strip = xb*SPB + sib;
+  const int slot = s;                      // the block's slot among the S blocks of its tile: indexes its pose-sum entry
+  // Four scales (round 5), fewer than four waves per strip: the block's waves are SPB SCALES of ONE strip — the decode's scale index picks the strip
+  // within a tile of SPB adjacent strips and the group of SPB scales — instead of SPB strips of one scale.  A wave that takes its supports in turn
+  // re-reads the strip's target-side rows (target pixel, window terms: 44 of the 49 bytes per pixel are the same for every scale) once per support;
+  // waves that walk the same rows of the same strip share them through one L1, and gather near the same texels.
+  const bool scales_block = SPB > 1 && a.scales_block != 0;
+  const int strip = scales_block ? xb*SPB + slot % SPB : xb*SPB + sib;
+  if (scales_block) s = (slot/SPB)*SPB + sib;
   if (tail) bi += a.b1;
   const int sxi = strip % a.nsx, syi = strip/a.nsx;
   // Liveness of this wave's first support (round 5), asked BEFORE the block's start-up barrier so that the scalar loads of the table entries are in
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
   __syncthreads();                                           // the only block barrier: at the start, where every wave still is
   constexpr int nw = NS;                                   // waves that work on a strip
   if (strip >= nstrips) return;                // nothing to do (the chain below counts live waves only)
-  const int live_waves = min(SPB, nstrips - xb*SPB)*nw;
+  const int live_waves = scales_block ? SPB*nw : min(SPB, nstrips - xb*SPB)*nw;   // (scales_block: the host guarantees nstrips % SPB == 0, every block has its strip)
   const int h = a.h, w = a.w;
   const int r0 = syi*seg_rh, r1 = min(r0 + seg_rh, h);
   const int u = sxi*kBwdCols - 2 + lane;
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(64*kWavesPerBlock, 4) void k_recon_bwd(const ReconB
     float v = 0.f;
 #pragma unroll
     for (int wv = 0; wv < SPB*NS; ++wv) v += pose_lds[wv*kPoseArea + e];
-    float* pp = a.pose_partial + (((size_t)i*a.b + bi)*(size_t)a.pose_stride + (size_t)s*nbx + xb)*kPoseSums;
+    float* pp = a.pose_partial + (((size_t)i*a.b + bi)*(size_t)a.pose_stride + (size_t)slot*nbx + xb)*kPoseSums;
     __hip_atomic_store((unsigned*)(pp + k), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (a.arrive == nullptr) return;   // the sample's epilogue rides in the launch that follows (K0 adjoint: smd_depth.hip), no hand-off needed

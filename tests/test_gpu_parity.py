@@ -1766,6 +1766,10 @@ def test_one_wave_per_strip_equals_one_wave_per_support(F, knobs, monkeypatch, b
         return [v.grad for v in d] + [T.grad], _lib.lib.smd_last_kernel_variant(1).decode()
     g1, k1 = run(1); gn, kn = run(min(n, 4))
     assert f', 1, true' in k1 and f', {min(n, 4)}, true' in kn, (k1, kn)
+    # with four scales a one-wave-per-strip block is the four SCALES of a strip (where every block then has its strip) — against four strips of a scale
+    knobs('bwd_scales_block', 0); gs, _ = run(1); knobs('bwd_scales_block', 1)
+    for k, (x, y) in enumerate(zip(g1[:-1], gs[:-1])): assert torch.equal(x, y), f'd loss / d disp[{k}]: blocks of four scales differ from blocks of four strips (max {(x - y).abs().max().item():.3e})'
+    assert rel_to_max(g1[-1], gs[-1]) <= 1e-6
     for k, (x, y) in enumerate(zip(g1[:-1], gn[:-1])): assert torch.equal(x, y), f'd loss / d disp[{k}]: one wave per strip differs from one wave per support (max {(x - y).abs().max().item():.3e})'
     # dL/dT: a block's pose sums are added in fp32 over its waves before the fp64 sum over the blocks, and a block is now four strips instead of one
     assert rel_to_max(g1[-1], gn[-1]) <= 1e-6
