@@ -184,6 +184,20 @@ def wrap_ddp(step: StepModule, device: torch.device, bucket_cap_mb: int = 25) ->
                                                bucket_cap_mb=bucket_cap_mb)  # (static_graph would forbid no_sync() on the first micro-step)
 
 
+_SEEDS: dict = {}
+
+
+def _grad_seed(loss: torch.Tensor, accumulate: int) -> torch.Tensor:
+    """The gradient `(loss/accumulate).backward()` would start from — fl(1/accumulate) in the loss's dtype, the quotient the division's own backward
+    forms — as a cached tensor: the division, the `ones_like` fill and the division's backward are three latency-sized launches that sit between the
+    loss path's forward and backward on every step."""
+    key = (loss.device, loss.dtype, tuple(loss.shape), int(accumulate))
+    seed = _SEEDS.get(key)
+    if seed is None:
+        seed = _SEEDS[key] = torch.ones(loss.shape, device=loss.device, dtype=loss.dtype)/accumulate
+    return seed
+
+
 def train_steps(model: nn.Module, opt: torch.optim.Optimizer, batch_fn, steps: int, accumulate: int = 1, clip=None, detect_anomaly: bool = False):
     """Run `steps` optimizer micro-steps (each = forward + backward on one batch; the optimizer fires every `accumulate`).
     LR schedulers step per epoch in the reference (Lightning's default interval), so they are the caller's business.
@@ -199,7 +213,7 @@ def train_steps(model: nn.Module, opt: torch.optim.Optimizer, batch_fn, steps: i
         with ctx:
             loss, _ = model(batch_fn(it))
             if detect_anomaly and not torch.isfinite(loss).item(): raise ValueError(f'Detected NaN/Infinite loss: "{loss.item()}"')
-            (loss/accumulate).backward()
+            loss.backward(gradient=_grad_seed(loss, accumulate))    # == (loss/accumulate).backward(), without its three launches per step
         if boundary:
             if flat: model.sync_gradients()
             if clip: torch.nn.utils.clip_grad_norm_(model.parameters(), clip)

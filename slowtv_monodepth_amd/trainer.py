@@ -238,8 +238,9 @@ class MonoDepthModule(nn.Module):
         pose = {k: v.float() for k, v in pose.items()}
         idxs = [i for i in idxs_all if i != 0]
         flags = [bool(inv(i)) for i in idxs for _ in range(sh[1])]
-        aa, tr = pose['R'][:, 0], pose['t'][:, 0]
+        aa, tr = pose['R'][:, 0].contiguous(), pose['t'][:, 0].contiguous()   # (strided views of the head's output: packed ONCE, for `pose_matrices` and for the loss path)
         Ts = self.backend.pose_matrices(aa, tr, flags).unflatten(0, sh)
+        self._Ts_all = Ts
         self._pose_leaves = (aa, tr, flags, idxs)   # for the fused loss path: its backward hands the gradients to the network's outputs directly
         for i, T in zip(idxs, Ts): out[f'T_{i}'] = T
         if 'fs' in pose:
@@ -253,7 +254,12 @@ class MonoDepthModule(nn.Module):
                                                             want_disp_up=self.want_aux)
         if disp_up is not None: fwd['disp_up'] = disp_up   # only the image logger reads the un-scaled up-sampled disparity
         # a stereo support (index 0) brings its known pose with the batch instead of a predicted one (src/core/trainer.py:347)
-        fwd['Ts'] = torch.stack([(y['T_stereo'] if int(i) == 0 else fwd[f'T_{int(i)}']) for i in x['supp_idxs']])
+        leaves, Ts_all = getattr(self, '_pose_leaves', None), getattr(self, '_Ts_all', None)
+        if (leaves is not None and Ts_all is not None and [int(i) for i in x['supp_idxs']] == list(leaves[3])
+                and all(fwd[f'T_{i}'].data_ptr() == Ts_all[k].data_ptr() for k, i in enumerate(leaves[3]))):    # (this `fwd` is that call's)
+            fwd['Ts'] = Ts_all     # every support's pose came out of ONE `pose_matrices` call, already stacked in this order: no copy
+        else:
+            fwd['Ts'] = torch.stack([(y['T_stereo'] if int(i) == 0 else fwd[f'T_{int(i)}']) for i in x['supp_idxs']])
         return fwd
 
     def forward_loss(self, fwd: dict, x: dict, y: dict):
@@ -329,7 +335,7 @@ class MonoDepthModule(nn.Module):
         x, y, m = batch
         self.synth = ViewSynth(x['imgs'].shape[-2:])
         self._prepared = self._prepare_frames(y) if self.prep_ahead == 'own' else None
-        self._y, self._K_inv, self._pose_leaves = y, None, None
+        self._y, self._K_inv, self._pose_leaves, self._Ts_all = y, None, None, None
         try:
             with self.timer('Total'):
                 with self.timer('Forward'): fwd = self.forward(x)
@@ -338,7 +344,7 @@ class MonoDepthModule(nn.Module):
         finally:
             # the prep-ahead state belongs to THIS step: a later `module.forward(x)` (validation, inference) must neither launch the
             # prep for the previous batch nor keep that batch (and its 150 MB packed buffer) alive
-            self._y = self._prepared = self._K_inv = self._pose_leaves = None
+            self._y = self._prepared = self._K_inv = self._pose_leaves = self._Ts_all = None
         return loss, loss_dict, fwd
 
     def _prepare_frames(self, y: dict, stream=None):
