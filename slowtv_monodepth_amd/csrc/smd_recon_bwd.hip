@@ -701,7 +701,8 @@ template <bool SSIM, int SKIP, int NS, bool ACC>
 static void launch_bwd_t(dim3 grid, dim3 block, hipStream_t st, const ReconBwdArgs& a) {
   // the common case — every support has its own wave, nothing else feeds the depth — runs the instantiation without the two per-step branches
   const bool xtra = a.g_in != nullptr || a.n > NS;
-  note_variant(1, "smd::k_recon_bwd<%s, %d, %d, %s, %s>", SSIM ? "true" : "false", SKIP, NS, ACC ? "true" : "false", xtra ? "true" : "false");
+  note_variant(1, "smd::k_recon_bwd<%s, %d, %d, %s, %s>%s", SSIM ? "true" : "false", SKIP, NS, ACC ? "true" : "false", xtra ? "true" : "false",
+               (a.scales_block && kWavesPerBlock/NS > 1) ? " [a block = the scales of one strip]" : "");
   if (xtra) hipLaunchKernelGGL((k_recon_bwd<SSIM, SKIP, NS, ACC, true>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_recon_bwd<SSIM, SKIP, NS, ACC, false>), grid, block, 0, st, a);
 }

@@ -160,6 +160,59 @@ def test_random_shapes_single_node_loss_path_equals_the_separate_operators(seed)
     for k in ('aa', 't') + (('fs', 'cs') if learn_k else ()): assert rel_to_max(bb[5][k].grad, a[5][k].grad) <= 2e-6, f'{what}: d loss / d {k}: {rel_to_max(bb[5][k].grad, a[5][k].grad):.2e}'
 
 
+@pytest.mark.parametrize('seed', _more(16))
+def test_random_shapes_backward_block_composition(seed, knobs):
+    """Round 5: with four scales the fused backward's blocks are the SCALES of one strip (knob `bwd_scales_block`) wherever the partition leaves every
+    block its strip, else strips of one scale; and a strip's supports go to one wave in turn or to a wave each (knob `bwd_wps`).  Random sizes, two to
+    four supports, either row loop: whatever the composition, the same disparity gradients bit for bit (the pose gradient to 2e-6: its per-block fp32
+    sums group other waves), and the launch says which composition it ran."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as F, _lib
+    r = random.Random(8100 + seed)
+    b = r.choice([1, 2, 3, 6])
+    h = r.choice([r.randint(17, 40), r.randint(41, 130), 64, 96])
+    w = r.choice([r.randint(55, 70), r.randint(110, 135), r.randint(200, 500), 240, 480])
+    n = r.choice([2, 2, 3, 4])
+    lows = [(max(h >> s, 1), max(w >> s, 1)) for s in range(4)]
+    use_min, automask = r.random() < 0.8, r.random() < 0.7
+    skip = r.choice(['0', '0', '2'])
+    gen = torch.Generator(device='cuda').manual_seed(seed)
+    imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
+    supp = 0.5*imgs[None] + 0.5*torch.rand(n, b, 3, h, w, device='cuda', generator=gen)
+    d0 = [0.05 + 0.9*torch.rand(b, 1, hs, ws, device='cuda', generator=gen) for hs, ws in lows]
+    T0 = torch.eye(4, device='cuda').repeat(n, b, 1, 1); T0[..., :3, 3] = 0.02*torch.randn(n, b, 3, device='cuda', generator=gen)
+    K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    flags = F.recon_flags('ssim', use_min, automask)
+    what = f'seed {seed}: b={b} {h}x{w} n={n} min={use_min} automask={automask} row loop {skip}'
+    os.environ['SMD_BWD_SKIP'] = skip
+    try:
+        def run(wps, scales):
+            knobs('bwd_wps', wps); knobs('bwd_scales_block', scales)
+            d = [v.clone().requires_grad_(True) for v in d0]; T = T0.clone().requires_grad_(True)
+            loss, *_ = F.image_recon_fused_disp(d, imgs, supp, T, K, flags=flags, min_depth=0.1, max_depth=100, seed=seed, want_err=False)
+            loss.backward(); torch.cuda.synchronize()
+            return [v.grad for v in d], T.grad, _lib.lib.smd_last_kernel_variant(1).decode()
+        ref = run(min(n, 4), 0)
+        assert 'scales' not in ref[2], ref[2]
+        seen = []
+        for wps in sorted({1, 2, min(n, 4)}):
+            # one wave per strip adds the supports' shares in the order one wave per support does; two waves for three or four supports pair them
+            # otherwise ((g0 + g2) + (g1 + g3)): equal to rounding there, and bit-equal between its own two block compositions
+            own = ref if wps == min(n, 4) else run(wps, 0)
+            assert 'scales' not in own[2], own[2]
+            if wps in (1, min(n, 4)):
+                for k, (x, y) in enumerate(zip(own[0], ref[0])): assert torch.equal(x, y), f'{what}: d loss / d disp[{k}] with bwd_wps={wps} differs by {(x - y).abs().max().item():.3e} ({own[2]})'
+            else:
+                for k, (x, y) in enumerate(zip(own[0], ref[0])): assert rel_to_max(x, y) <= 1e-6, f'{what}: d loss / d disp[{k}] with bwd_wps={wps}: {rel_to_max(x, y):.2e}'
+            assert rel_to_max(own[1], ref[1]) <= 2e-6, f'{what}: d loss / d T with bwd_wps={wps}: {rel_to_max(own[1], ref[1]):.2e}'
+            g, gT, label = run(wps, 1)
+            seen.append('scales' in label)
+            for k, (x, y) in enumerate(zip(g, own[0])): assert torch.equal(x, y), f'{what}: d loss / d disp[{k}] with bwd_wps={wps}: blocks of scales differ by {(x - y).abs().max().item():.3e} ({label})'
+            assert rel_to_max(gT, own[1]) <= 2e-6, f'{what}: d loss / d T with bwd_wps={wps}, blocks of scales: {rel_to_max(gT, own[1]):.2e}'
+    finally: del os.environ['SMD_BWD_SKIP']
+    print(f'{what}: blocks of scales ran in {sum(seen)} of {len(seen)} compositions')
+
+
 @pytest.mark.parametrize('seed', _more(12))
 def test_random_smoothness_options_match_the_oracle(seed):
     """`handlers.disp_smooth` over random image / pyramid sizes with `use_edges` and `use_laplacian` drawn at random (the first-order form is
