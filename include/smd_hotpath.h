@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 6
+#define SMD_ABI_VERSION 7
 
 #define SMD_OK 0
 #define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
@@ -282,6 +282,16 @@ int smd_elu_up_cat_pad_fwd(const void* a, const float* bias, const void* skip, v
                            void* stream);
 int smd_elu_up_cat_pad_bwd(const void* a, const float* bias, const void* g_out, void* g_a, void* g_skip, float* g_bias,
                            void* workspace, size_t workspace_bytes, int B, int Ca, int Cs, int h, int w, int dtypes, void* stream);
+
+/* Output head of the Monodepth decoder (ABI 7, round 5; reference: src/networks/decoders/monodepth.py:52, 86-87 — `self.act(self.out[i](x))` with
+ * `conv3x3(num_ch_dec[i], 1)`, decoders/utils.py:44-46): y (B,1,h,w) = act(conv3x3(xp; weight (1,C,3,3)) + bias (1) or NULL), where xp (B,C,h+2,w+2)
+ * is the reflection-padded activation smd_elu_pad_fwd leaves; act 0: identity, 1: sigmoid.  A one-output-channel convolution is a stencil: three
+ * streaming kernels, fp32, deterministic.  Backward: g_y and the saved y -> g_xp (B,C,h+2,w+2) (or NULL), g_weight (1,C,3,3) with g_bias (1) (g_weight
+ * NULL: neither; g_bias may be NULL alone); the weight gradient needs the workspace. */
+size_t smd_conv3x3_head_workspace_bytes(int B, int C, int h, int w);
+int smd_conv3x3_head_fwd(const float* xp, const float* weight, const float* bias, float* y, int B, int C, int h, int w, int act, void* stream);
+int smd_conv3x3_head_bwd(const float* xp, const float* weight, const float* y, const float* g_y, float* g_xp, float* g_weight, float* g_bias,
+                         void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Producer side of the path: training-mode BatchNorm2d of the ResNet encoders fused with the residual add and ReLU

@@ -67,6 +67,9 @@ PROTOTYPES = {
     'smd_recon_reduce_fwd': (_i, [_vp]*4 + [_u64] + [_vp]*4 + [_sz] + [_i]*5 + [_vp]),
     'smd_recon_reduce_bwd': (_i, [_vp]*7 + [_i]*5 + [_vp]),
     'smd_decoder_glue_workspace_bytes': (_sz, [_i]*4),
+    'smd_conv3x3_head_workspace_bytes': (_sz, [_i]*4),
+    'smd_conv3x3_head_fwd': (_i, [_vp]*4 + [_i]*5 + [_vp]),
+    'smd_conv3x3_head_bwd': (_i, [_vp]*8 + [_sz] + [_i]*5 + [_vp]),
     'smd_elu_pad_fwd': (_i, [_vp]*3 + [_i]*6 + [_vp]),
     'smd_elu_pad_bwd': (_i, [_vp]*6 + [_sz] + [_i]*6 + [_vp]),
     'smd_elu_up_cat_pad_fwd': (_i, [_vp]*4 + [_i]*6 + [_vp]),
@@ -111,7 +114,7 @@ def _load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if handle.smd_abi_version() != 6: raise ImportError(f'ABI version mismatch in {lib_path}')
+    if handle.smd_abi_version() != 7: raise ImportError(f'ABI version mismatch in {lib_path}')
     return handle
 
 

@@ -780,6 +780,25 @@ int smd_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g
   if (g_bias && workspace_bytes < smd_decoder_glue_workspace_bytes(B, C, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
   return check_launch(smd::launch_elu_pad_bwd(x, bias, g_out, g_x, g_bias, (float*)workspace, B, C, h, w, apply_elu, dtypes, (hipStream_t)stream), "elu_pad_bwd");
 }
+static bool head_sizes_ok(int B, int C, int h, int w) {
+  return B >= 1 && C >= 1 && C < 65535 && dec_sizes_ok((long long)B*C, h, w) && (long long)B*((h + 47)/48) < 65536 && h < 65536 && (long long)B*C*(h + 2)*(w + 2) < (1ll << 40);
+}
+size_t smd_conv3x3_head_workspace_bytes(int B, int C, int h, int w) {
+  if (!head_sizes_ok(B, C, h, w)) return 0;
+  return align256(smd::conv_head_partials(B, C, h, w)*sizeof(float));
+}
+int smd_conv3x3_head_fwd(const float* xp, const float* weight, const float* bias, float* y, int B, int C, int h, int w, int act, void* stream) {
+  if (!xp || !weight || !y) return fail(SMD_E_INVALID, "null pointer");
+  if (!head_sizes_ok(B, C, h, w) || (act != 0 && act != 1)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d act=%d", B, C, h, w, act);
+  return check_launch(smd::launch_conv_head_fwd(xp, weight, bias, y, B, C, h, w, act, (hipStream_t)stream), "conv3x3_head_fwd");
+}
+int smd_conv3x3_head_bwd(const float* xp, const float* weight, const float* y, const float* g_y, float* g_xp, float* g_weight, float* g_bias,
+                         void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int act, void* stream) {
+  if (!weight || !y || !g_y || (!g_xp && !g_weight) || (g_weight && (!xp || !workspace)) || (g_bias && !g_weight)) return fail(SMD_E_INVALID, "null pointer");
+  if (!head_sizes_ok(B, C, h, w) || (act != 0 && act != 1)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d act=%d", B, C, h, w, act);
+  if (g_weight && workspace_bytes < smd_conv3x3_head_workspace_bytes(B, C, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_conv_head_bwd(xp, weight, y, g_y, g_xp, g_weight, g_bias, (float*)workspace, B, C, h, w, act, (hipStream_t)stream), "conv3x3_head_bwd");
+}
 int smd_elu_up_cat_pad_fwd(const void* a, const float* bias, const void* skip, void* out, int B, int Ca, int Cs, int h, int w, int dtypes, void* stream) {
   if (!a || !out || (Cs > 0 && !skip)) return fail(SMD_E_INVALID, "null pointer");
   if (B < 1 || Ca < 1 || Cs < 0 || h < 1 || w < 1 || !dec_sizes_ok((long long)B*(Ca + Cs), 2*h, 2*w))

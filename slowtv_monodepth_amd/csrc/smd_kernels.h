@@ -261,6 +261,10 @@ hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, floa
                                    const float* mask, float* g_mask, int n, int B, int h, int w, int flags, hipStream_t st);
 hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
 hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, int mode, hipStream_t st);
+size_t conv_head_partials(int B, int C, int h, int w);
+hipError_t launch_conv_head_fwd(const float* xp, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st);
+hipError_t launch_conv_head_bwd(const float* xp, const float* wgt, const float* y, const float* gy, float* g_xp, float* g_w, float* g_bias, float* partial,
+                                int B, int C, int h, int w, int act, hipStream_t st);
 size_t decoder_bias_partials(int B, int C, int h, int w);
 hipError_t launch_elu_pad_fwd(const void* x, const float* bias, void* out, int B, int C, int h, int w, int apply_elu, int dt, hipStream_t st);
 hipError_t launch_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g_x, float* g_bias, float* ws, int B, int C, int h, int w,

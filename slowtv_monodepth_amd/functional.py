@@ -823,6 +823,46 @@ def elu_pad(x, bias=None, apply_elu: bool = True, out_dtype=None):
     return _EluPad.apply(x, bias, apply_elu, out_dtype or x.dtype)
 
 
+class _Conv3x3Head(torch.autograd.Function):
+    """`act(conv3x3(xp, weight (1,C,3,3)) + bias)` on an already reflection-padded input (`smd_conv3x3_head_*`): the decoder's output heads."""
+    @staticmethod
+    def forward(ctx, xp, weight, bias, act):
+        xp = _check('xp', xp)
+        if xp.ndim != 4 or xp.shape[2] < 4 or xp.shape[3] < 4: raise ValueError(f'expected a padded (B,C,h+2,w+2) with h, w >= 2, got {tuple(xp.shape)}')
+        B, C, H, W = xp.shape
+        weight = _check('weight', weight, (1, C, 3, 3))
+        if bias is not None: bias = _check('bias', bias, (1,))
+        y = torch.empty((B, 1, H - 2, W - 2), device=xp.device, dtype=torch.float32)
+        call('smd_conv3x3_head_fwd', xp.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), B, C, H - 2, W - 2, int(act), _stream())
+        ctx.save_for_backward(xp, weight, y); ctx.act, ctx.has_bias = int(act), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        xp, weight, y = ctx.saved_tensors
+        dev = _on(xp)
+        B, C, H, W = xp.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        g_y = _check('grad(y)', g_y, (B, 1, H - 2, W - 2))
+        g_xp = torch.empty_like(xp) if need_x else None
+        g_w = torch.empty_like(weight) if (need_w or need_b) else None
+        g_b = torch.empty(1, device=dev, dtype=torch.float32) if need_b else None
+        nbytes = _lib.lib.smd_conv3x3_head_workspace_bytes(B, C, H - 2, W - 2) if g_w is not None else 0
+        ws = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8) if g_w is not None else None
+        if g_xp is not None or g_w is not None:
+            call('smd_conv3x3_head_bwd', xp.data_ptr(), weight.data_ptr(), y.data_ptr(), g_y.data_ptr(), g_xp.data_ptr() if g_xp is not None else None,
+                 g_w.data_ptr() if g_w is not None else None, g_b.data_ptr() if g_b is not None else None, ws.data_ptr() if ws is not None else None, nbytes,
+                 B, C, H - 2, W - 2, ctx.act, _stream())
+        return g_xp, (g_w if need_w else None), g_b, None
+
+
+def conv3x3_head(xp, weight, bias=None, act: str | None = 'sigmoid'):
+    """`act(F.conv2d(xp, weight, bias))` for ONE output channel and an input that is already reflection-padded (`elu_pad`'s output): the decoder's
+    output heads (src/networks/decoders/monodepth.py:52, 86-87).  xp (B,C,h+2,w+2), weight (1,C,3,3), bias (1) or None -> (B,1,h,w); act 'sigmoid' | None."""
+    if act not in ('sigmoid', 'none', None): raise ValueError(f"act must be 'sigmoid' or None, got {act!r}")
+    return _Conv3x3Head.apply(xp, weight, bias, 1 if act == 'sigmoid' else 0)
+
+
 class _EluUpCatPad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, bias, skip, out_dtype):

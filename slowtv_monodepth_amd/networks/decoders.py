@@ -72,5 +72,10 @@ class MonodepthDecoder(nn.Module):
             skip = feat[self.enc_sc.index(2**i)] if (self.use_skip and 2**i in self.enc_sc) else None
             c = conv(m1, HF.elu_up_cat_pad(conv(m0, xp), skip, bias=m0.bias.float(), out_dtype=out_dtype))
             if i in self.out_sc or i > 0: xp = HF.elu_pad(c, bias=m1.bias.float(), apply_elu=True, out_dtype=out_dtype)
-            if i in self.out_sc: out[i] = self.act(F.conv2d(xp, self.out[str(i)].weight, self.out[str(i)].bias))
+            if i in self.out_sc:
+                m = self.out[str(i)]
+                if self.out_ch == 1 and xp.dtype == torch.float32 and isinstance(self.act, (nn.Sigmoid, nn.Identity)):   # a one-channel head is a stencil: smd_conv3x3_head_*
+                    out[i] = HF.conv3x3_head(xp, m.weight.float(), m.bias.float() if m.bias is not None else None, 'sigmoid' if isinstance(self.act, nn.Sigmoid) else None)
+                else:
+                    out[i] = self.act(F.conv2d(xp, m.weight, m.bias))
         return out

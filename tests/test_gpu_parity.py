@@ -1044,6 +1044,37 @@ def test_elu_up_cat_pad_kernel(F, B, Ca, Cs, h, w):
     if Cs: torch.testing.assert_close(sg.grad.cpu(), sr.grad, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('B,C,h,w', [(2, 16, 50, 70), (1, 128, 24, 80), (3, 5, 2, 2), (2, 32, 17, 129), (1, 64, 96, 64), (12, 16, 192, 640)])
+@pytest.mark.parametrize('act', ['sigmoid', None])
+def test_conv3x3_head_kernel(F, B, C, h, w, act):
+    """The decoder's one-channel output heads (src/networks/decoders/monodepth.py:52, 86-87) as a stencil (`smd_conv3x3_head_*`, round 5) against
+    ATen's `conv2d` (+ `sigmoid`) in fp64 on the same padded input: output, and the gradients w.r.t. input, weight and bias; sizes off the 64 x 16 tiles,
+    the smallest legal image, the widest head (128 channels) and cfg 2's full-resolution head."""
+    import torch.nn.functional as TF
+    gen = torch.Generator(device='cuda').manual_seed(B*1000 + C*10 + h + w)
+    xp = torch.randn(B, C, h + 2, w + 2, device='cuda', generator=gen)
+    wt = torch.randn(1, C, 3, 3, device='cuda', generator=gen)/(3*C**0.5)
+    bs = torch.randn(1, device='cuda', generator=gen)
+    gy = torch.randn(B, 1, h, w, device='cuda', generator=gen)
+    for bias in (bs, None):
+        L = [t.clone().requires_grad_(True) for t in (xp, wt)] + ([bias.clone().requires_grad_(True)] if bias is not None else [])
+        y = F.conv3x3_head(L[0], L[1], L[2] if bias is not None else None, act)
+        y.backward(gy)
+        R = [t.double().clone().requires_grad_(True) for t in (xp, wt)] + ([bias.double().clone().requires_grad_(True)] if bias is not None else [])
+        yr = TF.conv2d(R[0], R[1], R[2] if bias is not None else None)
+        if act == 'sigmoid': yr = torch.sigmoid(yr)
+        yr.backward(gy.double())
+        assert rel_to_max(y.double(), yr) <= 2e-6, rel_to_max(y.double(), yr)
+        for nm, a, r in zip(('g_xp', 'g_weight', 'g_bias'), L, R): assert rel_to_max(a.grad.double(), r.grad) <= 2e-6, (nm, rel_to_max(a.grad.double(), r.grad))
+    # only the weights ask for a gradient (a frozen encoder side), and only the input
+    L = [xp.clone(), wt.clone().requires_grad_(True)]
+    F.conv3x3_head(L[0], L[1], None, act).backward(gy); assert L[1].grad is not None
+    L = [xp.clone().requires_grad_(True), wt.clone()]
+    F.conv3x3_head(L[0], L[1], bs, act).backward(gy); assert L[0].grad is not None
+    with pytest.raises(ValueError): F.conv3x3_head(xp, wt.repeat(2, 1, 1, 1), None, act)
+    with pytest.raises(RuntimeError): F.conv3x3_head(xp.cpu(), wt.cpu(), None, act)
+
+
 def test_glued_decoder_equals_plain_decoder(F):
     """The decoder with the glue kernels and the same decoder evaluated op by op (as the reference does) on the same weights."""
     import slowtv_monodepth_amd as amd
