@@ -293,6 +293,14 @@ int smd_conv3x3_head_fwd(const float* xp, const float* weight, const float* bias
 int smd_conv3x3_head_bwd(const float* xp, const float* weight, const float* y, const float* g_y, float* g_xp, float* g_weight, float* g_bias,
                          void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int act, void* stream);
 
+/* The decoder's thin up-convolutions (ABI 7, round 5; reference: src/networks/decoders/monodepth.py:45-50, 80-84 — `ConvELU(cin, 16)`; the bias and the ELU
+ * are the next glue kernel's): y (B,16,h,w) = conv3x3(xp (B,C,h+2,w+2); weight (16,C,3,3)), bias-free, as a direct convolution on the vector ALU.
+ * Backward: g_y (B,16,h,w) -> g_xp (B,C,h+2,w+2) (or NULL; C = 16 only, else SMD_E_UNSUPPORTED) and g_weight (16,C,3,3) (or NULL; needs xp and the workspace). */
+size_t smd_conv3x3_thin_workspace_bytes(int B, int C, int h, int w);
+int smd_conv3x3_thin_fwd(const float* xp, const float* weight, float* y, int B, int C, int h, int w, void* stream);
+int smd_conv3x3_thin_bwd(const float* xp, const float* weight, const float* g_y, float* g_xp, float* g_weight, void* workspace, size_t workspace_bytes,
+                         int B, int C, int h, int w, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Producer side of the path: training-mode BatchNorm2d of the ResNet encoders fused with the residual add and ReLU
  * that follow it (timm resnet blocks built at src/networks/depth.py:95-98, src/networks/pose.py:39-41;

@@ -34,6 +34,13 @@ for name, ci, co, h, w in layers:
     byts = 4.0*b*(ci*(h + 2)*(w + 2) + co*h*w)
     tf += f; tb += fb - f
     print(f'{name:8s} {ci:4d} {co:4d} {h:4d}x{w:<4d} {f:8.1f} {flop/f/1e6:6.1f} {byts/f/1e3:6.0f} {fb - f:8.1f} {2*flop/(fb - f)/1e6:6.1f}')
+    if co == 16:  # the library's direct convolution for the thin layers (smd_conv3x3_thin_*)
+        hf = timeit(lambda: HF.conv3x3_thin(x, wt))
+        def tbwd():
+            x.grad = wt.grad = None
+            HF.conv3x3_thin(x, wt).backward(g)
+        hb = timeit(tbwd) - hf
+        print(f'{"  thin":8s} {"":4s} {"":4s} {"":9s} {hf:8.1f} {flop/hf/1e6:6.1f} {byts/hf/1e3:6.0f} {hb:8.1f} {2*flop/hb/1e6:6.1f}   <- smd_conv3x3_thin')
     if co == 1:   # the library's stencil for one-channel heads (smd_conv3x3_head_*), sigmoid included
         bias = torch.zeros(1, device='cuda', requires_grad=True)
         hf = timeit(lambda: HF.conv3x3_head(x, wt, bias, 'sigmoid'))

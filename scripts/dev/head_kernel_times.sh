@@ -3,7 +3,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.OrderedDict()
 for r in rows:
-    if "k_head" in r["Kernel_Name"]:
+    if "k_head" in r["Kernel_Name"] or "k_thin" in r["Kernel_Name"]:
         k = (r["Kernel_Name"][5:30], r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
         agg.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))/1e3)
 for k, v in agg.items(): print(k, len(v), "median", sorted(v)[len(v)//2])

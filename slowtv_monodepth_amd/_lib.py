@@ -67,6 +67,9 @@ PROTOTYPES = {
     'smd_recon_reduce_fwd': (_i, [_vp]*4 + [_u64] + [_vp]*4 + [_sz] + [_i]*5 + [_vp]),
     'smd_recon_reduce_bwd': (_i, [_vp]*7 + [_i]*5 + [_vp]),
     'smd_decoder_glue_workspace_bytes': (_sz, [_i]*4),
+    'smd_conv3x3_thin_workspace_bytes': (_sz, [_i]*4),
+    'smd_conv3x3_thin_fwd': (_i, [_vp]*3 + [_i]*4 + [_vp]),
+    'smd_conv3x3_thin_bwd': (_i, [_vp]*6 + [_sz] + [_i]*4 + [_vp]),
     'smd_conv3x3_head_workspace_bytes': (_sz, [_i]*4),
     'smd_conv3x3_head_fwd': (_i, [_vp]*4 + [_i]*5 + [_vp]),
     'smd_conv3x3_head_bwd': (_i, [_vp]*8 + [_sz] + [_i]*5 + [_vp]),

@@ -799,6 +799,28 @@ int smd_conv3x3_head_bwd(const float* xp, const float* weight, const float* y, c
   if (g_weight && workspace_bytes < smd_conv3x3_head_workspace_bytes(B, C, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
   return check_launch(smd::launch_conv_head_bwd(xp, weight, y, g_y, g_xp, g_weight, g_bias, (float*)workspace, B, C, h, w, act, (hipStream_t)stream), "conv3x3_head_bwd");
 }
+static bool thin_sizes_ok(int B, int C, int h, int w) { return (C == 16 || C == 32) && head_sizes_ok(B, C, h, w) && dec_sizes_ok((long long)B*16, h, w) && B < 65536 && h + 2 < 4*65536; }
+size_t smd_conv3x3_thin_workspace_bytes(int B, int C, int h, int w) {
+  if (!thin_sizes_ok(B, C, h, w)) return 0;
+  return align256(smd::conv_thin_partials(B, C, h, w)*sizeof(float));
+}
+int smd_conv3x3_thin_bwd(const float* xp, const float* weight, const float* g_y, float* g_xp, float* g_weight, void* workspace, size_t workspace_bytes,
+                         int B, int C, int h, int w, void* stream) {
+  if (!g_y || (!g_xp && !g_weight) || (g_xp && !weight) || (g_weight && (!xp || !workspace))) return fail(SMD_E_INVALID, "null pointer");
+  if (C != 16 && C != 32 && C >= 1) return fail(SMD_E_UNSUPPORTED, "the thin convolution serves 16 or 32 input channels, not %d", C);
+  if (!thin_sizes_ok(B, C, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
+  if (g_weight && workspace_bytes < smd_conv3x3_thin_workspace_bytes(B, C, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (g_xp) { if (int rc = check_launch(smd::launch_conv_thin_bwd_data(g_y, weight, g_xp, B, C, h, w, st), "conv3x3_thin_bwd (data)")) return rc; }
+  if (g_weight) { if (int rc = check_launch(smd::launch_conv_thin_bwd_wgt(xp, g_y, g_weight, (float*)workspace, B, C, h, w, st), "conv3x3_thin_bwd (weights)")) return rc; }
+  return SMD_OK;
+}
+int smd_conv3x3_thin_fwd(const float* xp, const float* weight, float* y, int B, int C, int h, int w, void* stream) {
+  if (!xp || !weight || !y) return fail(SMD_E_INVALID, "null pointer");
+  if (C != 16 && C != 32 && C >= 1) return fail(SMD_E_UNSUPPORTED, "the thin convolution serves 16 or 32 input channels, not %d", C);
+  if (!thin_sizes_ok(B, C, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
+  return check_launch(smd::launch_conv_thin_fwd(xp, weight, y, B, C, h, w, (hipStream_t)stream), "conv3x3_thin_fwd");
+}
 int smd_elu_up_cat_pad_fwd(const void* a, const float* bias, const void* skip, void* out, int B, int Ca, int Cs, int h, int w, int dtypes, void* stream) {
   if (!a || !out || (Cs > 0 && !skip)) return fail(SMD_E_INVALID, "null pointer");
   if (B < 1 || Ca < 1 || Cs < 0 || h < 1 || w < 1 || !dec_sizes_ok((long long)B*(Ca + Cs), 2*h, 2*w))

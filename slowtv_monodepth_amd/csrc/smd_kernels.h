@@ -265,6 +265,10 @@ size_t conv_head_partials(int B, int C, int h, int w);
 hipError_t launch_conv_head_fwd(const float* xp, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st);
 hipError_t launch_conv_head_bwd(const float* xp, const float* wgt, const float* y, const float* gy, float* g_xp, float* g_w, float* g_bias, float* partial,
                                 int B, int C, int h, int w, int act, hipStream_t st);
+hipError_t launch_conv_thin_fwd(const float* xp, const float* wgt, float* y, int B, int C, int h, int w, hipStream_t st);
+size_t conv_thin_partials(int B, int C, int h, int w);
+hipError_t launch_conv_thin_bwd_wgt(const float* xp, const float* gy, float* g_w, float* partial, int B, int C, int h, int w, hipStream_t st);
+hipError_t launch_conv_thin_bwd_data(const float* gy, const float* wgt, float* g_xp, int B, int C, int h, int w, hipStream_t st);
 size_t decoder_bias_partials(int B, int C, int h, int w);
 hipError_t launch_elu_pad_fwd(const void* x, const float* bias, void* out, int B, int C, int h, int w, int apply_elu, int dt, hipStream_t st);
 hipError_t launch_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g_x, float* g_bias, float* ws, int B, int C, int h, int w,

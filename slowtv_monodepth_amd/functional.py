@@ -863,6 +863,44 @@ def conv3x3_head(xp, weight, bias=None, act: str | None = 'sigmoid'):
     return _Conv3x3Head.apply(xp, weight, bias, 1 if act == 'sigmoid' else 0)
 
 
+class _Conv3x3Thin(torch.autograd.Function):
+    """`F.conv2d(xp, weight (16,C,3,3))` on an already reflection-padded input as a direct convolution (`smd_conv3x3_thin_*`): the decoder's last stage."""
+    @staticmethod
+    def forward(ctx, xp, weight):
+        xp = _check('xp', xp)
+        if xp.ndim != 4 or xp.shape[2] < 4 or xp.shape[3] < 4: raise ValueError(f'expected a padded (B,C,h+2,w+2) with h, w >= 2, got {tuple(xp.shape)}')
+        B, C, H, W = xp.shape
+        weight = _check('weight', weight, (16, C, 3, 3))
+        y = torch.empty((B, 16, H - 2, W - 2), device=xp.device, dtype=torch.float32)
+        call('smd_conv3x3_thin_fwd', xp.data_ptr(), weight.data_ptr(), y.data_ptr(), B, C, H - 2, W - 2, _stream())
+        ctx.save_for_backward(xp, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        xp, weight = ctx.saved_tensors
+        dev = _on(xp)
+        B, C, H, W = xp.shape
+        need_x, need_w = ctx.needs_input_grad
+        g_y = _check('grad(y)', g_y, (B, 16, H - 2, W - 2))
+        g_xp = g_w = None
+        if need_x: g_xp = torch.empty_like(xp)
+        if need_w: g_w = torch.empty_like(weight)
+        if need_x or need_w:
+            nbytes = _lib.lib.smd_conv3x3_thin_workspace_bytes(B, C, H - 2, W - 2) if need_w else 0
+            ws = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8) if need_w else None
+            call('smd_conv3x3_thin_bwd', xp.data_ptr(), weight.data_ptr(), g_y.data_ptr(), g_xp.data_ptr() if need_x else None, g_w.data_ptr() if need_w else None,
+                 ws.data_ptr() if ws is not None else None, nbytes, B, C, H - 2, W - 2, _stream())
+        return g_xp, g_w
+
+
+def conv3x3_thin(xp, weight):
+    """`F.conv2d(xp, weight)` for sixteen output channels and an input that is already reflection-padded: the thin up-convolution of the decoder's last
+    stage (src/networks/decoders/monodepth.py:45-50, 80-84), bias-free (the next glue kernel adds it).  xp (B,C,h+2,w+2), weight (16,C,3,3) -> (B,16,h,w);
+    C = 16 or 32 (`_lib.Unsupported` otherwise)."""
+    return _Conv3x3Thin.apply(xp, weight)
+
+
 class _EluUpCatPad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, bias, skip, out_dtype):

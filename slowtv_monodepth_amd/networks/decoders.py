@@ -64,7 +64,10 @@ class MonodepthDecoder(nn.Module):
         the two gather kernels of `csrc/smd_decoder.hip`, each writing the next convolution's padded input, and the
         padded ELU output of a stage is shared by its output head and the next stage (the reference pads it twice)."""
         from .. import functional as HF
-        conv = lambda m, xp: F.conv2d(xp, m.weight)            # input already reflection-padded; the bias is added by the next glue kernel
+        def conv(m, xp):   # input already reflection-padded; the bias is added by the next glue kernel
+            if xp.dtype == torch.float32 and m.weight.shape[0] == 16 and m.weight.shape[1] in (16, 32):   # the thin last stage: smd_conv3x3_thin_* (fp32 MFMA)
+                return HF.conv3x3_thin(xp, m.weight.float())
+            return F.conv2d(xp, m.weight)
         out = {}
         xp = HF.elu_pad(feat[-1], apply_elu=False, out_dtype=out_dtype)   # under bf16 autocast the glue writes bf16 for the bf16 convolutions
         for i in range(4, -1, -1):

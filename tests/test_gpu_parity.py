@@ -1075,6 +1075,31 @@ def test_conv3x3_head_kernel(F, B, C, h, w, act):
     with pytest.raises(RuntimeError): F.conv3x3_head(xp.cpu(), wt.cpu(), None, act)
 
 
+@pytest.mark.parametrize('B,C,h,w', [(2, 16, 50, 70), (1, 16, 2, 2), (3, 16, 17, 129), (2, 32, 33, 65), (1, 32, 96, 320), (12, 16, 192, 640)])
+def test_conv3x3_thin_kernel(F, B, C, h, w):
+    """The decoder's thin up-convolution (sixteen output channels; src/networks/decoders/monodepth.py:45-50, 80-84) as a direct convolution
+    (`smd_conv3x3_thin_*`, round 5: fp32 MFMA) against ATen's `conv2d` in fp64 on the same padded input: output and both gradients; sizes off the 64 x 4 tiles,
+    the smallest legal image, both input widths the library serves and cfg 2's full-resolution layer."""
+    import torch.nn.functional as TF
+    gen = torch.Generator(device='cuda').manual_seed(B*1000 + C*10 + h + w)
+    xp = torch.randn(B, C, h + 2, w + 2, device='cuda', generator=gen)
+    wt = torch.randn(16, C, 3, 3, device='cuda', generator=gen)/(3*C**0.5)
+    gy = torch.randn(B, 16, h, w, device='cuda', generator=gen)
+    L = [t.clone().requires_grad_(True) for t in (xp, wt)]
+    y = F.conv3x3_thin(L[0], L[1]); y.backward(gy)
+    R = [t.double().clone().requires_grad_(True) for t in (xp, wt)]
+    yr = TF.conv2d(R[0], R[1]); yr.backward(gy.double())
+    assert rel_to_max(y.double(), yr) <= 2e-6, rel_to_max(y.double(), yr)
+    for nm, a, r in zip(('g_xp', 'g_weight'), L, R): assert rel_to_max(a.grad.double(), r.grad) <= 2e-6, (nm, rel_to_max(a.grad.double(), r.grad))
+    L = [xp.clone(), wt.clone().requires_grad_(True)]
+    F.conv3x3_thin(L[0], L[1]).backward(gy); assert rel_to_max(L[1].grad.double(), R[1].grad) <= 2e-6
+    L = [xp.clone().requires_grad_(True), wt.clone()]
+    F.conv3x3_thin(L[0], L[1]).backward(gy); assert rel_to_max(L[0].grad.double(), R[0].grad) <= 2e-6
+    with pytest.raises(ValueError): F.conv3x3_thin(xp, wt[:8])
+    from slowtv_monodepth_amd._lib import Unsupported
+    with pytest.raises(Unsupported): F.conv3x3_thin(xp[:, :5].contiguous(), wt[:, :5].contiguous())
+
+
 def test_glued_decoder_equals_plain_decoder(F):
     """The decoder with the glue kernels and the same decoder evaluated op by op (as the reference does) on the same weights."""
     import slowtv_monodepth_amd as amd
