@@ -44,28 +44,15 @@ __global__ __launch_bounds__(256) void k_thin_mfma(const float* __restrict__ in,
   static_assert(CS >= (TR + 2)*LW && CS % 32 == 16, "channel stride of the input tile");
   __shared__ float tile[TT::kTile];
   __shared__ float wl[TT::kW];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, q = lane >> 4;   // (wv on the scalar unit: row addresses are wave-uniform)
   const int xb = blockIdx.x*64, y0 = blockIdx.y*TR, b = blockIdx.z;
   // weights: forward w[co][c][tap]; data gradient (in = dL/dy with CI = the layer's output channels, out = the layer's NT*16 input channels) w[c][co][8 - tap]
   // (both staging loops request a batch of loads before they file it: one load per trip would cost a block forty memory latencies in a row — measured,
   // 164 us instead of 120)
-  {
-    constexpr int kW = 9*CI*NT*16, kTrips = (kW + 255)/256;
-    float wv_[kTrips];
+  constexpr int kW = 9*CI*NT*16, kTrips = (kW + 255)/256;
+  float wv_[kTrips];
 #pragma unroll
-    for (int t = 0; t < kTrips; ++t) { const int e = t*256 + threadIdx.x; wv_[t] = e < kW ? wgt[e] : 0.f; }
-#pragma unroll
-    for (int t = 0; t < kTrips; ++t) {
-      const int e = t*256 + threadIdx.x;
-      if (e < kW) {
-        const int tap_m = e % 9, r1 = e/9;
-        int c, co;
-        if (BWD) { co = r1 % (NT*16); c = r1/(NT*16); } else { c = r1 % CI; co = r1/CI; }
-        const int tap = BWD ? 8 - tap_m : tap_m;
-        wl[((tap*KC + (c >> 2))*NT + (co >> 4))*64 + (c & 3)*16 + (co & 15)] = wv_[t];
-      }
-    }
-  }
+  for (int t = 0; t < kTrips; ++t) { const int e = t*256 + threadIdx.x; wv_[t] = e < kW ? wgt[e] : 0.f; }
   // input tile: rows y0 - off .. y0 - off + TR + 1, columns xb - off .. xb - off + 65 of every channel; a wave per row of 66, kBatch rows in flight
   {
     const size_t plane = (size_t)hi*wi;
@@ -88,6 +75,19 @@ __global__ __launch_bounds__(256) void k_thin_mfma(const float* __restrict__ in,
           const float* rowp = src + (size_t)c*plane + (size_t)min(yy, hi - 1)*wi;
           v0[k] = rowp[min(xx0, wi - 1)];
           v1[k] = lane < 2 ? rowp[min(xx1, wi - 1)] : 0.f;
+        }
+      }
+      if (r0 == 0) {                                // the weights were requested before the tile's rows: one latency for both
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+          const int e = t*256 + threadIdx.x;
+          if (e < kW) {
+            const int tap_m = e % 9, r1 = e/9;
+            int c, co;
+            if (BWD) { co = r1 % (NT*16); c = r1/(NT*16); } else { c = r1 % CI; co = r1/CI; }
+            const int tap = BWD ? 8 - tap_m : tap_m;
+            wl[((tap*KC + (c >> 2))*NT + (co >> 4))*64 + (c & 3)*16 + (co & 15)] = wv_[t];
+          }
         }
       }
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_thin_wgt_mfma(const float* __restrict__
   __shared__ float lds[kStage > kRed ? kStage : kRed];
   float* const tg = lds;
   float* const tx = lds + CO*GS;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, q = lane >> 4;   // (wv on the scalar unit: row addresses are wave-uniform)
   const int xb = blockIdx.x*64, b = blockIdx.z, W = w + 2, H = h + 2;
   const int ylo = blockIdx.y*kThinWgtRows, yhi = min(ylo + kThinWgtRows, h);
   f32x4 acc[NTL];
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void k_thin_wgt_mfma(const float* __restrict__
     }
     __syncthreads();                               // before the next tile overwrites this one
   }
+  // (requesting the next tile's rows before this tile's MFMAs costs 64 more live registers: 252 VGPRs, one wave per SIMD, 140 us instead of 113)
   // the block's sums: D[row = 4 q + v -> co][col = i -> c] of tile (tap, g)
 #pragma unroll
   for (int t = 0; t < NTL; ++t)
