@@ -27,7 +27,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CI, int NT, bool BWD>
 struct ThinTile {
-  static constexpr int TR = 4;                                              // rows of a block's tile (8: 53 KB of LDS, three blocks per CU, 105 us at cfg 2)
+  static constexpr int TR = (CI*NT <= 16) ? 2 : 4;   // rows of a block's tile.  16 -> 16 at cfg 2: 8 rows (53 KB of LDS, 3 blocks per CU) 105-120 us forward, 4 rows 88-95,
+                                                      // 2 rows (27 KB, 6 blocks) 93 forward and 101 instead of 112-119 for the data gradient: more blocks to overlap the phases of
   static constexpr int LW = 66;                                             // 64 columns + halo
   static constexpr int CS = (((TR + 2)*LW + 15)/32)*32 + 16;                // channel stride of the input tile (floats), = 16 mod 32, >= (TR + 2) LW
   static constexpr int OS = TR*64 + 4;                                      // channel stride of the output tile
