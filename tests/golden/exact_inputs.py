@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import torch
 
-__all__ = ['make_inputs_exact', 'frame_shifts', 'bit_checksum']
+__all__ = ['make_inputs_exact', 'frame_shifts', 'bit_checksum', 'decoder_state', 'decoder_feats', 'decoder_out_grads', 'DECODER_KW']
 
 
 def _box_sum(x: torch.Tensor, r: int) -> torch.Tensor:
@@ -93,3 +93,34 @@ def make_inputs_exact(seed: int, b: int, h: int, w: int, n: int, scales, learn_K
     K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)[None].repeat(b, 1, 1)
     noise = _irwin_hall(g, (len(scales)*b, 1, h, w))
     return dict(imgs=imgs, supp_imgs=supp, disp=disp, K=K, noise=noise)
+
+
+# --------------------------------------------------------------------------------------------------
+# The decoder fixture (`net_decoder_64x96.npz`): weights, encoder features and output gradients by name and seed, so that the fixture holds only what
+# the reference's `MonodepthDecoder` PRODUCED.  `torch.randn` on a CPU generator is reproducible for a given torch build (the build container and the GPU
+# box run the same image); `chk_*` in the fixture are the bit checksums of what was drawn, and the test refuses to compare if they differ.
+# --------------------------------------------------------------------------------------------------
+DECODER_KW = dict(num_ch_enc=[64, 64, 128, 256, 512], enc_sc=[2, 4, 8, 16, 32], out_sc=[0, 1, 2, 3], out_ch=1, out_act='sigmoid')
+
+
+def decoder_state(shapes: dict, seed: int = 77) -> dict:
+    """{reference key: tensor} for {reference key: shape}: keys in sorted order, weights ~ N(0, 1/fan_in), biases ~ 0.1 N(0, 1)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k in sorted(shapes):
+        shape = tuple(shapes[k])
+        fan = 1
+        for d in shape[1:]: fan *= d
+        v = torch.randn(shape, generator=g)
+        out[k] = v/float(fan)**0.5 if len(shape) > 1 else 0.1*v
+    return out
+
+
+def decoder_feats(seed: int = 78, b: int = 2, h: int = 64, w: int = 96) -> list:
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(b, c, h//s, w//s, generator=g) for c, s in zip(DECODER_KW['num_ch_enc'], DECODER_KW['enc_sc'])]
+
+
+def decoder_out_grads(seed: int = 79, b: int = 2, h: int = 64, w: int = 96) -> dict:
+    g = torch.Generator().manual_seed(seed)
+    return {i: torch.randn(b, 1, h >> i, w >> i, generator=g) for i in DECODER_KW['out_sc']}

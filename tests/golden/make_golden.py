@@ -531,6 +531,36 @@ def run_baseline_cases(R, kbr):
                      learn_K=True, compact=8, **kbr)
 
 
+def run_decoder_case(R):
+    """§8f rank 4: the reference's `MonodepthDecoder` (src/networks/decoders/monodepth.py) on named, seeded weights / encoder features / output
+    gradients (exact_inputs.py): its four sigmoid disparities, the gradients w.r.t. every encoder feature, and per parameter the gradient's sum,
+    sum of magnitudes and — for the small ones (heads, the thin last stage, biases) — the gradient itself."""
+    from exact_inputs import DECODER_KW, bit_checksum, decoder_feats, decoder_out_grads, decoder_state
+    from src.networks.decoders.monodepth import MonodepthDecoder as RefDec
+    dec = RefDec(**DECODER_KW)
+    holder = torch.nn.Module(); holder.decoders = torch.nn.ModuleDict({'disp': dec})
+    shapes = {k: tuple(v.shape) for k, v in holder.state_dict().items()}
+    state = decoder_state(shapes)
+    holder.load_state_dict(state, strict=True)
+    feats = [f.requires_grad_(True) for f in decoder_feats()]
+    gouts = decoder_out_grads()
+    out = dec(feats)
+    sum((out[i]*gouts[i]).sum() for i in out).backward()
+    rec = {'meta_keys': np.array(sorted(shapes)), 'chk_state': np.int64(sum(bit_checksum(v) for v in state.values())),
+           'chk_feats': np.int64(sum(bit_checksum(f.detach()) for f in feats)), 'chk_gouts': np.int64(sum(bit_checksum(v) for v in gouts.values()))}
+    for i, o in out.items(): rec[f'out_{i}'] = o
+    for j, f in enumerate(feats): rec[f'gfeat_{j}'] = f.grad
+    named = dict(holder.named_parameters())
+    stats = []
+    for k in sorted(shapes):
+        g = named[k].grad.double()
+        stats.append([g.sum().item(), g.abs().sum().item()])
+        if g.numel() <= 5000: rec['gparam_' + k] = named[k].grad
+    rec['gparam_stats'] = np.array(stats)
+    save('net_decoder_64x96', rec)
+    print('net_decoder_64x96: out_0 mean', out[0].mean().item(), 'params', len(shapes))
+
+
 def save(name, rec):
     arrs = {}
     for k, v in rec.items():
@@ -555,6 +585,9 @@ def main():
                min_depth=0.1, max_depth=100)
     if '--baseline-only' in sys.argv:
         run_baseline_cases(R, kbr)
+        return
+    if '--decoder-only' in sys.argv:     # regenerate just the §8f rank-4 decoder fixture (round 5)
+        run_decoder_case(R)
         return
     run_baseline_cases(R, kbr)
     kbr = dict(loss_kw=dict(loss_name='ssim', use_min=True, use_automask=True), smooth_kw=dict(use_edges=True),
@@ -584,6 +617,7 @@ def main():
     run_handler_cases(R)
     run_option_cases(R)
     run_aspect_cases(R)
+    run_decoder_case(R)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,69 @@
+"""§8f rank 4 pinned on the reference: `net_decoder_64x96.npz` holds what the REFERENCE's `MonodepthDecoder` (src/networks/decoders/monodepth.py) produced —
+its four sigmoid disparities, the gradients w.r.t. every encoder feature and every parameter — on named, seeded weights / features / output gradients
+(tests/golden/exact_inputs.py; written by `make_golden.py --decoder-only`, which imports the reference in the build container).
+
+CPU: this package's decoder evaluated op by op (the ATen composition, as the reference) reproduces it.
+GPU: so does the path the trainer runs — glue kernels between the convolutions (`smd_elu_pad_*`, `smd_elu_up_cat_pad_*`), the one-channel heads as stencils
+(`smd_conv3x3_head_*`), the thin last stage on fp32 MFMA (`smd_conv3x3_thin_*`), MIOpen for the rest."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_to_max
+from exact_inputs import DECODER_KW, bit_checksum, decoder_feats, decoder_out_grads, decoder_state
+
+
+def build(device):
+    from slowtv_monodepth_amd.networks import checkpoint as ck
+    from slowtv_monodepth_amd.networks.decoders import MonodepthDecoder
+    dec = MonodepthDecoder(**DECODER_KW)
+    holder = torch.nn.Module(); holder.decoders = torch.nn.ModuleDict({'disp': dec})
+    shapes = {k: tuple(v.shape) for k, v in ck.to_reference_state_dict(holder).items()}
+    state = decoder_state(shapes)
+    ck.load_reference_state_dict(holder, state, strict=True)
+    holder.to(device)
+    return dec, holder, shapes, state
+
+
+def run_and_compare(device, out_tol, grad_tol):
+    from slowtv_monodepth_amd.networks import checkpoint as ck
+    g = load_golden('net_decoder_64x96')
+    with np.load(GOLDEN/'net_decoder_64x96.npz') as z: keys = [str(k) for k in z['meta_keys']]
+    dec, holder, shapes, state = build(device)
+    assert sorted(shapes) == keys, 'the key bridge no longer yields the reference decoder\'s parameter names'
+    feats, gouts = decoder_feats(), decoder_out_grads()
+    assert sum(bit_checksum(v) for v in state.values()) == int(g['chk_state']) and sum(bit_checksum(f) for f in feats) == int(g['chk_feats']) \
+        and sum(bit_checksum(v) for v in gouts.values()) == int(g['chk_gouts']), 'the seeded inputs are not the ones the fixture was made from'
+    feats = [f.to(device).requires_grad_(True) for f in feats]
+    out = dec(feats)
+    sum((out[i]*gouts[i].to(device)).sum() for i in out).backward()
+    for i in DECODER_KW['out_sc']:
+        d = (out[i].detach().cpu() - g[f'out_{i}']).abs().max().item()
+        assert d <= out_tol, f'disparity at scale {i}: {d:.2e}'
+    for j, f in enumerate(feats):
+        r = rel_to_max(f.grad.cpu(), g[f'gfeat_{j}'])
+        assert r <= grad_tol, f'gradient w.r.t. encoder feature {j}: {r:.2e}'
+    # parameters by REFERENCE name: the small ones element by element, all of them through their sum and sum of magnitudes
+    grads = {k: v for k, v in zip(ck.to_reference_state_dict(holder).keys(), (p.grad for p in holder.state_dict(keep_vars=True).values()))}
+    stats = g['gparam_stats']
+    for n, k in enumerate(keys):
+        gk = grads[k].detach().double().cpu()
+        if f'gparam_{k}' in g:
+            r = rel_to_max(gk, g[f'gparam_{k}'].double())
+            assert r <= grad_tol, f'gradient of {k}: {r:.2e}'
+        assert abs(gk.abs().sum().item() - stats[n, 1].item()) <= 10*grad_tol*stats[n, 1].item(), f'sum of |gradient| of {k}'
+        assert abs(gk.sum().item() - stats[n, 0].item()) <= 10*grad_tol*stats[n, 1].item(), f'sum of the gradient of {k}'
+    return out
+
+
+def test_decoder_matches_the_reference_decoder_on_the_cpu():
+    run_and_compare('cpu', 1e-6, 1e-5)
+
+
+@pytest.mark.gpu
+def test_decoder_kernels_match_the_reference_decoder():
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import _lib
+    _lib.lib.smd_last_error()
+    out = run_and_compare('cuda', 2e-5, 2e-4)
+    assert all(o.is_cuda for o in out.values())
