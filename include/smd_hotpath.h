@@ -294,8 +294,9 @@ int smd_conv3x3_head_bwd(const float* xp, const float* weight, const float* y, c
                          void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int act, void* stream);
 
 /* The decoder's thin up-convolutions (ABI 7, round 5; reference: src/networks/decoders/monodepth.py:45-50, 80-84 — `ConvELU(cin, 16)`; the bias and the ELU
- * are the next glue kernel's): y (B,16,h,w) = conv3x3(xp (B,C,h+2,w+2); weight (16,C,3,3)), bias-free, as a direct convolution on the vector ALU.
- * Backward: g_y (B,16,h,w) -> g_xp (B,C,h+2,w+2) (or NULL; C = 16 only, else SMD_E_UNSUPPORTED) and g_weight (16,C,3,3) (or NULL; needs xp and the workspace). */
+ * are the next glue kernel's): y (B,16,h,w) = conv3x3(xp (B,C,h+2,w+2); weight (16,C,3,3)), bias-free, C = 16 or 32 (anything else: SMD_E_UNSUPPORTED),
+ * on the matrix cores in fp32 (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation; the order of the sum differs from ATen's).
+ * Backward: g_y (B,16,h,w) -> g_xp (B,C,h+2,w+2) (or NULL) and g_weight (16,C,3,3) (or NULL; needs xp and the workspace); deterministic. */
 size_t smd_conv3x3_thin_workspace_bytes(int B, int C, int h, int w);
 int smd_conv3x3_thin_fwd(const float* xp, const float* weight, float* y, int B, int C, int h, int w, void* stream);
 int smd_conv3x3_thin_bwd(const float* xp, const float* weight, const float* g_y, float* g_xp, float* g_weight, void* workspace, size_t workspace_bytes,
