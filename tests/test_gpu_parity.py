@@ -1075,7 +1075,7 @@ def test_conv3x3_head_kernel(F, B, C, h, w, act):
     with pytest.raises(RuntimeError): F.conv3x3_head(xp.cpu(), wt.cpu(), None, act)
 
 
-@pytest.mark.parametrize('B,C,h,w', [(2, 16, 50, 70), (1, 16, 2, 2), (3, 16, 17, 129), (2, 32, 33, 65), (1, 32, 96, 320), (12, 16, 192, 640)])
+@pytest.mark.parametrize('B,C,h,w', [(2, 16, 50, 70), (1, 16, 2, 2), (3, 16, 17, 129), (2, 32, 33, 65), (1, 32, 96, 320), (3, 16, 13, 128), (2, 16, 8, 64), (12, 16, 192, 640)])
 def test_conv3x3_thin_kernel(F, B, C, h, w):
     """The decoder's thin up-convolution (sixteen output channels; src/networks/decoders/monodepth.py:45-50, 80-84) as a direct convolution
     (`smd_conv3x3_thin_*`, round 5: fp32 MFMA) against ATen's `conv2d` in fp64 on the same padded input: output and both gradients; sizes off the 64 x 4 tiles,
