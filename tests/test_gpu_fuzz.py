@@ -213,6 +213,41 @@ def test_random_shapes_backward_block_composition(seed, knobs):
     print(f'{what}: blocks of scales ran in {sum(seen)} of {len(seen)} compositions')
 
 
+@pytest.mark.parametrize('seed', _more(24))
+def test_random_shapes_decoder_convolutions(seed):
+    """Round 5: the decoder's one-channel heads (`conv3x3_head`: stencil kernels, three forward instantiations chosen by size) and its thin last stage
+    (`conv3x3_thin`: fp32 MFMA, tiles of 64 x 2 / 64 x 4 pixels, the 16-byte-store path for rows that allow it) on random batch / channel / image sizes
+    — one-pixel-wide remainders, images smaller than a tile, channel counts off every unroll — against ATen's `conv2d` (+ sigmoid) in fp64: outputs
+    and all gradients."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    import torch.nn.functional as TF
+    from slowtv_monodepth_amd import functional as F
+    r = random.Random(8800 + seed)
+    B = r.choice([1, 2, 3, 5])
+    h = r.choice([2, 3, r.randint(4, 20), r.randint(21, 70), r.randint(71, 140)])
+    w = r.choice([2, 3, r.randint(4, 63), 64, 65, 128, r.randint(66, 200), r.randint(201, 330)])
+    gen = torch.Generator(device='cuda').manual_seed(seed)
+    for kind in ('head', 'thin'):
+        C = r.choice([1, 2, 3, 7, 8, 16, 33, 64, 130]) if kind == 'head' else r.choice([16, 32])
+        Co = 1 if kind == 'head' else 16
+        act = r.choice(['sigmoid', None]) if kind == 'head' else None
+        xp = torch.randn(B, C, h + 2, w + 2, device='cuda', generator=gen)
+        wt = torch.randn(Co, C, 3, 3, device='cuda', generator=gen)/(3*C**0.5)
+        bs = torch.randn(1, device='cuda', generator=gen) if (kind == 'head' and r.random() < 0.7) else None
+        gy = torch.randn(B, Co, h, w, device='cuda', generator=gen)
+        what = f'seed {seed}: {kind} B={B} C={C} {h}x{w} act={act} bias={bs is not None}'
+        L = [t.clone().requires_grad_(True) for t in (xp, wt)] + ([bs.clone().requires_grad_(True)] if bs is not None else [])
+        y = F.conv3x3_head(L[0], L[1], L[2] if bs is not None else None, act) if kind == 'head' else F.conv3x3_thin(L[0], L[1])
+        y.backward(gy)
+        R = [t.double().clone().requires_grad_(True) for t in (xp, wt)] + ([bs.double().clone().requires_grad_(True)] if bs is not None else [])
+        yr = TF.conv2d(R[0], R[1], R[2] if bs is not None else None)
+        if act == 'sigmoid': yr = torch.sigmoid(yr)
+        yr.backward(gy.double())
+        assert rel_to_max(y.double(), yr) <= 3e-6, f'{what}: output {rel_to_max(y.double(), yr):.2e}'
+        for nm, a, ref in zip(('g_xp', 'g_weight', 'g_bias'), L, R):
+            assert rel_to_max(a.grad.double(), ref.grad) <= 3e-6, f'{what}: {nm} {rel_to_max(a.grad.double(), ref.grad):.2e}'
+
+
 @pytest.mark.parametrize('seed', _more(12))
 def test_random_smoothness_options_match_the_oracle(seed):
     """`handlers.disp_smooth` over random image / pyramid sizes with `use_edges` and `use_laplacian` drawn at random (the first-order form is
