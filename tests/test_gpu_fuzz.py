@@ -244,8 +244,12 @@ def test_random_shapes_decoder_convolutions(seed):
         if act == 'sigmoid': yr = torch.sigmoid(yr)
         yr.backward(gy.double())
         assert rel_to_max(y.double(), yr) <= 3e-6, f'{what}: output {rel_to_max(y.double(), yr):.2e}'
-        for nm, a, ref in zip(('g_xp', 'g_weight', 'g_bias'), L, R):
+        for nm, a, ref in zip(('g_xp', 'g_weight'), L, R):
             assert rel_to_max(a.grad.double(), ref.grad) <= 3e-6, f'{what}: {nm} {rel_to_max(a.grad.double(), ref.grad):.2e}'
+        if bs is not None:      # one sum over every pixel, which may cancel (seed 26 of a 300-seed hunt: 0.059 from 702 terms of +-0.2): judged against the sum of magnitudes
+            gp = gy.double()*(yr.detach()*(1 - yr.detach()) if act == 'sigmoid' else 1.0)
+            err = (L[2].grad.double() - R[2].grad).abs().item()
+            assert err <= 1e-6*gp.abs().sum().item(), f'{what}: g_bias off by {err:.2e} of {gp.abs().sum().item():.2e}'
 
 
 @pytest.mark.parametrize('seed', _more(12))
