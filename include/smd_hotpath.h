@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 7
+#define SMD_ABI_VERSION 8
 
 #define SMD_OK 0
 #define SMD_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unsupported flag combination) */
@@ -301,6 +301,26 @@ size_t smd_conv3x3_thin_workspace_bytes(int B, int C, int h, int w);
 int smd_conv3x3_thin_fwd(const float* xp, const float* weight, float* y, int B, int C, int h, int w, void* stream);
 int smd_conv3x3_thin_bwd(const float* xp, const float* weight, const float* g_y, float* g_xp, float* g_weight, void* workspace, size_t workspace_bytes,
                          int B, int C, int h, int w, void* stream);
+
+/* The decoder's wide up-convolutions (ABI 8, round 6; reference: src/networks/decoders/monodepth.py:40-50, 71-84 — `ConvELU(cin, cout)`, decoders/utils.py:44-54;
+ * the bias and the ELU are the next glue kernel's): y (B,CO,h,w) = conv3x3(xp (B,C,h+2,w+2); weight (CO,C,3,3)), bias-free, fp32 in and out, computed on the
+ * bf16 matrix cores with every fp32 operand split exactly into `pieces` bf16 pieces (3: six bf16 products per fp32 product, what is dropped is below
+ * 2^-25 of the product — fp32-class results at 6/16 of the f32 MFMA's time; 2: three products, 16 significant bits, an experiment setting, never the
+ * library's choice).  smd_conv3x3_mfma_pack writes the weights' pieces in the operand order of the forward (wp_fwd) and of the data gradient (wp_bwd), each
+ * smd_conv3x3_mfma_packed_bytes(C, CO, pieces) bytes (either may be NULL); the backward reads what the forward's pack left.
+ * Served: pieces in {2, 3}; forward C % 16 == 0 and CO % 32 == 0; data gradient CO % 16 == 0 and C % 32 == 0; weight gradient CO % 32 == 0 (any C);
+ * anything else SMD_E_UNSUPPORTED, nothing launched.  g_xp (B,C,h+2,w+2) is the gradient of the PADDED input.  Every call takes a workspace of
+ * smd_conv3x3_mfma_workspace_bytes (the coarse decoder levels — few pixels, thousands of K — split K over blocks and add the splits' outputs in split
+ * order; the weight gradient leaves per-block sums that a fixed-order fp64 second stage adds).  Deterministic. */
+size_t smd_conv3x3_mfma_packed_bytes(int C, int CO, int pieces);
+size_t smd_conv3x3_mfma_workspace_bytes(int B, int C, int CO, int h, int w);
+int smd_conv3x3_mfma_pack(const float* weight, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, void* stream);
+int smd_conv3x3_mfma_fwd(const float* xp, const void* wp_fwd, float* y, void* workspace, size_t workspace_bytes,
+                         int B, int C, int CO, int h, int w, int pieces, void* stream);
+int smd_conv3x3_mfma_bwd_data(const float* g_y, const void* wp_bwd, float* g_xp, void* workspace, size_t workspace_bytes,
+                              int B, int C, int CO, int h, int w, int pieces, void* stream);
+int smd_conv3x3_mfma_bwd_weight(const float* xp, const float* g_y, float* g_weight, void* workspace, size_t workspace_bytes,
+                                int B, int C, int CO, int h, int w, int pieces, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Producer side of the path: training-mode BatchNorm2d of the ResNet encoders fused with the residual add and ReLU

@@ -70,6 +70,12 @@ PROTOTYPES = {
     'smd_conv3x3_thin_workspace_bytes': (_sz, [_i]*4),
     'smd_conv3x3_thin_fwd': (_i, [_vp]*3 + [_i]*4 + [_vp]),
     'smd_conv3x3_thin_bwd': (_i, [_vp]*6 + [_sz] + [_i]*4 + [_vp]),
+    'smd_conv3x3_mfma_packed_bytes': (_sz, [_i]*3),
+    'smd_conv3x3_mfma_workspace_bytes': (_sz, [_i]*5),
+    'smd_conv3x3_mfma_pack': (_i, [_vp]*3 + [_i]*3 + [_vp]),
+    'smd_conv3x3_mfma_fwd': (_i, [_vp]*4 + [_sz] + [_i]*6 + [_vp]),
+    'smd_conv3x3_mfma_bwd_data': (_i, [_vp]*4 + [_sz] + [_i]*6 + [_vp]),
+    'smd_conv3x3_mfma_bwd_weight': (_i, [_vp]*4 + [_sz] + [_i]*6 + [_vp]),
     'smd_conv3x3_head_workspace_bytes': (_sz, [_i]*4),
     'smd_conv3x3_head_fwd': (_i, [_vp]*4 + [_i]*5 + [_vp]),
     'smd_conv3x3_head_bwd': (_i, [_vp]*8 + [_sz] + [_i]*5 + [_vp]),
@@ -117,7 +123,7 @@ def _load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if handle.smd_abi_version() != 7: raise ImportError(f'ABI version mismatch in {lib_path}')
+    if handle.smd_abi_version() != 8: raise ImportError(f'ABI version mismatch in {lib_path}')
     return handle
 
 

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 
 #include "smd_kernels.h"
 #include "smd_smooth_dev.h"   // block counts of the smoothness sweep / adjoint (host-side inline helpers)
@@ -820,6 +821,57 @@ int smd_conv3x3_thin_fwd(const float* xp, const float* weight, float* y, int B, 
   if (C != 16 && C != 32 && C >= 1) return fail(SMD_E_UNSUPPORTED, "the thin convolution serves 16 or 32 input channels, not %d", C);
   if (!thin_sizes_ok(B, C, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
   return check_launch(smd::launch_conv_thin_fwd(xp, weight, y, B, C, h, w, (hipStream_t)stream), "conv3x3_thin_fwd");
+}
+static bool mfma_sizes_ok(int B, int C, int CO, int h, int w) {   // grid dimensions below 65536, element counts that int arithmetic inside a plane can hold
+  return B >= 1 && C >= 1 && CO >= 1 && C <= 4096 && CO <= 4096 && h >= 1 && w >= 1 && h < 32768 && w < 32768 && (long long)(h + 2)*(w + 2) < (1ll << 30) &&
+         (long long)B*((C + 31)/32)*((CO + 31)/32) < 65536;
+}
+size_t smd_conv3x3_mfma_packed_bytes(int C, int CO, int pieces) {
+  if (C < 1 || CO < 1 || (pieces != 2 && pieces != 3)) return 0;
+  return align256(smd::conv_mfma_packed_elems(C, CO, pieces)*2);
+}
+size_t smd_conv3x3_mfma_workspace_bytes(int B, int C, int CO, int h, int w) {   // one size for the three operators
+  if (!mfma_sizes_ok(B, C, CO, h, w)) return 0;
+  size_t n = 64;
+  if (C % 16 == 0 && CO % 32 == 0) n = std::max(n, smd::conv_mfma_fwd_split_elems(B, C, CO, h, w));
+  if (CO % 16 == 0 && C % 32 == 0) n = std::max(n, smd::conv_mfma_bwd_split_elems(B, C, CO, h, w));
+  if (CO % 32 == 0) n = std::max(n, smd::conv_mfma_wgrad_partials(B, C, CO, h, w));
+  return align256(n*sizeof(float));
+}
+int smd_conv3x3_mfma_pack(const float* weight, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, void* stream) {
+  if (!weight || (!wp_fwd && !wp_bwd)) return fail(SMD_E_INVALID, "null pointer");
+  if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
+  if (C < 1 || CO < 1 || C > 4096 || CO > 4096) return fail(SMD_E_INVALID, "invalid sizes C=%d CO=%d", C, CO);
+  if (wp_fwd && (C % 16 || CO % 32)) return fail(SMD_E_UNSUPPORTED, "the forward form serves C %% 16 == 0 and CO %% 32 == 0, not C=%d CO=%d", C, CO);
+  if (wp_bwd && (CO % 16 || C % 32)) return fail(SMD_E_UNSUPPORTED, "the data-gradient form serves CO %% 16 == 0 and C %% 32 == 0, not C=%d CO=%d", C, CO);
+  return check_launch(smd::launch_conv_mfma_pack(weight, wp_fwd, wp_bwd, C, CO, pieces, (hipStream_t)stream), "conv3x3_mfma_pack");
+}
+int smd_conv3x3_mfma_fwd(const float* xp, const void* wp_fwd, float* y, void* workspace, size_t workspace_bytes,
+                         int B, int C, int CO, int h, int w, int pieces, void* stream) {
+  if (!xp || !wp_fwd || !y || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
+  if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
+  if (C % 16 || CO % 32) return fail(SMD_E_UNSUPPORTED, "the forward serves C %% 16 == 0 and CO %% 32 == 0, not C=%d CO=%d", C, CO);
+  if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_conv_mfma_fwd(xp, wp_fwd, y, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_fwd");
+}
+int smd_conv3x3_mfma_bwd_data(const float* g_y, const void* wp_bwd, float* g_xp, void* workspace, size_t workspace_bytes,
+                              int B, int C, int CO, int h, int w, int pieces, void* stream) {
+  if (!g_y || !wp_bwd || !g_xp || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
+  if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
+  if (CO % 16 || C % 32) return fail(SMD_E_UNSUPPORTED, "the data gradient serves CO %% 16 == 0 and C %% 32 == 0, not C=%d CO=%d", C, CO);
+  if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_conv_mfma_bwd_data(g_y, wp_bwd, g_xp, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_bwd_data");
+}
+int smd_conv3x3_mfma_bwd_weight(const float* xp, const float* g_y, float* g_weight, void* workspace, size_t workspace_bytes,
+                                int B, int C, int CO, int h, int w, int pieces, void* stream) {
+  if (!xp || !g_y || !g_weight || !workspace) return fail(SMD_E_INVALID, "null pointer");
+  if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
+  if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
+  if (CO % 32) return fail(SMD_E_UNSUPPORTED, "the weight gradient serves CO %% 32 == 0, not CO=%d", CO);
+  if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  return check_launch(smd::launch_conv_mfma_bwd_wgt(xp, g_y, g_weight, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_bwd_weight");
 }
 int smd_elu_up_cat_pad_fwd(const void* a, const float* bias, const void* skip, void* out, int B, int Ca, int Cs, int h, int w, int dtypes, void* stream) {
   if (!a || !out || (Cs > 0 && !skip)) return fail(SMD_E_INVALID, "null pointer");

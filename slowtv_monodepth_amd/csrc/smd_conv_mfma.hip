@@ -1,0 +1,511 @@
+// smd_conv_mfma.hip — the Monodepth decoder's wide 3x3 convolutions on the bf16 matrix cores with fp32-class results (SURVEY.md §8f rank 4, round 6;
+// reference: src/networks/decoders/monodepth.py:40-50, 71-84 — `ConvELU(cin, cout)` = reflection-padded conv3x3 + ELU; decoders/utils.py:44-54).
+//
+// Why not the f32 MFMA (smd_conv_thin.hip): on gfx950 `v_mfma_f32_32x32x2_f32` runs at the vector rate, 157 TFLOP/s — 1/16 of the bf16 matrix rate — and
+// there is no xf32/TF32 form.  MIOpen's fp32 Winograd reaches 87-93 TFLOP/s effective on these layers forward and 55-75 backward.  Here every fp32 operand
+// is SPLIT EXACTLY into three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 significant bits: x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1, each
+// difference exact in fp32), and a product a.b is formed as the six bf16 products with i + j <= 2,
+//     a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0),
+// each exact in the fp32 accumulator's product stage; what is dropped (a1 b2 + a2 b1 + a2 b2) is below 2^-25 |a b|, under the rounding of an fp32
+// multiply-add.  Six `v_mfma_f32_32x32x16_bf16` per K step of 16 = 6/16 of the f32 MFMA's time for the same arithmetic: a ceiling of 2.67 x the fp32
+// matrix peak with fp32-class error (tests: <= 2e-6 of the tensor's max against fp64 `conv2d`, the same bound the f32-MFMA kernels are held to).
+// PIECES = 2 (three products, 16 significant bits, "better than TF32") exists as an experiment knob only; PIECES = 1 is plain bf16.
+//
+// Forward and data gradient are one kernel (implicit GEMM, M = output channels, N = pixels, K = (tap, input channel)); the weight gradient is a GEMM
+// with K = pixels (M = output channels, N = input channels, one accumulator tile per tap).  Operand layouts, per `v_mfma_f32_32x32x16_bf16`:
+// A: lane l holds row i = l & 31, K slots 8 (l >> 5) .. + 7; B: column j = l & 31, same K slots; D: column = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+#include "smd_common.h"
+#include "smd_kernels.h"
+#include <algorithm>
+
+namespace smd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// the products kept of (a0 + a1 + a2)(b0 + b1 + b2), smallest terms first
+__host__ __device__ constexpr int n_products(int P) { return P == 3 ? 6 : P == 2 ? 3 : 1; }
+__host__ __device__ constexpr int prod_a(int P, int t) { return P == 3 ? (t == 0 ? 2 : t == 1 ? 1 : t == 2 ? 0 : t == 3 ? 1 : 0) : P == 2 ? (t == 0 ? 1 : 0) : 0; }
+__host__ __device__ constexpr int prod_b(int P, int t) { return P == 3 ? (t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 1 : 0) : P == 2 ? (t == 1 ? 1 : 0) : 0; }
+
+__device__ __forceinline__ unsigned pack_bf16_rne(float a, float b) { const f32x2v v = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v)); }   // v_cvt_pk_bf16_f32
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+// two fp32 values -> P dwords of two bf16 each (low half = a's piece, high half = b's)
+template <int P> __device__ __forceinline__ void split_pair(float a, float b, unsigned (&p)[P]) {
+  p[0] = pack_bf16_rne(a, b);
+  if constexpr (P > 1) { a -= bf16_lo(p[0]); b -= bf16_hi(p[0]); p[1] = pack_bf16_rne(a, b); }
+  if constexpr (P > 2) { a -= bf16_lo(p[1]); b -= bf16_hi(p[1]); p[2] = pack_bf16_rne(a, b); }
+}
+__device__ __forceinline__ bf16x8 as_frag(const uint4& u) { return __builtin_bit_cast(bf16x8, u); }
+
+// ---- weights -> bf16 pieces in the A-operand order of both convolution forms (one launch per layer and step; the backward reads what the forward packed) ----
+// forward form:       Wt[m = co][k = c][tap]      = w[co][c][tap]          (M = CO, CK = C)
+// data-gradient form: Wt[m = c][k = co][tap]      = w[co][c][8 - tap]      (M = C, CK = CO): the convolution of the zero-extended dL/dy with the flipped kernel
+// element (m, k, tap, piece) at ((((m >> 5) KC + (k >> 4)) 9 + tap) P + piece) 512 + (((k >> 3) & 1) 32 + (m & 31)) 8 + (k & 7): a wave's fragment is 1 KiB, lane-major
+template <int P>
+__global__ __launch_bounds__(256) void k_conv_pack_w(const float* __restrict__ w, unsigned short* __restrict__ wp_fwd, unsigned short* __restrict__ wp_bwd, int CO, int C) {
+  const int idx = blockIdx.x*256 + threadIdx.x;
+  if (idx >= CO*C*9) return;
+  const int tap = idx % 9, c = (idx/9) % C, co = idx/(9*C);
+  unsigned pk[P];
+  split_pair<P>(w[idx], 0.f, pk);
+  if (wp_fwd) {
+    const size_t base = ((((size_t)(co >> 5)*(C >> 4) + (c >> 4))*9 + tap)*P)*512 + (((c >> 3) & 1)*32 + (co & 31))*8 + (c & 7);
+#pragma unroll
+    for (int p = 0; p < P; ++p) wp_fwd[base + (size_t)p*512] = (unsigned short)(pk[p] & 0xffffu);
+  }
+  if (wp_bwd) {
+    const size_t base = ((((size_t)(c >> 5)*(CO >> 4) + (co >> 4))*9 + (8 - tap))*P)*512 + (((co >> 3) & 1)*32 + (c & 31))*8 + (co & 7);
+#pragma unroll
+    for (int p = 0; p < P; ++p) wp_bwd[base + (size_t)p*512] = (unsigned short)(pk[p] & 0xffffu);
+  }
+}
+
+// ---- forward / data gradient ----
+// out[b][m][y][x] = sum over k < CK and taps of in[b][k][y + ky - off][x + kx - off] Wt[m][k][tap]; off = 0 for the forward (in = the reflection-padded input,
+// every read of a stored output is inside it), off = 2 for the data gradient (in = dL/dy, zero outside; out = the gradient of the PADDED input).
+// A block of four waves owns 8 pixel tiles of 32 consecutive pixels (TC = 64: 4 rows x 64 columns, a wave per row; TC = 32: 8 rows x 32 columns, a wave
+// per row pair) and one tile of 32 output channels; K runs in chunks of 16 input channels x 9 taps.  Per chunk the block stages its (TRB + 2) x (TC + 2)
+// patch of the 16 channels in LDS — coalesced row pieces, split into the bf16 pieces ONCE per element (it is used by 9 taps x every output channel),
+// filed pixel-major with the 16 channels of a pixel contiguous (32 B per piece): the B operand of a tap is then one ds_read_b128 per lane whatever the tap's
+// shift.  The two 16-byte halves of a pixel are swapped where bit 3 of the pixel index is set: the 16-lane groups that serve a ds_read_b128
+// ({0-3, 12-15, 20-27}, ...) then cover all 64 banks instead of colliding two ways.  Two patches: the next chunk's loads are requested before this chunk's
+// MFMAs and filed after them, one barrier per chunk.  The weights come as whole fragments from `k_conv_pack_w`'s image (1 KiB per wave and piece, lane-major:
+// every block reads the same ones, L1 / L2 hits), a ring of three requested two taps ahead.
+// What was measured on the way to this form (cfg 2's 96 -> 32 layer at 96x320, MIOpen 217 us; scripts/dev/conv_mfma_check.py, profiles/r06_conv_mfma_*):
+// one load per loop trip, 134 us; every staging load before its first use + the ring, 135 (the pieces — MFMAs alone 59 us, operand reads 40, staging 79-97 —
+// hardly overlap: a CU's one memory pipeline carries the staging loads AND four waves' copies of the weight fragments, 133 KB per chunk and block);
+// weights through LDS as well (one patch + one weight image, two barriers per chunk), 171; the chunk's loads spread over the taps, 205 (284 registers: one
+// wave per SIMD); two producer waves + four MFMA waves per block, 158-174.  Next: chunks of 8 channels (two taps per MFMA), so that patch AND weights fit
+// twice in 65 KB and no wave of the tap loop touches vector memory.
+template <int TC> struct ConvTile {
+  static constexpr int TRB = (TC == 64) ? 4 : 8;
+  static constexpr int PW = TC + 2, PH = TRB + 2, NPIX = PW*PH;
+};
+
+template <int TC, int P, bool BWD>
+__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, const uint4* __restrict__ wp, float* __restrict__ out,
+                                                   int CK, int M, int hi, int wi, int ho, int wo, int KS, int kc_per_split, size_t split_stride,
+                                                   unsigned gx, unsigned gy, unsigned gz) {
+  using T = ConvTile<TC>;
+  constexpr int NPIX = T::NPIX, PW = T::PW, off = BWD ? 2 : 0, NPROD = n_products(P);
+  constexpr int kBuf = P*NPIX*2;
+  __shared__ uint4 tile[2*kBuf];                                  // two patches, [piece][pixel][half]
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, g = lane >> 5;
+  // Block -> (channel tile, K split, tile column, tile row, sample), XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each
+  // with its own L2.  Here XCD k works through the k-th eighth of the tile list in order, so the blocks in flight on an XCD are neighbours in the image —
+  // the halo rows / columns two tiles share, and the one patch the channel tiles of a pixel tile all read, come from HBM once (the natural order sends every
+  // neighbour to another L2: 329 MB fetched for a 145 MB input at cfg 2's 96 -> 32 layer).
+  const int MG = M >> 5;
+  const unsigned nblk = (unsigned)(MG*KS)*gx*gy*gz, per = (nblk + 7)/8;
+  const unsigned lid = (blockIdx.x & 7)*per + (blockIdx.x >> 3);
+  if (lid >= nblk) return;
+  const int mg = lid % MG, ks = (lid/MG) % KS;
+  const unsigned tl = lid/(MG*KS);
+  const int x0 = (int)(tl % gx)*TC, y0 = (int)((tl/gx) % gy)*T::TRB, b = (int)(tl/(gx*gy));
+  const int KC = CK >> 4, kc0 = ks*kc_per_split, kc1 = min(KC, kc0 + kc_per_split);
+  const size_t plane = (size_t)hi*wi;
+  const float* src = in + (size_t)b*CK*plane;
+
+  // staging: an item = 8 channels of one patch pixel; its address inside a channel plane does not depend on the chunk
+  constexpr int ITEMS = 2*NPIX, TRIPS = (ITEMS + 255)/256;
+  int pofs[TRIPS];                                               // offset inside the plane, or -1: outside (data gradient: zero)
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int item = min(t*256 + (int)threadIdx.x, ITEMS - 1);
+    const int half = item >= NPIX ? 1 : 0, pix = item - half*NPIX;
+    const int r = pix/PW, cc = pix - r*PW;
+    const int yy = y0 + r - off, xx = x0 + cc - off;
+    if (BWD) pofs[t] = (yy >= 0 && yy < hi && xx >= 0 && xx < wi) ? yy*wi + xx : -1;
+    else pofs[t] = min(yy, hi - 1)*wi + min(xx, wi - 1);         // (beyond the image: any valid address, those outputs are not stored)
+  }
+  float v[TRIPS][8];
+  auto request = [&](int kc) {                                    // every load of a chunk is issued before anything waits for one
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      const int item = min(t*256 + (int)threadIdx.x, ITEMS - 1);
+      const int half = item >= NPIX ? 1 : 0;
+      const float* p = src + (size_t)(kc*16 + half*8)*plane + (size_t)max(pofs[t], 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[t][e] = (!BWD || pofs[t] >= 0) ? p[(size_t)e*plane] : 0.f;
+    }
+  };
+  auto file = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      const int item = t*256 + (int)threadIdx.x;
+      if (item < ITEMS) {
+        const int half = item >= NPIX ? 1 : 0, pix = item - half*NPIX;
+        unsigned pk[4][P];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split_pair<P>(v[t][2*q], v[t][2*q + 1], pk[q]);
+        const int slot = pix*2 + (half ^ ((pix >> 3) & 1));
+#pragma unroll
+        for (int p = 0; p < P; ++p) tile[buf*kBuf + p*NPIX*2 + slot] = uint4{pk[0][p], pk[1][p], pk[2][p], pk[3][p]};
+      }
+    }
+  };
+
+  // the leading product a0 b0 and the five small ones run in accumulators of their own: adding a term 2^-8 or 2^-16 the size of the sum costs a rounding of
+  // the SUM's size, so six products in one accumulator carry six times the roundings of one (measured: 2.5e-6 of the output's max at K = 4608 against
+  // MIOpen's 6e-7; split: 1.0e-6 against 6e-7 there, at or below MIOpen's elsewhere); the small accumulator's roundings are 2^-8 of that
+  f32x16 acc[2], lo[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[nt][r] = 0.f; lo[nt][r] = 0.f; }
+
+  // the weights' fragments: a ring of three, requested two taps ahead; the patch's fragments (LDS) one tap ahead.  Nine taps = three turns of the ring:
+  // every position is a compile-time constant.
+  bf16x8 A[3][P], Bf[2][2][P];
+  const uint4* wq = wp + ((size_t)mg*KC*9*P)*64 + lane;
+  auto fetch_a = [&](bf16x8 (&dst)[P], int kc, int tap) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) dst[p] = as_frag(wq[(size_t)((kc*9 + tap)*P + p)*64]);
+  };
+  auto read_b = [&](bf16x8 (&dst)[2][P], int buf, int tap) {
+    const int ky = tap/3, kx = tap % 3;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int r = (TC == 64) ? wv : 2*wv + nt, cb = (TC == 64) ? nt*32 : 0;
+      const int pix = (r + ky)*PW + cb + j + kx;
+      const int slot = pix*2 + (g ^ ((pix >> 3) & 1));
+#pragma unroll
+      for (int p = 0; p < P; ++p) dst[nt][p] = as_frag(tile[buf*kBuf + p*NPIX*2 + slot]);
+    }
+  };
+
+  if (kc0 < kc1) {
+    request(kc0);
+    fetch_a(A[0], kc0, 0);
+    fetch_a(A[1], kc0, 1);
+    file(0);
+  }
+  __syncthreads();
+  for (int kc = kc0; kc < kc1; ++kc) {
+    const int cur = (kc - kc0) & 1;
+    const bool more = kc + 1 < kc1;
+    if (more) request(kc + 1);                                    // lands during this chunk's MFMAs
+    read_b(Bf[0], cur, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 7) fetch_a(A[(tap + 2) % 3], kc, tap + 2);
+      else if (more) fetch_a(A[(tap + 2) % 3], kc + 1, tap - 7);
+      if (tap < 8) read_b(Bf[(tap + 1) & 1], cur, tap + 1);
+#pragma unroll
+      for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (t == NPROD - 1) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap % 3][0], Bf[tap & 1][nt][0], acc[nt], 0, 0, 0);
+          else lo[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap % 3][prod_a(P, t)], Bf[tap & 1][nt][prod_b(P, t)], lo[nt], 0, 0, 0);
+        }
+    }
+    if (more) file(cur ^ 1);
+    __syncthreads();                                              // the other patch is complete, and nobody reads this one any more
+  }
+  // D[row = output channel][column = pixel]: a register is 32 consecutive pixels of one channel per half wave (128-byte runs)
+  float* dst = out + (size_t)ks*split_stride;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int r = (TC == 64) ? wv : 2*wv + nt, cb = (TC == 64) ? nt*32 : 0;
+    const int y = y0 + r, x = x0 + cb + j;
+    if (y < ho && x < wo) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int m = mg*32 + (rr & 3) + 8*(rr >> 2) + 4*g;
+        dst[(((size_t)b*M + m)*ho + y)*wo + x] = acc[nt][rr] + lo[nt][rr];
+      }
+    }
+  }
+}
+
+// out = the sum of the K splits' partial outputs, in split order (the coarse decoder levels: few pixels, thousands of K — the splits are what fills the chip)
+__global__ __launch_bounds__(256) void k_conv_split_sum(const float* __restrict__ part, float* __restrict__ out, size_t n4, int KS) {
+  const size_t i = (size_t)blockIdx.x*256 + threadIdx.x;
+  if (i >= n4) return;
+  const f4* p = reinterpret_cast<const f4*>(part);
+  f4 s = p[i];
+  for (int k = 1; k < KS; ++k) s += p[(size_t)k*n4 + i];
+  reinterpret_cast<f4*>(out)[i] = s;
+}
+
+// ---- weight gradient ----
+// g_w[co][c][tap] = sum over samples and pixels of g_y[co][y][x] xp[c][y + ky][x + kx]: per tap a GEMM with M = output channels, N = input channels,
+// K = pixels.  Both operands want 8 consecutive K per lane = 8 consecutive pixels of a row of one channel: the tensors' own (NCHW) order.  A K step is 16
+// pixels of a row (lane group g: pixels 8 g .. 8 g + 7); A = g_y, B = the padded input shifted by the tap — the shift by kx is a funnel shift of the five
+// dwords a lane reads (kx = 0: dwords 0-3, kx = 2: dwords 1-4, kx = 1: v_alignbit of neighbours), so one aligned ds_read_b128 + b32 per (ky, piece)
+// serves three taps.  A wave owns ONE pair (tile of 32 output channels, tile of 32 input channels) and all nine taps: 9 x 16 accumulator registers.
+// A block of four waves = COT x CT such pairs (x KS = 4 / (COT CT) waves per pair that split a row's two K steps) walks down a strip of 32 columns:
+// per row it needs one new row of g_y and one new row of the padded input (rows y .. y + 2 sit in a ring of four slots), requested from memory before
+// the row's MFMAs and split + filed after them: one barrier per row.  The block leaves its sums as one set of partials [tap][co][c];
+// k_conv_wgrad_finalize adds the blocks' sets in fp64 in block order (deterministic, as everywhere in this library).
+template <int COT, int CT>
+struct WgradTile {
+  static constexpr int COB = 32*COT, CB = 32*CT, KS = 4/(COT*CT);
+  static constexpr int XROW = 20, XCH = 4*XROW + 4;     // dwords: a row slot = 40 bf16 (34 used), a channel = 4 slots + 16 bytes (336 B = 16 x 21: odd, the 16 lanes of a ds_read_b128 group cover all banks)
+  static constexpr int GROW = 16, GCH = 2*GROW + 4;     // dwords: a row slot = 32 bf16, a channel = 2 slots + 16 bytes (144 B = 16 x 9)
+};
+
+template <int COT, int CT, int P>
+__global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const float* __restrict__ xp, const float* __restrict__ gy, float* __restrict__ partial,
+                                                         int C, int CO, int h, int w, int rows_per_block) {
+  using T = WgradTile<COT, CT>;
+  constexpr int COB = T::COB, CB = T::CB, KS = T::KS, XROW = T::XROW, XCH = T::XCH, GROW = T::GROW, GCH = T::GCH, NPROD = n_products(P);
+  static_assert(KS == 1 || KS == 2, "waves per pair");
+  constexpr int kXs = P*CB*XCH, kGs = P*COB*GCH;
+  constexpr int kRed = (KS == 2) ? 2*144*64 : 0;          // the second wave of a pair parks its accumulators
+  __shared__ __attribute__((aligned(16))) unsigned lds[(kXs + kGs) > kRed ? (kXs + kGs) : kRed];
+  unsigned* const xs = lds;
+  unsigned* const gs = lds + kXs;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, g = lane >> 5;
+  const int cot = wv % COT, ct = (wv/COT) % CT, ks = wv/(COT*CT);
+  const int CGRP = (C + CB - 1)/CB, COGRP = CO/COB;
+  const int cg = blockIdx.z % CGRP, cog = (blockIdx.z/CGRP) % COGRP, b = blockIdx.z/(CGRP*COGRP);
+  const int x0 = blockIdx.x*32, ybeg = blockIdx.y*rows_per_block, nrows = min(rows_per_block, h - ybeg);
+  const int W = w + 2, H = h + 2;
+  const float* xsrc = xp + (size_t)b*C*H*W;
+  const float* gsrc = gy + ((size_t)b*CO + (size_t)cog*COB)*h*w;
+
+  constexpr int XITEMS = CB*17, XTRIPS = (XITEMS + 255)/256;     // an item = two adjacent columns of one channel's row
+  constexpr int GITEMS = COB*16, GTRIPS = GITEMS/256;
+  static_assert(GITEMS % 256 == 0, "g_y items per thread");
+  float xv[XTRIPS][2], gv[GTRIPS][2];
+  auto load_x = [&](int yy) {                                     // padded row yy (clamped: rows past the strip are requested but never used)
+    yy = min(yy, H - 1);
+#pragma unroll
+    for (int t = 0; t < XTRIPS; ++t) {
+      const int item = t*256 + (int)threadIdx.x;
+      const int ch = min(item/17, CB - 1), pr = item % 17;
+      const int c = min(cg*CB + ch, C - 1);
+      const float* rowp = xsrc + ((size_t)c*H + yy)*W;
+      xv[t][0] = rowp[min(x0 + 2*pr, W - 1)];
+      xv[t][1] = rowp[min(x0 + 2*pr + 1, W - 1)];
+    }
+  };
+  auto file_x = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < XTRIPS; ++t) {
+      const int item = t*256 + (int)threadIdx.x;
+      if (item < XITEMS) {
+        const int ch = item/17, pr = item % 17;
+        unsigned pk[P];
+        split_pair<P>(xv[t][0], xv[t][1], pk);
+#pragma unroll
+        for (int p = 0; p < P; ++p) xs[(p*CB + ch)*XCH + slot*XROW + pr] = pk[p];
+      }
+    }
+  };
+  auto load_g = [&](int y) {                                      // beyond the image or the block's rows: zeros, those pixels add nothing
+#pragma unroll
+    for (int t = 0; t < GTRIPS; ++t) {
+      const int item = t*256 + (int)threadIdx.x;
+      const int co = item >> 4, pr = item & 15;
+      const int xa = x0 + 2*pr;
+      const bool yok = y < ybeg + nrows;
+      const float* rowp = gsrc + ((size_t)co*h + (yok ? y : 0))*w;
+      gv[t][0] = (yok && xa < w) ? rowp[xa] : 0.f;
+      gv[t][1] = (yok && xa + 1 < w) ? rowp[xa + 1] : 0.f;
+    }
+  };
+  auto file_g = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < GTRIPS; ++t) {
+      const int item = t*256 + (int)threadIdx.x;
+      const int co = item >> 4, pr = item & 15;
+      unsigned pk[P];
+      split_pair<P>(gv[t][0], gv[t][1], pk);
+#pragma unroll
+      for (int p = 0; p < P; ++p) gs[(p*COB + co)*GCH + slot*GROW + pr] = pk[p];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // fill: padded rows ybeg .. ybeg + 2 and g_y's row ybeg
+  for (int r = 0; r < 3; ++r) { load_x(ybeg + r); file_x(r); }
+  load_g(ybeg); file_g(0);
+  __syncthreads();
+
+  for (int it = 0; it < nrows; ++it) {
+    const int y = ybeg + it;
+    load_x(y + 3);
+    load_g(y + 1);
+    const int gslot = it & 1;
+#pragma unroll
+    for (int s = 0; s < 2/KS; ++s) {
+      const int xsi = (KS == 2) ? ks : s;                         // K step: columns 16 xsi + 8 g .. + 7
+      bf16x8 A[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) A[p] = as_frag(*reinterpret_cast<const uint4*>(&gs[(p*COB + cot*32 + j)*GCH + gslot*GROW + xsi*8 + g*4]));
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int slot = (it + ky) & 3;
+        bf16x8 Bx[3][P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const unsigned* q = &xs[(p*CB + ct*32 + j)*XCH + slot*XROW + xsi*8 + g*4];
+          const uint4 d = *reinterpret_cast<const uint4*>(q);
+          const unsigned d4 = q[4];
+          Bx[0][p] = as_frag(d);
+          Bx[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16), __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(d4, d.w, 16)});
+          Bx[2][p] = as_frag(uint4{d.y, d.z, d.w, d4});
+        }
+#pragma unroll
+        for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc[ky*3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[prod_a(P, t)], Bx[kx][prod_b(P, t)], acc[ky*3 + kx], 0, 0, 0);
+      }
+    }
+    file_x((it + 3) & 3);
+    file_g((it + 1) & 1);
+    __syncthreads();
+  }
+
+  // D[row = co][column = c] of tap t
+  if constexpr (KS == 2) {
+    float* red = reinterpret_cast<float*>(lds);                   // (everybody is past the last barrier of the loop: the ring is free)
+    if (ks == 1) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((cot + COT*ct)*144 + t*16 + r)*64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += red[((cot + COT*ct)*144 + t*16 + r)*64 + lane];
+    }
+  }
+  if (ks == 0) {
+    const size_t blk = ((size_t)b*gridDim.y + blockIdx.y)*gridDim.x + blockIdx.x;
+    const int c = (cg*CT + ct)*32 + j;
+    if (c < C) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (cog*COT + cot)*32 + (r & 3) + 8*(r >> 2) + 4*g;
+          partial[((blk*9 + t)*CO + co)*C + c] = acc[t][r];
+        }
+    }
+  }
+}
+
+// partial[t][tap][co][c] -> g_w[co][c][tap]: a block = 64 weights x 4 waves that take every fourth block's sums (fp64), added in wave order
+__global__ __launch_bounds__(256) void k_conv_wgrad_finalize(const float* __restrict__ partial, unsigned T, int CO, int C, float* __restrict__ g_w) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = CO*C*9, i = blockIdx.x*64 + lane;
+  double s = 0.0;
+  if (i < n) for (unsigned t = wv; t < T; t += 4) s += (double)partial[(size_t)t*n + i];
+  part[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && i < n) {
+    const double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const int c = i % C, co = (i/C) % CO, tap = i/(C*CO);
+    g_w[((size_t)co*C + c)*9 + tap] = (float)tot;
+  }
+}
+
+// ---- launch shapes ----
+static inline int wgrad_ct(int C, int CO) { return (CO % 64 == 0) ? 2 : (C > 64 ? 4 : 2); }      // pairs per block: 2 x 2 (64 output channels and up), 1 x 4, 1 x 2 (two waves per pair)
+static inline int wgrad_cot(int C, int CO) { return (CO % 64 == 0) ? 2 : 1; }
+static void wgrad_shape(int B, int C, int CO, int h, int w, dim3& grid, int& rows) {
+  const int CB = 32*wgrad_ct(C, CO), COB = 32*wgrad_cot(C, CO);
+  const int strips = ceil_div(w, 32), base = strips*B*ceil_div(C, CB)*(CO/COB);
+  const int groups = std::max(1, std::min(256/std::max(base, 1), ceil_div(h, 4)));   // one block per CU (its ring takes most of the LDS): one generation of equal blocks where the layer allows
+  rows = ceil_div(h, groups);
+  grid = dim3(strips, ceil_div(h, rows), B*ceil_div(C, CB)*(CO/COB));
+}
+size_t conv_mfma_wgrad_partials(int B, int C, int CO, int h, int w) {
+  dim3 grid; int rows;
+  wgrad_shape(B, C, CO, h, w, grid, rows);
+  return (size_t)grid.x*grid.y*B*9*CO*C;
+}
+size_t conv_mfma_packed_elems(int C, int CO, int pieces) { return (size_t)CO*C*9*pieces; }
+
+hipError_t launch_conv_mfma_pack(const float* w, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, hipStream_t st) {
+  const dim3 grid(ceil_div(CO*C*9, 256));
+  if (pieces == 3) hipLaunchKernelGGL((k_conv_pack_w<3>), grid, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)wp_bwd, CO, C);
+  else hipLaunchKernelGGL((k_conv_pack_w<2>), grid, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)wp_bwd, CO, C);
+  return hipGetLastError();
+}
+
+// Launch shape of the forward / data-gradient form: tile columns, channel tiles per wave, K splits (each split a whole number of 16-channel chunks).
+struct ConvShape { int TC, TRB, MT, KS, kcs; unsigned gx, gy, gz; dim3 grid; size_t out_elems; };
+static ConvShape conv_shape(int B, int CK, int M, int ho, int wo) {
+  ConvShape s;
+  s.TC = wo >= 48 ? 64 : 32; s.TRB = wo >= 48 ? 4 : 8;
+  const long long tiles = (long long)ceil_div(wo, s.TC)*ceil_div(ho, s.TRB)*B;
+  s.MT = 1;                                                      // (two channel tiles per wave: 92 KB of LDS and 300 registers — one block per CU; not built)
+  const long long base = tiles*(M/(32*s.MT));
+  const int KC = CK >> 4;
+  int ks = 1;
+  if (base < 384) ks = (int)std::min<long long>(std::max(KC/2, 1), (512 + base - 1)/base);   // under 1.5 blocks per CU: split K, at least two chunks per split
+  s.kcs = ceil_div(KC, ks); s.KS = ceil_div(KC, s.kcs);
+  s.gx = ceil_div(wo, s.TC); s.gy = ceil_div(ho, s.TRB); s.gz = B;
+  s.grid = dim3(8*(unsigned)ceil_div((long long)s.gx*s.gy*s.gz*(M/32)*s.KS, 8ll));
+  s.out_elems = (size_t)B*M*ho*wo;
+  return s;
+}
+size_t conv_mfma_split_elems(int B, int CK, int M, int ho, int wo) {
+  const ConvShape s = conv_shape(B, CK, M, ho, wo);
+  return s.KS > 1 ? (size_t)s.KS*s.out_elems : 0;
+}
+
+template <int P, bool BWD>
+static void launch_conv_form(const float* in, const void* wp, float* out, float* split_ws, int B, int CK, int M, int hi, int wi, int ho, int wo, hipStream_t st) {
+  const ConvShape s = conv_shape(B, CK, M, ho, wo);
+  const uint4* wq = (const uint4*)wp;
+  float* dst = s.KS > 1 ? split_ws : out;
+  if (s.TC == 64) hipLaunchKernelGGL((k_conv_mfma<64, P, BWD>), s.grid, dim3(256), 0, st, in, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
+  else hipLaunchKernelGGL((k_conv_mfma<32, P, BWD>), s.grid, dim3(256), 0, st, in, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
+  if (s.KS > 1) {
+    const size_t n4 = s.out_elems/4;                              // (B M ho wo is a multiple of 4: M is a multiple of 32)
+    hipLaunchKernelGGL(k_conv_split_sum, dim3((unsigned)((n4 + 255)/256)), dim3(256), 0, st, split_ws, out, n4, s.KS);
+  }
+}
+
+// y (B, CO, h, w) = conv3x3(xp (B, C, h + 2, w + 2)): C % 16 == 0, CO % 32 == 0
+size_t conv_mfma_fwd_split_elems(int B, int C, int CO, int h, int w) { return conv_mfma_split_elems(B, C, CO, h, w); }
+size_t conv_mfma_bwd_split_elems(int B, int C, int CO, int h, int w) { return conv_mfma_split_elems(B, CO, C, h + 2, w + 2); }
+hipError_t launch_conv_mfma_fwd(const float* xp, const void* wp_fwd, float* y, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+  if (pieces == 3) launch_conv_form<3, false>(xp, wp_fwd, y, split_ws, B, C, CO, h + 2, w + 2, h, w, st);
+  else launch_conv_form<2, false>(xp, wp_fwd, y, split_ws, B, C, CO, h + 2, w + 2, h, w, st);
+  return hipGetLastError();
+}
+// g_xp (B, C, h + 2, w + 2) from g_y (B, CO, h, w): CO % 16 == 0, C % 32 == 0
+hipError_t launch_conv_mfma_bwd_data(const float* gy, const void* wp_bwd, float* g_xp, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+  if (pieces == 3) launch_conv_form<3, true>(gy, wp_bwd, g_xp, split_ws, B, CO, C, h, w, h + 2, w + 2, st);
+  else launch_conv_form<2, true>(gy, wp_bwd, g_xp, split_ws, B, CO, C, h, w, h + 2, w + 2, st);
+  return hipGetLastError();
+}
+// g_w (CO, C, 3, 3): CO % 32 == 0, any C >= 1 (channel tiles past C are computed on clamped reads and not stored)
+template <int P>
+static void launch_wgrad(const float* xp, const float* gy, float* partial, int B, int C, int CO, int h, int w, hipStream_t st) {
+  dim3 grid; int rows;
+  wgrad_shape(B, C, CO, h, w, grid, rows);
+  const int cot = wgrad_cot(C, CO), ct = wgrad_ct(C, CO);
+  if (cot == 2) hipLaunchKernelGGL((k_conv_wgrad_mfma<2, 2, P>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+  else if (ct == 4) hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 4, P>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+  else hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 2, P>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+}
+hipError_t launch_conv_mfma_bwd_wgt(const float* xp, const float* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+  if (pieces == 3) launch_wgrad<3>(xp, gy, partial, B, C, CO, h, w, st);
+  else launch_wgrad<2>(xp, gy, partial, B, C, CO, h, w, st);
+  dim3 grid; int rows;
+  wgrad_shape(B, C, CO, h, w, grid, rows);
+  hipLaunchKernelGGL(k_conv_wgrad_finalize, dim3(ceil_div(CO*C*9, 64)), dim3(256), 0, st, partial, (unsigned)(grid.x*grid.y*B), CO, C, g_w);
+  return hipGetLastError();
+}
+
+}  // namespace smd

@@ -269,6 +269,15 @@ hipError_t launch_conv_thin_fwd(const float* xp, const float* wgt, float* y, int
 size_t conv_thin_partials(int B, int C, int h, int w);
 hipError_t launch_conv_thin_bwd_wgt(const float* xp, const float* gy, float* g_w, float* partial, int B, int C, int h, int w, hipStream_t st);
 hipError_t launch_conv_thin_bwd_data(const float* gy, const float* wgt, float* g_xp, int B, int C, int h, int w, hipStream_t st);
+// smd_conv_mfma.hip: the wide decoder convolutions on the bf16 matrix cores, fp32 operands split into `pieces` bf16 pieces (3: fp32-class results)
+size_t conv_mfma_packed_elems(int C, int CO, int pieces);
+size_t conv_mfma_wgrad_partials(int B, int C, int CO, int h, int w);
+hipError_t launch_conv_mfma_pack(const float* w, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, hipStream_t st);
+size_t conv_mfma_fwd_split_elems(int B, int C, int CO, int h, int w);     // floats of K-split partial outputs the forward / the data gradient wants (0: none)
+size_t conv_mfma_bwd_split_elems(int B, int C, int CO, int h, int w);
+hipError_t launch_conv_mfma_fwd(const float* xp, const void* wp_fwd, float* y, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
+hipError_t launch_conv_mfma_bwd_data(const float* gy, const void* wp_bwd, float* g_xp, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
+hipError_t launch_conv_mfma_bwd_wgt(const float* xp, const float* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
 size_t decoder_bias_partials(int B, int C, int h, int w);
 hipError_t launch_elu_pad_fwd(const void* x, const float* bias, void* out, int B, int C, int h, int w, int apply_elu, int dt, hipStream_t st);
 hipError_t launch_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g_x, float* g_bias, float* ws, int B, int C, int h, int w,

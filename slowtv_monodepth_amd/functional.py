@@ -901,6 +901,60 @@ def conv3x3_thin(xp, weight):
     return _Conv3x3Thin.apply(xp, weight)
 
 
+class _Conv3x3Mfma(torch.autograd.Function):
+    """`F.conv2d(xp, weight (CO,C,3,3))` on an already reflection-padded input on the bf16 matrix cores with fp32-class results (`smd_conv3x3_mfma_*`)."""
+    @staticmethod
+    def forward(ctx, xp, weight, pieces):
+        xp = _check('xp', xp)
+        if xp.ndim != 4 or xp.shape[2] < 3 or xp.shape[3] < 3: raise ValueError(f'expected a padded (B,C,h+2,w+2), got {tuple(xp.shape)}')
+        B, C, H, W = xp.shape
+        if weight.ndim != 4 or tuple(weight.shape[1:]) != (C, 3, 3): raise ValueError(f'weight: expected (CO,{C},3,3), got {tuple(weight.shape)}')
+        CO = weight.shape[0]
+        weight = _check('weight', weight, (CO, C, 3, 3))
+        dev = xp.device
+        nbytes = _lib.lib.smd_conv3x3_mfma_packed_bytes(C, CO, pieces)
+        wp_fwd = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+        bwd_form = CO % 16 == 0 and C % 32 == 0            # the data gradient's own operand order (what the backward kernel serves)
+        wp_bwd = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8) if bwd_form else None
+        call('smd_conv3x3_mfma_pack', weight.data_ptr(), wp_fwd.data_ptr(), wp_bwd.data_ptr() if bwd_form else None, C, CO, pieces, _stream())
+        y = torch.empty((B, CO, H - 2, W - 2), device=dev, dtype=torch.float32)
+        nws = _lib.lib.smd_conv3x3_mfma_workspace_bytes(B, C, CO, H - 2, W - 2)
+        ws = torch.empty(max(nws, 256), device=dev, dtype=torch.uint8)
+        call('smd_conv3x3_mfma_fwd', xp.data_ptr(), wp_fwd.data_ptr(), y.data_ptr(), ws.data_ptr(), nws, B, C, CO, H - 2, W - 2, pieces, _stream())
+        ctx.save_for_backward(xp, weight, wp_bwd); ctx.pieces = pieces
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        xp, weight, wp_bwd = ctx.saved_tensors
+        dev = _on(xp)
+        B, C, H, W = xp.shape
+        CO, pieces = weight.shape[0], ctx.pieces
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_y = _check('grad(y)', g_y, (B, CO, H - 2, W - 2))
+        g_xp = g_w = None
+        nbytes = _lib.lib.smd_conv3x3_mfma_workspace_bytes(B, C, CO, H - 2, W - 2)
+        ws = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+        if need_x:
+            if wp_bwd is not None:
+                g_xp = torch.empty_like(xp)
+                call('smd_conv3x3_mfma_bwd_data', g_y.data_ptr(), wp_bwd.data_ptr(), g_xp.data_ptr(), ws.data_ptr(), nbytes, B, C, CO, H - 2, W - 2, pieces, _stream())
+            else:                                           # channel counts the data-gradient kernel does not tile: the general operator
+                g_xp = torch.nn.grad.conv2d_input(xp.shape, weight, g_y)
+        if need_w:
+            g_w = torch.empty_like(weight)
+            call('smd_conv3x3_mfma_bwd_weight', xp.data_ptr(), g_y.data_ptr(), g_w.data_ptr(), ws.data_ptr(), nbytes, B, C, CO, H - 2, W - 2, pieces, _stream())
+        return g_xp, g_w, None
+
+
+def conv3x3_mfma(xp, weight, pieces: int = 3):
+    """`F.conv2d(xp, weight)` for an input that is already reflection-padded: the wide up-convolutions of the decoder
+    (src/networks/decoders/monodepth.py:40-50, 71-84), bias-free (the next glue kernel adds it).  xp (B,C,h+2,w+2) fp32, weight (CO,C,3,3) fp32 -> (B,CO,h,w)
+    fp32; C % 16 == 0 and CO % 32 == 0 (`_lib.Unsupported` otherwise).  Computed on the bf16 matrix cores with every fp32 operand split exactly into three
+    bf16 pieces and six products kept per fp32 product (`pieces=3`: fp32-class error, see csrc/smd_conv_mfma.hip; `pieces=2` is an experiment setting)."""
+    return _Conv3x3Mfma.apply(xp, weight, int(pieces))
+
+
 class _EluUpCatPad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, bias, skip, out_dtype):

@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol():
         proto = _lib.PROTOTYPES[name][1]
         got = ['p' if t in (C.c_void_p, C.c_char_p) else ('f' if t is C.c_float else 'i') for t in proto]
         assert got == kinds, f'{name}: ctypes prototype {got} does not match the header {kinds}'
-    assert _lib.lib.smd_abi_version() == 7
+    assert _lib.lib.smd_abi_version() == 8
     # launch-shape knobs (the parity tests' pins): known name, unknown name, experiments-only name in the product build; and nothing reads the environment
     assert _lib.set_knob('fwd_rh', 12) is True and _lib.set_knob('bwd_pair', 1) is False
     with pytest.raises(ValueError): _lib.set_knob('no_such_knob', 1)
