@@ -151,6 +151,8 @@ def main():
                                                           'replays: what the host has to enqueue per step drops from ~1000 launches to one (multi-GPU readiness: eight ranks\' Python '
                                                           'threads); the library\'s event profile is off in this mode, so the roofline fields are null')
     ap.add_argument('--knob', action='append', default=[], metavar='NAME=VALUE', help='pin a launch-shape knob of the library (smd_set_knob) for an A/B run, e.g. --knob bwd_live=0; recorded in config.knobs')
+    ap.add_argument('--conv-route', default='auto', choices=['auto', 'mfma', 'miopen'], help="who serves the decoder's wide convolutions: 'auto' = this box's A/B per operator and shape on first use "
+                    "(functional._conv_route; recorded in config.decoder_conv_routes), 'mfma' / 'miopen' pin every one of them for an A/B run")
     ap.add_argument('--precision', default=None, choices=['32', 'bf16'], help='override the network autocast precision of the workload (the loss path is always fp32)')
     args = ap.parse_args()
 
@@ -159,6 +161,8 @@ def main():
     from slowtv_monodepth_amd.train import StepModule, init_distributed, train_steps, wrap_ddp
     from slowtv_monodepth_amd.trainer import MonoDepthModule
 
+    from slowtv_monodepth_amd import functional as _HF
+    _HF.set_conv_route(args.conv_route)
     for kv in args.knob:
         k_, v_ = kv.split('=')
         if not _lib.set_knob(k_, int(v_)): raise SystemExit(f'bench.py: knob {k_} is not in this build of the library')
@@ -338,6 +342,7 @@ def main():
                        'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3), 'host_cpu_ms_per_step': round(host_cpu/args.steps*1e3, 3), 'hip_graph': graph_note,
                        'prep_ahead': module.prep_ahead if not args.graph else 'False (forced by --graph: the prep-ahead hand-off across streams crashes hipStreamEndCapture on this stack; the default bench runs prep_ahead=pose)',
                        'loss_path': getattr(module.backend, 'last_path', None), 'knobs': args.knob or None,
+                       'decoder_conv_routes': {'mode': args.conv_route, 'decisions': {f'{k[0]} {k[2]}->{k[3]} {k[4]}x{k[5]} b{k[1]}': ('split-bf16 mfma' if v[0] else ('f32 mfma' if k[3] == 16 else 'miopen')) + f' ({v[1]:.0f} vs {v[2]:.0f} us)' for k, v in sorted(_HF.conv_routes().items(), key=lambda kv: (-kv[0][4], kv[0][0]))}},
                        'automasked_share': sel_stats['automasked_share'] if sel_stats else None, 'routed_share_per_support': sel_stats['routed_share_per_support'] if sel_stats else None,
                        'dead_wave_share_per_support': sel_stats['dead_wave_share_per_support'] if sel_stats else None},
             'roofline': {'kernel': f'{k_fwd} (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; the instantiation the library reports for the last forward launch, name as rocprofv3 prints it)', 'bound': 'hbm',

@@ -308,7 +308,8 @@ int smd_conv3x3_thin_bwd(const float* xp, const float* weight, const float* g_y,
  * 2^-25 of the product — fp32-class results at 6/16 of the f32 MFMA's time; 2: three products, 16 significant bits, an experiment setting, never the
  * library's choice).  smd_conv3x3_mfma_pack writes the weights' pieces in the operand order of the forward (wp_fwd) and of the data gradient (wp_bwd), each
  * smd_conv3x3_mfma_packed_bytes(C, CO, pieces) bytes (either may be NULL); the backward reads what the forward's pack left.
- * Served: pieces in {2, 3}; forward C % 16 == 0 and CO % 32 == 0; data gradient CO % 16 == 0 and C % 32 == 0; weight gradient CO % 32 == 0 (any C);
+ * Served: pieces in {2, 3}; forward C % 16 == 0 and CO % 32 == 0; data gradient CO % 16 == 0 and C % 32 == 0; weight gradient CO % 32 == 0 (any C); and the
+ * thin last stage, CO == 16 with C == 16 or 32 (`ConvELU(cin, 16)`, monodepth.py:45-50: all three operators, on the 16 x 16 x 32 form of the instruction);
  * anything else SMD_E_UNSUPPORTED, nothing launched.  g_xp (B,C,h+2,w+2) is the gradient of the PADDED input.  Every call takes a workspace of
  * smd_conv3x3_mfma_workspace_bytes (the coarse decoder levels — few pixels, thousands of K — split K over blocks and add the splits' outputs in split
  * order; the weight gradient leaves per-block sums that a fixed-order fp64 second stage adds).  Deterministic. */

@@ -15,9 +15,9 @@ ap.add_argument('--hw', default='192x640'); ap.add_argument('--no-time', action=
 args = ap.parse_args()
 H, W = map(int, args.hw.split('x'))
 b = args.b
-layers = [('up1_1', 96, 32, H//2, W//2), ('up0_1', 64, 32, H//4, W//4), ('up1_2', 128, 64, H//4, W//4), ('up0_2', 128, 64, H//8, W//8),
+layers = [('up1_0', 16, 16, H, W), ('up0_0', 32, 16, H//2, W//2), ('up1_1', 96, 32, H//2, W//2), ('up0_1', 64, 32, H//4, W//4), ('up1_2', 128, 64, H//4, W//4), ('up0_2', 128, 64, H//8, W//8),
           ('up1_3', 256, 128, H//8, W//8), ('up0_3', 256, 128, H//16, W//16), ('up1_4', 512, 256, H//16, W//16), ('up0_4', 512, 256, H//32, W//32)]
-small = [('odd_a', 16, 32, 5, 7), ('odd_b', 48, 64, 9, 70), ('odd_c', 32, 32, 33, 65), ('odd_d', 96, 32, 13, 100), ('odd_e', 32, 96, 7, 33), ('odd_f', 64, 128, 4, 20)]
+small = [('odd_t', 16, 16, 7, 70), ('odd_u', 32, 16, 9, 33), ('odd_a', 16, 32, 5, 7), ('odd_b', 48, 64, 9, 70), ('odd_c', 32, 32, 33, 65), ('odd_d', 96, 32, 13, 100), ('odd_e', 32, 96, 7, 33), ('odd_f', 64, 128, 4, 20)]
 if args.layers: layers = [l for l in layers if l[0] in args.layers]
 
 
@@ -61,6 +61,13 @@ for name, C, CO, h, w in (small if args.quick else small + layers):
         t_f = timeit(lambda: TF.conv2d(xp, wt))
         t_d = timeit(lambda: torch.ops.aten.convolution_backward(gy, xp, wt, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False]))
         t_w = timeit(lambda: torch.ops.aten.convolution_backward(gy, xp, wt, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]))
+        if CO == 16:
+            yt = torch.empty(B, CO, h, w, device='cuda'); gxt = torch.empty_like(xp); gwt = torch.empty_like(wt)
+            nb = _lib.lib.smd_conv3x3_thin_workspace_bytes(B, C, h, w); wst = torch.empty(nb, device='cuda', dtype=torch.uint8)
+            a_f = timeit(lambda: call('smd_conv3x3_thin_fwd', xp.data_ptr(), wt.data_ptr(), yt.data_ptr(), B, C, h, w, stream()))
+            a_d = timeit(lambda: call('smd_conv3x3_thin_bwd', xp.data_ptr(), wt.data_ptr(), gy.data_ptr(), gxt.data_ptr(), None, None, 0, B, C, h, w, stream()))
+            a_w = timeit(lambda: call('smd_conv3x3_thin_bwd', xp.data_ptr(), wt.data_ptr(), gy.data_ptr(), None, gwt.data_ptr(), wst.data_ptr(), nb, B, C, h, w, stream()))
+            print(f'        f32MFMA fwd {a_f:6.1f} ({flop/a_f/1e6:5.1f} TF/s) data {a_d:7.1f} ({flop/a_d/1e6:5.1f}) wgt {a_w:7.1f} ({flop/a_w/1e6:5.1f})')
         line = f'        MIOpen fwd {t_f:7.1f} ({flop/t_f/1e6:5.1f} TF/s) data {t_d:7.1f} ({flop/t_d/1e6:5.1f}) wgt {t_w:7.1f} ({flop/t_w/1e6:5.1f})'
         for P in args.pieces:
             nb = _lib.lib.smd_conv3x3_mfma_packed_bytes(C, CO, P)

@@ -826,6 +826,9 @@ static bool mfma_sizes_ok(int B, int C, int CO, int h, int w) {   // grid dimens
   return B >= 1 && C >= 1 && CO >= 1 && C <= 4096 && CO <= 4096 && h >= 1 && w >= 1 && h < 32768 && w < 32768 && (long long)(h + 2)*(w + 2) < (1ll << 30) &&
          (long long)B*((C + 31)/32)*((CO + 31)/32) < 65536;
 }
+static bool mfma_fwd_served(int C, int CO) { return (C % 16 == 0 && CO % 32 == 0) || (CO == 16 && (C == 16 || C == 32)); }
+static bool mfma_wgt_served(int C, int CO) { return CO % 32 == 0 || (CO == 16 && (C == 16 || C == 32)); }
+static bool mfma_data_served(int C, int CO) { return (CO % 16 == 0 && C % 32 == 0) || (C == 16 && CO == 16); }
 size_t smd_conv3x3_mfma_packed_bytes(int C, int CO, int pieces) {
   if (C < 1 || CO < 1 || (pieces != 2 && pieces != 3)) return 0;
   return align256(smd::conv_mfma_packed_elems(C, CO, pieces)*2);
@@ -833,17 +836,17 @@ size_t smd_conv3x3_mfma_packed_bytes(int C, int CO, int pieces) {
 size_t smd_conv3x3_mfma_workspace_bytes(int B, int C, int CO, int h, int w) {   // one size for the three operators
   if (!mfma_sizes_ok(B, C, CO, h, w)) return 0;
   size_t n = 64;
-  if (C % 16 == 0 && CO % 32 == 0) n = std::max(n, smd::conv_mfma_fwd_split_elems(B, C, CO, h, w));
-  if (CO % 16 == 0 && C % 32 == 0) n = std::max(n, smd::conv_mfma_bwd_split_elems(B, C, CO, h, w));
-  if (CO % 32 == 0) n = std::max(n, smd::conv_mfma_wgrad_partials(B, C, CO, h, w));
+  if (mfma_fwd_served(C, CO)) n = std::max(n, smd::conv_mfma_fwd_split_elems(B, C, CO, h, w));
+  if (mfma_data_served(C, CO)) n = std::max(n, smd::conv_mfma_bwd_split_elems(B, C, CO, h, w));
+  if (mfma_wgt_served(C, CO)) n = std::max(n, smd::conv_mfma_wgrad_partials(B, C, CO, h, w));
   return align256(n*sizeof(float));
 }
 int smd_conv3x3_mfma_pack(const float* weight, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, void* stream) {
   if (!weight || (!wp_fwd && !wp_bwd)) return fail(SMD_E_INVALID, "null pointer");
   if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
   if (C < 1 || CO < 1 || C > 4096 || CO > 4096) return fail(SMD_E_INVALID, "invalid sizes C=%d CO=%d", C, CO);
-  if (wp_fwd && (C % 16 || CO % 32)) return fail(SMD_E_UNSUPPORTED, "the forward form serves C %% 16 == 0 and CO %% 32 == 0, not C=%d CO=%d", C, CO);
-  if (wp_bwd && (CO % 16 || C % 32)) return fail(SMD_E_UNSUPPORTED, "the data-gradient form serves CO %% 16 == 0 and C %% 32 == 0, not C=%d CO=%d", C, CO);
+  if (wp_fwd && !mfma_fwd_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the forward form serves C %% 16 == 0 with CO %% 32 == 0, or CO == 16 with C == 16 | 32, not C=%d CO=%d", C, CO);
+  if (wp_bwd && !mfma_data_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the data-gradient form serves CO %% 16 == 0 with C %% 32 == 0, or C == CO == 16, not C=%d CO=%d", C, CO);
   return check_launch(smd::launch_conv_mfma_pack(weight, wp_fwd, wp_bwd, C, CO, pieces, (hipStream_t)stream), "conv3x3_mfma_pack");
 }
 int smd_conv3x3_mfma_fwd(const float* xp, const void* wp_fwd, float* y, void* workspace, size_t workspace_bytes,
@@ -851,7 +854,7 @@ int smd_conv3x3_mfma_fwd(const float* xp, const void* wp_fwd, float* y, void* wo
   if (!xp || !wp_fwd || !y || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
   if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
-  if (C % 16 || CO % 32) return fail(SMD_E_UNSUPPORTED, "the forward serves C %% 16 == 0 and CO %% 32 == 0, not C=%d CO=%d", C, CO);
+  if (!mfma_fwd_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the forward serves C %% 16 == 0 with CO %% 32 == 0, or CO == 16 with C == 16 | 32, not C=%d CO=%d", C, CO);
   if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
   return check_launch(smd::launch_conv_mfma_fwd(xp, wp_fwd, y, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_fwd");
 }
@@ -860,7 +863,7 @@ int smd_conv3x3_mfma_bwd_data(const float* g_y, const void* wp_bwd, float* g_xp,
   if (!g_y || !wp_bwd || !g_xp || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
   if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
-  if (CO % 16 || C % 32) return fail(SMD_E_UNSUPPORTED, "the data gradient serves CO %% 16 == 0 and C %% 32 == 0, not C=%d CO=%d", C, CO);
+  if (!mfma_data_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the data gradient serves CO %% 16 == 0 with C %% 32 == 0, or C == CO == 16, not C=%d CO=%d", C, CO);
   if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
   return check_launch(smd::launch_conv_mfma_bwd_data(g_y, wp_bwd, g_xp, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_bwd_data");
 }
@@ -869,7 +872,7 @@ int smd_conv3x3_mfma_bwd_weight(const float* xp, const float* g_y, float* g_weig
   if (!xp || !g_y || !g_weight || !workspace) return fail(SMD_E_INVALID, "null pointer");
   if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
   if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
-  if (CO % 32) return fail(SMD_E_UNSUPPORTED, "the weight gradient serves CO %% 32 == 0, not CO=%d", CO);
+  if (!mfma_wgt_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the weight gradient serves CO %% 32 == 0, or CO == 16 with C == 16 | 32, not C=%d CO=%d", C, CO);
   if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
   return check_launch(smd::launch_conv_mfma_bwd_wgt(xp, g_y, g_weight, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_bwd_weight");
 }

@@ -222,6 +222,136 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
   }
 }
 
+// ---- sixteen output channels (the decoder's thin last stage: 32 -> 16 at half resolution, 16 -> 16 at full resolution) ----
+// The same split-bf16 arithmetic on `v_mfma_f32_16x16x32_bf16` (A: row i = l & 15, K slots 8 (l >> 4) .. + 7; B: column j = l & 15; D: column = l & 15,
+// row = 4 (l >> 4) + v), pixels as rows, output channels as columns: a lane ends with four consecutive pixels of one channel — a 16-byte store.  A K step of
+// 32 = TWO taps x 16 channels (lane group q: tap 2 s + (q >> 1), channels 8 (q & 1) .. + 7); the ninth tap's partner is a zero weight.  With 2304 multiply-adds
+// per pixel on 128 bytes the layer is HBM-bound once its arithmetic costs 6/16 of the f32 MFMA's time (the f32-MFMA kernel of smd_conv_thin.hip: 82 us
+// forward at cfg 2, its K loop at half the f32 matrix rate; 189 MB / 5 TB/s = 38 us).  The weights (<= 2 chunks x 5 K steps x P fragments) stay in registers;
+// a wave owns 16 columns x 4 rows of a 64 x 4 tile (four accumulator pairs); the patch is staged and read exactly as in k_conv_mfma.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte store that is only 4-byte aligned (the padded gradient's rows)
+
+// thin operand image: element (chunk, K step s, piece, lane = 16 q + j, e) = Wt[m = j][k = 16 chunk + 8 (q & 1) + e][tap = 2 s + (q >> 1)] (zero for tap 9)
+template <int P>
+__global__ __launch_bounds__(256) void k_conv_pack_w16(const float* __restrict__ w, unsigned short* __restrict__ wp_fwd, unsigned short* __restrict__ wp_bwd, int C) {
+  const int idx = blockIdx.x*256 + threadIdx.x;                   // w is (16, C, 3, 3)
+  const int nslots = (C >> 4)*5*64*8;
+  if (idx < nslots && wp_fwd) {                                   // forward form: m = co, k = c
+    const int e = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) % 5, ch = idx/(512*5);
+    const int j = lane & 15, q = lane >> 4, tap = 2*s + (q >> 1), k = 16*ch + 8*(q & 1) + e;
+    unsigned pk[P];
+    split_pair<P>(tap < 9 ? w[((size_t)j*C + k)*9 + tap] : 0.f, 0.f, pk);
+#pragma unroll
+    for (int p = 0; p < P; ++p) wp_fwd[(((size_t)(ch*5 + s)*P + p)*64 + lane)*8 + e] = (unsigned short)(pk[p] & 0xffffu);
+  }
+  if (idx < 5*64*8 && wp_bwd && C == 16) {                        // data-gradient form (16 -> 16 only): m = c, k = co, flipped taps
+    const int e = idx & 7, lane = (idx >> 3) & 63, s = idx >> 9;
+    const int j = lane & 15, q = lane >> 4, tap = 2*s + (q >> 1), k = 8*(q & 1) + e;
+    unsigned pk[P];
+    split_pair<P>(tap < 9 ? w[((size_t)k*C + j)*9 + (8 - tap)] : 0.f, 0.f, pk);
+#pragma unroll
+    for (int p = 0; p < P; ++p) wp_bwd[(((size_t)s*P + p)*64 + lane)*8 + e] = (unsigned short)(pk[p] & 0xffffu);
+  }
+}
+
+template <int NCH, int P, bool BWD>
+__global__ __launch_bounds__(256) void k_conv16_mfma(const float* __restrict__ in, const uint4* __restrict__ wp, float* __restrict__ out,
+                                                     int hi, int wi, int ho, int wo, unsigned gx, unsigned gy, unsigned gz) {
+  using T = ConvTile<64>;
+  constexpr int NPIX = T::NPIX, PW = T::PW, off = BWD ? 2 : 0, NPROD = n_products(P), CK = 16*NCH;
+  __shared__ uint4 tile[P*NPIX*2];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, q = lane >> 4;
+  const unsigned nblk = gx*gy*gz, per = (nblk + 7)/8;             // XCD-aware order, as in k_conv_mfma
+  const unsigned lid = (blockIdx.x & 7)*per + (blockIdx.x >> 3);
+  if (lid >= nblk) return;
+  const int x0 = (int)(lid % gx)*64, y0 = (int)((lid/gx) % gy)*4, b = (int)(lid/(gx*gy));
+  const size_t plane = (size_t)hi*wi;
+  const float* src = in + (size_t)b*CK*plane;
+
+  bf16x8 Wr[NCH][5][P];                                           // every weight fragment of the layer: requested first, used last
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+      for (int p = 0; p < P; ++p) Wr[ch][s][p] = as_frag(wp[((ch*5 + s)*P + p)*64 + lane]);
+
+  constexpr int ITEMS = 2*NPIX, TRIPS = (ITEMS + 255)/256;
+  int pofs[TRIPS];
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int item = min(t*256 + (int)threadIdx.x, ITEMS - 1);
+    const int half = item >= NPIX ? 1 : 0, pix = item - half*NPIX;
+    const int r = pix/PW, cc = pix - r*PW;
+    const int yy = y0 + r - off, xx = x0 + cc - off;
+    if (BWD) pofs[t] = (yy >= 0 && yy < hi && xx >= 0 && xx < wi) ? yy*wi + xx : -1;
+    else pofs[t] = min(yy, hi - 1)*wi + min(xx, wi - 1);
+  }
+  int dpix[5];                                                    // this lane group's tap of K step s, as an offset inside the patch
+#pragma unroll
+  for (int s = 0; s < 5; ++s) { const int tq = min(2*s + (q >> 1), 8); dpix[s] = (tq/3)*PW + tq % 3; }
+
+  f32x4v acc[4], lo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r] = f32x4v{0.f, 0.f, 0.f, 0.f}; lo[r] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    float v[TRIPS][8];
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {                             // every load of the chunk before its first use
+      const int item = min(t*256 + (int)threadIdx.x, ITEMS - 1);
+      const int half = item >= NPIX ? 1 : 0;
+      const float* p = src + (size_t)(ch*16 + half*8)*plane + (size_t)max(pofs[t], 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[t][e] = (!BWD || pofs[t] >= 0) ? p[(size_t)e*plane] : 0.f;
+    }
+    if (ch > 0) __syncthreads();                                  // nobody reads the previous chunk any more
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      const int item = t*256 + (int)threadIdx.x;
+      if (item < ITEMS) {
+        const int half = item >= NPIX ? 1 : 0, pix = item - half*NPIX;
+        unsigned pk[4][P];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) split_pair<P>(v[t][2*k], v[t][2*k + 1], pk[k]);
+        const int slot = pix*2 + (half ^ ((pix >> 3) & 1));
+#pragma unroll
+        for (int p = 0; p < P; ++p) tile[p*NPIX*2 + slot] = uint4{pk[0][p], pk[1][p], pk[2][p], pk[3][p]};
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pix = r*PW + 16*wv + i + dpix[s];
+        const int slot = pix*2 + ((q & 1) ^ ((pix >> 3) & 1));
+        bf16x8 A[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) A[p] = as_frag(tile[p*NPIX*2 + slot]);
+#pragma unroll
+        for (int t = 0; t < NPROD; ++t) {
+          if (t == NPROD - 1) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], Wr[ch][s][0], acc[r], 0, 0, 0);
+          else lo[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[prod_a(P, t)], Wr[ch][s][prod_b(P, t)], lo[r], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[row = pixel 4 q + v][column = channel i]: four consecutive pixels of one channel per lane
+  const int x = x0 + 16*wv + 4*q;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = y0 + r;
+    if (y >= ho || x >= wo) continue;
+    float* dstp = out + (((size_t)b*16 + i)*ho + y)*wo + x;
+    const f32x4v o = acc[r] + lo[r];
+    if (x + 3 < wo) *reinterpret_cast<f32x4u*>(dstp) = o;
+    else { dstp[0] = o[0]; if (x + 1 < wo) dstp[1] = o[1]; if (x + 2 < wo) dstp[2] = o[2]; }
+  }
+}
+
 // out = the sum of the K splits' partial outputs, in split order (the coarse decoder levels: few pixels, thousands of K — the splits are what fills the chip)
 __global__ __launch_bounds__(256) void k_conv_split_sum(const float* __restrict__ part, float* __restrict__ out, size_t n4, int KS) {
   const size_t i = (size_t)blockIdx.x*256 + threadIdx.x;
@@ -352,7 +482,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const float* __restrict
         for (int p = 0; p < P; ++p) {
           const unsigned* q = &xs[(p*CB + ct*32 + j)*XCH + slot*XROW + xsi*8 + g*4];
           const uint4 d = *reinterpret_cast<const uint4*>(q);
-          const unsigned d4 = q[4];
+          const unsigned d4 = reinterpret_cast<const uint4*>(q)[1].x;   // the fifth dword as part of an aligned 16-byte read: as a ds_read_b32 its 32-lane groups meet 4-way on the
+                                                                        // 32 banks that instruction sees (channel stride 84 dwords = 20 mod 32: 64 % of this kernel's LDS cycles were conflicts)
           Bx[0][p] = as_frag(d);
           Bx[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16), __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(d4, d.w, 16)});
           Bx[2][p] = as_frag(uint4{d.y, d.z, d.w, d4});
@@ -400,6 +531,117 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const float* __restrict
   }
 }
 
+// Sixteen output channels (the thin last stage): the same GEMM on `v_mfma_f32_16x16x32_bf16` — a K step is 32 pixels of a row (lane group q: pixels 8 q .. + 7),
+// A = g_y (16 channels), B = the padded input shifted by the tap, one 16 x 16 accumulator tile per (tap, group of 16 input channels).  HBM-bound once the
+// arithmetic is cheap (128-192 B per pixel for 2304-4608 multiply-adds), so the structure is the plain one: a block of four waves stages a tile of 32 columns
+// x 4 rows (g_y) and its 34 x 6 halo tile of every input channel, a wave takes one row (one K step: 54 NC MFMAs), the block walks down `rows` rows and
+// leaves one set of sums per block ([tap][co][c], its waves' accumulators added in LDS in wave order).
+template <int NC, int P>
+__global__ __launch_bounds__(256) void k_conv16_wgrad_mfma(const float* __restrict__ xp, const float* __restrict__ gy, float* __restrict__ partial, int h, int w, int rows) {
+  constexpr int C = 16*NC, NPROD = n_products(P);
+  constexpr int XROW = 20, XCH = 6*XROW + 4;            // dwords: a row = 40 bf16 (34 used), a channel = 6 rows + 16 bytes (496 B = 16 x 31)
+  constexpr int GROW = 16, GCH = 4*GROW + 4;            // dwords: a row = 32 bf16, a channel = 4 rows + 16 bytes (272 B = 16 x 17)
+  constexpr int kXs = P*C*XCH, kGs = P*16*GCH, kRed = 4*9*NC*4*64;
+  __shared__ __attribute__((aligned(16))) unsigned lds[(kXs + kGs) > kRed ? (kXs + kGs) : kRed];
+  unsigned* const xs = lds;
+  unsigned* const gs = lds + kXs;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+  const int x0 = blockIdx.x*32, ybeg = blockIdx.y*rows, yend = min(ybeg + rows, h), b = blockIdx.z;
+  const int W = w + 2, H = h + 2;
+  const float* xsrc = xp + (size_t)b*C*H*W;
+  const float* gsrc = gy + (size_t)b*16*h*w;
+  f32x4v acc[9][NC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc) acc[t][nc] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int XITEMS = C*6*17, XTRIPS = (XITEMS + 255)/256;     // an item = two adjacent columns of one row of one channel
+  constexpr int GITEMS = 16*4*16, GTRIPS = GITEMS/256;
+  for (int y0 = ybeg; y0 < yend; y0 += 4) {
+    float xv[XTRIPS][2], gv[GTRIPS][2];
+#pragma unroll
+    for (int t = 0; t < XTRIPS; ++t) {                            // every load of the tile before its first use
+      const int item = min(t*256 + (int)threadIdx.x, XITEMS - 1);
+      const int pr = item % 17, rc = item/17, r = rc % 6, c = rc/6;
+      const float* rowp = xsrc + ((size_t)c*H + min(y0 + r, H - 1))*W;
+      xv[t][0] = rowp[min(x0 + 2*pr, W - 1)];
+      xv[t][1] = rowp[min(x0 + 2*pr + 1, W - 1)];
+    }
+#pragma unroll
+    for (int t = 0; t < GTRIPS; ++t) {                            // beyond the image or the block's rows: zeros, those pixels add nothing
+      const int item = t*256 + (int)threadIdx.x;
+      const int pr = item & 15, r = (item >> 4) & 3, co = item >> 6;
+      const int yy = y0 + r, xa = x0 + 2*pr;
+      const bool yok = yy < yend;
+      const float* rowp = gsrc + ((size_t)co*h + (yok ? yy : 0))*w;
+      gv[t][0] = (yok && xa < w) ? rowp[xa] : 0.f;
+      gv[t][1] = (yok && xa + 1 < w) ? rowp[xa + 1] : 0.f;
+    }
+    if (y0 > ybeg) __syncthreads();                               // nobody reads the previous tile any more
+#pragma unroll
+    for (int t = 0; t < XTRIPS; ++t) {
+      const int item = t*256 + (int)threadIdx.x;
+      if (item < XITEMS) {
+        const int pr = item % 17, rc = item/17, r = rc % 6, c = rc/6;
+        unsigned pk[P];
+        split_pair<P>(xv[t][0], xv[t][1], pk);
+#pragma unroll
+        for (int p = 0; p < P; ++p) xs[(p*C + c)*XCH + r*XROW + pr] = pk[p];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < GTRIPS; ++t) {
+      const int item = t*256 + (int)threadIdx.x;
+      const int pr = item & 15, r = (item >> 4) & 3, co = item >> 6;
+      unsigned pk[P];
+      split_pair<P>(gv[t][0], gv[t][1], pk);
+#pragma unroll
+      for (int p = 0; p < P; ++p) gs[(p*16 + co)*GCH + r*GROW + pr] = pk[p];
+    }
+    __syncthreads();
+    bf16x8 A[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) A[p] = as_frag(*reinterpret_cast<const uint4*>(&gs[(p*16 + j)*GCH + wv*GROW + q*4]));
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int nc = 0; nc < NC; ++nc) {
+        bf16x8 Bx[3][P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const uint4* qp = reinterpret_cast<const uint4*>(&xs[(p*C + nc*16 + j)*XCH + (wv + ky)*XROW + q*4]);
+          const uint4 d = qp[0];
+          const unsigned d4 = qp[1].x;
+          Bx[0][p] = as_frag(d);
+          Bx[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16), __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(d4, d.w, 16)});
+          Bx[2][p] = as_frag(uint4{d.y, d.z, d.w, d4});
+        }
+#pragma unroll
+        for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            acc[ky*3 + kx][nc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[prod_a(P, t)], Bx[kx][prod_b(P, t)], acc[ky*3 + kx][nc], 0, 0, 0);
+      }
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);                     // D[row = co 4 q + v][column = c j] of (tap, channel group)
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[((wv*9*NC + t*NC + nc)*4 + v)*64 + lane] = acc[t][nc][v];
+  __syncthreads();
+  const size_t blk = ((size_t)b*gridDim.y + blockIdx.y)*gridDim.x + blockIdx.x;
+  for (int e = threadIdx.x; e < 9*NC*4*64; e += 256) {
+    const float sum = (red[e] + red[9*NC*256 + e]) + (red[2*9*NC*256 + e] + red[3*9*NC*256 + e]);
+    const int l = e & 63, v = (e >> 6) & 3, tn = e >> 8, nc = tn % NC, t = tn/NC;
+    const int co = (l >> 4)*4 + v, c = nc*16 + (l & 15);
+    partial[((blk*9 + t)*16 + co)*C + c] = sum;
+  }
+}
+
 // partial[t][tap][co][c] -> g_w[co][c][tap]: a block = 64 weights x 4 waves that take every fourth block's sums (fp64), added in wave order
 __global__ __launch_bounds__(256) void k_conv_wgrad_finalize(const float* __restrict__ partial, unsigned T, int CO, int C, float* __restrict__ g_w) {
   __shared__ double part[4][64];
@@ -426,14 +668,43 @@ static void wgrad_shape(int B, int C, int CO, int h, int w, dim3& grid, int& row
   rows = ceil_div(h, groups);
   grid = dim3(strips, ceil_div(h, rows), B*ceil_div(C, CB)*(CO/COB));
 }
+static void wgrad16_shape(int B, int h, int w, dim3& grid, int& rows) {
+  const int strips = ceil_div(w, 32);
+  const long long tiles = (long long)strips*B*ceil_div(h, 4);     // 32 x 4 pixel tiles; about six blocks per CU
+  rows = 4*(int)std::max(1ll, tiles/1536);
+  grid = dim3(strips, ceil_div(h, rows), B);
+}
 size_t conv_mfma_wgrad_partials(int B, int C, int CO, int h, int w) {
   dim3 grid; int rows;
+  if (CO == 16) { wgrad16_shape(B, h, w, grid, rows); return (size_t)grid.x*grid.y*B*9*16*C; }
   wgrad_shape(B, C, CO, h, w, grid, rows);
   return (size_t)grid.x*grid.y*B*9*CO*C;
 }
-size_t conv_mfma_packed_elems(int C, int CO, int pieces) { return (size_t)CO*C*9*pieces; }
+static size_t thin_packed_elems(int C, int pieces) { return (size_t)(C >> 4)*5*pieces*512; }
+size_t conv_mfma_packed_elems(int C, int CO, int pieces) { return std::max((size_t)CO*C*9*pieces, CO == 16 ? thin_packed_elems(C, pieces) : (size_t)0); }
+
+// 16 output channels: the thin operand image (forward: C = 16 or 32; data gradient: the thin image for C = 16, the wide one — 32 rows — for C = 32)
+template <int P>
+static void launch_conv16(const float* in, const void* wp, float* out, int B, int CK, bool bwd, int hi, int wi, int ho, int wo, hipStream_t st) {
+  const unsigned gx = ceil_div(wo, 64), gy = ceil_div(ho, 4), gz = B;
+  const dim3 grid(8*(unsigned)ceil_div((long long)gx*gy*gz, 8ll));
+  const uint4* wq = (const uint4*)wp;
+  if (bwd) hipLaunchKernelGGL((k_conv16_mfma<1, P, true>), grid, dim3(256), 0, st, in, wq, out, hi, wi, ho, wo, gx, gy, gz);
+  else if (CK == 16) hipLaunchKernelGGL((k_conv16_mfma<1, P, false>), grid, dim3(256), 0, st, in, wq, out, hi, wi, ho, wo, gx, gy, gz);
+  else hipLaunchKernelGGL((k_conv16_mfma<2, P, false>), grid, dim3(256), 0, st, in, wq, out, hi, wi, ho, wo, gx, gy, gz);
+}
 
 hipError_t launch_conv_mfma_pack(const float* w, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, hipStream_t st) {
+  if (CO == 16) {
+    void* thin_bwd = (C == 16) ? wp_bwd : nullptr;
+    if (wp_fwd || thin_bwd) {
+      const dim3 g16(ceil_div((C >> 4)*5*512, 256));
+      if (pieces == 3) hipLaunchKernelGGL((k_conv_pack_w16<3>), g16, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)thin_bwd, C);
+      else hipLaunchKernelGGL((k_conv_pack_w16<2>), g16, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)thin_bwd, C);
+    }
+    if (C == 16 || !wp_bwd) return hipGetLastError();
+    wp_fwd = nullptr;                                             // C = 32: the data gradient is a 32-row layer of the wide kernel
+  }
   const dim3 grid(ceil_div(CO*C*9, 256));
   if (pieces == 3) hipLaunchKernelGGL((k_conv_pack_w<3>), grid, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)wp_bwd, CO, C);
   else hipLaunchKernelGGL((k_conv_pack_w<2>), grid, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)wp_bwd, CO, C);
@@ -476,15 +747,25 @@ static void launch_conv_form(const float* in, const void* wp, float* out, float*
 }
 
 // y (B, CO, h, w) = conv3x3(xp (B, C, h + 2, w + 2)): C % 16 == 0, CO % 32 == 0
-size_t conv_mfma_fwd_split_elems(int B, int C, int CO, int h, int w) { return conv_mfma_split_elems(B, C, CO, h, w); }
-size_t conv_mfma_bwd_split_elems(int B, int C, int CO, int h, int w) { return conv_mfma_split_elems(B, CO, C, h + 2, w + 2); }
+size_t conv_mfma_fwd_split_elems(int B, int C, int CO, int h, int w) { return CO % 32 ? 0 : conv_mfma_split_elems(B, C, CO, h, w); }
+size_t conv_mfma_bwd_split_elems(int B, int C, int CO, int h, int w) { return C % 32 ? 0 : conv_mfma_split_elems(B, CO, C, h + 2, w + 2); }
 hipError_t launch_conv_mfma_fwd(const float* xp, const void* wp_fwd, float* y, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+  if (CO == 16) {
+    if (pieces == 3) launch_conv16<3>(xp, wp_fwd, y, B, C, false, h + 2, w + 2, h, w, st);
+    else launch_conv16<2>(xp, wp_fwd, y, B, C, false, h + 2, w + 2, h, w, st);
+    return hipGetLastError();
+  }
   if (pieces == 3) launch_conv_form<3, false>(xp, wp_fwd, y, split_ws, B, C, CO, h + 2, w + 2, h, w, st);
   else launch_conv_form<2, false>(xp, wp_fwd, y, split_ws, B, C, CO, h + 2, w + 2, h, w, st);
   return hipGetLastError();
 }
 // g_xp (B, C, h + 2, w + 2) from g_y (B, CO, h, w): CO % 16 == 0, C % 32 == 0
 hipError_t launch_conv_mfma_bwd_data(const float* gy, const void* wp_bwd, float* g_xp, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+  if (CO == 16 && C == 16) {
+    if (pieces == 3) launch_conv16<3>(gy, wp_bwd, g_xp, B, 16, true, h, w, h + 2, w + 2, st);
+    else launch_conv16<2>(gy, wp_bwd, g_xp, B, 16, true, h, w, h + 2, w + 2, st);
+    return hipGetLastError();
+  }
   if (pieces == 3) launch_conv_form<3, true>(gy, wp_bwd, g_xp, split_ws, B, CO, C, h, w, h + 2, w + 2, st);
   else launch_conv_form<2, true>(gy, wp_bwd, g_xp, split_ws, B, CO, C, h, w, h + 2, w + 2, st);
   return hipGetLastError();
@@ -500,6 +781,14 @@ static void launch_wgrad(const float* xp, const float* gy, float* partial, int B
   else hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 2, P>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
 }
 hipError_t launch_conv_mfma_bwd_wgt(const float* xp, const float* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+  if (CO == 16) {                                                 // C = 16 or 32
+    dim3 grid; int rows;
+    wgrad16_shape(B, h, w, grid, rows);
+    if (C == 16) { if (pieces == 3) hipLaunchKernelGGL((k_conv16_wgrad_mfma<1, 3>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows); else hipLaunchKernelGGL((k_conv16_wgrad_mfma<1, 2>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows); }
+    else { if (pieces == 3) hipLaunchKernelGGL((k_conv16_wgrad_mfma<2, 3>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows); else hipLaunchKernelGGL((k_conv16_wgrad_mfma<2, 2>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows); }
+    hipLaunchKernelGGL(k_conv_wgrad_finalize, dim3(ceil_div(16*C*9, 64)), dim3(256), 0, st, partial, (unsigned)(grid.x*grid.y*B), 16, C, g_w);
+    return hipGetLastError();
+  }
   if (pieces == 3) launch_wgrad<3>(xp, gy, partial, B, C, CO, h, w, st);
   else launch_wgrad<2>(xp, gy, partial, B, C, CO, h, w, st);
   dim3 grid; int rows;

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import FLAGS, REGR_FLAGS, SEL_MASKED, int_array, ptr_array
 from ._lib import call as _raw_call
 
-__all__ = ['loss_path_fused', 'crop_resize', 'disp_to_depth', 'image_recon_prep', 'PreparedFrames', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
+__all__ = ['conv3x3_mfma', 'conv3x3_wide', 'set_conv_route', 'conv_routes', 'loss_path_fused', 'crop_resize', 'disp_to_depth', 'image_recon_prep', 'PreparedFrames', 'image_recon_fused', 'image_recon_fused_disp', 'disp_smooth_fused', 'view_synth', 'photo_error', 'recon_reduce',
            'lane_shift_selftest', 'recon_flags', 'regression_loss', 'elu_pad', 'elu_up_cat_pad', 'batch_norm_act', 'max_pool3x3s2', 'dwconv7x7', 'layer_norm_cf', 'pose_matrices', 'intrinsics', 'inv_intrinsics']
 
 
@@ -901,27 +901,97 @@ def conv3x3_thin(xp, weight):
     return _Conv3x3Thin.apply(xp, weight)
 
 
-class _Conv3x3Mfma(torch.autograd.Function):
-    """`F.conv2d(xp, weight (CO,C,3,3))` on an already reflection-padded input on the bf16 matrix cores with fp32-class results (`smd_conv3x3_mfma_*`)."""
+# ---- the wide decoder convolutions: split-bf16 MFMA kernels (smd_conv3x3_mfma_*) or MIOpen, per operator and shape --------------------------------
+# Which of the two serves an (operator, shape) pair is decided by a same-box A/B the first time the pair is seen: both run on the call's own tensors,
+# interleaved, a few times each; the faster one is cached for the process ("only where a same-box A/B against MIOpen wins").
+# `set_conv_route('mfma' | 'miopen')` pins the choice (tests, profiles); inside a HIP-graph capture nothing is timed and a static rule stands in.
+_CONV_ROUTE_MODE = 'auto'
+_CONV_ROUTES: dict = {}
+
+
+def set_conv_route(mode: str = 'auto'):
+    """'auto' (A/B on first use), 'mfma' or 'miopen' for every wide decoder convolution; clears the cached decisions."""
+    global _CONV_ROUTE_MODE
+    if mode not in ('auto', 'mfma', 'miopen'): raise ValueError(mode)
+    _CONV_ROUTE_MODE = mode
+    _CONV_ROUTES.clear()
+
+
+def conv_routes() -> dict:
+    """The decisions taken so far: {(op, B, C, CO, h, w): (use_mfma, us_mfma, us_miopen)}."""
+    return dict(_CONV_ROUTES)
+
+
+def _conv_static_rule(op, B, C, CO, h, w):
+    """Stand-in where nothing may be timed (graph capture): the shapes that won on an MI355X at cfg 2 (profiles/r06_decoder_convs.txt)."""
+    px = B*h*w
+    if op == 'fwd': return px >= 20000 and C*CO <= 128*64
+    if op == 'data': return px >= 5000 and C <= 256
+    return px >= 20000 and CO <= 64
+
+
+def _conv_route(op, B, C, CO, h, w, run_mfma, run_ref):
+    if _CONV_ROUTE_MODE != 'auto': return _CONV_ROUTE_MODE == 'mfma'
+    key = (op, B, C, CO, h, w)
+    r = _CONV_ROUTES.get(key)
+    if r is None:
+        if torch.cuda.is_current_stream_capturing(): return _conv_static_rule(op, B, C, CO, h, w)
+        for _ in range(2): run_mfma(); run_ref()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(5)]
+        for e in ev:                     # interleaved: a box's clocks drift over the first milliseconds, whatever is timed first looks slower
+            e[0].record(); run_mfma(); e[1].record(); run_ref(); e[2].record()
+        torch.cuda.synchronize()
+        t_m = sorted(e[0].elapsed_time(e[1]) for e in ev)[2]*1e3
+        t_r = sorted(e[1].elapsed_time(e[2]) for e in ev)[2]*1e3
+        r = _CONV_ROUTES[key] = (t_m < 0.97*t_r, t_m, t_r)
+    return r[0]
+
+
+def _mfma_pack(weight, C, CO, pieces, want_fwd, want_bwd):
+    nbytes = _lib.lib.smd_conv3x3_mfma_packed_bytes(C, CO, pieces)
+    wf = torch.empty(max(nbytes, 256), device=weight.device, dtype=torch.uint8) if want_fwd else None
+    wb = torch.empty(max(nbytes, 256), device=weight.device, dtype=torch.uint8) if want_bwd else None
+    call('smd_conv3x3_mfma_pack', weight.data_ptr(), wf.data_ptr() if wf is not None else None, wb.data_ptr() if wb is not None else None, C, CO, pieces, _stream())
+    return wf, wb
+
+
+def _mfma_ws(B, C, CO, h, w, dev):
+    nws = _lib.lib.smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)
+    return torch.empty(max(nws, 256), device=dev, dtype=torch.uint8), nws
+
+
+class _Conv3x3Wide(torch.autograd.Function):
+    """`F.conv2d(xp, weight (CO,C,3,3))` on an already reflection-padded input; each of the three operators (forward, data gradient, weight gradient) runs
+    on the bf16 matrix cores with fp32-class results (`smd_conv3x3_mfma_*`) or through MIOpen, as `_conv_route` says (`force`: always the MFMA kernels)."""
     @staticmethod
-    def forward(ctx, xp, weight, pieces):
+    def forward(ctx, xp, weight, pieces, force):
         xp = _check('xp', xp)
         if xp.ndim != 4 or xp.shape[2] < 3 or xp.shape[3] < 3: raise ValueError(f'expected a padded (B,C,h+2,w+2), got {tuple(xp.shape)}')
         B, C, H, W = xp.shape
         if weight.ndim != 4 or tuple(weight.shape[1:]) != (C, 3, 3): raise ValueError(f'weight: expected (CO,{C},3,3), got {tuple(weight.shape)}')
         CO = weight.shape[0]
         weight = _check('weight', weight, (CO, C, 3, 3))
-        dev = xp.device
-        nbytes = _lib.lib.smd_conv3x3_mfma_packed_bytes(C, CO, pieces)
-        wp_fwd = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
-        bwd_form = CO % 16 == 0 and C % 32 == 0            # the data gradient's own operand order (what the backward kernel serves)
-        wp_bwd = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8) if bwd_form else None
-        call('smd_conv3x3_mfma_pack', weight.data_ptr(), wp_fwd.data_ptr(), wp_bwd.data_ptr() if bwd_form else None, C, CO, pieces, _stream())
-        y = torch.empty((B, CO, H - 2, W - 2), device=dev, dtype=torch.float32)
-        nws = _lib.lib.smd_conv3x3_mfma_workspace_bytes(B, C, CO, H - 2, W - 2)
-        ws = torch.empty(max(nws, 256), device=dev, dtype=torch.uint8)
-        call('smd_conv3x3_mfma_fwd', xp.data_ptr(), wp_fwd.data_ptr(), y.data_ptr(), ws.data_ptr(), nws, B, C, CO, H - 2, W - 2, pieces, _stream())
-        ctx.save_for_backward(xp, weight, wp_bwd); ctx.pieces = pieces
+        h, w, dev = H - 2, W - 2, xp.device
+        thin = CO == 16 and C in (16, 32)                   # the last stage: the alternative is the f32-MFMA kernel (smd_conv3x3_thin_*), not MIOpen
+        fwd_ok = (C % 16 == 0 and CO % 32 == 0) or thin
+        if force and not fwd_ok:
+            raise _lib.Unsupported(f'the MFMA forward serves C % 16 == 0 with CO % 32 == 0, or CO = 16 with C = 16 | 32, not C={C} CO={CO}')
+        bwd_form = (CO % 16 == 0 and C % 32 == 0) or (C == 16 and CO == 16)   # the data gradient's own operand order (what the backward kernel serves)
+        y = torch.empty((B, CO, h, w), device=dev, dtype=torch.float32)
+        packed = {}
+
+        def run_mfma():
+            if 'wf' not in packed: packed['wf'], packed['wb'] = _mfma_pack(weight, C, CO, pieces, True, bwd_form)
+            ws, nws = _mfma_ws(B, C, CO, h, w, dev)
+            call('smd_conv3x3_mfma_fwd', xp.data_ptr(), packed['wf'].data_ptr(), y.data_ptr(), ws.data_ptr(), nws, B, C, CO, h, w, pieces, _stream())
+        def run_ref():
+            if thin: call('smd_conv3x3_thin_fwd', xp.data_ptr(), weight.data_ptr(), y.data_ptr(), B, C, h, w, _stream()); return y
+            return torch.conv2d(xp, weight)
+        use = fwd_ok and (force or _conv_route('fwd', B, C, CO, h, w, run_mfma, run_ref))
+        if use: run_mfma()
+        else: y = run_ref()
+        ctx.save_for_backward(xp, weight, packed.get('wb'))
+        ctx.pieces, ctx.force = pieces, force
         return y
 
     @staticmethod
@@ -929,30 +999,57 @@ class _Conv3x3Mfma(torch.autograd.Function):
         xp, weight, wp_bwd = ctx.saved_tensors
         dev = _on(xp)
         B, C, H, W = xp.shape
-        CO, pieces = weight.shape[0], ctx.pieces
+        CO, pieces, force, h, w = weight.shape[0], ctx.pieces, ctx.force, H - 2, W - 2
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g_y = _check('grad(y)', g_y, (B, CO, H - 2, W - 2))
+        g_y = _check('grad(y)', g_y, (B, CO, h, w))
         g_xp = g_w = None
-        nbytes = _lib.lib.smd_conv3x3_mfma_workspace_bytes(B, C, CO, H - 2, W - 2)
-        ws = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+        thin = CO == 16 and C in (16, 32)
+        cb = lambda mask: torch.ops.aten.convolution_backward(g_y, xp, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, mask)
+
+        def thin_bwd(want_x, want_w):                       # the f32-MFMA kernels of the last stage (smd_conv3x3_thin_bwd)
+            gx_ = torch.empty_like(xp) if want_x else None
+            gw_ = torch.empty_like(weight) if want_w else None
+            nb = _lib.lib.smd_conv3x3_thin_workspace_bytes(B, C, h, w) if want_w else 0
+            ws_ = torch.empty(max(nb, 256), device=dev, dtype=torch.uint8) if want_w else None
+            call('smd_conv3x3_thin_bwd', xp.data_ptr(), weight.data_ptr(), g_y.data_ptr(), gx_.data_ptr() if want_x else None, gw_.data_ptr() if want_w else None,
+                 ws_.data_ptr() if want_w else None, nb, B, C, h, w, _stream())
+            return gx_, gw_
         if need_x:
-            if wp_bwd is not None:
-                g_xp = torch.empty_like(xp)
-                call('smd_conv3x3_mfma_bwd_data', g_y.data_ptr(), wp_bwd.data_ptr(), g_xp.data_ptr(), ws.data_ptr(), nbytes, B, C, CO, H - 2, W - 2, pieces, _stream())
-            else:                                           # channel counts the data-gradient kernel does not tile: the general operator
-                g_xp = torch.nn.grad.conv2d_input(xp.shape, weight, g_y)
+            g_xp = torch.empty_like(xp)
+            packed = {'wb': wp_bwd}
+
+            def run_data():
+                if packed['wb'] is None: packed['wb'] = _mfma_pack(weight, C, CO, pieces, False, True)[1]
+                ws, nws = _mfma_ws(B, C, CO, h, w, dev)
+                call('smd_conv3x3_mfma_bwd_data', g_y.data_ptr(), packed['wb'].data_ptr(), g_xp.data_ptr(), ws.data_ptr(), nws, B, C, CO, h, w, pieces, _stream())
+            ok = (CO % 16 == 0 and C % 32 == 0) or (C == 16 and CO == 16)
+            ref_data = (lambda: thin_bwd(True, False)[0]) if thin else (lambda: cb([True, False, False])[0])
+            if ok and (force or _conv_route('data', B, C, CO, h, w, run_data, ref_data)): run_data()
+            else: g_xp = ref_data()                         # (also: channel counts the data-gradient kernel does not tile)
         if need_w:
             g_w = torch.empty_like(weight)
-            call('smd_conv3x3_mfma_bwd_weight', xp.data_ptr(), g_y.data_ptr(), g_w.data_ptr(), ws.data_ptr(), nbytes, B, C, CO, H - 2, W - 2, pieces, _stream())
-        return g_xp, g_w, None
+
+            def run_wgt():
+                ws, nws = _mfma_ws(B, C, CO, h, w, dev)
+                call('smd_conv3x3_mfma_bwd_weight', xp.data_ptr(), g_y.data_ptr(), g_w.data_ptr(), ws.data_ptr(), nws, B, C, CO, h, w, pieces, _stream())
+            ok = CO % 32 == 0 or thin
+            ref_wgt = (lambda: thin_bwd(False, True)[1]) if thin else (lambda: cb([False, True, False])[1])
+            if ok and (force or _conv_route('wgt', B, C, CO, h, w, run_wgt, ref_wgt)): run_wgt()
+            else: g_w = ref_wgt()
+        return g_xp, g_w, None, None
 
 
 def conv3x3_mfma(xp, weight, pieces: int = 3):
-    """`F.conv2d(xp, weight)` for an input that is already reflection-padded: the wide up-convolutions of the decoder
-    (src/networks/decoders/monodepth.py:40-50, 71-84), bias-free (the next glue kernel adds it).  xp (B,C,h+2,w+2) fp32, weight (CO,C,3,3) fp32 -> (B,CO,h,w)
-    fp32; C % 16 == 0 and CO % 32 == 0 (`_lib.Unsupported` otherwise).  Computed on the bf16 matrix cores with every fp32 operand split exactly into three
-    bf16 pieces and six products kept per fp32 product (`pieces=3`: fp32-class error, see csrc/smd_conv_mfma.hip; `pieces=2` is an experiment setting)."""
-    return _Conv3x3Mfma.apply(xp, weight, int(pieces))
+    """`F.conv2d(xp, weight)` for an input that is already reflection-padded, ALWAYS through the split-bf16 MFMA kernels (`smd_conv3x3_mfma_*`): the wide
+    up-convolutions of the decoder (src/networks/decoders/monodepth.py:40-50, 71-84), bias-free (the next glue kernel adds it).  xp (B,C,h+2,w+2) fp32,
+    weight (CO,C,3,3) fp32 -> (B,CO,h,w) fp32; C % 16 == 0 and CO % 32 == 0 (`_lib.Unsupported` otherwise).  Every fp32 operand is split exactly into three
+    bf16 pieces and six products are kept per fp32 product (`pieces=3`: fp32-class error, see csrc/smd_conv_mfma.hip; `pieces=2` is an experiment setting)."""
+    return _Conv3x3Wide.apply(xp, weight, int(pieces), True)
+
+
+def conv3x3_wide(xp, weight):
+    """The same convolution, each operator through whichever of the MFMA kernels and MIOpen won this box's A/B for its shape (`_conv_route`)."""
+    return _Conv3x3Wide.apply(xp, weight, 3, False)
 
 
 class _EluUpCatPad(torch.autograd.Function):

@@ -65,8 +65,11 @@ class MonodepthDecoder(nn.Module):
         padded ELU output of a stage is shared by its output head and the next stage (the reference pads it twice)."""
         from .. import functional as HF
         def conv(m, xp):   # input already reflection-padded; the bias is added by the next glue kernel
-            if xp.dtype == torch.float32 and m.weight.shape[0] == 16 and m.weight.shape[1] in (16, 32):   # the thin last stage: smd_conv3x3_thin_* (fp32 MFMA)
-                return HF.conv3x3_thin(xp, m.weight.float())
+            co, ci = m.weight.shape[:2]
+            if xp.dtype == torch.float32 and ((co % 32 == 0 and ci % 16 == 0) or (co == 16 and ci in (16, 32))):
+                # smd_conv3x3_mfma_* (bf16 matrix cores, three-way split operands: fp32-class results) or, per operator and shape by this box's A/B, MIOpen
+                # (the wide stages) / the f32-MFMA kernels smd_conv3x3_thin_* (the 16-channel last stage)
+                return HF.conv3x3_wide(xp, m.weight.float())
             return F.conv2d(xp, m.weight)
         out = {}
         xp = HF.elu_pad(feat[-1], apply_elu=False, out_dtype=out_dtype)   # under bf16 autocast the glue writes bf16 for the bf16 convolutions

@@ -4,7 +4,8 @@ its four sigmoid disparities, the gradients w.r.t. every encoder feature and eve
 
 CPU: this package's decoder evaluated op by op (the ATen composition, as the reference) reproduces it.
 GPU: so does the path the trainer runs — glue kernels between the convolutions (`smd_elu_pad_*`, `smd_elu_up_cat_pad_*`), the one-channel heads as stencils
-(`smd_conv3x3_head_*`), the thin last stage on fp32 MFMA (`smd_conv3x3_thin_*`), MIOpen for the rest."""
+(`smd_conv3x3_head_*`), the thin last stage on fp32 MFMA (`smd_conv3x3_thin_*`), the wide stages on the bf16 matrix cores with three-way split operands
+(`smd_conv3x3_mfma_*`) or MIOpen."""
 import numpy as np
 import pytest
 import torch
@@ -61,9 +62,17 @@ def test_decoder_matches_the_reference_decoder_on_the_cpu():
 
 
 @pytest.mark.gpu
-def test_decoder_kernels_match_the_reference_decoder():
+@pytest.mark.parametrize('route', ['mfma', 'auto', 'miopen'])
+def test_decoder_kernels_match_the_reference_decoder(route):
+    """`route` = who serves the wide convolutions: 'mfma' pins every one of them (forward, data and weight gradients) on the split-bf16 MFMA kernels
+    (`smd_conv3x3_mfma_*`, round 6) — the reference's outputs and parameter gradients are then the yardstick for those kernels too; 'auto' is what the
+    trainer runs (this box's A/B per operator and shape); 'miopen' the round-5 composition."""
     if not torch.cuda.is_available(): pytest.skip('needs a GPU')
-    from slowtv_monodepth_amd import _lib
+    from slowtv_monodepth_amd import _lib, functional as HF
     _lib.lib.smd_last_error()
-    out = run_and_compare('cuda', 2e-5, 2e-4)
+    HF.set_conv_route(route)
+    try:
+        out = run_and_compare('cuda', 2e-5, 2e-4)
+    finally:
+        HF.set_conv_route('auto')
     assert all(o.is_cuda for o in out.values())

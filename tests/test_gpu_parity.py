@@ -1100,6 +1100,68 @@ def test_conv3x3_thin_kernel(F, B, C, h, w):
     with pytest.raises(Unsupported): F.conv3x3_thin(xp[:, :5].contiguous(), wt[:, :5].contiguous())
 
 
+@pytest.mark.parametrize('B,C,CO,h,w', [(2, 16, 32, 5, 7), (2, 48, 64, 9, 70), (1, 32, 32, 33, 65), (2, 96, 32, 13, 100), (2, 32, 96, 7, 33), (2, 64, 128, 4, 20),
+                                         (1, 16, 32, 1, 1), (3, 160, 64, 6, 20), (2, 512, 256, 6, 20), (12, 96, 32, 96, 320), (12, 128, 64, 24, 80),
+                                         (2, 16, 16, 7, 70), (1, 16, 16, 2, 2), (2, 32, 16, 9, 33), (3, 16, 16, 13, 129), (12, 16, 16, 192, 640), (12, 32, 16, 96, 320)])
+def test_conv3x3_mfma_kernel(F, B, C, CO, h, w):
+    """The decoder's wide up-convolutions (src/networks/decoders/monodepth.py:40-50, 71-84) on the bf16 matrix cores with every fp32 operand split exactly
+    into three bf16 pieces (`smd_conv3x3_mfma_*`, round 6) against ATen's `conv2d` in fp64 on the same padded input: output and both gradients, held to the
+    bound the f32-MFMA kernels are held to (2e-6 of the tensor's max; MIOpen's fp32 kernels sit at 2-8e-7 on these shapes, these at 1e-7 - 1e-6:
+    profiles/r06_decoder_convs.txt).  Sizes off both tile shapes (64 x 4 and 32 x 8 pixels), the smallest image, channel counts off the weight gradient's
+    128-channel blocks (ConvNeXt's 160), a K-split shape (6 x 20 at 512 -> 256), two of cfg 2's own wide layers, and the thin last stage (sixteen output
+    channels: the 16 x 16 x 32 form of the instruction, two taps per K step) incl. both of cfg 2's thin layers."""
+    import torch.nn.functional as TF
+    gen = torch.Generator(device='cuda').manual_seed(B*1000 + C*10 + CO + h + w)
+    xp = torch.randn(B, C, h + 2, w + 2, device='cuda', generator=gen)
+    wt = torch.randn(CO, C, 3, 3, device='cuda', generator=gen)/(3*C**0.5)
+    gy = torch.randn(B, CO, h, w, device='cuda', generator=gen)
+    L = [t.clone().requires_grad_(True) for t in (xp, wt)]
+    y = F.conv3x3_mfma(L[0], L[1]); y.backward(gy)
+    R = [t.double().clone().requires_grad_(True) for t in (xp, wt)]
+    yr = TF.conv2d(R[0], R[1]); yr.backward(gy.double())
+    assert rel_to_max(y.double(), yr) <= 2e-6, rel_to_max(y.double(), yr)
+    for nm, a, r in zip(('g_xp', 'g_weight'), L, R): assert rel_to_max(a.grad.double(), r.grad) <= 2e-6, (nm, rel_to_max(a.grad.double(), r.grad))
+    y2 = F.conv3x3_mfma(xp, wt)                                   # deterministic: the same bits on a second call
+    assert torch.equal(y2, y.detach())
+    L = [xp.clone(), wt.clone().requires_grad_(True)]
+    F.conv3x3_mfma(L[0], L[1]).backward(gy)                          # only the weights ask for a gradient, and only the input
+    assert rel_to_max(L[1].grad.double(), R[1].grad) <= 2e-6
+    L = [xp.clone().requires_grad_(True), wt.clone()]
+    F.conv3x3_mfma(L[0], L[1]).backward(gy); assert rel_to_max(L[0].grad.double(), R[0].grad) <= 2e-6
+
+
+def test_conv3x3_mfma_refuses_what_it_does_not_tile(F):
+    from slowtv_monodepth_amd._lib import Unsupported
+    xp = torch.randn(1, 16, 6, 6, device='cuda')
+    with pytest.raises(Unsupported): F.conv3x3_mfma(torch.randn(1, 48, 6, 6, device='cuda'), torch.randn(16, 48, 3, 3, device='cuda'))   # 16 output channels: 16 or 32 inputs only
+    with pytest.raises(Unsupported): F.conv3x3_mfma(xp[:, :5].contiguous(), torch.randn(32, 5, 3, 3, device='cuda'))
+    with pytest.raises(ValueError): F.conv3x3_mfma(xp, torch.randn(32, 8, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError): F.conv3x3_mfma(xp.cpu(), torch.randn(32, 16, 3, 3))
+
+
+def test_conv3x3_wide_routes_by_ab_and_agrees(F):
+    """`conv3x3_wide` = the same convolution with each operator served by whichever of the MFMA kernels and MIOpen won this box's A/B for the shape: whatever
+    the routes are, results agree with fp64 to the fp32 bound, the decisions are recorded, and pinning the route changes nothing but rounding."""
+    import torch.nn.functional as TF
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    xp = torch.randn(4, 64, 26, 82, device='cuda', generator=gen); wt = torch.randn(32, 64, 3, 3, device='cuda', generator=gen)/24; gy = torch.randn(4, 32, 24, 80, device='cuda', generator=gen)
+    R = [t.double().clone().requires_grad_(True) for t in (xp, wt)]
+    yr = TF.conv2d(R[0], R[1]); yr.backward(gy.double())
+    try:
+        for mode in ('auto', 'mfma', 'miopen'):
+            F.set_conv_route(mode)
+            L = [t.clone().requires_grad_(True) for t in (xp, wt)]
+            y = F.conv3x3_wide(L[0], L[1]); y.backward(gy)
+            assert rel_to_max(y.double(), yr) <= 2e-6
+            for a, r in zip(L, R): assert rel_to_max(a.grad.double(), r.grad) <= 2e-6
+            if mode == 'auto':
+                routes = F.conv_routes()
+                assert {k[0] for k in routes} == {'fwd', 'data', 'wgt'} and all(k[1:] == (4, 64, 32, 24, 80) for k in routes), routes
+                print('routes:', {k[0]: (v[0], round(v[1], 1), round(v[2], 1)) for k, v in routes.items()})
+    finally:
+        F.set_conv_route('auto')
+
+
 def test_glued_decoder_equals_plain_decoder(F):
     """The decoder with the glue kernels and the same decoder evaluated op by op (as the reference does) on the same weights."""
     import slowtv_monodepth_amd as amd
