@@ -139,6 +139,59 @@ def measured_hbm_ceilings(lib, device, nbytes=1 << 30, reps=10):
     return out
 
 
+def decoder_roofline(wl, device):
+    """The decoder's own kernels on the workload's full-resolution shapes, outside the timed region (driver-timed, not only under
+    profiles/): HIP events on the launch stream around 20 raw C calls each.  The thin last stage `conv3x3(16 -> 16)` in both of its forms — the f32 MFMA
+    (smd_conv3x3_thin_*: exact f32 products at the vector rate, peak 157.3 TFLOP/s) and the bf16 matrix cores with three-way split operands
+    (smd_conv3x3_mfma_*: six bf16 products per f32 product; bound by HBM once the arithmetic costs 6/16) — as fp32-equivalent TFLOP/s against the f32
+    matrix peak and as bytes against 8 TB/s; the widest-image wide layer (32 output channels at half resolution); the full-resolution head as a stencil."""
+    from slowtv_monodepth_amd import _lib, functional as F
+    call, lib = _lib.call, _lib.lib
+    B, h, w = wl['b'], wl['h'], wl['w']
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    def timeit(fn, n=20):
+        for _ in range(3): fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n): fn()
+        e.record(); torch.cuda.synchronize()
+        return s.elapsed_time(e)/n
+    gen = torch.Generator(device=device).manual_seed(7)
+    rnd = lambda *sh: torch.randn(*sh, device=device, generator=gen)
+    out = {'note': 'HIP events (torch.cuda.Event on the launch stream) over 20 raw C calls per operator, after the timed region; TFLOP/s = fp32-equivalent 2 x 9 x C x CO x pixels / time; '
+                   'f32_mfma_peak 157.3 TFLOP/s (v_mfma_f32_*_f32 = the vector rate), hbm_peak 8000 GB/s; bytes = 4 (C (h+2)(w+2) + CO h w) b'}
+    def conv_block(C, CO, hh, ww):
+        xp, wt, gy = rnd(B, C, hh + 2, ww + 2), rnd(CO, C, 3, 3)/(3*C**0.5), rnd(B, CO, hh, ww)
+        y, gx, gw = torch.empty(B, CO, hh, ww, device=device), torch.empty_like(xp), torch.empty_like(wt)
+        flop, byts = 2.0*9*C*CO*B*hh*ww, 4.0*B*(C*(hh + 2)*(ww + 2) + CO*hh*ww)
+        nb = lib.smd_conv3x3_mfma_packed_bytes(C, CO, 3)
+        wf, wb = torch.empty(nb, device=device, dtype=torch.uint8), torch.empty(nb, device=device, dtype=torch.uint8)
+        nws = lib.smd_conv3x3_mfma_workspace_bytes(B, C, CO, hh, ww); ws = torch.empty(max(nws, 256), device=device, dtype=torch.uint8)
+        call('smd_conv3x3_mfma_pack', wt.data_ptr(), wf.data_ptr(), wb.data_ptr(), C, CO, 3, st())
+        ms = {'fwd': timeit(lambda: call('smd_conv3x3_mfma_fwd', xp.data_ptr(), wf.data_ptr(), y.data_ptr(), ws.data_ptr(), nws, B, C, CO, hh, ww, 3, st())),
+              'bwd_data': timeit(lambda: call('smd_conv3x3_mfma_bwd_data', gy.data_ptr(), wb.data_ptr(), gx.data_ptr(), ws.data_ptr(), nws, B, C, CO, hh, ww, 3, st())),
+              'bwd_weight': timeit(lambda: call('smd_conv3x3_mfma_bwd_weight', xp.data_ptr(), gy.data_ptr(), gw.data_ptr(), ws.data_ptr(), nws, B, C, CO, hh, ww, 3, st()))}
+        blk = {'shape': f'{C}->{CO} at {hh}x{ww}, b={B}', 'split_bf16_mfma': {k: {'ms': round(v, 5), 'tflops': round(flop/v/1e9, 1), 'frac_of_f32_mfma_peak': round(flop/v/1e9/157.3, 3),
+                                                                                  'GBps': round(byts/v/1e6, 1), 'frac_of_hbm_peak': round(byts/v/1e6/HBM_PEAK_GBPS, 3)} for k, v in ms.items()}}
+        if CO == 16:
+            nt = lib.smd_conv3x3_thin_workspace_bytes(B, C, hh, ww); wt_ws = torch.empty(max(nt, 256), device=device, dtype=torch.uint8)
+            mt = {'fwd': timeit(lambda: call('smd_conv3x3_thin_fwd', xp.data_ptr(), wt.data_ptr(), y.data_ptr(), B, C, hh, ww, st())),
+                  'bwd_data': timeit(lambda: call('smd_conv3x3_thin_bwd', xp.data_ptr(), wt.data_ptr(), gy.data_ptr(), gx.data_ptr(), None, None, 0, B, C, hh, ww, st())),
+                  'bwd_weight': timeit(lambda: call('smd_conv3x3_thin_bwd', xp.data_ptr(), wt.data_ptr(), gy.data_ptr(), None, gw.data_ptr(), wt_ws.data_ptr(), nt, B, C, hh, ww, st()))}
+            blk['f32_mfma'] = {k: {'ms': round(v, 5), 'tflops': round(flop/v/1e9, 1), 'frac_of_f32_mfma_peak': round(flop/v/1e9/157.3, 3)} for k, v in mt.items()}
+        return blk
+    out['thin_stage'] = conv_block(16, 16, h, w)
+    out['thin_stage']['bound'] = 'mfma (f32 form) / hbm (split-bf16 form)'
+    out['wide_stage'] = conv_block(96 if wl['depth'].startswith('resnet') else 32, 32, h//2, w//2)
+    out['wide_stage']['bound'] = 'mfma (bf16 pipe: 6 products per f32 product; ceiling 2.67 x the f32 matrix peak)'
+    xp, wt1, bs = rnd(B, 16, h + 2, w + 2), rnd(1, 16, 3, 3)/12, rnd(1)
+    y1 = torch.empty(B, 1, h, w, device=device)
+    t_h = timeit(lambda: call('smd_conv3x3_head_fwd', xp.data_ptr(), wt1.data_ptr(), bs.data_ptr(), y1.data_ptr(), B, 16, h, w, 1, st()))
+    hb = 4.0*B*(16*(h + 2)*(w + 2) + h*w)
+    out['head_full_resolution_fwd'] = {'shape': f'16->1 at {h}x{w}, b={B} (+ sigmoid)', 'bound': 'hbm', 'ms': round(t_h, 5), 'GBps': round(hb/t_h/1e6, 1), 'frac_of_hbm_peak': round(hb/t_h/1e6/HBM_PEAK_GBPS, 3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -372,6 +425,9 @@ def main():
                              'whole_backward_ms': round(ba_ms, 5), 'whole_backward_launches': 'k_recon_bwd alone (events around the fused backward\'s launch; the K0 adjoint — two launches, the first also carrying the pose epilogue through to the pose network\'s outputs and the smoothness adjoint as guest blocks — follows outside this pair)'},
         }
         note(f'timed region done: {out["value"]} img/s')
+        if world == 1 and profiled:
+            try: out['roofline_decoder'] = decoder_roofline(wl, device)
+            except Exception as e: out['roofline_decoder'] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl)
             note('cpu baseline done')

@@ -46,6 +46,8 @@ extern "C" {
                                         * scores and back-propagates only the rows a pixel of its columns routes gradient through.  Same result bit for bit; all-masked
                                         * input: 52 instead of 117 us at 12x192x640; pays from ~75 % dead (row, strip) units on, costs 12-24 % where every row is live
                                         * (profiles/r04_skip_regimes.txt).  Default: off.  (The knob `bwd_skip`, smd_set_knob, overrides.) */
+#define SMD_BWD_NO_LIVE 0x1000         /* smd_image_recon*_bwd, smd_loss_path_bwd: do not consult the forward's liveness table (the caller knows that a launch-shape knob
+                                        * changed between the forward that filled it and this call: the table's strip heights would be read with another partition) */
 #define SMD_USE_LAPLACIAN 0x200        /* smd_disp_smooth_*: SmoothReg(use_laplacian=True): second-order differences (smooth.py:33-48) */
 #define SMD_EDGES_READY 0x800  /* smd_disp_smooth_fwd: `edge_weights` was already filled by smd_disp_smooth_prep() for this frame and pyramid */
 #define SMD_PACKED_READY 0x40  /* smd_image_recon_*_fwd: `supp_packed` was already filled by smd_image_recon_prep() for these frames */

@@ -12,13 +12,13 @@ from pathlib import Path
 
 import torch  # noqa: F401  MUST precede the CDLL below: the library binds to the HIP runtime torch has already loaded
 
-__all__ = ['lib', 'call', 'set_knob', 'reset_knobs', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError', 'Unsupported']
+__all__ = ['lib', 'call', 'set_knob', 'reset_knobs', 'knob_epoch', 'lib_path', 'FLAGS', 'REGR_FLAGS', 'SEL_MASKED', 'ptr_array', 'int_array', 'HotpathError', 'Unsupported']
 
 _HERE = Path(__file__).resolve().parent
 lib_path = Path(os.environ.get('SMD_HOTPATH_LIB', _HERE/'libsmd_hotpath.so'))
 
 FLAGS = {'use_min': 0x1, 'use_automask': 0x2, 'loss_l1': 0x4, 'need_k_grad': 0x8, 'use_edges': 0x10, 'loss_l2': 0x20, 'packed_ready': 0x40,
-         'mask_explainability': 0x80, 'mask_uncertainty': 0x100, 'use_laplacian': 0x200, 'bwd_skip_rows': 0x400, 'edges_ready': 0x800}
+         'mask_explainability': 0x80, 'mask_uncertainty': 0x100, 'use_laplacian': 0x200, 'bwd_skip_rows': 0x400, 'edges_ready': 0x800, 'bwd_no_live': 0x1000}
 REGR_FLAGS = {'l1': 0x0, 'log_l1': 0x1, 'berhu': 0x2, 'invert': 0x4}
 SEL_MASKED = 255
 MAX_SCALES = 8
@@ -144,13 +144,23 @@ def call(name: str, *args):
 def set_knob(name: str, value: int) -> bool:
     """Pin a launch-shape knob of the library (`smd_set_knob`: partitions / code paths that must give identical results; the parity tests
     compare both sides).  -> False if this build does not have the knob (experiments-only), ValueError for an unknown name."""
+    global knob_epoch
     rc = lib.smd_set_knob(name.encode(), int(value))
     if rc == -1: raise ValueError(lib.smd_last_error().decode())
+    knob_epoch += 1
     return rc == 0
 
 
 def reset_knobs() -> None:
+    global knob_epoch
     lib.smd_reset_knobs()
+    knob_epoch += 1
+
+
+# Every knob change in this process passes through the two functions above.  A forward call records the epoch it ran under; a backward that finds another
+# one passes FLAGS['bwd_no_live']: the forward's liveness table was written under the forward's strip partition, which the backward re-derives from the
+# knobs in force when IT runs (ADVICE r5: with other knobs live waves would be read as dead and their gradients silently become zeros).
+knob_epoch = 0
 
 
 def ptr_array(ptrs):

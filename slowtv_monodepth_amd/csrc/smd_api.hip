@@ -404,7 +404,7 @@ static int recon_bwd_impl(const float* depth, float* supp_packed, const float* T
   a.g_in = g_in; a.k0_scale = k0_scale; a.g_scale = g_scale;
   a.g_direct = g_direct; a.direct_scale = g_direct ? direct_scale : -1;
   a.arrive = packed_arrive(supp_packed, b, n, h, w) + 1;
-  a.live = (n <= smd::kLiveSupports && knob("bwd_live", 1) != 0) ? packed_live(supp_packed, b, n, h, w) : nullptr;   // (written by the forward on this buffer)
+  a.live = (n <= smd::kLiveSupports && knob("bwd_live", 1) != 0 && !(flags & SMD_BWD_NO_LIVE)) ? packed_live(supp_packed, b, n, h, w) : nullptr;   // (written by the forward on this buffer)
   { int fnsy2; const StripPlan fp = fwd_partition(b, S, h, w, a.fwd_b1, a.fwd_rh2, fnsy2); a.fwd_rh = fp.rh; }             // (same knobs as the forward call that filled it)
   a.g_T = g_T; a.g_K = (flags & SMD_NEED_K_GRAD) ? g_K : nullptr; a.g_Kinv = (flags & SMD_NEED_K_GRAD) ? g_Kinv : nullptr;
   a.b = b; a.n = n; a.S = S; a.h = h; a.w = w; a.flags = flags;
@@ -592,7 +592,7 @@ int smd_loss_path_bwd(const float* const* disp, const int* hs, const int* ws, co
   job.chain.fs = fs; job.chain.cs = cs; job.chain.g_fs = g_fs; job.chain.g_cs = g_cs; job.chain.h = h; job.chain.w = w;
   job.sm.stats = stats; job.sm.edge_w = edge_weights; job.sm.g_loss = g_loss; job.sm.g_scale = w_smooth; job.sm.accumulate_scale = direct;
   job.sm.blocks_per_sample = guests ? smd::smooth_bwd_blocks_per_sample(sc) : 0;
-  const int rflags = flags & (SMD_USE_MIN | SMD_USE_AUTOMASK | SMD_NEED_K_GRAD | SMD_BWD_SKIP_DEAD_ROWS);
+  const int rflags = flags & (SMD_USE_MIN | SMD_USE_AUTOMASK | SMD_NEED_K_GRAD | SMD_BWD_SKIP_DEAD_ROWS | SMD_BWD_NO_LIVE);
   if (int rc = recon_bwd_impl(depth_up, supp_packed, T, K, K_inv, sel, g_loss, nullptr, a_scale, g_depth, g_T, g_K, g_Kinv, workspace, base,
                               b, n, S, h, w, rflags, stream, &job, direct >= 0 ? g_disp[direct] : nullptr, direct, w_recon)) return rc;
   if (!guests) {   // the smoothness adjoint as a launch of its own, between the reconstruction backward (which wrote the direct level) and the K0 adjoint (which adds)

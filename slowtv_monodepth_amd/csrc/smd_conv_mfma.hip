@@ -79,8 +79,10 @@ __global__ __launch_bounds__(256) void k_conv_pack_w(const float* __restrict__ w
 // one load per loop trip, 134 us; every staging load before its first use + the ring, 135 (the pieces — MFMAs alone 59 us, operand reads 40, staging 79-97 —
 // hardly overlap: a CU's one memory pipeline carries the staging loads AND four waves' copies of the weight fragments, 133 KB per chunk and block);
 // weights through LDS as well (one patch + one weight image, two barriers per chunk), 171; the chunk's loads spread over the taps, 205 (284 registers: one
-// wave per SIMD); two producer waves + four MFMA waves per block, 158-174.  Next: chunks of 8 channels (two taps per MFMA), so that patch AND weights fit
-// twice in 65 KB and no wave of the tap loop touches vector memory.
+// wave per SIMD); two producer waves + four MFMA waves per block, 158-174; chunks of 8 channels (two taps per MFMA K step) so that patch AND weight fragments
+// fit twice in 68 KB and the MFMA loop touches no vector memory, 158.  What the series says: the limiter is the bytes a CU pulls through its vector-memory path
+// (~10 B/clk for L2 / HBM data: 25 KB of patch per chunk and block = 2.5 k cycles against 3.5 k of MFMAs for 32 output channels) — weight fragments fetched
+// once per block from L2 cost more than four waves' L1-hit copies.  The lever left is arithmetic per staged byte: two or three channel tiles per patch.
 template <int TC> struct ConvTile {
   static constexpr int TRB = (TC == 64) ? 4 : 8;
   static constexpr int PW = TC + 2, PH = TRB + 2, NPIX = PW*PH;

@@ -1,12 +1,14 @@
-// smd_conv_thin.hip — the Monodepth decoder's last up-convolution, conv3x3(16 -> 16) at full resolution (SURVEY.md §8f rank 4;
-// reference: src/networks/decoders/monodepth.py:45-50, 80-84 — `self.up1['0'] = ConvELU(16, 16)`; decoders/utils.py:44-54).
+// smd_conv_thin.hip — the Monodepth decoder's thin last stage on the f32 MFMA: conv3x3(32 -> 16) at half resolution and conv3x3(16 -> 16) at full resolution
+// (reference: src/networks/decoders/monodepth.py:45-50, 80-84 — `self.up0['0'] = ConvELU(32, 16)`, `self.up1['0'] = ConvELU(16, 16)`;
+// decoders/utils.py:44-54).
 //
-// With sixteen channels either side a 3x3 convolution has 2304 multiply-adds per pixel on 128 bytes of traffic: compute-bound, but far too thin for the
-// tiles of MIOpen's wide-layer kernels — at cfg 2 (b = 12, 192x640) 196 us forward and 534 us backward, 35 / 25 TFLOP/s (scripts/dev/decoder_conv_times.py),
-// where the fat layers of the same decoder reach 90.  Here it is a direct convolution on the vector ALU: a thread owns one column of R output rows and all
-// sixteen output channels (16 R accumulators), walks the input channels with the 144 weights of a channel as SCALAR operands of v_fmac, and reads
-// (R + 2) x 3 inputs per 144 R multiply-adds.  The same kernel computes the data gradient (the convolution of the zero-extended output gradient with the
-// transposed, flipped weights); the weight gradient is a per-block sum over pixels followed by a fixed-order fp64 sum, as for the heads (smd_conv_head.hip).
+// With sixteen output channels a 3x3 convolution has 2304-4608 multiply-adds per pixel on 128-192 bytes: compute-bound in fp32, but far too thin for the tiles
+// of MIOpen's wide-layer kernels (cfg 2, b = 12: 16 -> 16 at 192x640 196 us forward and 534 us backward, 35 / 25 TFLOP/s, where the fat layers of the same
+// decoder reach 90).  Here: `v_mfma_f32_16x16x4_f32` (exact f32 products and accumulation at the vector ALU's peak rate, 157 TFLOP/s, without its issue costs),
+// operands staged through LDS (the matrix core's operand layout is the transpose of the memory's).  Forward and data gradient are one kernel form; the weight
+// gradient is a GEMM with K = pixels, per-block sums and a fixed-order fp64 second stage.  Round 6: smd_conv_mfma.hip serves the same layers on the bf16
+// matrix cores with three-way split operands (fp32-class results at 6/16 of this instruction's time: forward 88 -> 52 us, data gradient 100 -> 63 at cfg 2);
+// `functional._conv_route` keeps whichever form wins this box's A/B per operator — this file's weight gradient still does.
 #include "smd_common.h"
 #include "smd_kernels.h"
 

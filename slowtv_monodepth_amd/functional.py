@@ -282,6 +282,17 @@ class _RowSkipTuner:
 
 
 _tuners: dict = {}
+def supports_per_pass() -> int:
+    """Supports the fused reconstruction kernels take in one pass (more: passes carrying the running minimum; the single-node loss path: unsupported)."""
+    return int(_lib.lib.smd_image_recon_supports_per_pass())
+
+
+def _stale_table(ctx) -> int:
+    """FLAGS['bwd_no_live'] when a launch-shape knob changed since the forward that filled the liveness table of this node's packed buffer: the backward
+    re-derives the forward's strip partition from the knobs in force when it runs, and a table read with another partition calls live waves dead."""
+    return FLAGS['bwd_no_live'] if getattr(ctx, 'knob_epoch', _lib.knob_epoch) != _lib.knob_epoch else 0
+
+
 def row_skip_tuner(device) -> _RowSkipTuner:
     return _tuners.setdefault(torch.device(device).index, _RowSkipTuner())
 
@@ -312,6 +323,7 @@ class _ImageRecon(torch.autograd.Function):
              warp0.data_ptr() if want_warp else None, ws.data_ptr(), nbytes, b, n, S, h, w, cflags, _stream())
         ctx.save_for_backward(depth, tgt, supp_pk, T, K, K_inv, sel)
         ctx.meta = (b, n, S, h, w, int(flags))
+        ctx.knob_epoch = _lib.knob_epoch
         ctx.need_k = bool(ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
         ctx.mark_non_differentiable(*([err, sel] if err is not None else [sel]))
         if want_warp: ctx.mark_non_differentiable(warp0)
@@ -334,7 +346,7 @@ class _ImageRecon(torch.autograd.Function):
         call('smd_image_recon_bwd', depth.data_ptr(), tgt.data_ptr(), supp_pk.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              sel.data_ptr(), g_loss.data_ptr(), g_depth.data_ptr(), g_T.data_ptr(),
              g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
-             ws.data_ptr(), nbytes, b, n, S, h, w, flags | tflag, _stream())
+             ws.data_ptr(), nbytes, b, n, S, h, w, flags | tflag | _stale_table(ctx), _stream())
         tuner.end(token)
         return g_depth, None, None, g_T, (g_K if ctx.needs_input_grad[4] else None), (g_Ki if ctx.needs_input_grad[5] else None), None, None, None, None, None, None
 
@@ -389,6 +401,7 @@ class _ImageReconDisp(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.meta = (b, n, S, h, w, int(flags), hs, ws, float(min_depth or 0), float(max_depth or 0))
         ctx.need_k = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        ctx.knob_epoch = _lib.knob_epoch
         ctx.mark_non_differentiable(*([err, sel] if err is not None else [sel]))
         if want_warp: ctx.mark_non_differentiable(warp0)
         return loss, err, sel, warp0, depth_up
@@ -412,7 +425,7 @@ class _ImageReconDisp(torch.autograd.Function):
         call('smd_image_recon_disp_bwd', hs_a, ws_a, S, mn, mx, depth_up.data_ptr(), packed.data_ptr(), T.data_ptr(), K.data_ptr(), K_inv.data_ptr(),
              sel.data_ptr(), g_loss.data_ptr(), g_depth_up.data_ptr() if g_depth_up is not None else None,
              ptr_array([g.data_ptr() for g in g_disps]), g_T.data_ptr(), g_K.data_ptr() if ctx.need_k else None, g_Ki.data_ptr() if ctx.need_k else None,
-             wsp.data_ptr(), nbytes, b, n, h, w, flags | tflag, _stream())
+             wsp.data_ptr(), nbytes, b, n, h, w, flags | tflag | _stale_table(ctx), _stream())
         tuner.end(token)
         return (None, None, g_T, (g_K if ctx.needs_input_grad[3] else None), (g_Ki if ctx.needs_input_grad[4] else None),
                 None, None, None, None, None, None, None, None, *g_disps)
@@ -537,6 +550,7 @@ class _LossPath(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.meta = (b, n, S, h, w, int(flags), hs, ws, list(keys), float(min_depth or 0), float(max_depth or 0), float(w_rec), float(w_sm))
         ctx.need_k = bool(fs is not None or ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        ctx.knob_epoch = _lib.knob_epoch
         total, l_rec, l_sm = loss3[0], loss3[1], loss3[2]
         ctx.mark_non_differentiable(l_rec, l_sm, sel)
         return total, l_rec, l_sm, sel, depth_up
@@ -565,7 +579,7 @@ class _LossPath(torch.autograd.Function):
         call('smd_loss_path_bwd', ptr_array([d.data_ptr() for d in disps]), hs_a, ws_a, keys_a, S, mn, mx, depth_up.data_ptr(), packed.data_ptr(), T.data_ptr(),
              K.data_ptr(), K_inv.data_ptr(), sel.data_ptr(), stats.data_ptr(), ew.data_ptr(), g_loss.data_ptr(), w_rec, w_sm,
              P(aa), P(t), P(invert), P(fs), P(cs), ptr_array([g.data_ptr() for g in g_disps]), g_T.data_ptr(), P(g_K), P(g_Ki), P(g_aa), P(g_t), P(g_fs), P(g_cs),
-             wsp.data_ptr(), nbytes, b, n, h, w, cflags | tflag, _stream())
+             wsp.data_ptr(), nbytes, b, n, h, w, cflags | tflag | _stale_table(ctx), _stream())
         tuner.end(token)
         need = ctx.needs_input_grad
         return (None, None, (g_T if need[2] else None), (g_K if need[3] else None), (g_Ki if need[4] else None), g_aa, g_t, None, g_fs, g_cs,
@@ -589,6 +603,8 @@ def loss_path_fused(disps: dict, imgs, supp_imgs, Ts, Ks, K_inv=None, *, pose=No
     if pose is not None: Ts = Ts.detach()
     if intrinsics is not None:
         if K_inv is None: raise ValueError('intrinsics=(fs, cs) goes with the K, K_inv that `functional.intrinsics(fs, cs, size)` returned')
+        if pose is None:    # the intrinsics' chain rule rides on the pose chain's guest block (smd_loss_path_bwd): without it the backward would fail, after a forward that succeeded
+            raise _lib.Unsupported('intrinsics=(fs, cs) needs pose=(aa, t, invert): pass K, K_inv alone and let autograd carry their gradients')
         Ks, K_inv = Ks.detach(), K_inv.detach()
     if K_inv is None: K_inv = torch.linalg.inv(Ks) if Ks.requires_grad else inv_intrinsics(Ks)
     keys = [int(k) for k in disps.keys()]
@@ -864,7 +880,8 @@ def conv3x3_head(xp, weight, bias=None, act: str | None = 'sigmoid'):
 
 
 class _Conv3x3Thin(torch.autograd.Function):
-    """`F.conv2d(xp, weight (16,C,3,3))` on an already reflection-padded input as a direct convolution (`smd_conv3x3_thin_*`): the decoder's last stage."""
+    """`F.conv2d(xp, weight (16,C,3,3))` on an already reflection-padded input on the f32 MFMA (`smd_conv3x3_thin_*`: `v_mfma_f32_16x16x4_f32`, operands staged
+    through LDS): the decoder's last stage in its round-5 form (round 6: `conv3x3_wide` routes between this and the split-bf16 form per operator)."""
     @staticmethod
     def forward(ctx, xp, weight):
         xp = _check('xp', xp)
@@ -1042,7 +1059,7 @@ class _Conv3x3Wide(torch.autograd.Function):
 def conv3x3_mfma(xp, weight, pieces: int = 3):
     """`F.conv2d(xp, weight)` for an input that is already reflection-padded, ALWAYS through the split-bf16 MFMA kernels (`smd_conv3x3_mfma_*`): the wide
     up-convolutions of the decoder (src/networks/decoders/monodepth.py:40-50, 71-84), bias-free (the next glue kernel adds it).  xp (B,C,h+2,w+2) fp32,
-    weight (CO,C,3,3) fp32 -> (B,CO,h,w) fp32; C % 16 == 0 and CO % 32 == 0 (`_lib.Unsupported` otherwise).  Every fp32 operand is split exactly into three
+    weight (CO,C,3,3) fp32 -> (B,CO,h,w) fp32; C % 16 == 0 and CO % 32 == 0, or the thin stage CO = 16 with C = 16 | 32 (`_lib.Unsupported` otherwise).  Every fp32 operand is split exactly into three
     bf16 pieces and six products are kept per fp32 product (`pieces=3`: fp32-class error, see csrc/smd_conv_mfma.hip; `pieces=2` is an experiment setting)."""
     return _Conv3x3Wide.apply(xp, weight, int(pieces), True)
 

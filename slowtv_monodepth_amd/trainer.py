@@ -24,6 +24,8 @@ __all__ = ['MonoDepthModule', 'HipLossBackend', 'EventTimer']
 class HipLossBackend:
     """The product loss path: K0 kernel + fused handlers.  (Tests may inject another object with the same three methods,
     e.g. the CPU oracle, to exercise the host logic on machines without a GPU; the product never does.)"""
+    def __init__(self): self._unserved = set()   # configurations `loss_path` found the single-node operator does not serve: not tried again
+
     def postprocess(self, disps: dict, size, min_depth, max_depth, want_disp_up=True):
         from . import functional as F
         from .handlers import LazyDepths, ScaleDict
@@ -92,6 +94,10 @@ class HipLossBackend:
         if not (isinstance(depths, LazyDepths) and depths.pending and imgs.is_cuda and imgs.shape[1] == 3 and imgs.dtype == torch.float32): return None
         if crit.loss_name != 'ssim' or getattr(crit, 'mask_name', None): return None
         if not reg.use_edges or getattr(reg, 'use_laplacian', False) or getattr(reg, 'use_blur', False): return None
+        # what the operator is known not to serve, checked before anything is allocated or a tie-break seed is drawn (a consumed seed would shift the noise
+        # sequence of the handlers' path that then runs): more supports than one pass takes, a single pyramid level; and any configuration that raised once
+        n_supp, cfg_key = supp_imgs.shape[0], (supp_imgs.shape[0], len(depths.disps), tuple(imgs.shape), crit.use_min, crit.use_automask, intrinsics is not None, pose is not None)
+        if n_supp > F.supports_per_pass() or len(depths.disps) < 2 or cfg_key in self._unserved: return None
         flags = F.recon_flags(crit.loss_name, crit.use_min, crit.use_automask)
         dl = [d.float() for d in depths.disps]
         if prepared is not None and not prepared.matches(imgs, supp_imgs, flags, [d.shape[-2] for d in dl], [d.shape[-1] for d in dl]): prepared = None
@@ -100,6 +106,7 @@ class HipLossBackend:
                                                                   flags=flags, min_depth=depths.min_depth, max_depth=depths.max_depth, seed=crit.next_seed(),
                                                                   w_recon=w_recon, w_smooth=w_smooth, prepared=prepared)
         except Unsupported:
+            self._unserved.add(cfg_key)
             return None
         self.last_sel, self.last_path = _sel, 'single node: smd_loss_path_fwd (1 launch) / smd_loss_path_bwd (3 launches)'   # (references only: what bench.py reports about the last step)
         depths.adopt(depth_up.detach())    # `fwd['depth_up']` for later readers (metrics, logging); no differentiable consumer may follow
@@ -145,7 +152,7 @@ class MonoDepthModule(nn.Module):
         self.nets = parsers.get_net(cfg['net'])
         self.losses, self.weights = parsers.get_loss(copy.deepcopy(cfg['loss']))
         self.backend = loss_backend or HipLossBackend()
-        self._w = {k: float(v) for k, v in self.weights.items()}   # the frozen loss weights as host numbers (read once, here, while they are on the CPU)
+        self._w_cache = {}     # the frozen loss weights as host numbers, re-read whenever a state dict (checkpoint, --resume) rewrote them: `_loss_weight`
         # Losses whose inputs only networks outside this package produce (the autoencoder network and the
         # virtual-stereo decoder head are out of scope; their handlers and criteria exist and are parity-tested on their own):
         # refuse at construction instead of failing with a KeyError in the middle of the first step.
@@ -218,8 +225,9 @@ class MonoDepthModule(nn.Module):
                             self._K_inv = inv(self._y['K'])
                             if self._K_inv is not None: self._K_inv.record_stream(main)
                 if side is not None:
-                    for v in produced.values(): v.record_stream(main)
-                    for v in (getattr(self, '_pose_leaves', None) or ())[:2]: v.record_stream(main)   # read by the loss path's backward on the main stream
+                    for k_, v in produced.items():
+                        if isinstance(v, torch.Tensor): v.record_stream(main)
+                    for v in (produced.get('_pose_leaves') or ())[:2]: v.record_stream(main)   # read by the loss path's backward on the main stream
                 fwd.update(produced)
             else:
                 raise KeyError(f'Unrecognized key: {key}.')
@@ -240,8 +248,9 @@ class MonoDepthModule(nn.Module):
         flags = [bool(inv(i)) for i in idxs for _ in range(sh[1])]
         aa, tr = pose['R'][:, 0].contiguous(), pose['t'][:, 0].contiguous()   # (strided views of the head's output: packed ONCE, for `pose_matrices` and for the loss path)
         Ts = self.backend.pose_matrices(aa, tr, flags).unflatten(0, sh)
-        self._Ts_all = Ts
-        self._pose_leaves = (aa, tr, flags, idxs)   # for the fused loss path: its backward hands the gradients to the network's outputs directly
+        # for the fused loss path (its backward hands the gradients to the network's outputs directly): they travel with `fwd`, not on the module — a bare
+        # `module.forward(x)` (validation, export) must not keep graph-attached tensors alive until the next call
+        out['_Ts_all'], out['_pose_leaves'] = Ts, (aa, tr, flags, idxs)
         for i, T in zip(idxs, Ts): out[f'T_{i}'] = T
         if 'fs' in pose:
             out['fs'], out['cs'] = pose['fs'].unflatten(0, sh), pose['cs'].unflatten(0, sh)
@@ -254,7 +263,7 @@ class MonoDepthModule(nn.Module):
                                                             want_disp_up=self.want_aux)
         if disp_up is not None: fwd['disp_up'] = disp_up   # only the image logger reads the un-scaled up-sampled disparity
         # a stereo support (index 0) brings its known pose with the batch instead of a predicted one (src/core/trainer.py:347)
-        leaves, Ts_all = getattr(self, '_pose_leaves', None), getattr(self, '_Ts_all', None)
+        leaves, Ts_all = fwd.get('_pose_leaves'), fwd.get('_Ts_all')
         if (leaves is not None and Ts_all is not None and [int(i) for i in x['supp_idxs']] == list(leaves[3])
                 and all(fwd[f'T_{i}'].data_ptr() == Ts_all[k].data_ptr() for k, i in enumerate(leaves[3]))):    # (this `fwd` is that call's)
             fwd['Ts'] = Ts_all     # every support's pose came out of ONE `pose_matrices` call, already stacked in this order: no copy
@@ -305,6 +314,16 @@ class MonoDepthModule(nn.Module):
             loss_dict.update(ld)
         return loss, loss_dict
 
+    def _loss_weight(self, k: str) -> float:
+        """`self.weights[k]` as a host float for the single-node loss path (the kernel takes the weights as scalars).  The `ParameterDict` is part of the state
+        dict: `load_state_dict` / a reference checkpoint / `--resume` overwrite it in place, and the handlers' path (`self.weights[k]*l`) and the reference
+        then use the checkpoint's values — so the cached number is keyed on the parameter's version counter and storage (one device read per change)."""
+        p = self.weights[k]
+        key = (p._version, p.data_ptr(), p.device)
+        c = self._w_cache.get(k)
+        if c is None or c[0] != key: c = self._w_cache[k] = (key, float(p.detach()))
+        return c[1]
+
     def _forward_loss_fused(self, fwd: dict, x: dict, y: dict):
         """The kbr loss configuration — `img_recon` + `disp_smooth`, nothing else, no image logging — through ONE autograd node
         (`HipLossBackend.loss_path`).  None: not that configuration / not served; `forward_loss` then runs the handlers one by one."""
@@ -314,18 +333,23 @@ class MonoDepthModule(nn.Module):
         learned = 'K' in fwd
         K_inv = fwd.get('K_inv') if learned else getattr(self, '_K_inv', None)
         if K_inv is None and not learned and hasattr(self.backend, 'inv_intrinsics'): K_inv = self.backend.inv_intrinsics(y['K'])
-        pose, leaves = None, getattr(self, '_pose_leaves', None)
+        pose, leaves = None, fwd.get('_pose_leaves')
         if leaves is not None and [int(i) for i in x['supp_idxs']] == list(leaves[3]):   # every support's pose is predicted (no stereo frame): Ts is exactly pose_matrices(aa, t)
             inv = self.backend.invert_mask(leaves[2], leaves[0].device) if hasattr(self.backend, 'invert_mask') else None
             pose = (leaves[0].float(), leaves[1].float(), inv)
-        intr = (fwd['fs'][0].float(), fwd['cs'][0].float()) if (learned and 'fs' in fwd and K_inv is not None) else None
+        # (a stereo support brings a known pose: no pose leaves — then the intrinsics go in as the K, K_inv tensors and autograd carries their gradients;
+        # the kernel's own chain rule for (fs, cs) rides on the pose chain's guest block and would fail in backward without it: ADVICE r5)
+        intr = (fwd['fs'][0].float(), fwd['cs'][0].float()) if (learned and 'fs' in fwd and K_inv is not None and pose is not None) else None
         with self.timer('Loss-img_recon'):
             out = fn(crit, reg, fwd['depth_up'], fwd['disp'], y['imgs'], y['supp_imgs'], fwd['Ts'], fwd.get('K', y['K']), K_inv,
-                     self._w['img_recon'], self._w['disp_smooth'], pose=pose, intrinsics=intr, prepared=self._prepared)
+                     self._loss_weight('img_recon'), self._loss_weight('disp_smooth'), pose=pose, intrinsics=intr, prepared=self._prepared)
         if out is None: return None
         loss, l_rec, l_sm = out
         ld = {'loss_img_recon': l_rec, 'loss_disp_smooth': l_sm}
-        return loss, {f'loss_{k}': ld[f'loss_{k}'] for k in self.losses}
+        out_ld = {f'loss_{k}': ld[f'loss_{k}'] for k in self.losses}
+        sel = getattr(self.backend, 'last_sel', None)
+        if crit.use_automask and sel is not None: out_ld['automask'] = sel[0] != 255    # the entry the handlers' path adds (handlers.image_recon): same keys whichever path ran
+        return loss, out_ld
 
     def step(self, batch, mode: str = 'train'):
         """One forward pass + losses (src/core/trainer.py:115-190) -> (loss, loss_dict, fwd)."""
@@ -335,7 +359,7 @@ class MonoDepthModule(nn.Module):
         x, y, m = batch
         self.synth = ViewSynth(x['imgs'].shape[-2:])
         self._prepared = self._prepare_frames(y) if self.prep_ahead == 'own' else None
-        self._y, self._K_inv, self._pose_leaves, self._Ts_all = y, None, None, None
+        self._y, self._K_inv = y, None
         try:
             with self.timer('Total'):
                 with self.timer('Forward'): fwd = self.forward(x)
@@ -344,7 +368,7 @@ class MonoDepthModule(nn.Module):
         finally:
             # the prep-ahead state belongs to THIS step: a later `module.forward(x)` (validation, inference) must neither launch the
             # prep for the previous batch nor keep that batch (and its 150 MB packed buffer) alive
-            self._y = self._prepared = self._K_inv = self._pose_leaves = self._Ts_all = None
+            self._y = self._prepared = self._K_inv = None
         return loss, loss_dict, fwd
 
     def _prepare_frames(self, y: dict, stream=None):

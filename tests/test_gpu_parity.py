@@ -510,34 +510,45 @@ def test_baseline_size_in_kernel_noise_matches_oracle_off_the_ties(F):
     assert differ.float().mean().item() <= 3e-3
 
 
-@pytest.mark.parametrize('shape', [(12, 192, 640, 2, 4), (3, 384, 640, 4, 4), (1, 50, 70, 3, 2)])
+@pytest.mark.parametrize('shape', [(12, 192, 640, 2, 4), (3, 384, 640, 4, 4), (1, 50, 70, 3, 2), (12, 384, 640, 2, 4, 'learn_K')])
 def test_full_size_properties(F, shape):
     """Size-independent properties at BASELINE sizes (on top of the value-for-value comparisons above):
     (1) identity pose + constant depth + fixed K: warped support == bilinear resample with the known w/(w-1) stretch,
         so err is finite, within [0, 1], and `loss == err.mean()`;
     (2) swapping the support order leaves the min-reprojection error unchanged and permutes `sel`;
     (3) batch linearity: evaluating two half-batches separately gives the same per-pixel maps;
-    (4) gradients are finite and g_T's last row is zero."""
-    b, h, w, n, S = shape
+    (4) gradients are finite and g_T's last row is zero.
+    The last case is BASELINE cfg 4 at its full batch (b = 12, 384x640, two supports) with LEARNED intrinsics: K, K_inv come out of `functional.intrinsics`
+    and the gradients must reach its (fs, cs) leaves, finite."""
+    b, h, w, n, S = shape[:5]
+    learn_K = len(shape) > 5
     gen = torch.Generator(device='cuda').manual_seed(5)
     imgs = torch.rand(b, 3, h, w, device='cuda', generator=gen)
     supp = torch.rand(n, b, 3, h, w, device='cuda', generator=gen)
     depth = (1 + 20*torch.rand(S, b, 1, h, w, device='cuda', generator=gen)).requires_grad_(True)
     K = torch.tensor([[0.58*w, 0, 0.5*w, 0], [0, 1.92*h, 0.5*h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device='cuda')[None].repeat(b, 1, 1)
+    K_inv, fs, cs = None, None, None
+    if learn_K:   # normalised focal lengths / principal points around the fixed K's, one pair per sample (what PoseNet.build_K emits: src/networks/pose.py:60-73)
+        fs = (torch.tensor([0.58, 1.92], device='cuda') + 0.02*torch.randn(b, 2, device='cuda', generator=gen)).requires_grad_(True)
+        cs = (0.5 + 0.01*torch.randn(b, 2, device='cuda', generator=gen)).requires_grad_(True)
+        K, K_inv = F.intrinsics(fs, cs, (h, w))
     T = torch.eye(4, device='cuda').repeat(n, b, 1, 1)
     T[..., :3, 3] = 0.05*torch.randn(n, b, 3, device='cuda', generator=gen)
     T.requires_grad_(True)
     flags = F.recon_flags('ssim', True, True)
     noise = torch.randn(S, b, 1, h, w, device='cuda', generator=gen)
-    loss, err, sel, _ = F.image_recon_fused(depth, imgs, supp, T, K, flags=flags, noise=noise)
+    loss, err, sel, _ = F.image_recon_fused(depth, imgs, supp, T, K, K_inv, flags=flags, noise=noise)
     assert torch.isfinite(err).all() and (err >= -1e-6).all() and (err <= 1 + 1e-6).all()
     torch.testing.assert_close(loss, err.double().mean().float(), rtol=1e-5, atol=1e-7)
     loss.backward()
     assert torch.isfinite(depth.grad).all() and torch.isfinite(T.grad).all()
     assert (T.grad[..., 3, :] == 0).all()
+    if learn_K:
+        assert torch.isfinite(fs.grad).all() and torch.isfinite(cs.grad).all() and fs.grad.abs().max() > 0 and cs.grad.abs().max() > 0
+        K, K_inv = K.detach(), K_inv.detach()
     # (2) permutation of supports
     perm = list(reversed(range(n)))
-    loss_p, err_p, sel_p, _ = F.image_recon_fused(depth.detach(), imgs, supp[perm], T.detach()[perm], K, flags=flags, noise=noise)
+    loss_p, err_p, sel_p, _ = F.image_recon_fused(depth.detach(), imgs, supp[perm], T.detach()[perm], K, K_inv, flags=flags, noise=noise)
     torch.testing.assert_close(err_p, err, rtol=0, atol=1e-6)
     kept = (sel != 255) & (sel_p != 255)
     same = (torch.tensor(perm, device='cuda', dtype=torch.uint8)[sel_p[kept].long()] == sel[kept]).float().mean().item()
@@ -545,8 +556,8 @@ def test_full_size_properties(F, shape):
     # (3) batch split
     if b >= 2:
         hb = b//2
-        _, err_a, sel_a, _ = F.image_recon_fused(depth.detach()[:, :hb], imgs[:hb], supp[:, :hb], T.detach()[:, :hb], K[:hb], flags=flags,
-                                                 noise=noise[:, :hb])
+        _, err_a, sel_a, _ = F.image_recon_fused(depth.detach()[:, :hb], imgs[:hb], supp[:, :hb], T.detach()[:, :hb], K[:hb], K_inv[:hb] if K_inv is not None else None,
+                                                 flags=flags, noise=noise[:, :hb])
         assert torch.equal(err_a, err[:, :hb]) and torch.equal(sel_a, sel[:, :hb])
 
 
@@ -735,6 +746,39 @@ def test_whole_chain_at_baseline_resolution_matches_reference(F, golden, knobs, 
     assert ((e_hip - e_ref).abs() > 2e-4).float().mean().item() <= 1e-3
     report, ok = judge_against_reference_at_baseline_size(g, name, {k: v.grad for k, v in leaves.items()}, sel_own)
     parity_note(f'{name} (whole chain, K0 fused): loss hip={loss.item():.8f} ref={g["out_loss"].item():.8f}; ' + '; '.join(report))
+    assert ok, report
+
+
+@pytest.mark.parametrize('name', TRAIN_CASES_BASELINE)
+def test_single_node_loss_path_at_baseline_resolution_matches_reference(F, golden, knobs, name):
+    """The entry point `bench.py` times and the trainer calls — `smd_loss_path_fwd/_bwd` (`functional.loss_path_fused`: reconstruction + smoothness + weighted
+    sum as ONE autograd node, the pose / intrinsics chain rule inside its backward) — put on the REFERENCE's fixtures at the resolutions BASELINE.json quotes
+    DIRECTLY (until now it was held to them through bit-equality with the separate operators): total loss, both terms, `depth_up`, the
+    decision map, and the gradient of every network output (aa, t, (fs, cs), the disparity pyramid) under the reference's routing.  The tie-break noise is
+    the in-kernel draw (this entry point takes a seed, not a tensor): it moves the loss by ~1e-7/sqrt(N) and decides exact ties only."""
+    g = golden(name)
+    leaves, static = case_inputs(g, device='cuda')
+    scales, idxs = static['scales'], static['supp_idxs']
+    n, b = leaves['aa'].shape[:2]
+    h, w = static['imgs'].shape[-2:]
+    if g['meta_loss_name'] != 'ssim' or not g['meta_use_edges']: pytest.skip('not the configuration the single-node operator serves')
+    inv = torch.tensor([bool(g['meta_always_fwd_pose']) and i < 0 for i in idxs for _ in range(b)], dtype=torch.uint8).cuda()
+    aa, t = leaves['aa'].flatten(0, 1), leaves['t'].flatten(0, 1)              # views of the leaves: the backward hands their gradients over directly
+    Ts = F.pose_matrices(aa, t, inv).unflatten(0, (n, b))
+    if g['meta_learn_K']: K, K_inv = F.intrinsics(leaves['fs'], leaves['cs'], (h, w)); intr = (leaves['fs'], leaves['cs'])
+    else: K, K_inv, intr = static['K'], None, None
+    flags = F.recon_flags('ssim', bool(g['meta_use_min']), bool(g['meta_use_automask']))
+    loss, l_rec, l_sm, sel, depth_up = F.loss_path_fused({s: leaves[f'disp_{s}'] for s in scales}, static['imgs'], static['supp_imgs'], Ts, K, K_inv,
+                                                         pose=(aa, t, inv), intrinsics=intr, flags=flags, min_depth=g['meta_min_depth'] or None,
+                                                         max_depth=g['meta_max_depth'] or None, seed=1234, w_recon=1.0, w_smooth=float(g['meta_w_smooth']))
+    sel_own = impose_reference_routing(g, sel, knobs)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g['out_loss'], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(l_rec.detach().cpu(), g['out_loss_img_recon'], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(l_sm.detach().cpu(), g['out_loss_disp_smooth'], rtol=2e-5, atol=1e-7)
+    for k, s in enumerate(scales): torch.testing.assert_close(*ref_map(g, f'out_depth_up_{s}', depth_up[k].cpu()), rtol=2e-5, atol=1e-5)
+    report, ok = judge_against_reference_at_baseline_size(g, name, {k: v.grad for k, v in leaves.items()}, sel_own)
+    parity_note(f'{name} (single node: smd_loss_path_fwd/_bwd): loss hip={loss.item():.8f} ref={g["out_loss"].item():.8f}; ' + '; '.join(report))
     assert ok, report
 
 

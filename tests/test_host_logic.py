@@ -219,6 +219,57 @@ def test_training_step_on_cpu_with_oracle_backend(learn_K):
         bad.step(batch)
 
 
+class _RecordingBackend(OracleBackend):
+    """The oracle backend plus a `loss_path` that only records what the trainer hands the single-node operator (and declines, so the handlers run)."""
+    def __init__(self): super().__init__(); self.calls = []
+    def intrinsics(self, fs, cs, size):
+        K, _ = super().intrinsics(fs, cs, size)
+        return K, torch.linalg.inv(K)                             # (the HIP backend returns the pair; the single-node path is only offered leaves when K_inv exists)
+    def loss_path(self, crit, reg, depths, disps, imgs, supp_imgs, Ts, Ks, K_inv, w_recon, w_smooth, pose=None, intrinsics=None, prepared=None):
+        self.calls.append({'w': (w_recon, w_smooth), 'pose': pose, 'intrinsics': intrinsics, 'K_inv': K_inv})
+        return None
+
+
+def test_single_node_loss_path_gets_intrinsics_leaves_only_with_pose_leaves():
+    """a learned-K pose network with a STEREO support (index 0: its pose comes with the batch) has no pose leaves for the loss path; handing it
+    `intrinsics=(fs, cs)` anyway let the forward succeed and the backward die (`the intrinsics' chain rule needs the pose chain`).  The trainer must then pass
+    K / K_inv as tensors (autograd carries their gradients) — and the operator itself must refuse the combination before launching anything."""
+    torch.manual_seed(0)
+    cfg = _cfg(True)
+    for idxs, want_leaves in (((-1, 1), True), ((-1, 0), False)):
+        be = _RecordingBackend()
+        m = MonoDepthModule(copy.deepcopy(cfg), loss_backend=be)
+        m.want_aux = False                                       # (the single-node path is the no-image-logging path)
+        x, y, meta = make_batch(2, 64, 96, idxs, seed=1)
+        if 0 in idxs: y['T_stereo'] = torch.eye(4).expand(2, 4, 4).clone()
+        be.inv_intrinsics = lambda K: torch.linalg.inv(K)
+        loss, ld, fwd = m.step((x, y, meta))
+        assert len(be.calls) == 1
+        c = be.calls[0]
+        assert (c['pose'] is not None) == want_leaves and (c['intrinsics'] is not None) == want_leaves, (idxs, c['pose'] is not None, c['intrinsics'] is not None)
+        assert '_pose_leaves' in fwd and not hasattr(m, '_pose_leaves')          # they travel with `fwd`, nothing graph-attached stays on the module
+        loss.backward()                                                          # the handlers' path that ran instead: gradients reach the intrinsics heads
+        assert all(p.grad is not None for n, p in m.nets['pose'].named_parameters() if ('focal' in n or 'offset' in n))
+
+
+def test_single_node_loss_path_follows_the_state_dict_weights():
+    """`weights` is a ParameterDict in the state dict; a checkpoint / --resume overwrites it in place and the handlers' path (and the reference)
+    then weigh the losses with the CHECKPOINT's values.  The single-node path takes the weights as host scalars: they must follow."""
+    torch.manual_seed(0)
+    be = _RecordingBackend()
+    m = MonoDepthModule(copy.deepcopy(_cfg(False)), loss_backend=be)
+    m.want_aux = False
+    batch = make_batch(2, 64, 96, (-1, 1), seed=1)
+    m.step(batch)
+    assert be.calls[-1]['w'] == (1.0, pytest.approx(0.001))
+    sd = m.state_dict()
+    sd['weights.disp_smooth'] = torch.tensor(0.25); sd['weights.img_recon'] = torch.tensor(2.0)
+    m.load_state_dict(sd)
+    loss, ld, _ = m.step(batch)
+    assert be.calls[-1]['w'] == (2.0, 0.25)
+    torch.testing.assert_close(loss, 2.0*ld['loss_img_recon'] + 0.25*ld['loss_disp_smooth'])   # (the handlers' path that ran: same weights)
+
+
 def test_loss_phases_reproduce_the_reference_numbers(golden):
     """forward_postprocess + forward_loss of the module (oracle backend) on the reference's own fixture."""
     g = golden('train_kbr_24x32')
