@@ -395,7 +395,7 @@ def main():
                        'host_enqueue_ms_per_step': round(host_enqueue/args.steps*1e3, 3), 'host_cpu_ms_per_step': round(host_cpu/args.steps*1e3, 3), 'hip_graph': graph_note,
                        'prep_ahead': module.prep_ahead if not args.graph else 'False (forced by --graph: the prep-ahead hand-off across streams crashes hipStreamEndCapture on this stack; the default bench runs prep_ahead=pose)',
                        'loss_path': getattr(module.backend, 'last_path', None), 'knobs': args.knob or None,
-                       'decoder_conv_routes': {'mode': args.conv_route, 'decisions': {f'{k[0]} {k[2]}->{k[3]} {k[4]}x{k[5]} b{k[1]}': ('split-bf16 mfma' if v[0] else ('f32 mfma' if k[3] == 16 else 'miopen')) + f' ({v[1]:.0f} vs {v[2]:.0f} us)' for k, v in sorted(_HF.conv_routes().items(), key=lambda kv: (-kv[0][4], kv[0][0]))}},
+                       'decoder_conv_routes': {'mode': args.conv_route, 'decisions': {f'{k[0]} {k[2]}->{k[3]} {k[4]}x{k[5]} b{k[1]}': (('bf16 mfma' if k[0].endswith('_bf16') else 'split-bf16 mfma') if v[0] else ('f32 mfma' if (k[3] == 16 and not k[0].endswith('_bf16')) else 'miopen')) + f' ({v[1]:.0f} vs {v[2]:.0f} us)' for k, v in sorted(_HF.conv_routes().items(), key=lambda kv: (-kv[0][4], kv[0][0]))}},
                        'automasked_share': sel_stats['automasked_share'] if sel_stats else None, 'routed_share_per_support': sel_stats['routed_share_per_support'] if sel_stats else None,
                        'dead_wave_share_per_support': sel_stats['dead_wave_share_per_support'] if sel_stats else None},
             'roofline': {'kernel': f'{k_fwd} (disp->depth + warp + SSIM + L1 + min-reproj + automask forward in one launch; the instantiation the library reports for the last forward launch, name as rocprofv3 prints it)', 'bound': 'hbm',

@@ -289,10 +289,13 @@ int smd_elu_up_cat_pad_bwd(const void* a, const float* bias, const void* g_out, 
  * `conv3x3(num_ch_dec[i], 1)`, decoders/utils.py:44-46): y (B,1,h,w) = act(conv3x3(xp; weight (1,C,3,3)) + bias (1) or NULL), where xp (B,C,h+2,w+2)
  * is the reflection-padded activation smd_elu_pad_fwd leaves; act 0: identity, 1: sigmoid.  A one-output-channel convolution is a stencil: three
  * streaming kernels, fp32, deterministic.  Backward: g_y and the saved y -> g_xp (B,C,h+2,w+2) (or NULL), g_weight (1,C,3,3) with g_bias (1) (g_weight
- * NULL: neither; g_bias may be NULL alone); the weight gradient needs the workspace. */
+ * NULL: neither; g_bias may be NULL alone); the weight gradient needs the workspace.
+ * act | SMD_HEAD_X_BF16 (ABI 8): xp and g_xp are bfloat16 (the decoder under bf16 autocast: `cfg/kbr/default.yaml` trains in bf16-mixed — the glue kernels
+ * then leave a bf16 activation; these kernels are HBM-bound, so half the bytes); weights, bias, y, g_y and every sum stay fp32. */
+#define SMD_HEAD_X_BF16 2
 size_t smd_conv3x3_head_workspace_bytes(int B, int C, int h, int w);
-int smd_conv3x3_head_fwd(const float* xp, const float* weight, const float* bias, float* y, int B, int C, int h, int w, int act, void* stream);
-int smd_conv3x3_head_bwd(const float* xp, const float* weight, const float* y, const float* g_y, float* g_xp, float* g_weight, float* g_bias,
+int smd_conv3x3_head_fwd(const void* xp, const float* weight, const float* bias, float* y, int B, int C, int h, int w, int act, void* stream);
+int smd_conv3x3_head_bwd(const void* xp, const float* weight, const float* y, const float* g_y, void* g_xp, float* g_weight, float* g_bias,
                          void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int act, void* stream);
 
 /* The decoder's thin up-convolutions (ABI 7, round 5; reference: src/networks/decoders/monodepth.py:45-50, 80-84 — `ConvELU(cin, 16)`; the bias and the ELU
@@ -310,7 +313,9 @@ int smd_conv3x3_thin_bwd(const float* xp, const float* weight, const float* g_y,
  * 2^-25 of the product — fp32-class results at 6/16 of the f32 MFMA's time; 2: three products, 16 significant bits, an experiment setting, never the
  * library's choice).  smd_conv3x3_mfma_pack writes the weights' pieces in the operand order of the forward (wp_fwd) and of the data gradient (wp_bwd), each
  * smd_conv3x3_mfma_packed_bytes(C, CO, pieces) bytes (either may be NULL); the backward reads what the forward's pack left.
- * Served: pieces in {2, 3}; forward C % 16 == 0 and CO % 32 == 0; data gradient CO % 16 == 0 and C % 32 == 0; weight gradient CO % 32 == 0 (any C); and the
+ * pieces = 1 (ABI 8): the tensors xp, y, g_y, g_xp are BFLOAT16 (the decoder under bf16 autocast, `cfg/kbr/default.yaml`): one bf16 product per product, the
+ * weights enter as their bf16 rounding (what autocast hands a bf16 convolution), accumulation and the weight gradient stay fp32.
+ * Served: pieces in {1, 2, 3}; forward C % 16 == 0 and CO % 32 == 0; data gradient CO % 16 == 0 and C % 32 == 0; weight gradient CO % 32 == 0 (any C); and the
  * thin last stage, CO == 16 with C == 16 or 32 (`ConvELU(cin, 16)`, monodepth.py:45-50: all three operators, on the 16 x 16 x 32 form of the instruction);
  * anything else SMD_E_UNSUPPORTED, nothing launched.  g_xp (B,C,h+2,w+2) is the gradient of the PADDED input.  Every call takes a workspace of
  * smd_conv3x3_mfma_workspace_bytes (the coarse decoder levels — few pixels, thousands of K — split K over blocks and add the splits' outputs in split
@@ -318,11 +323,11 @@ int smd_conv3x3_thin_bwd(const float* xp, const float* weight, const float* g_y,
 size_t smd_conv3x3_mfma_packed_bytes(int C, int CO, int pieces);
 size_t smd_conv3x3_mfma_workspace_bytes(int B, int C, int CO, int h, int w);
 int smd_conv3x3_mfma_pack(const float* weight, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, void* stream);
-int smd_conv3x3_mfma_fwd(const float* xp, const void* wp_fwd, float* y, void* workspace, size_t workspace_bytes,
+int smd_conv3x3_mfma_fwd(const void* xp, const void* wp_fwd, void* y, void* workspace, size_t workspace_bytes,
                          int B, int C, int CO, int h, int w, int pieces, void* stream);
-int smd_conv3x3_mfma_bwd_data(const float* g_y, const void* wp_bwd, float* g_xp, void* workspace, size_t workspace_bytes,
+int smd_conv3x3_mfma_bwd_data(const void* g_y, const void* wp_bwd, void* g_xp, void* workspace, size_t workspace_bytes,
                               int B, int C, int CO, int h, int w, int pieces, void* stream);
-int smd_conv3x3_mfma_bwd_weight(const float* xp, const float* g_y, float* g_weight, void* workspace, size_t workspace_bytes,
+int smd_conv3x3_mfma_bwd_weight(const void* xp, const void* g_y, float* g_weight, void* workspace, size_t workspace_bytes,
                                 int B, int C, int CO, int h, int w, int pieces, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

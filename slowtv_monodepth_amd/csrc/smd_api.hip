@@ -788,17 +788,17 @@ size_t smd_conv3x3_head_workspace_bytes(int B, int C, int h, int w) {
   if (!head_sizes_ok(B, C, h, w)) return 0;
   return align256(smd::conv_head_partials(B, C, h, w)*sizeof(float));
 }
-int smd_conv3x3_head_fwd(const float* xp, const float* weight, const float* bias, float* y, int B, int C, int h, int w, int act, void* stream) {
+int smd_conv3x3_head_fwd(const void* xp, const float* weight, const float* bias, float* y, int B, int C, int h, int w, int act, void* stream) {
   if (!xp || !weight || !y) return fail(SMD_E_INVALID, "null pointer");
-  if (!head_sizes_ok(B, C, h, w) || (act != 0 && act != 1)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d act=%d", B, C, h, w, act);
-  return check_launch(smd::launch_conv_head_fwd(xp, weight, bias, y, B, C, h, w, act, (hipStream_t)stream), "conv3x3_head_fwd");
+  if (!head_sizes_ok(B, C, h, w) || (act & ~(1 | SMD_HEAD_X_BF16))) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d act=%d", B, C, h, w, act);
+  return check_launch(smd::launch_conv_head_fwd(xp, (act & SMD_HEAD_X_BF16) != 0, weight, bias, y, B, C, h, w, act & 1, (hipStream_t)stream), "conv3x3_head_fwd");
 }
-int smd_conv3x3_head_bwd(const float* xp, const float* weight, const float* y, const float* g_y, float* g_xp, float* g_weight, float* g_bias,
+int smd_conv3x3_head_bwd(const void* xp, const float* weight, const float* y, const float* g_y, void* g_xp, float* g_weight, float* g_bias,
                          void* workspace, size_t workspace_bytes, int B, int C, int h, int w, int act, void* stream) {
   if (!weight || !y || !g_y || (!g_xp && !g_weight) || (g_weight && (!xp || !workspace)) || (g_bias && !g_weight)) return fail(SMD_E_INVALID, "null pointer");
-  if (!head_sizes_ok(B, C, h, w) || (act != 0 && act != 1)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d act=%d", B, C, h, w, act);
+  if (!head_sizes_ok(B, C, h, w) || (act & ~(1 | SMD_HEAD_X_BF16))) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d act=%d", B, C, h, w, act);
   if (g_weight && workspace_bytes < smd_conv3x3_head_workspace_bytes(B, C, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
-  return check_launch(smd::launch_conv_head_bwd(xp, weight, y, g_y, g_xp, g_weight, g_bias, (float*)workspace, B, C, h, w, act, (hipStream_t)stream), "conv3x3_head_bwd");
+  return check_launch(smd::launch_conv_head_bwd(xp, (act & SMD_HEAD_X_BF16) != 0, weight, y, g_y, g_xp, g_weight, g_bias, (float*)workspace, B, C, h, w, act & 1, (hipStream_t)stream), "conv3x3_head_bwd");
 }
 static bool thin_sizes_ok(int B, int C, int h, int w) { return (C == 16 || C == 32) && head_sizes_ok(B, C, h, w) && dec_sizes_ok((long long)B*16, h, w) && B < 65536 && h + 2 < 4*65536; }
 size_t smd_conv3x3_thin_workspace_bytes(int B, int C, int h, int w) {
@@ -830,7 +830,7 @@ static bool mfma_fwd_served(int C, int CO) { return (C % 16 == 0 && CO % 32 == 0
 static bool mfma_wgt_served(int C, int CO) { return CO % 32 == 0 || (CO == 16 && (C == 16 || C == 32)); }
 static bool mfma_data_served(int C, int CO) { return (CO % 16 == 0 && C % 32 == 0) || (C == 16 && CO == 16); }
 size_t smd_conv3x3_mfma_packed_bytes(int C, int CO, int pieces) {
-  if (C < 1 || CO < 1 || (pieces != 2 && pieces != 3)) return 0;
+  if (C < 1 || CO < 1 || pieces < 1 || pieces > 3) return 0;
   return align256(smd::conv_mfma_packed_elems(C, CO, pieces)*2);
 }
 size_t smd_conv3x3_mfma_workspace_bytes(int B, int C, int CO, int h, int w) {   // one size for the three operators
@@ -843,34 +843,34 @@ size_t smd_conv3x3_mfma_workspace_bytes(int B, int C, int CO, int h, int w) {   
 }
 int smd_conv3x3_mfma_pack(const float* weight, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, void* stream) {
   if (!weight || (!wp_fwd && !wp_bwd)) return fail(SMD_E_INVALID, "null pointer");
-  if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
+  if (pieces < 1 || pieces > 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 1 (bfloat16 tensors), 2 or 3 (float tensors), not %d", pieces);
   if (C < 1 || CO < 1 || C > 4096 || CO > 4096) return fail(SMD_E_INVALID, "invalid sizes C=%d CO=%d", C, CO);
   if (wp_fwd && !mfma_fwd_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the forward form serves C %% 16 == 0 with CO %% 32 == 0, or CO == 16 with C == 16 | 32, not C=%d CO=%d", C, CO);
   if (wp_bwd && !mfma_data_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the data-gradient form serves CO %% 16 == 0 with C %% 32 == 0, or C == CO == 16, not C=%d CO=%d", C, CO);
   return check_launch(smd::launch_conv_mfma_pack(weight, wp_fwd, wp_bwd, C, CO, pieces, (hipStream_t)stream), "conv3x3_mfma_pack");
 }
-int smd_conv3x3_mfma_fwd(const float* xp, const void* wp_fwd, float* y, void* workspace, size_t workspace_bytes,
+int smd_conv3x3_mfma_fwd(const void* xp, const void* wp_fwd, void* y, void* workspace, size_t workspace_bytes,
                          int B, int C, int CO, int h, int w, int pieces, void* stream) {
   if (!xp || !wp_fwd || !y || !workspace) return fail(SMD_E_INVALID, "null pointer");
-  if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
+  if (pieces < 1 || pieces > 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 1 (bfloat16 tensors), 2 or 3 (float tensors), not %d", pieces);
   if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
   if (!mfma_fwd_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the forward serves C %% 16 == 0 with CO %% 32 == 0, or CO == 16 with C == 16 | 32, not C=%d CO=%d", C, CO);
   if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
   return check_launch(smd::launch_conv_mfma_fwd(xp, wp_fwd, y, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_fwd");
 }
-int smd_conv3x3_mfma_bwd_data(const float* g_y, const void* wp_bwd, float* g_xp, void* workspace, size_t workspace_bytes,
+int smd_conv3x3_mfma_bwd_data(const void* g_y, const void* wp_bwd, void* g_xp, void* workspace, size_t workspace_bytes,
                               int B, int C, int CO, int h, int w, int pieces, void* stream) {
   if (!g_y || !wp_bwd || !g_xp || !workspace) return fail(SMD_E_INVALID, "null pointer");
-  if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
+  if (pieces < 1 || pieces > 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 1 (bfloat16 tensors), 2 or 3 (float tensors), not %d", pieces);
   if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
   if (!mfma_data_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the data gradient serves CO %% 16 == 0 with C %% 32 == 0, or C == CO == 16, not C=%d CO=%d", C, CO);
   if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
   return check_launch(smd::launch_conv_mfma_bwd_data(g_y, wp_bwd, g_xp, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_bwd_data");
 }
-int smd_conv3x3_mfma_bwd_weight(const float* xp, const float* g_y, float* g_weight, void* workspace, size_t workspace_bytes,
+int smd_conv3x3_mfma_bwd_weight(const void* xp, const void* g_y, float* g_weight, void* workspace, size_t workspace_bytes,
                                 int B, int C, int CO, int h, int w, int pieces, void* stream) {
   if (!xp || !g_y || !g_weight || !workspace) return fail(SMD_E_INVALID, "null pointer");
-  if (pieces != 2 && pieces != 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 2 or 3, not %d", pieces);
+  if (pieces < 1 || pieces > 3) return fail(SMD_E_UNSUPPORTED, "pieces must be 1 (bfloat16 tensors), 2 or 3 (float tensors), not %d", pieces);
   if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
   if (!mfma_wgt_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the weight gradient serves CO %% 32 == 0, or CO == 16 with C == 16 | 32, not C=%d CO=%d", C, CO);
   if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");

@@ -25,8 +25,10 @@ __device__ __forceinline__ float head_act(float v, int act) { return act == 1 ? 
 // R output rows per thread.  SPLIT = false: the block's four waves are four row groups (a tile of 64 x 4R outputs), every wave walks all channels.
 // SPLIT = true (small images, many channels: the coarse pyramid levels): the four waves share ONE row group (64 x R outputs) and take the channels
 // c = wave, wave + 4, ...; their partial sums meet in LDS and wave 0 adds them in wave order.
-template <int R, bool SPLIT>
-__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ xp, const float* __restrict__ wgt, const float* __restrict__ bias, float* __restrict__ y,
+// TX: the padded activation's element type (float, or bf16 under bf16 autocast: the glue kernels then write bf16 — half the bytes of an HBM-bound kernel;
+// weights, bias, the output and every sum stay fp32).
+template <int R, bool SPLIT, typename TX>
+__global__ __launch_bounds__(256) void k_head_fwd(const TX* __restrict__ xp, const float* __restrict__ wgt, const float* __restrict__ bias, float* __restrict__ y,
                                                   int C, int h, int w, int act) {
   __shared__ float red[SPLIT ? 3 : 1][R][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ xp, 
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
   if (live) {
     const int c0 = SPLIT ? wv : 0, cs = SPLIT ? 4 : 1;
-    const float* p = xp + (((size_t)b*C + c0)*H + y0)*W + x;
+    const TX* p = xp + (((size_t)b*C + c0)*H + y0)*W + x;
 #pragma unroll SPLIT ? 4 : 2   // (a split wave has few outputs and a long chain: more channels' loads in flight)
     for (int c = c0; c < C; c += cs, p += (size_t)cs*H*W) {
       const float* wc = wgt + c*9;               // wave-uniform: scalar loads
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ xp, 
       for (int r = 0; r < R + 2; ++r) {
         const bool in = r < rows + 2;            // (rows beyond the image's last: not read)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v[r][k] = in ? p[(size_t)r*W + k] : 0.f;
+        for (int k = 0; k < 3; ++k) v[r][k] = in ? ld_as_float<TX>(p, (size_t)r*W + k) : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -86,7 +88,8 @@ __device__ __forceinline__ float head_gp(const float* __restrict__ gy, const flo
 }
 
 // grid (ceil(W/64), ceil(H/4), B * G): channel group blockIdx.z % G takes channels [g * Cg, (g + 1) * Cg)
-__global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ wgt, float* __restrict__ g_xp,
+template <typename TX>
+__global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ wgt, TX* __restrict__ g_xp,
                                                        int C, int h, int w, int G, int Cg, int act) {
   const int W = w + 2, H = h + 2;
   const int q = blockIdx.x*64 + (threadIdx.x & 63), p = blockIdx.y*4 + (threadIdx.x >> 6), b = blockIdx.z/G, g = blockIdx.z - b*G;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) nb[ky][kx] = head_gp(gy, y, base, p - ky, q - kx, h, w, act);
   const int c0 = g*Cg, c1 = min(c0 + Cg, C);
-  float* o = g_xp + (((size_t)b*C + c0)*H + p)*W + q;
+  TX* o = g_xp + (((size_t)b*C + c0)*H + p)*W + q;
   for (int c = c0; c < c1; ++c, o += (size_t)H*W) {
     const float* wc = wgt + c*9;
     float s = 0.f;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) s = fmaf(wc[ky*3 + kx], nb[ky][kx], s);
-    *o = s;
+    st_from_float<TX>(o, 0, s);
   }
 }
 
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
 // set of nine sums (one tile per block: the block's reduction costs as much as its sums; a whole column: too few waves for the loads' latency); channel C
 // is the bias' job (sum of gp).  partial[(c * T + blockIdx.y * tiles_x + blockIdx.x) * 9 + k], T = tiles_x * B * chunks_y.
 constexpr int kHeadWgtTiles = 3;
-__global__ __launch_bounds__(256) void k_head_bwd_wgt(const float* __restrict__ xp, const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ partial,
+template <typename TX>
+__global__ __launch_bounds__(256) void k_head_bwd_wgt(const TX* __restrict__ xp, const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ partial,
                                                       int C, int h, int w, int chunks_y, int act) {
   __shared__ float red[4][9];
   const int W = w + 2, H = h + 2;
@@ -135,13 +139,13 @@ __global__ __launch_bounds__(256) void k_head_bwd_wgt(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < kHeadRows; ++r) acc[0] += g[r];
       } else {
-        const float* p = xp + (((size_t)b*C + c)*H + y0)*W + x;
+        const TX* p = xp + (((size_t)b*C + c)*H + y0)*W + x;
         float v[kHeadRows + 2][3];
 #pragma unroll
         for (int r = 0; r < kHeadRows + 2; ++r) {
           const bool in = r < rows + 2;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) v[r][k] = in ? p[(size_t)r*W + k] : 0.f;
+          for (int k = 0; k < 3; ++k) v[r][k] = in ? ld_as_float<TX>(p, (size_t)r*W + k) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < kHeadRows; ++r)
@@ -183,19 +187,25 @@ __global__ __launch_bounds__(64) void k_head_wgt_finalize(const float* __restric
 static inline int head_wgt_chunks(int h) { return ceil_div(ceil_div(h, kHeadTileH), kHeadWgtTiles); }
 size_t conv_head_partials(int B, int C, int h, int w) { return (size_t)(C + 1)*ceil_div(w, kHeadTileW)*B*head_wgt_chunks(h)*9; }
 
-hipError_t launch_conv_head_fwd(const float* xp, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st) {
+template <typename TX>
+static void head_fwd_t(const TX* xp, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st) {
   const int tx = ceil_div(w, kHeadTileW);
   if ((long long)B*tx*ceil_div(h, kHeadTileH)*4 >= kHeadEnoughWaves || C < 8)
-    hipLaunchKernelGGL((k_head_fwd<kHeadRows, false>), dim3(tx, ceil_div(h, kHeadTileH), B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
+    hipLaunchKernelGGL((k_head_fwd<kHeadRows, false, TX>), dim3(tx, ceil_div(h, kHeadTileH), B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
   else if ((long long)B*tx*ceil_div(h, 2)*4 >= kHeadEnoughWaves)
-    hipLaunchKernelGGL((k_head_fwd<2, true>), dim3(tx, ceil_div(h, 2), B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
+    hipLaunchKernelGGL((k_head_fwd<2, true, TX>), dim3(tx, ceil_div(h, 2), B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
   else
-    hipLaunchKernelGGL((k_head_fwd<1, true>), dim3(tx, h, B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
+    hipLaunchKernelGGL((k_head_fwd<1, true, TX>), dim3(tx, h, B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
+}
+hipError_t launch_conv_head_fwd(const void* xp, int x_bf16, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st) {
+  if (x_bf16) head_fwd_t<bf16>((const bf16*)xp, wgt, bias, y, B, C, h, w, act, st);
+  else head_fwd_t<float>((const float*)xp, wgt, bias, y, B, C, h, w, act, st);
   return hipGetLastError();
 }
 
-hipError_t launch_conv_head_bwd(const float* xp, const float* wgt, const float* y, const float* gy, float* g_xp, float* g_w, float* g_bias, float* partial,
-                                int B, int C, int h, int w, int act, hipStream_t st) {
+template <typename TX>
+static void head_bwd_t(const TX* xp, const float* wgt, const float* y, const float* gy, TX* g_xp, float* g_w, float* g_bias, float* partial,
+                       int B, int C, int h, int w, int act, hipStream_t st) {
   if (g_xp) {
     const long long waves = (long long)B*ceil_div(w + 2, 64)*ceil_div(h + 2, 4)*4;
     int G = (int)((kHeadEnoughWaves + waves - 1)/waves);
@@ -204,14 +214,19 @@ hipError_t launch_conv_head_bwd(const float* xp, const float* wgt, const float* 
     if ((long long)B*G > 65535) G = 65535/B > 0 ? 65535/B : 1;
     const int Cg = ceil_div(C, G);
     G = ceil_div(C, Cg);
-    hipLaunchKernelGGL(k_head_bwd_data, dim3(ceil_div(w + 2, 64), ceil_div(h + 2, 4), B*G), dim3(256), 0, st, gy, y, wgt, g_xp, C, h, w, G, Cg, act);
+    hipLaunchKernelGGL((k_head_bwd_data<TX>), dim3(ceil_div(w + 2, 64), ceil_div(h + 2, 4), B*G), dim3(256), 0, st, gy, y, wgt, g_xp, C, h, w, G, Cg, act);
   }
   if (g_w) {
     const int tx = ceil_div(w, kHeadTileW);
     const int cy = head_wgt_chunks(h);
-    hipLaunchKernelGGL(k_head_bwd_wgt, dim3(tx, B*cy, C + 1), dim3(256), 0, st, xp, gy, y, partial, C, h, w, cy, act);
+    hipLaunchKernelGGL((k_head_bwd_wgt<TX>), dim3(tx, B*cy, C + 1), dim3(256), 0, st, xp, gy, y, partial, C, h, w, cy, act);
     hipLaunchKernelGGL(k_head_wgt_finalize, dim3(C + 1), dim3(64), 0, st, partial, (unsigned)(tx*B*cy), C, g_w, g_bias);
   }
+}
+hipError_t launch_conv_head_bwd(const void* xp, int x_bf16, const float* wgt, const float* y, const float* gy, void* g_xp, float* g_w, float* g_bias, float* partial,
+                                int B, int C, int h, int w, int act, hipStream_t st) {
+  if (x_bf16) head_bwd_t<bf16>((const bf16*)xp, wgt, y, gy, (bf16*)g_xp, g_w, g_bias, partial, B, C, h, w, act, st);
+  else head_bwd_t<float>((const float*)xp, wgt, y, gy, (float*)g_xp, g_w, g_bias, partial, B, C, h, w, act, st);
   return hipGetLastError();
 }
 

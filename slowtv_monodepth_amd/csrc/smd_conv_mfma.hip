@@ -40,6 +40,16 @@ template <int P> __device__ __forceinline__ void split_pair(float a, float b, un
   if constexpr (P > 2) { a -= bf16_lo(p[1]); b -= bf16_hi(p[1]); p[2] = pack_bf16_rne(a, b); }
 }
 __device__ __forceinline__ bf16x8 as_frag(const uint4& u) { return __builtin_bit_cast(bf16x8, u); }
+// bfloat16 tensors (the decoder under bf16 autocast, `pieces` = 1): an element IS its one piece — loaded as 16 raw bits, two of them a dword
+template <int P> __device__ __forceinline__ void split_pair(unsigned short a, unsigned short b, unsigned (&p)[P]) {
+  static_assert(P == 1, "bfloat16 operands have one piece");
+  p[0] = (unsigned)a | ((unsigned)b << 16);
+}
+template <typename T> struct RawOf { typedef float type; };                  // what a staging load leaves in a register
+template <> struct RawOf<bf16> { typedef unsigned short type; };
+template <typename T> __device__ __forceinline__ void store_out(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void store_out<bf16>(bf16* p, size_t i, float v) { p[i] = __float2bfloat16(v); }
 
 // ---- weights -> bf16 pieces in the A-operand order of both convolution forms (one launch per layer and step; the backward reads what the forward packed) ----
 // forward form:       Wt[m = co][k = c][tap]      = w[co][c][tap]          (M = CO, CK = C)
@@ -88,8 +98,8 @@ template <int TC> struct ConvTile {
   static constexpr int PW = TC + 2, PH = TRB + 2, NPIX = PW*PH;
 };
 
-template <int TC, int P, bool BWD>
-__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, const uint4* __restrict__ wp, float* __restrict__ out,
+template <int TC, int P, bool BWD, typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_conv_mfma(const TI* __restrict__ in_, const uint4* __restrict__ wp, TO* __restrict__ out,
                                                    int CK, int M, int hi, int wi, int ho, int wo, int KS, int kc_per_split, size_t split_stride,
                                                    unsigned gx, unsigned gy, unsigned gz) {
   using T = ConvTile<TC>;
@@ -110,7 +120,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
   const int x0 = (int)(tl % gx)*TC, y0 = (int)((tl/gx) % gy)*T::TRB, b = (int)(tl/(gx*gy));
   const int KC = CK >> 4, kc0 = ks*kc_per_split, kc1 = min(KC, kc0 + kc_per_split);
   const size_t plane = (size_t)hi*wi;
-  const float* src = in + (size_t)b*CK*plane;
+  typedef typename RawOf<TI>::type R;
+  const R* src = reinterpret_cast<const R*>(in_) + (size_t)b*CK*plane;
 
   // staging: an item = 8 channels of one patch pixel; its address inside a channel plane does not depend on the chunk
   constexpr int ITEMS = 2*NPIX, TRIPS = (ITEMS + 255)/256;
@@ -124,15 +135,15 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
     if (BWD) pofs[t] = (yy >= 0 && yy < hi && xx >= 0 && xx < wi) ? yy*wi + xx : -1;
     else pofs[t] = min(yy, hi - 1)*wi + min(xx, wi - 1);         // (beyond the image: any valid address, those outputs are not stored)
   }
-  float v[TRIPS][8];
+  R v[TRIPS][8];
   auto request = [&](int kc) {                                    // every load of a chunk is issued before anything waits for one
 #pragma unroll
     for (int t = 0; t < TRIPS; ++t) {
       const int item = min(t*256 + (int)threadIdx.x, ITEMS - 1);
       const int half = item >= NPIX ? 1 : 0;
-      const float* p = src + (size_t)(kc*16 + half*8)*plane + (size_t)max(pofs[t], 0);
+      const R* p = src + (size_t)(kc*16 + half*8)*plane + (size_t)max(pofs[t], 0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[t][e] = (!BWD || pofs[t] >= 0) ? p[(size_t)e*plane] : 0.f;
+      for (int e = 0; e < 8; ++e) v[t][e] = (!BWD || pofs[t] >= 0) ? p[(size_t)e*plane] : R(0);
     }
   };
   auto file = [&](int buf) {
@@ -209,7 +220,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
     __syncthreads();                                              // the other patch is complete, and nobody reads this one any more
   }
   // D[row = output channel][column = pixel]: a register is 32 consecutive pixels of one channel per half wave (128-byte runs)
-  float* dst = out + (size_t)ks*split_stride;
+  // (a K split's partial output is always fp32: `out` is then the workspace the splits' sum reads)
+  float* dstf = reinterpret_cast<float*>(out) + (size_t)ks*split_stride;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int r = (TC == 64) ? wv : 2*wv + nt, cb = (TC == 64) ? nt*32 : 0;
@@ -218,7 +230,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
         const int m = mg*32 + (rr & 3) + 8*(rr >> 2) + 4*g;
-        dst[(((size_t)b*M + m)*ho + y)*wo + x] = acc[nt][rr] + lo[nt][rr];
+        const size_t o = (((size_t)b*M + m)*ho + y)*wo + x;
+        if (KS > 1) dstf[o] = acc[nt][rr] + lo[nt][rr];
+        else store_out<TO>(out, o, acc[nt][rr] + lo[nt][rr]);
       }
     }
   }
@@ -257,8 +271,8 @@ __global__ __launch_bounds__(256) void k_conv_pack_w16(const float* __restrict__
   }
 }
 
-template <int NCH, int P, bool BWD>
-__global__ __launch_bounds__(256) void k_conv16_mfma(const float* __restrict__ in, const uint4* __restrict__ wp, float* __restrict__ out,
+template <int NCH, int P, bool BWD, typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_conv16_mfma(const TI* __restrict__ in_, const uint4* __restrict__ wp, TO* __restrict__ out,
                                                      int hi, int wi, int ho, int wo, unsigned gx, unsigned gy, unsigned gz) {
   using T = ConvTile<64>;
   constexpr int NPIX = T::NPIX, PW = T::PW, off = BWD ? 2 : 0, NPROD = n_products(P), CK = 16*NCH;
@@ -269,7 +283,8 @@ __global__ __launch_bounds__(256) void k_conv16_mfma(const float* __restrict__ i
   if (lid >= nblk) return;
   const int x0 = (int)(lid % gx)*64, y0 = (int)((lid/gx) % gy)*4, b = (int)(lid/(gx*gy));
   const size_t plane = (size_t)hi*wi;
-  const float* src = in + (size_t)b*CK*plane;
+  typedef typename RawOf<TI>::type R;
+  const R* src = reinterpret_cast<const R*>(in_) + (size_t)b*CK*plane;
 
   bf16x8 Wr[NCH][5][P];                                           // every weight fragment of the layer: requested first, used last
 #pragma unroll
@@ -300,14 +315,14 @@ __global__ __launch_bounds__(256) void k_conv16_mfma(const float* __restrict__ i
 
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    float v[TRIPS][8];
+    R v[TRIPS][8];
 #pragma unroll
     for (int t = 0; t < TRIPS; ++t) {                             // every load of the chunk before its first use
       const int item = min(t*256 + (int)threadIdx.x, ITEMS - 1);
       const int half = item >= NPIX ? 1 : 0;
-      const float* p = src + (size_t)(ch*16 + half*8)*plane + (size_t)max(pofs[t], 0);
+      const R* p = src + (size_t)(ch*16 + half*8)*plane + (size_t)max(pofs[t], 0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[t][e] = (!BWD || pofs[t] >= 0) ? p[(size_t)e*plane] : 0.f;
+      for (int e = 0; e < 8; ++e) v[t][e] = (!BWD || pofs[t] >= 0) ? p[(size_t)e*plane] : R(0);
     }
     if (ch > 0) __syncthreads();                                  // nobody reads the previous chunk any more
 #pragma unroll
@@ -347,21 +362,35 @@ __global__ __launch_bounds__(256) void k_conv16_mfma(const float* __restrict__ i
   for (int r = 0; r < 4; ++r) {
     const int y = y0 + r;
     if (y >= ho || x >= wo) continue;
-    float* dstp = out + (((size_t)b*16 + i)*ho + y)*wo + x;
+    TO* dstp = out + (((size_t)b*16 + i)*ho + y)*wo + x;
     const f32x4v o = acc[r] + lo[r];
-    if (x + 3 < wo) *reinterpret_cast<f32x4u*>(dstp) = o;
-    else { dstp[0] = o[0]; if (x + 1 < wo) dstp[1] = o[1]; if (x + 2 < wo) dstp[2] = o[2]; }
+    if constexpr (sizeof(TO) == 4) {
+      if (x + 3 < wo) *reinterpret_cast<f32x4u*>(dstp) = o;
+      else { dstp[0] = o[0]; if (x + 1 < wo) dstp[1] = o[1]; if (x + 2 < wo) dstp[2] = o[2]; }
+    } else {                                                      // bfloat16: dword stores where the row pitch keeps pixel pairs 4-byte aligned
+      const unsigned lo2 = pack_bf16_rne(o[0], o[1]), hi2 = pack_bf16_rne(o[2], o[3]);
+      if (x + 3 < wo && (wo & 1) == 0) { reinterpret_cast<unsigned*>(dstp)[0] = lo2; reinterpret_cast<unsigned*>(dstp)[1] = hi2; }
+      else {
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(dstp);
+        d16[0] = (unsigned short)(lo2 & 0xffffu);
+        if (x + 1 < wo) d16[1] = (unsigned short)(lo2 >> 16);
+        if (x + 2 < wo) d16[2] = (unsigned short)(hi2 & 0xffffu);
+        if (x + 3 < wo) d16[3] = (unsigned short)(hi2 >> 16);
+      }
+    }
   }
 }
 
 // out = the sum of the K splits' partial outputs, in split order (the coarse decoder levels: few pixels, thousands of K — the splits are what fills the chip)
-__global__ __launch_bounds__(256) void k_conv_split_sum(const float* __restrict__ part, float* __restrict__ out, size_t n4, int KS) {
+template <typename TO>
+__global__ __launch_bounds__(256) void k_conv_split_sum(const float* __restrict__ part, TO* __restrict__ out, size_t n4, int KS) {
   const size_t i = (size_t)blockIdx.x*256 + threadIdx.x;
   if (i >= n4) return;
   const f4* p = reinterpret_cast<const f4*>(part);
   f4 s = p[i];
   for (int k = 1; k < KS; ++k) s += p[(size_t)k*n4 + i];
-  reinterpret_cast<f4*>(out)[i] = s;
+  if constexpr (sizeof(TO) == 4) reinterpret_cast<f4*>(out)[i] = s;
+  else { unsigned* o = reinterpret_cast<unsigned*>(out) + 2*i; o[0] = pack_bf16_rne(s.x, s.y); o[1] = pack_bf16_rne(s.z, s.w); }
 }
 
 // ---- weight gradient ----
@@ -381,8 +410,8 @@ struct WgradTile {
   static constexpr int GROW = 16, GCH = 2*GROW + 4;     // dwords: a row slot = 32 bf16, a channel = 2 slots + 16 bytes (144 B = 16 x 9)
 };
 
-template <int COT, int CT, int P>
-__global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const float* __restrict__ xp, const float* __restrict__ gy, float* __restrict__ partial,
+template <int COT, int CT, int P, typename TI>
+__global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const TI* __restrict__ xp, const TI* __restrict__ gy, float* __restrict__ partial,
                                                          int C, int CO, int h, int w, int rows_per_block) {
   using T = WgradTile<COT, CT>;
   constexpr int COB = T::COB, CB = T::CB, KS = T::KS, XROW = T::XROW, XCH = T::XCH, GROW = T::GROW, GCH = T::GCH, NPROD = n_products(P);
@@ -398,13 +427,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const float* __restrict
   const int cg = blockIdx.z % CGRP, cog = (blockIdx.z/CGRP) % COGRP, b = blockIdx.z/(CGRP*COGRP);
   const int x0 = blockIdx.x*32, ybeg = blockIdx.y*rows_per_block, nrows = min(rows_per_block, h - ybeg);
   const int W = w + 2, H = h + 2;
-  const float* xsrc = xp + (size_t)b*C*H*W;
-  const float* gsrc = gy + ((size_t)b*CO + (size_t)cog*COB)*h*w;
+  typedef typename RawOf<TI>::type R;
+  const R* xsrc = reinterpret_cast<const R*>(xp) + (size_t)b*C*H*W;
+  const R* gsrc = reinterpret_cast<const R*>(gy) + ((size_t)b*CO + (size_t)cog*COB)*h*w;
 
   constexpr int XITEMS = CB*17, XTRIPS = (XITEMS + 255)/256;     // an item = two adjacent columns of one channel's row
   constexpr int GITEMS = COB*16, GTRIPS = GITEMS/256;
   static_assert(GITEMS % 256 == 0, "g_y items per thread");
-  float xv[XTRIPS][2], gv[GTRIPS][2];
+  R xv[XTRIPS][2], gv[GTRIPS][2];
   auto load_x = [&](int yy) {                                     // padded row yy (clamped: rows past the strip are requested but never used)
     yy = min(yy, H - 1);
 #pragma unroll
@@ -412,7 +442,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const float* __restrict
       const int item = t*256 + (int)threadIdx.x;
       const int ch = min(item/17, CB - 1), pr = item % 17;
       const int c = min(cg*CB + ch, C - 1);
-      const float* rowp = xsrc + ((size_t)c*H + yy)*W;
+      const R* rowp = xsrc + ((size_t)c*H + yy)*W;
       xv[t][0] = rowp[min(x0 + 2*pr, W - 1)];
       xv[t][1] = rowp[min(x0 + 2*pr + 1, W - 1)];
     }
@@ -437,9 +467,9 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const float* __restrict
       const int co = item >> 4, pr = item & 15;
       const int xa = x0 + 2*pr;
       const bool yok = y < ybeg + nrows;
-      const float* rowp = gsrc + ((size_t)co*h + (yok ? y : 0))*w;
-      gv[t][0] = (yok && xa < w) ? rowp[xa] : 0.f;
-      gv[t][1] = (yok && xa + 1 < w) ? rowp[xa + 1] : 0.f;
+      const R* rowp = gsrc + ((size_t)co*h + (yok ? y : 0))*w;
+      gv[t][0] = (yok && xa < w) ? rowp[xa] : R(0);
+      gv[t][1] = (yok && xa + 1 < w) ? rowp[xa + 1] : R(0);
     }
   };
   auto file_g = [&](int slot) {
@@ -538,8 +568,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const float* __restrict
 // arithmetic is cheap (128-192 B per pixel for 2304-4608 multiply-adds), so the structure is the plain one: a block of four waves stages a tile of 32 columns
 // x 4 rows (g_y) and its 34 x 6 halo tile of every input channel, a wave takes one row (one K step: 54 NC MFMAs), the block walks down `rows` rows and
 // leaves one set of sums per block ([tap][co][c], its waves' accumulators added in LDS in wave order).
-template <int NC, int P>
-__global__ __launch_bounds__(256) void k_conv16_wgrad_mfma(const float* __restrict__ xp, const float* __restrict__ gy, float* __restrict__ partial, int h, int w, int rows) {
+template <int NC, int P, typename TI>
+__global__ __launch_bounds__(256) void k_conv16_wgrad_mfma(const TI* __restrict__ xp, const TI* __restrict__ gy, float* __restrict__ partial, int h, int w, int rows) {
   constexpr int C = 16*NC, NPROD = n_products(P);
   constexpr int XROW = 20, XCH = 6*XROW + 4;            // dwords: a row = 40 bf16 (34 used), a channel = 6 rows + 16 bytes (496 B = 16 x 31)
   constexpr int GROW = 16, GCH = 4*GROW + 4;            // dwords: a row = 32 bf16, a channel = 4 rows + 16 bytes (272 B = 16 x 17)
@@ -550,8 +580,9 @@ __global__ __launch_bounds__(256) void k_conv16_wgrad_mfma(const float* __restri
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
   const int x0 = blockIdx.x*32, ybeg = blockIdx.y*rows, yend = min(ybeg + rows, h), b = blockIdx.z;
   const int W = w + 2, H = h + 2;
-  const float* xsrc = xp + (size_t)b*C*H*W;
-  const float* gsrc = gy + (size_t)b*16*h*w;
+  typedef typename RawOf<TI>::type R;
+  const R* xsrc = reinterpret_cast<const R*>(xp) + (size_t)b*C*H*W;
+  const R* gsrc = reinterpret_cast<const R*>(gy) + (size_t)b*16*h*w;
   f32x4v acc[9][NC];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -561,12 +592,12 @@ __global__ __launch_bounds__(256) void k_conv16_wgrad_mfma(const float* __restri
   constexpr int XITEMS = C*6*17, XTRIPS = (XITEMS + 255)/256;     // an item = two adjacent columns of one row of one channel
   constexpr int GITEMS = 16*4*16, GTRIPS = GITEMS/256;
   for (int y0 = ybeg; y0 < yend; y0 += 4) {
-    float xv[XTRIPS][2], gv[GTRIPS][2];
+    R xv[XTRIPS][2], gv[GTRIPS][2];
 #pragma unroll
     for (int t = 0; t < XTRIPS; ++t) {                            // every load of the tile before its first use
       const int item = min(t*256 + (int)threadIdx.x, XITEMS - 1);
       const int pr = item % 17, rc = item/17, r = rc % 6, c = rc/6;
-      const float* rowp = xsrc + ((size_t)c*H + min(y0 + r, H - 1))*W;
+      const R* rowp = xsrc + ((size_t)c*H + min(y0 + r, H - 1))*W;
       xv[t][0] = rowp[min(x0 + 2*pr, W - 1)];
       xv[t][1] = rowp[min(x0 + 2*pr + 1, W - 1)];
     }
@@ -576,9 +607,9 @@ __global__ __launch_bounds__(256) void k_conv16_wgrad_mfma(const float* __restri
       const int pr = item & 15, r = (item >> 4) & 3, co = item >> 6;
       const int yy = y0 + r, xa = x0 + 2*pr;
       const bool yok = yy < yend;
-      const float* rowp = gsrc + ((size_t)co*h + (yok ? yy : 0))*w;
-      gv[t][0] = (yok && xa < w) ? rowp[xa] : 0.f;
-      gv[t][1] = (yok && xa + 1 < w) ? rowp[xa + 1] : 0.f;
+      const R* rowp = gsrc + ((size_t)co*h + (yok ? yy : 0))*w;
+      gv[t][0] = (yok && xa < w) ? rowp[xa] : R(0);
+      gv[t][1] = (yok && xa + 1 < w) ? rowp[xa + 1] : R(0);
     }
     if (y0 > ybeg) __syncthreads();                               // nobody reads the previous tile any more
 #pragma unroll
@@ -685,15 +716,20 @@ size_t conv_mfma_wgrad_partials(int B, int C, int CO, int h, int w) {
 static size_t thin_packed_elems(int C, int pieces) { return (size_t)(C >> 4)*5*pieces*512; }
 size_t conv_mfma_packed_elems(int C, int CO, int pieces) { return std::max((size_t)CO*C*9*pieces, CO == 16 ? thin_packed_elems(C, pieces) : (size_t)0); }
 
+// ---- launches.  `pieces`: 3 (or the experiment's 2): fp32 tensors, split operands; 1: bfloat16 tensors in and out (fp32 weights, packed as their bf16 rounding;
+// fp32 accumulation, fp32 weight gradient) — the decoder under bf16 autocast ----
+#define SMD_BY_PIECES(pieces, CALL) do { if ((pieces) == 3) { CALL(3, float); } else if ((pieces) == 2) { CALL(2, float); } else { CALL(1, bf16); } } while (0)
+
 // 16 output channels: the thin operand image (forward: C = 16 or 32; data gradient: the thin image for C = 16, the wide one — 32 rows — for C = 32)
-template <int P>
-static void launch_conv16(const float* in, const void* wp, float* out, int B, int CK, bool bwd, int hi, int wi, int ho, int wo, hipStream_t st) {
+template <int P, typename T>
+static void launch_conv16(const void* in, const void* wp, void* out, int B, int CK, bool bwd, int hi, int wi, int ho, int wo, hipStream_t st) {
   const unsigned gx = ceil_div(wo, 64), gy = ceil_div(ho, 4), gz = B;
   const dim3 grid(8*(unsigned)ceil_div((long long)gx*gy*gz, 8ll));
   const uint4* wq = (const uint4*)wp;
-  if (bwd) hipLaunchKernelGGL((k_conv16_mfma<1, P, true>), grid, dim3(256), 0, st, in, wq, out, hi, wi, ho, wo, gx, gy, gz);
-  else if (CK == 16) hipLaunchKernelGGL((k_conv16_mfma<1, P, false>), grid, dim3(256), 0, st, in, wq, out, hi, wi, ho, wo, gx, gy, gz);
-  else hipLaunchKernelGGL((k_conv16_mfma<2, P, false>), grid, dim3(256), 0, st, in, wq, out, hi, wi, ho, wo, gx, gy, gz);
+  const T* i_ = (const T*)in; T* o_ = (T*)out;
+  if (bwd) hipLaunchKernelGGL((k_conv16_mfma<1, P, true, T, T>), grid, dim3(256), 0, st, i_, wq, o_, hi, wi, ho, wo, gx, gy, gz);
+  else if (CK == 16) hipLaunchKernelGGL((k_conv16_mfma<1, P, false, T, T>), grid, dim3(256), 0, st, i_, wq, o_, hi, wi, ho, wo, gx, gy, gz);
+  else hipLaunchKernelGGL((k_conv16_mfma<2, P, false, T, T>), grid, dim3(256), 0, st, i_, wq, o_, hi, wi, ho, wo, gx, gy, gz);
 }
 
 hipError_t launch_conv_mfma_pack(const float* w, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, hipStream_t st) {
@@ -701,26 +737,27 @@ hipError_t launch_conv_mfma_pack(const float* w, void* wp_fwd, void* wp_bwd, int
     void* thin_bwd = (C == 16) ? wp_bwd : nullptr;
     if (wp_fwd || thin_bwd) {
       const dim3 g16(ceil_div((C >> 4)*5*512, 256));
-      if (pieces == 3) hipLaunchKernelGGL((k_conv_pack_w16<3>), g16, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)thin_bwd, C);
-      else hipLaunchKernelGGL((k_conv_pack_w16<2>), g16, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)thin_bwd, C);
+#define SMD_CALL(P, T) hipLaunchKernelGGL((k_conv_pack_w16<P>), g16, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)thin_bwd, C)
+      SMD_BY_PIECES(pieces, SMD_CALL);
+#undef SMD_CALL
     }
     if (C == 16 || !wp_bwd) return hipGetLastError();
     wp_fwd = nullptr;                                             // C = 32: the data gradient is a 32-row layer of the wide kernel
   }
   const dim3 grid(ceil_div(CO*C*9, 256));
-  if (pieces == 3) hipLaunchKernelGGL((k_conv_pack_w<3>), grid, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)wp_bwd, CO, C);
-  else hipLaunchKernelGGL((k_conv_pack_w<2>), grid, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)wp_bwd, CO, C);
+#define SMD_CALL(P, T) hipLaunchKernelGGL((k_conv_pack_w<P>), grid, dim3(256), 0, st, w, (unsigned short*)wp_fwd, (unsigned short*)wp_bwd, CO, C)
+  SMD_BY_PIECES(pieces, SMD_CALL);
+#undef SMD_CALL
   return hipGetLastError();
 }
 
-// Launch shape of the forward / data-gradient form: tile columns, channel tiles per wave, K splits (each split a whole number of 16-channel chunks).
-struct ConvShape { int TC, TRB, MT, KS, kcs; unsigned gx, gy, gz; dim3 grid; size_t out_elems; };
+// Launch shape of the forward / data-gradient form: tile columns, K splits (each split a whole number of 16-channel chunks).
+struct ConvShape { int TC, TRB, KS, kcs; unsigned gx, gy, gz; dim3 grid; size_t out_elems; };
 static ConvShape conv_shape(int B, int CK, int M, int ho, int wo) {
   ConvShape s;
   s.TC = wo >= 48 ? 64 : 32; s.TRB = wo >= 48 ? 4 : 8;
   const long long tiles = (long long)ceil_div(wo, s.TC)*ceil_div(ho, s.TRB)*B;
-  s.MT = 1;                                                      // (two channel tiles per wave: 92 KB of LDS and 300 registers — one block per CU; not built)
-  const long long base = tiles*(M/(32*s.MT));
+  const long long base = tiles*(M/32);
   const int KC = CK >> 4;
   int ks = 1;
   if (base < 384) ks = (int)std::min<long long>(std::max(KC/2, 1), (512 + base - 1)/base);   // under 1.5 blocks per CU: split K, at least two chunks per split
@@ -735,66 +772,71 @@ size_t conv_mfma_split_elems(int B, int CK, int M, int ho, int wo) {
   return s.KS > 1 ? (size_t)s.KS*s.out_elems : 0;
 }
 
-template <int P, bool BWD>
-static void launch_conv_form(const float* in, const void* wp, float* out, float* split_ws, int B, int CK, int M, int hi, int wi, int ho, int wo, hipStream_t st) {
+template <int P, bool BWD, typename T>
+static void launch_conv_form(const void* in, const void* wp, void* out, float* split_ws, int B, int CK, int M, int hi, int wi, int ho, int wo, hipStream_t st) {
   const ConvShape s = conv_shape(B, CK, M, ho, wo);
   const uint4* wq = (const uint4*)wp;
-  float* dst = s.KS > 1 ? split_ws : out;
-  if (s.TC == 64) hipLaunchKernelGGL((k_conv_mfma<64, P, BWD>), s.grid, dim3(256), 0, st, in, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
-  else hipLaunchKernelGGL((k_conv_mfma<32, P, BWD>), s.grid, dim3(256), 0, st, in, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
+  const T* i_ = (const T*)in;
+  T* dst = s.KS > 1 ? reinterpret_cast<T*>(split_ws) : (T*)out;    // (the kernel writes a split's partial output as fp32 whatever T)
+  if (s.TC == 64) hipLaunchKernelGGL((k_conv_mfma<64, P, BWD, T, T>), s.grid, dim3(256), 0, st, i_, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
+  else hipLaunchKernelGGL((k_conv_mfma<32, P, BWD, T, T>), s.grid, dim3(256), 0, st, i_, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
   if (s.KS > 1) {
     const size_t n4 = s.out_elems/4;                              // (B M ho wo is a multiple of 4: M is a multiple of 32)
-    hipLaunchKernelGGL(k_conv_split_sum, dim3((unsigned)((n4 + 255)/256)), dim3(256), 0, st, split_ws, out, n4, s.KS);
+    hipLaunchKernelGGL((k_conv_split_sum<T>), dim3((unsigned)((n4 + 255)/256)), dim3(256), 0, st, split_ws, (T*)out, n4, s.KS);
   }
 }
 
 // y (B, CO, h, w) = conv3x3(xp (B, C, h + 2, w + 2)): C % 16 == 0, CO % 32 == 0
 size_t conv_mfma_fwd_split_elems(int B, int C, int CO, int h, int w) { return CO % 32 ? 0 : conv_mfma_split_elems(B, C, CO, h, w); }
 size_t conv_mfma_bwd_split_elems(int B, int C, int CO, int h, int w) { return C % 32 ? 0 : conv_mfma_split_elems(B, CO, C, h + 2, w + 2); }
-hipError_t launch_conv_mfma_fwd(const float* xp, const void* wp_fwd, float* y, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+hipError_t launch_conv_mfma_fwd(const void* xp, const void* wp_fwd, void* y, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
   if (CO == 16) {
-    if (pieces == 3) launch_conv16<3>(xp, wp_fwd, y, B, C, false, h + 2, w + 2, h, w, st);
-    else launch_conv16<2>(xp, wp_fwd, y, B, C, false, h + 2, w + 2, h, w, st);
+#define SMD_CALL(P, T) launch_conv16<P, T>(xp, wp_fwd, y, B, C, false, h + 2, w + 2, h, w, st)
+    SMD_BY_PIECES(pieces, SMD_CALL);
+#undef SMD_CALL
     return hipGetLastError();
   }
-  if (pieces == 3) launch_conv_form<3, false>(xp, wp_fwd, y, split_ws, B, C, CO, h + 2, w + 2, h, w, st);
-  else launch_conv_form<2, false>(xp, wp_fwd, y, split_ws, B, C, CO, h + 2, w + 2, h, w, st);
+#define SMD_CALL(P, T) launch_conv_form<P, false, T>(xp, wp_fwd, y, split_ws, B, C, CO, h + 2, w + 2, h, w, st)
+  SMD_BY_PIECES(pieces, SMD_CALL);
+#undef SMD_CALL
   return hipGetLastError();
 }
 // g_xp (B, C, h + 2, w + 2) from g_y (B, CO, h, w): CO % 16 == 0, C % 32 == 0
-hipError_t launch_conv_mfma_bwd_data(const float* gy, const void* wp_bwd, float* g_xp, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+hipError_t launch_conv_mfma_bwd_data(const void* gy, const void* wp_bwd, void* g_xp, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
   if (CO == 16 && C == 16) {
-    if (pieces == 3) launch_conv16<3>(gy, wp_bwd, g_xp, B, 16, true, h, w, h + 2, w + 2, st);
-    else launch_conv16<2>(gy, wp_bwd, g_xp, B, 16, true, h, w, h + 2, w + 2, st);
+#define SMD_CALL(P, T) launch_conv16<P, T>(gy, wp_bwd, g_xp, B, 16, true, h, w, h + 2, w + 2, st)
+    SMD_BY_PIECES(pieces, SMD_CALL);
+#undef SMD_CALL
     return hipGetLastError();
   }
-  if (pieces == 3) launch_conv_form<3, true>(gy, wp_bwd, g_xp, split_ws, B, CO, C, h, w, h + 2, w + 2, st);
-  else launch_conv_form<2, true>(gy, wp_bwd, g_xp, split_ws, B, CO, C, h, w, h + 2, w + 2, st);
+#define SMD_CALL(P, T) launch_conv_form<P, true, T>(gy, wp_bwd, g_xp, split_ws, B, CO, C, h, w, h + 2, w + 2, st)
+  SMD_BY_PIECES(pieces, SMD_CALL);
+#undef SMD_CALL
   return hipGetLastError();
 }
-// g_w (CO, C, 3, 3): CO % 32 == 0, any C >= 1 (channel tiles past C are computed on clamped reads and not stored)
-template <int P>
-static void launch_wgrad(const float* xp, const float* gy, float* partial, int B, int C, int CO, int h, int w, hipStream_t st) {
+// g_w (CO, C, 3, 3) fp32: CO % 32 == 0, any C >= 1 (channel tiles past C are computed on clamped reads and not stored); or CO == 16 with C == 16 | 32
+template <int P, typename T>
+static void launch_wgrad(const void* xp_, const void* gy_, float* partial, int B, int C, int CO, int h, int w, hipStream_t st) {
+  const T* xp = (const T*)xp_; const T* gy = (const T*)gy_;
   dim3 grid; int rows;
+  if (CO == 16) {
+    wgrad16_shape(B, h, w, grid, rows);
+    if (C == 16) hipLaunchKernelGGL((k_conv16_wgrad_mfma<1, P, T>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows);
+    else hipLaunchKernelGGL((k_conv16_wgrad_mfma<2, P, T>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows);
+    return;
+  }
   wgrad_shape(B, C, CO, h, w, grid, rows);
   const int cot = wgrad_cot(C, CO), ct = wgrad_ct(C, CO);
-  if (cot == 2) hipLaunchKernelGGL((k_conv_wgrad_mfma<2, 2, P>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
-  else if (ct == 4) hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 4, P>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
-  else hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 2, P>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+  if (cot == 2) hipLaunchKernelGGL((k_conv_wgrad_mfma<2, 2, P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+  else if (ct == 4) hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 4, P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+  else hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 2, P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
 }
-hipError_t launch_conv_mfma_bwd_wgt(const float* xp, const float* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
-  if (CO == 16) {                                                 // C = 16 or 32
-    dim3 grid; int rows;
-    wgrad16_shape(B, h, w, grid, rows);
-    if (C == 16) { if (pieces == 3) hipLaunchKernelGGL((k_conv16_wgrad_mfma<1, 3>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows); else hipLaunchKernelGGL((k_conv16_wgrad_mfma<1, 2>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows); }
-    else { if (pieces == 3) hipLaunchKernelGGL((k_conv16_wgrad_mfma<2, 3>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows); else hipLaunchKernelGGL((k_conv16_wgrad_mfma<2, 2>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows); }
-    hipLaunchKernelGGL(k_conv_wgrad_finalize, dim3(ceil_div(16*C*9, 64)), dim3(256), 0, st, partial, (unsigned)(grid.x*grid.y*B), 16, C, g_w);
-    return hipGetLastError();
-  }
-  if (pieces == 3) launch_wgrad<3>(xp, gy, partial, B, C, CO, h, w, st);
-  else launch_wgrad<2>(xp, gy, partial, B, C, CO, h, w, st);
+hipError_t launch_conv_mfma_bwd_wgt(const void* xp, const void* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
+#define SMD_CALL(P, T) launch_wgrad<P, T>(xp, gy, partial, B, C, CO, h, w, st)
+  SMD_BY_PIECES(pieces, SMD_CALL);
+#undef SMD_CALL
   dim3 grid; int rows;
-  wgrad_shape(B, C, CO, h, w, grid, rows);
+  if (CO == 16) wgrad16_shape(B, h, w, grid, rows); else wgrad_shape(B, C, CO, h, w, grid, rows);
   hipLaunchKernelGGL(k_conv_wgrad_finalize, dim3(ceil_div(CO*C*9, 64)), dim3(256), 0, st, partial, (unsigned)(grid.x*grid.y*B), CO, C, g_w);
   return hipGetLastError();
 }

@@ -262,8 +262,8 @@ hipError_t launch_recon_reduce_bwd(const uint8_t* sel, const float* g_loss, floa
 hipError_t launch_debug_lane_shift(float* out_left, float* out_right, hipStream_t st);
 hipError_t launch_stream_copy(const void* src, void* dst, size_t nbytes, int mode, hipStream_t st);
 size_t conv_head_partials(int B, int C, int h, int w);
-hipError_t launch_conv_head_fwd(const float* xp, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st);
-hipError_t launch_conv_head_bwd(const float* xp, const float* wgt, const float* y, const float* gy, float* g_xp, float* g_w, float* g_bias, float* partial,
+hipError_t launch_conv_head_fwd(const void* xp, int x_bf16, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st);
+hipError_t launch_conv_head_bwd(const void* xp, int x_bf16, const float* wgt, const float* y, const float* gy, void* g_xp, float* g_w, float* g_bias, float* partial,
                                 int B, int C, int h, int w, int act, hipStream_t st);
 hipError_t launch_conv_thin_fwd(const float* xp, const float* wgt, float* y, int B, int C, int h, int w, hipStream_t st);
 size_t conv_thin_partials(int B, int C, int h, int w);
@@ -275,9 +275,9 @@ size_t conv_mfma_wgrad_partials(int B, int C, int CO, int h, int w);
 hipError_t launch_conv_mfma_pack(const float* w, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, hipStream_t st);
 size_t conv_mfma_fwd_split_elems(int B, int C, int CO, int h, int w);     // floats of K-split partial outputs the forward / the data gradient wants (0: none)
 size_t conv_mfma_bwd_split_elems(int B, int C, int CO, int h, int w);
-hipError_t launch_conv_mfma_fwd(const float* xp, const void* wp_fwd, float* y, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
-hipError_t launch_conv_mfma_bwd_data(const float* gy, const void* wp_bwd, float* g_xp, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
-hipError_t launch_conv_mfma_bwd_wgt(const float* xp, const float* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
+hipError_t launch_conv_mfma_fwd(const void* xp, const void* wp_fwd, void* y, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
+hipError_t launch_conv_mfma_bwd_data(const void* gy, const void* wp_bwd, void* g_xp, float* split_ws, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
+hipError_t launch_conv_mfma_bwd_wgt(const void* xp, const void* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st);
 size_t decoder_bias_partials(int B, int C, int h, int w);
 hipError_t launch_elu_pad_fwd(const void* x, const float* bias, void* out, int B, int C, int h, int w, int apply_elu, int dt, hipStream_t st);
 hipError_t launch_elu_pad_bwd(const void* x, const float* bias, const void* g_out, void* g_x, float* g_bias, float* ws, int B, int C, int h, int w,

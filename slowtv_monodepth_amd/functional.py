@@ -840,17 +840,19 @@ def elu_pad(x, bias=None, apply_elu: bool = True, out_dtype=None):
 
 
 class _Conv3x3Head(torch.autograd.Function):
-    """`act(conv3x3(xp, weight (1,C,3,3)) + bias)` on an already reflection-padded input (`smd_conv3x3_head_*`): the decoder's output heads."""
+    """`act(conv3x3(xp, weight (1,C,3,3)) + bias)` on an already reflection-padded input (`smd_conv3x3_head_*`): the decoder's output heads.  xp may be bfloat16
+    (the decoder under bf16 autocast): the output, the weights' gradient and every sum stay fp32, `g_xp` comes back in xp's type."""
     @staticmethod
     def forward(ctx, xp, weight, bias, act):
-        xp = _check('xp', xp)
+        xp = _check_fb('xp', xp)
         if xp.ndim != 4 or xp.shape[2] < 4 or xp.shape[3] < 4: raise ValueError(f'expected a padded (B,C,h+2,w+2) with h, w >= 2, got {tuple(xp.shape)}')
         B, C, H, W = xp.shape
         weight = _check('weight', weight, (1, C, 3, 3))
         if bias is not None: bias = _check('bias', bias, (1,))
         y = torch.empty((B, 1, H - 2, W - 2), device=xp.device, dtype=torch.float32)
-        call('smd_conv3x3_head_fwd', xp.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), B, C, H - 2, W - 2, int(act), _stream())
-        ctx.save_for_backward(xp, weight, y); ctx.act, ctx.has_bias = int(act), bias is not None
+        act = int(act) | (2 if xp.dtype == _BF else 0)            # SMD_HEAD_X_BF16
+        call('smd_conv3x3_head_fwd', xp.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), B, C, H - 2, W - 2, act, _stream())
+        ctx.save_for_backward(xp, weight, y); ctx.act, ctx.has_bias = act, bias is not None
         return y
 
     @staticmethod
@@ -859,7 +861,7 @@ class _Conv3x3Head(torch.autograd.Function):
         dev = _on(xp)
         B, C, H, W = xp.shape
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        g_y = _check('grad(y)', g_y, (B, 1, H - 2, W - 2))
+        g_y = _check('grad(y)', g_y.float(), (B, 1, H - 2, W - 2))
         g_xp = torch.empty_like(xp) if need_x else None
         g_w = torch.empty_like(weight) if (need_w or need_b) else None
         g_b = torch.empty(1, device=dev, dtype=torch.float32) if need_b else None
@@ -874,7 +876,7 @@ class _Conv3x3Head(torch.autograd.Function):
 
 def conv3x3_head(xp, weight, bias=None, act: str | None = 'sigmoid'):
     """`act(F.conv2d(xp, weight, bias))` for ONE output channel and an input that is already reflection-padded (`elu_pad`'s output): the decoder's
-    output heads (src/networks/decoders/monodepth.py:52, 86-87).  xp (B,C,h+2,w+2), weight (1,C,3,3), bias (1) or None -> (B,1,h,w); act 'sigmoid' | None."""
+    output heads (src/networks/decoders/monodepth.py:52, 86-87).  xp (B,C,h+2,w+2) fp32 or bf16, weight (1,C,3,3), bias (1) or None -> (B,1,h,w) fp32; act 'sigmoid' | None."""
     if act not in ('sigmoid', 'none', None): raise ValueError(f"act must be 'sigmoid' or None, got {act!r}")
     return _Conv3x3Head.apply(xp, weight, bias, 1 if act == 'sigmoid' else 0)
 
@@ -942,6 +944,8 @@ def conv_routes() -> dict:
 def _conv_static_rule(op, B, C, CO, h, w):
     """Stand-in where nothing may be timed (graph capture): the shapes that won on an MI355X at cfg 2 (profiles/r06_decoder_convs.txt)."""
     px = B*h*w
+    if op.endswith('_bf16'): return CO == 16           # (bf16 tensors: MIOpen's bf16 kernels serve the wide layers; the thin stage is the stencil-like case)
+    if CO == 16: return op != 'wgt'
     if op == 'fwd': return px >= 20000 and C*CO <= 128*64
     if op == 'data': return px >= 5000 and C <= 256
     return px >= 20000 and CO <= 64
@@ -979,32 +983,39 @@ def _mfma_ws(B, C, CO, h, w, dev):
 
 class _Conv3x3Wide(torch.autograd.Function):
     """`F.conv2d(xp, weight (CO,C,3,3))` on an already reflection-padded input; each of the three operators (forward, data gradient, weight gradient) runs
-    on the bf16 matrix cores with fp32-class results (`smd_conv3x3_mfma_*`) or through MIOpen, as `_conv_route` says (`force`: always the MFMA kernels)."""
+    on the bf16 matrix cores (`smd_conv3x3_mfma_*`) or through the alternative — MIOpen, or for the 16-channel last stage in fp32 the f32-MFMA kernels
+    `smd_conv3x3_thin_*` — as `_conv_route` says (`force`: always the MFMA kernels).  fp32 tensors: every operand split into three bf16 pieces, fp32-class
+    results.  bfloat16 tensors (the decoder under bf16 autocast): one piece, bf16 in and out, the weights as their bf16 rounding (what autocast hands a bf16
+    convolution), fp32 accumulation and an fp32 weight gradient."""
     @staticmethod
     def forward(ctx, xp, weight, pieces, force):
-        xp = _check('xp', xp)
+        xp = _check_fb('xp', xp)
         if xp.ndim != 4 or xp.shape[2] < 3 or xp.shape[3] < 3: raise ValueError(f'expected a padded (B,C,h+2,w+2), got {tuple(xp.shape)}')
         B, C, H, W = xp.shape
         if weight.ndim != 4 or tuple(weight.shape[1:]) != (C, 3, 3): raise ValueError(f'weight: expected (CO,{C},3,3), got {tuple(weight.shape)}')
         CO = weight.shape[0]
         weight = _check('weight', weight, (CO, C, 3, 3))
         h, w, dev = H - 2, W - 2, xp.device
-        thin = CO == 16 and C in (16, 32)                   # the last stage: the alternative is the f32-MFMA kernel (smd_conv3x3_thin_*), not MIOpen
+        bf = xp.dtype == _BF
+        if bf: pieces = 1
+        thin = CO == 16 and C in (16, 32)                   # the last stage
         fwd_ok = (C % 16 == 0 and CO % 32 == 0) or thin
         if force and not fwd_ok:
             raise _lib.Unsupported(f'the MFMA forward serves C % 16 == 0 with CO % 32 == 0, or CO = 16 with C = 16 | 32, not C={C} CO={CO}')
         bwd_form = (CO % 16 == 0 and C % 32 == 0) or (C == 16 and CO == 16)   # the data gradient's own operand order (what the backward kernel serves)
-        y = torch.empty((B, CO, h, w), device=dev, dtype=torch.float32)
+        y = torch.empty((B, CO, h, w), device=dev, dtype=xp.dtype)
         packed = {}
 
         def run_mfma():
             if 'wf' not in packed: packed['wf'], packed['wb'] = _mfma_pack(weight, C, CO, pieces, True, bwd_form)
             ws, nws = _mfma_ws(B, C, CO, h, w, dev)
             call('smd_conv3x3_mfma_fwd', xp.data_ptr(), packed['wf'].data_ptr(), y.data_ptr(), ws.data_ptr(), nws, B, C, CO, h, w, pieces, _stream())
+
         def run_ref():
+            if bf: return torch.conv2d(xp, weight.to(_BF))
             if thin: call('smd_conv3x3_thin_fwd', xp.data_ptr(), weight.data_ptr(), y.data_ptr(), B, C, h, w, _stream()); return y
             return torch.conv2d(xp, weight)
-        use = fwd_ok and (force or _conv_route('fwd', B, C, CO, h, w, run_mfma, run_ref))
+        use = fwd_ok and (force or _conv_route('fwd_bf16' if bf else 'fwd', B, C, CO, h, w, run_mfma, run_ref))
         if use: run_mfma()
         else: y = run_ref()
         ctx.save_for_backward(xp, weight, packed.get('wb'))
@@ -1018,12 +1029,15 @@ class _Conv3x3Wide(torch.autograd.Function):
         B, C, H, W = xp.shape
         CO, pieces, force, h, w = weight.shape[0], ctx.pieces, ctx.force, H - 2, W - 2
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g_y = _check('grad(y)', g_y, (B, CO, h, w))
+        bf = xp.dtype == _BF
+        g_y = _check_fb('grad(y)', g_y.to(xp.dtype), (B, CO, h, w))
         g_xp = g_w = None
         thin = CO == 16 and C in (16, 32)
-        cb = lambda mask: torch.ops.aten.convolution_backward(g_y, xp, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, mask)
+        w_ref = weight.to(_BF) if bf else weight
+        cb = lambda mask: torch.ops.aten.convolution_backward(g_y, xp, w_ref, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, mask)
+        sfx = '_bf16' if bf else ''
 
-        def thin_bwd(want_x, want_w):                       # the f32-MFMA kernels of the last stage (smd_conv3x3_thin_bwd)
+        def thin_bwd(want_x, want_w):                       # the f32-MFMA kernels of the last stage (smd_conv3x3_thin_bwd; fp32 tensors only)
             gx_ = torch.empty_like(xp) if want_x else None
             gw_ = torch.empty_like(weight) if want_w else None
             nb = _lib.lib.smd_conv3x3_thin_workspace_bytes(B, C, h, w) if want_w else 0
@@ -1040,8 +1054,8 @@ class _Conv3x3Wide(torch.autograd.Function):
                 ws, nws = _mfma_ws(B, C, CO, h, w, dev)
                 call('smd_conv3x3_mfma_bwd_data', g_y.data_ptr(), packed['wb'].data_ptr(), g_xp.data_ptr(), ws.data_ptr(), nws, B, C, CO, h, w, pieces, _stream())
             ok = (CO % 16 == 0 and C % 32 == 0) or (C == 16 and CO == 16)
-            ref_data = (lambda: thin_bwd(True, False)[0]) if thin else (lambda: cb([True, False, False])[0])
-            if ok and (force or _conv_route('data', B, C, CO, h, w, run_data, ref_data)): run_data()
+            ref_data = (lambda: thin_bwd(True, False)[0]) if (thin and not bf) else (lambda: cb([True, False, False])[0])
+            if ok and (force or _conv_route('data' + sfx, B, C, CO, h, w, run_data, ref_data)): run_data()
             else: g_xp = ref_data()                         # (also: channel counts the data-gradient kernel does not tile)
         if need_w:
             g_w = torch.empty_like(weight)
@@ -1050,8 +1064,8 @@ class _Conv3x3Wide(torch.autograd.Function):
                 ws, nws = _mfma_ws(B, C, CO, h, w, dev)
                 call('smd_conv3x3_mfma_bwd_weight', xp.data_ptr(), g_y.data_ptr(), g_w.data_ptr(), ws.data_ptr(), nws, B, C, CO, h, w, pieces, _stream())
             ok = CO % 32 == 0 or thin
-            ref_wgt = (lambda: thin_bwd(False, True)[1]) if thin else (lambda: cb([False, True, False])[1])
-            if ok and (force or _conv_route('wgt', B, C, CO, h, w, run_wgt, ref_wgt)): run_wgt()
+            ref_wgt = (lambda: thin_bwd(False, True)[1]) if (thin and not bf) else (lambda: cb([False, True, False])[1].float())
+            if ok and (force or _conv_route('wgt' + sfx, B, C, CO, h, w, run_wgt, ref_wgt)): run_wgt()
             else: g_w = ref_wgt()
         return g_xp, g_w, None, None
 

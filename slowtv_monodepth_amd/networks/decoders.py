@@ -48,7 +48,7 @@ class MonodepthDecoder(nn.Module):
 
     def forward(self, feat):
         x = feat[-1]
-        amp_bf16 = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        amp_bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
         if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and (amp_bf16 or not torch.is_autocast_enabled()) and self.upsample_mode == 'nearest':
             return self._forward_glued(feat, torch.bfloat16 if amp_bf16 else None)
         out = {}
@@ -66,9 +66,9 @@ class MonodepthDecoder(nn.Module):
         from .. import functional as HF
         def conv(m, xp):   # input already reflection-padded; the bias is added by the next glue kernel
             co, ci = m.weight.shape[:2]
-            if xp.dtype == torch.float32 and ((co % 32 == 0 and ci % 16 == 0) or (co == 16 and ci in (16, 32))):
-                # smd_conv3x3_mfma_* (bf16 matrix cores, three-way split operands: fp32-class results) or, per operator and shape by this box's A/B, MIOpen
-                # (the wide stages) / the f32-MFMA kernels smd_conv3x3_thin_* (the 16-channel last stage)
+            if (co % 32 == 0 and ci % 16 == 0) or (co == 16 and ci in (16, 32)):
+                # smd_conv3x3_mfma_* (bf16 matrix cores; fp32 tensors: three-way split operands, fp32-class results; bf16 tensors under autocast: one piece) or, per
+                # operator and shape by this box's A/B, MIOpen (the wide stages) / the f32-MFMA kernels smd_conv3x3_thin_* (the 16-channel last stage in fp32)
                 return HF.conv3x3_wide(xp, m.weight.float())
             return F.conv2d(xp, m.weight)
         out = {}
@@ -80,7 +80,7 @@ class MonodepthDecoder(nn.Module):
             if i in self.out_sc or i > 0: xp = HF.elu_pad(c, bias=m1.bias.float(), apply_elu=True, out_dtype=out_dtype)
             if i in self.out_sc:
                 m = self.out[str(i)]
-                if self.out_ch == 1 and xp.dtype == torch.float32 and isinstance(self.act, (nn.Sigmoid, nn.Identity)):   # a one-channel head is a stencil: smd_conv3x3_head_*
+                if self.out_ch == 1 and isinstance(self.act, (nn.Sigmoid, nn.Identity)):   # a one-channel head is a stencil: smd_conv3x3_head_* (fp32 or bf16 activation in, fp32 out)
                     out[i] = HF.conv3x3_head(xp, m.weight.float(), m.bias.float() if m.bias is not None else None, 'sigmoid' if isinstance(self.act, nn.Sigmoid) else None)
                 else:
                     out[i] = self.act(F.conv2d(xp, m.weight, m.bias))

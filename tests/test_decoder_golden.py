@@ -76,3 +76,40 @@ def test_decoder_kernels_match_the_reference_decoder(route):
     finally:
         HF.set_conv_route('auto')
     assert all(o.is_cuda for o in out.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['mfma', 'auto'])
+def test_decoder_under_bf16_autocast_stays_close_to_the_fp32_reference(route):
+    """BASELINE cfg 5 (the reference's `cfg/kbr/default.yaml`) trains the networks in bf16-mixed precision: under `torch.autocast(bfloat16)` the decoder's glue
+    kernels write bf16, its thin stage and (route 'mfma': every) wide stage run the one-piece bf16 form of `smd_conv3x3_mfma_*`, its heads the bf16-input
+    stencils.  Yardstick: the REFERENCE decoder's fp32 outputs and gradients (the fixture) at bf16's resolution — disparities to 1e-2,
+    every feature / weight gradient by its sum of magnitudes to 5e-2 (ten bf16 roundings deep) — i.e. the autocast path computes the same network."""
+    if not torch.cuda.is_available(): pytest.skip('needs a GPU')
+    from slowtv_monodepth_amd import functional as HF
+    from slowtv_monodepth_amd.networks import checkpoint as ck
+    g = load_golden('net_decoder_64x96')
+    dec, holder, shapes, state = build('cuda')
+    feats, gouts = decoder_feats(), decoder_out_grads()
+    feats = [f.cuda().requires_grad_(True) for f in feats]
+    HF.set_conv_route(route)
+    try:
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = dec(feats)
+        sum((out[i].float()*gouts[i].cuda()).sum() for i in out).backward()
+    finally:
+        HF.set_conv_route('auto')
+    for i in DECODER_KW['out_sc']:
+        d = (out[i].detach().float().cpu() - g[f'out_{i}']).abs().max().item()
+        assert d <= 1e-2, f'disparity at scale {i}: {d:.2e}'
+    for j, f in enumerate(feats):
+        ref = g[f'gfeat_{j}']
+        e = (f.grad.float().cpu() - ref).abs().sum().item()/ref.abs().sum().item()
+        assert e <= 5e-2, f'gradient w.r.t. encoder feature {j}: {e:.2e} of its sum of magnitudes'
+    grads = {k: v for k, v in zip(ck.to_reference_state_dict(holder).keys(), (p.grad for p in holder.state_dict(keep_vars=True).values()))}
+    with np.load(GOLDEN/'net_decoder_64x96.npz') as z: keys = [str(k) for k in z['meta_keys']]
+    stats = g['gparam_stats']
+    for n, k in enumerate(keys):      # the weights (a bias gradient is ONE sum per channel that may cancel: no yardstick for it at bf16's resolution in the fixture)
+        if not k.endswith('.weight'): continue
+        gk = grads[k].detach().double().cpu()
+        assert abs(gk.abs().sum().item() - stats[n, 1].item()) <= 5e-2*stats[n, 1].item(), f'sum of |gradient| of {k}'

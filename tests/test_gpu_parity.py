@@ -1183,6 +1183,50 @@ def test_conv3x3_mfma_refuses_what_it_does_not_tile(F):
     with pytest.raises(RuntimeError): F.conv3x3_mfma(xp.cpu(), torch.randn(32, 16, 3, 3))
 
 
+@pytest.mark.parametrize('B,C,CO,h,w', [(2, 16, 16, 7, 70), (2, 32, 16, 9, 33), (2, 64, 64, 9, 70), (2, 96, 32, 13, 100), (2, 512, 256, 6, 20), (12, 16, 16, 384, 640), (3, 32, 16, 192, 320)])
+def test_conv3x3_mfma_bf16_tensors(F, B, C, CO, h, w):
+    """The decoder under bf16 autocast (BASELINE cfg 5 = the reference's `cfg/kbr/default.yaml`: bf16-mixed): bf16 activations in and out, ONE bf16 product per
+    product, the fp32 weights as their bf16 rounding (what autocast hands a bf16 convolution), fp32 accumulation, fp32 weight gradient
+    (`smd_conv3x3_mfma_*`, pieces = 1).  Against fp64 `conv2d` on the SAME rounded operands: bf16 outputs to half an ulp of bf16 (2^-9 of the value, i.e.
+    <= 4e-3 of the tensor's max), the fp32 weight gradient to 1e-5 (its products are exact, only the order of the fp32 sums differs).  Incl. cfg 5's two thin
+    layers at full size."""
+    import torch.nn.functional as TF
+    BF = torch.bfloat16
+    gen = torch.Generator(device='cuda').manual_seed(B*1000 + C*10 + CO + h + w)
+    xp = torch.randn(B, C, h + 2, w + 2, device='cuda', generator=gen).to(BF)
+    wt = torch.randn(CO, C, 3, 3, device='cuda', generator=gen)/(3*C**0.5)
+    gy = torch.randn(B, CO, h, w, device='cuda', generator=gen).to(BF)
+    L = [xp.clone().requires_grad_(True), wt.clone().requires_grad_(True)]
+    y = F.conv3x3_mfma(L[0], L[1]); y.backward(gy)
+    assert y.dtype == BF and L[0].grad.dtype == BF and L[1].grad.dtype == torch.float32
+    R = [xp.double().requires_grad_(True), wt.to(BF).double().requires_grad_(True)]
+    yr = TF.conv2d(R[0], R[1]); yr.backward(gy.double())
+    assert rel_to_max(y.double(), yr) <= 4e-3, rel_to_max(y.double(), yr)
+    assert rel_to_max(L[0].grad.double(), R[0].grad) <= 4e-3, rel_to_max(L[0].grad.double(), R[0].grad)
+    assert rel_to_max(L[1].grad.double(), R[1].grad) <= 1e-5, rel_to_max(L[1].grad.double(), R[1].grad)
+    assert torch.equal(F.conv3x3_mfma(xp, wt), y.detach())        # deterministic
+
+
+@pytest.mark.parametrize('B,C,h,w', [(2, 16, 50, 70), (1, 128, 24, 80), (2, 32, 17, 129), (12, 16, 384, 640)])
+def test_conv3x3_head_bf16_activation(F, B, C, h, w):
+    """The output heads on a bf16 padded activation (`SMD_HEAD_X_BF16`; the decoder under bf16 autocast): fp32 output and weight gradient against fp64 on the
+    same rounded input (2e-6), `g_xp` back in bf16 (half an ulp: 4e-3 of the max)."""
+    import torch.nn.functional as TF
+    BF = torch.bfloat16
+    gen = torch.Generator(device='cuda').manual_seed(B*1000 + C*10 + h + w)
+    xp = torch.randn(B, C, h + 2, w + 2, device='cuda', generator=gen).to(BF)
+    wt = torch.randn(1, C, 3, 3, device='cuda', generator=gen)/(3*C**0.5); bs = torch.randn(1, device='cuda', generator=gen)
+    gy = torch.randn(B, 1, h, w, device='cuda', generator=gen)
+    L = [xp.clone().requires_grad_(True), wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)]
+    y = F.conv3x3_head(L[0], L[1], L[2], 'sigmoid'); y.backward(gy)
+    assert y.dtype == torch.float32 and L[0].grad.dtype == BF
+    R = [t.double().clone().requires_grad_(True) for t in (xp, wt, bs)]
+    yr = torch.sigmoid(TF.conv2d(R[0], R[1], R[2])); yr.backward(gy.double())
+    assert rel_to_max(y.double(), yr) <= 2e-6
+    assert rel_to_max(L[0].grad.double(), R[0].grad) <= 4e-3
+    assert rel_to_max(L[1].grad.double(), R[1].grad) <= 2e-6 and rel_to_max(L[2].grad.double(), R[2].grad) <= 2e-6
+
+
 def test_conv3x3_wide_routes_by_ab_and_agrees(F):
     """`conv3x3_wide` = the same convolution with each operator served by whichever of the MFMA kernels and MIOpen won this box's A/B for the shape: whatever
     the routes are, results agree with fp64 to the fp32 bound, the decisions are recorded, and pinning the route changes nothing but rounding."""
