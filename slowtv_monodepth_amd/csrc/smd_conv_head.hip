@@ -22,12 +22,36 @@ constexpr long long kHeadEnoughWaves = 4096;   // four generations of waves on t
 
 __device__ __forceinline__ float head_act(float v, int act) { return act == 1 ? 1.f/(1.f + __expf(-v)) : v; }
 
+// Three consecutive elements of a padded row for a thread's column.  bfloat16 with an even row pitch (every decoder level: w is even): the two ALIGNED dwords that
+// hold them and a funnel shift by the column's parity, the aligned base and the parity computed once per thread (2-byte loads made the bf16 forward three times
+// slower than the fp32 one on half the bytes: 152 vs 50 us at 16 -> 1, 384x640).
+template <typename TX, bool DW> struct Row3 {             // DW: bfloat16 rows read as aligned dwords (chosen at launch: even pitch); no run-time branch around a load
+  const TX* base; size_t e0; unsigned par;                // (offsets from the tensor's base, a 4-byte-aligned kernel argument: the pointer never passes through an integer —
+                                                          // that made every load a flat_load with vmcnt(0) behind it and cost 222 registers)
+  __device__ __forceinline__ Row3(const TX* base_, size_t e0_) : base(base_), e0(e0_), par((unsigned)(e0_ & 1)) {}
+  __device__ __forceinline__ void next_channel(size_t elems) { e0 += elems; }    // (an even number of elements: the parity stays)
+  // the loads of a channel's rows are all issued before the first is converted (left to the scheduler the dword form waited after every row: 23 waits per three
+  // channels where the fp32 form has 5)
+  __device__ __forceinline__ void request(size_t row_off, unsigned& d0, unsigned& d1) const {
+    const unsigned* pw = reinterpret_cast<const unsigned*>(base) + (e0 >> 1) + (row_off >> 1);   // (the pitch is even: the lane's part and the wave-uniform row part separate)
+    d0 = pw[0]; d1 = pw[1];
+  }
+  __device__ __forceinline__ void unpack(unsigned d0, unsigned d1, float& a, float& b, float& c) const {
+    const unsigned r = __builtin_amdgcn_alignbit(d1, d0, par*16), t = d1 >> (par*16);
+    a = __builtin_bit_cast(float, r << 16); b = __builtin_bit_cast(float, r & 0xffff0000u); c = __builtin_bit_cast(float, t << 16);
+  }
+  __device__ __forceinline__ void load(size_t row_off, float& a, float& b, float& c) const {   // row_off: elements from the thread's first row (a multiple of the pitch)
+    if constexpr (DW) { unsigned d0, d1; request(row_off, d0, d1); unpack(d0, d1, a, b, c); }
+    else { a = ld_as_float<TX>(base, e0 + row_off); b = ld_as_float<TX>(base, e0 + row_off + 1); c = ld_as_float<TX>(base, e0 + row_off + 2); }
+  }
+};
+
 // R output rows per thread.  SPLIT = false: the block's four waves are four row groups (a tile of 64 x 4R outputs), every wave walks all channels.
 // SPLIT = true (small images, many channels: the coarse pyramid levels): the four waves share ONE row group (64 x R outputs) and take the channels
 // c = wave, wave + 4, ...; their partial sums meet in LDS and wave 0 adds them in wave order.
 // TX: the padded activation's element type (float, or bf16 under bf16 autocast: the glue kernels then write bf16 — half the bytes of an HBM-bound kernel;
 // weights, bias, the output and every sum stay fp32).
-template <int R, bool SPLIT, typename TX>
+template <int R, bool SPLIT, typename TX, bool DW>
 __global__ __launch_bounds__(256) void k_head_fwd(const TX* __restrict__ xp, const float* __restrict__ wgt, const float* __restrict__ bias, float* __restrict__ y,
                                                   int C, int h, int w, int act) {
   __shared__ float red[SPLIT ? 3 : 1][R][64];
@@ -41,17 +65,27 @@ __global__ __launch_bounds__(256) void k_head_fwd(const TX* __restrict__ xp, con
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
   if (live) {
     const int c0 = SPLIT ? wv : 0, cs = SPLIT ? 4 : 1;
-    const TX* p = xp + (((size_t)b*C + c0)*H + y0)*W + x;
+    Row3<TX, DW> rp(xp, (((size_t)b*C + c0)*H + y0)*W + x);
 #pragma unroll SPLIT ? 4 : 2   // (a split wave has few outputs and a long chain: more channels' loads in flight)
-    for (int c = c0; c < C; c += cs, p += (size_t)cs*H*W) {
+    for (int c = c0; c < C; c += cs, rp.next_channel((size_t)cs*H*W)) {
       const float* wc = wgt + c*9;               // wave-uniform: scalar loads
       const float w00 = wc[0], w01 = wc[1], w02 = wc[2], w10 = wc[3], w11 = wc[4], w12 = wc[5], w20 = wc[6], w21 = wc[7], w22 = wc[8];
       float v[R + 2][3];
+      if constexpr (DW) {
+        unsigned d0[R + 2], d1[R + 2];
 #pragma unroll
-      for (int r = 0; r < R + 2; ++r) {
-        const bool in = r < rows + 2;            // (rows beyond the image's last: not read)
+        for (int r = 0; r < R + 2; ++r) rp.request((size_t)min(r, rows + 1)*W, d0[r], d1[r]);   // (rows beyond the image's last: the last one again, unused)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v[r][k] = in ? ld_as_float<TX>(p, (size_t)r*W + k) : 0.f;
+        for (int r = 0; r < R + 2; ++r) {
+          rp.unpack(d0[r], d1[r], v[r][0], v[r][1], v[r][2]);
+          if (r >= rows + 2) v[r][0] = v[r][1] = v[r][2] = 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r) {
+          if (r < rows + 2) rp.load((size_t)r*W, v[r][0], v[r][1], v[r][2]);   // (rows beyond the image's last: not read)
+          else v[r][0] = v[r][1] = v[r][2] = 0.f;
+        }
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -88,12 +122,13 @@ __device__ __forceinline__ float head_gp(const float* __restrict__ gy, const flo
 }
 
 // grid (ceil(W/64), ceil(H/4), B * G): channel group blockIdx.z % G takes channels [g * Cg, (g + 1) * Cg)
-template <typename TX>
+template <typename TX, bool DW>
 __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ wgt, TX* __restrict__ g_xp,
                                                        int C, int h, int w, int G, int Cg, int act) {
   const int W = w + 2, H = h + 2;
   const int q = blockIdx.x*64 + (threadIdx.x & 63), p = blockIdx.y*4 + (threadIdx.x >> 6), b = blockIdx.z/G, g = blockIdx.z - b*G;
-  if (q >= W || p >= H) return;
+  constexpr bool pairs = DW;                                    // bfloat16, even pitch: an even lane stores its neighbour's value with its own, one dword
+  if (q >= W || p >= H) return;                                 // (W even: the last column W - 1 is odd, its partner W - 2 is a live lane of the same wave)
   const size_t base = (size_t)b*h*w;
   float nb[3][3];                              // nb[ky][kx] = gp[p - ky, q - kx]: the outputs whose window holds padded position (p, q) at (ky, kx)
 #pragma unroll
@@ -109,7 +144,16 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) s = fmaf(wc[ky*3 + kx], nb[ky][kx], s);
-    st_from_float<TX>(o, 0, s);
+    if constexpr (sizeof(TX) == 2) {
+      if (pairs) {                                              // (lanes 2 j, 2 j + 1 are columns 2 j, 2 j + 1 of one row: W is even, so a pair never straddles rows)
+        const float nb = __shfl_down(s, 1, 64);
+        if ((q & 1) == 0) {
+          typedef float f2 __attribute__((ext_vector_type(2))); typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+          const f2 pr = {s, nb};
+          *reinterpret_cast<unsigned*>(o) = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, b2));
+        }
+      } else st_from_float<TX>(o, 0, s);
+    } else st_from_float<TX>(o, 0, s);
   }
 }
 
@@ -117,7 +161,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
 // set of nine sums (one tile per block: the block's reduction costs as much as its sums; a whole column: too few waves for the loads' latency); channel C
 // is the bias' job (sum of gp).  partial[(c * T + blockIdx.y * tiles_x + blockIdx.x) * 9 + k], T = tiles_x * B * chunks_y.
 constexpr int kHeadWgtTiles = 3;
-template <typename TX>
+template <typename TX, bool DW>
 __global__ __launch_bounds__(256) void k_head_bwd_wgt(const TX* __restrict__ xp, const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ partial,
                                                       int C, int h, int w, int chunks_y, int act) {
   __shared__ float red[4][9];
@@ -139,13 +183,23 @@ __global__ __launch_bounds__(256) void k_head_bwd_wgt(const TX* __restrict__ xp,
 #pragma unroll
         for (int r = 0; r < kHeadRows; ++r) acc[0] += g[r];
       } else {
-        const TX* p = xp + (((size_t)b*C + c)*H + y0)*W + x;
+        const Row3<TX, DW> rp(xp, (((size_t)b*C + c)*H + y0)*W + x);
         float v[kHeadRows + 2][3];
+        if constexpr (DW) {
+          unsigned d0[kHeadRows + 2], d1[kHeadRows + 2];
 #pragma unroll
-        for (int r = 0; r < kHeadRows + 2; ++r) {
-          const bool in = r < rows + 2;
+          for (int r = 0; r < kHeadRows + 2; ++r) rp.request((size_t)min(r, rows + 1)*W, d0[r], d1[r]);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) v[r][k] = in ? ld_as_float<TX>(p, (size_t)r*W + k) : 0.f;
+          for (int r = 0; r < kHeadRows + 2; ++r) {
+            rp.unpack(d0[r], d1[r], v[r][0], v[r][1], v[r][2]);
+            if (r >= rows + 2) v[r][0] = v[r][1] = v[r][2] = 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < kHeadRows + 2; ++r) {
+            if (r < rows + 2) rp.load((size_t)r*W, v[r][0], v[r][1], v[r][2]);
+            else v[r][0] = v[r][1] = v[r][2] = 0.f;
+          }
         }
 #pragma unroll
         for (int r = 0; r < kHeadRows; ++r)
@@ -187,23 +241,24 @@ __global__ __launch_bounds__(64) void k_head_wgt_finalize(const float* __restric
 static inline int head_wgt_chunks(int h) { return ceil_div(ceil_div(h, kHeadTileH), kHeadWgtTiles); }
 size_t conv_head_partials(int B, int C, int h, int w) { return (size_t)(C + 1)*ceil_div(w, kHeadTileW)*B*head_wgt_chunks(h)*9; }
 
-template <typename TX>
+template <typename TX, bool DW>
 static void head_fwd_t(const TX* xp, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st) {
   const int tx = ceil_div(w, kHeadTileW);
   if ((long long)B*tx*ceil_div(h, kHeadTileH)*4 >= kHeadEnoughWaves || C < 8)
-    hipLaunchKernelGGL((k_head_fwd<kHeadRows, false, TX>), dim3(tx, ceil_div(h, kHeadTileH), B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
+    hipLaunchKernelGGL((k_head_fwd<kHeadRows, false, TX, DW>), dim3(tx, ceil_div(h, kHeadTileH), B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
   else if ((long long)B*tx*ceil_div(h, 2)*4 >= kHeadEnoughWaves)
-    hipLaunchKernelGGL((k_head_fwd<2, true, TX>), dim3(tx, ceil_div(h, 2), B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
+    hipLaunchKernelGGL((k_head_fwd<2, true, TX, DW>), dim3(tx, ceil_div(h, 2), B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
   else
-    hipLaunchKernelGGL((k_head_fwd<1, true, TX>), dim3(tx, h, B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
+    hipLaunchKernelGGL((k_head_fwd<1, true, TX, DW>), dim3(tx, h, B), dim3(256), 0, st, xp, wgt, bias, y, C, h, w, act);
 }
 hipError_t launch_conv_head_fwd(const void* xp, int x_bf16, const float* wgt, const float* bias, float* y, int B, int C, int h, int w, int act, hipStream_t st) {
-  if (x_bf16) head_fwd_t<bf16>((const bf16*)xp, wgt, bias, y, B, C, h, w, act, st);
-  else head_fwd_t<float>((const float*)xp, wgt, bias, y, B, C, h, w, act, st);
+  if (x_bf16 && (w & 1) == 0) head_fwd_t<bf16, true>((const bf16*)xp, wgt, bias, y, B, C, h, w, act, st);      // (every decoder level has an even width)
+  else if (x_bf16) head_fwd_t<bf16, false>((const bf16*)xp, wgt, bias, y, B, C, h, w, act, st);
+  else head_fwd_t<float, false>((const float*)xp, wgt, bias, y, B, C, h, w, act, st);
   return hipGetLastError();
 }
 
-template <typename TX>
+template <typename TX, bool DW>
 static void head_bwd_t(const TX* xp, const float* wgt, const float* y, const float* gy, TX* g_xp, float* g_w, float* g_bias, float* partial,
                        int B, int C, int h, int w, int act, hipStream_t st) {
   if (g_xp) {
@@ -214,19 +269,20 @@ static void head_bwd_t(const TX* xp, const float* wgt, const float* y, const flo
     if ((long long)B*G > 65535) G = 65535/B > 0 ? 65535/B : 1;
     const int Cg = ceil_div(C, G);
     G = ceil_div(C, Cg);
-    hipLaunchKernelGGL((k_head_bwd_data<TX>), dim3(ceil_div(w + 2, 64), ceil_div(h + 2, 4), B*G), dim3(256), 0, st, gy, y, wgt, g_xp, C, h, w, G, Cg, act);
+    hipLaunchKernelGGL((k_head_bwd_data<TX, DW>), dim3(ceil_div(w + 2, 64), ceil_div(h + 2, 4), B*G), dim3(256), 0, st, gy, y, wgt, g_xp, C, h, w, G, Cg, act);
   }
   if (g_w) {
     const int tx = ceil_div(w, kHeadTileW);
     const int cy = head_wgt_chunks(h);
-    hipLaunchKernelGGL((k_head_bwd_wgt<TX>), dim3(tx, B*cy, C + 1), dim3(256), 0, st, xp, gy, y, partial, C, h, w, cy, act);
+    hipLaunchKernelGGL((k_head_bwd_wgt<TX, DW>), dim3(tx, B*cy, C + 1), dim3(256), 0, st, xp, gy, y, partial, C, h, w, cy, act);
     hipLaunchKernelGGL(k_head_wgt_finalize, dim3(C + 1), dim3(64), 0, st, partial, (unsigned)(tx*B*cy), C, g_w, g_bias);
   }
 }
 hipError_t launch_conv_head_bwd(const void* xp, int x_bf16, const float* wgt, const float* y, const float* gy, void* g_xp, float* g_w, float* g_bias, float* partial,
                                 int B, int C, int h, int w, int act, hipStream_t st) {
-  if (x_bf16) head_bwd_t<bf16>((const bf16*)xp, wgt, y, gy, (bf16*)g_xp, g_w, g_bias, partial, B, C, h, w, act, st);
-  else head_bwd_t<float>((const float*)xp, wgt, y, gy, (float*)g_xp, g_w, g_bias, partial, B, C, h, w, act, st);
+  if (x_bf16 && (w & 1) == 0) head_bwd_t<bf16, true>((const bf16*)xp, wgt, y, gy, (bf16*)g_xp, g_w, g_bias, partial, B, C, h, w, act, st);
+  else if (x_bf16) head_bwd_t<bf16, false>((const bf16*)xp, wgt, y, gy, (bf16*)g_xp, g_w, g_bias, partial, B, C, h, w, act, st);
+  else head_bwd_t<float, false>((const float*)xp, wgt, y, gy, (float*)g_xp, g_w, g_bias, partial, B, C, h, w, act, st);
   return hipGetLastError();
 }
 
