@@ -11,9 +11,10 @@ from slowtv_monodepth_amd._lib import call
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--quick', action='store_true'); ap.add_argument('--pieces', type=int, nargs='*', default=[3, 2]); ap.add_argument('--b', type=int, default=12)
-ap.add_argument('--hw', default='192x640'); ap.add_argument('--no-time', action='store_true'); ap.add_argument('--layers', nargs='*')
+ap.add_argument('--hw', default='192x640'); ap.add_argument('--two-tiles', type=int, default=None); ap.add_argument('--no-time', action='store_true'); ap.add_argument('--layers', nargs='*')
 args = ap.parse_args()
 H, W = map(int, args.hw.split('x'))
+if args.two_tiles is not None: _lib.set_knob('conv_two_tiles', args.two_tiles)
 b = args.b
 layers = [('up1_0', 16, 16, H, W), ('up0_0', 32, 16, H//2, W//2), ('up1_1', 96, 32, H//2, W//2), ('up0_1', 64, 32, H//4, W//4), ('up1_2', 128, 64, H//4, W//4), ('up0_2', 128, 64, H//8, W//8),
           ('up1_3', 256, 128, H//8, W//8), ('up0_3', 256, 128, H//16, W//16), ('up1_4', 512, 256, H//16, W//16), ('up0_4', 512, 256, H//32, W//32)]

@@ -47,11 +47,13 @@ int max_strips(int h, int w, int cols) { return smd::ceil_div(w, cols)*smd::ceil
 //   bwd_guest_finalize; bwd_direct_level; loss_path_guests (0: the fused loss path launches its guest work as kernels of their own);
 //   bwd_live (0: the backward ignores the forward's liveness table and runs every wave's row loop); bwd_scales_block (0: with one wave per strip a
 //   block stays four strips of one scale instead of the four scales of one strip).
+//   conv_two_tiles (1: the decoder's wide convolutions run two tiles of 32 output channels over one staged patch — eight waves per block — where the layer has
+//   them; default 0: measured neutral, profiles/r06_conv_mfma_ablations.txt; same bits either way).
 //   Experiments builds only: fwd_ahead (2: tap gathers two rows ahead, measured slower), bwd_pair (two supports per wave, dropped), smooth_chain.
 struct KnobDef { const char* name; bool experiment; };
 constexpr KnobDef kKnobs[] = {{"fwd_rh", false}, {"bwd_rh", false}, {"fwd_taper_b", false}, {"bwd_taper_b", false}, {"fwd_taper_rh", false},
                               {"bwd_taper_rh", false}, {"fwd_ni", false}, {"fwd_share", false}, {"bwd_skip", false}, {"bwd_wps", false},
-                              {"bwd_guest_finalize", false}, {"bwd_direct_level", false}, {"loss_path_guests", false}, {"bwd_live", false}, {"bwd_scales_block", false},
+                              {"bwd_guest_finalize", false}, {"bwd_direct_level", false}, {"loss_path_guests", false}, {"bwd_live", false}, {"bwd_scales_block", false}, {"conv_two_tiles", false},
                               {"fwd_ahead", true}, {"bwd_pair", true}, {"smooth_chain", true}};
 constexpr int kNumKnobs = sizeof(kKnobs)/sizeof(kKnobs[0]);
 constexpr int kKnobUnset = INT_MIN;
@@ -835,6 +837,7 @@ size_t smd_conv3x3_mfma_packed_bytes(int C, int CO, int pieces) {
 }
 size_t smd_conv3x3_mfma_workspace_bytes(int B, int C, int CO, int h, int w) {   // one size for the three operators
   if (!mfma_sizes_ok(B, C, CO, h, w)) return 0;
+  smd::set_conv_two_tiles(knob("conv_two_tiles", 0));
   size_t n = 64;
   if (mfma_fwd_served(C, CO)) n = std::max(n, smd::conv_mfma_fwd_split_elems(B, C, CO, h, w));
   if (mfma_data_served(C, CO)) n = std::max(n, smd::conv_mfma_bwd_split_elems(B, C, CO, h, w));
@@ -856,6 +859,7 @@ int smd_conv3x3_mfma_fwd(const void* xp, const void* wp_fwd, void* y, void* work
   if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
   if (!mfma_fwd_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the forward serves C %% 16 == 0 with CO %% 32 == 0, or CO == 16 with C == 16 | 32, not C=%d CO=%d", C, CO);
   if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  smd::set_conv_two_tiles(knob("conv_two_tiles", 0));
   return check_launch(smd::launch_conv_mfma_fwd(xp, wp_fwd, y, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_fwd");
 }
 int smd_conv3x3_mfma_bwd_data(const void* g_y, const void* wp_bwd, void* g_xp, void* workspace, size_t workspace_bytes,
@@ -865,6 +869,7 @@ int smd_conv3x3_mfma_bwd_data(const void* g_y, const void* wp_bwd, void* g_xp, v
   if (!mfma_sizes_ok(B, C, CO, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d CO=%d h=%d w=%d", B, C, CO, h, w);
   if (!mfma_data_served(C, CO)) return fail(SMD_E_UNSUPPORTED, "the data gradient serves CO %% 16 == 0 with C %% 32 == 0, or C == CO == 16, not C=%d CO=%d", C, CO);
   if (workspace_bytes < smd_conv3x3_mfma_workspace_bytes(B, C, CO, h, w)) return fail(SMD_E_WORKSPACE, "workspace too small");
+  smd::set_conv_two_tiles(knob("conv_two_tiles", 0));
   return check_launch(smd::launch_conv_mfma_bwd_data(g_y, wp_bwd, g_xp, (float*)workspace, B, C, CO, h, w, pieces, (hipStream_t)stream), "conv3x3_mfma_bwd_data");
 }
 int smd_conv3x3_mfma_bwd_weight(const void* xp, const void* g_y, float* g_weight, void* workspace, size_t workspace_bytes,

@@ -99,24 +99,29 @@ template <int TC> struct ConvTile {
   static constexpr int PW = TC + 2, PH = TRB + 2, NPIX = PW*PH;
 };
 
-template <int TC, int P, bool BWD, typename TI, typename TO>
-__global__ __launch_bounds__(256) void k_conv_mfma(const TI* __restrict__ in_, const uint4* __restrict__ wp, TO* __restrict__ out,
+// NM: channel tiles per block.  NM = 2 (knob conv_two_tiles, layers with a multiple of 64 output channels): EIGHT waves, waves 4 .. 7 multiply the same patch by
+// the next 32 output channels' weights — the patch is staged once for 64 channels (by all 512 lanes).  Built to halve what a block pulls through the CU's
+// vector-memory path per MFMA; measured neutral (128 -> 64 at 48x160: 103.0 vs 104.7 us forward, 108.0 vs 104.7 data gradient; 512 -> 256 at 12x40: 183 vs 171;
+// 128 -> 64 at 24x80 data gradient 42.7 vs 52.3), so the default stays one tile per block.  Same bits either way.
+template <int TC, int P, bool BWD, typename TI, typename TO, int NM>
+__global__ __launch_bounds__(256*NM) void k_conv_mfma(const TI* __restrict__ in_, const uint4* __restrict__ wp, TO* __restrict__ out,
                                                    int CK, int M, int hi, int wi, int ho, int wo, int KS, int kc_per_split, size_t split_stride,
                                                    unsigned gx, unsigned gy, unsigned gz) {
   using T = ConvTile<TC>;
   constexpr int NPIX = T::NPIX, PW = T::PW, off = BWD ? 2 : 0, NPROD = n_products(P);
   constexpr int kBuf = P*NPIX*2;
   __shared__ uint4 tile[2*kBuf];                                  // two patches, [piece][pixel][half]
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, g = lane >> 5;
+  const int lane = threadIdx.x & 63, wall = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wv = wall & 3, mt = wall >> 2, j = lane & 31, g = lane >> 5;
+  constexpr int NT = 256*NM;
   // Block -> (channel tile, K split, tile column, tile row, sample), XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each
   // with its own L2.  Here XCD k works through the k-th eighth of the tile list in order, so the blocks in flight on an XCD are neighbours in the image —
   // the halo rows / columns two tiles share, and the one patch the channel tiles of a pixel tile all read, come from HBM once (the natural order sends every
   // neighbour to another L2: 329 MB fetched for a 145 MB input at cfg 2's 96 -> 32 layer).
-  const int MG = M >> 5;
+  const int MG = M/(32*NM);
   const unsigned nblk = (unsigned)(MG*KS)*gx*gy*gz, per = (nblk + 7)/8;
   const unsigned lid = (blockIdx.x & 7)*per + (blockIdx.x >> 3);
   if (lid >= nblk) return;
-  const int mg = lid % MG, ks = (lid/MG) % KS;
+  const int mg = (int)(lid % MG)*NM + mt, ks = (lid/MG) % KS;     // mg: this wave's tile of 32 output channels
   const unsigned tl = lid/(MG*KS);
   const int x0 = (int)(tl % gx)*TC, y0 = (int)((tl/gx) % gy)*T::TRB, b = (int)(tl/(gx*gy));
   const int KC = CK >> 4, kc0 = ks*kc_per_split, kc1 = min(KC, kc0 + kc_per_split);
@@ -125,11 +130,11 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const TI* __restrict__ in_, c
   const R* src = reinterpret_cast<const R*>(in_) + (size_t)b*CK*plane;
 
   // staging: an item = 8 channels of one patch pixel; its address inside a channel plane does not depend on the chunk
-  constexpr int ITEMS = 2*NPIX, TRIPS = (ITEMS + 255)/256;
+  constexpr int ITEMS = 2*NPIX, TRIPS = (ITEMS + NT - 1)/NT;
   int pofs[TRIPS];                                               // offset inside the plane, or -1: outside (data gradient: zero)
 #pragma unroll
   for (int t = 0; t < TRIPS; ++t) {
-    const int item = min(t*256 + (int)threadIdx.x, ITEMS - 1);
+    const int item = min(t*NT + (int)threadIdx.x, ITEMS - 1);
     const int half = item >= NPIX ? 1 : 0, pix = item - half*NPIX;
     const int r = pix/PW, cc = pix - r*PW;
     const int yy = y0 + r - off, xx = x0 + cc - off;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const TI* __restrict__ in_, c
   auto request = [&](int kc) {                                    // every load of a chunk is issued before anything waits for one
 #pragma unroll
     for (int t = 0; t < TRIPS; ++t) {
-      const int item = min(t*256 + (int)threadIdx.x, ITEMS - 1);
+      const int item = min(t*NT + (int)threadIdx.x, ITEMS - 1);
       const int half = item >= NPIX ? 1 : 0;
       const R* p = src + (size_t)(kc*16 + half*8)*plane + (size_t)max(pofs[t], 0);
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const TI* __restrict__ in_, c
   auto file = [&](int buf) {
 #pragma unroll
     for (int t = 0; t < TRIPS; ++t) {
-      const int item = t*256 + (int)threadIdx.x;
+      const int item = t*NT + (int)threadIdx.x;
       if (item < ITEMS) {
         const int half = item >= NPIX ? 1 : 0, pix = item - half*NPIX;
         unsigned pk[4][P];
@@ -760,19 +765,23 @@ hipError_t launch_conv_mfma_pack(const float* w, void* wp_fwd, void* wp_bwd, int
   return hipGetLastError();
 }
 
-// Launch shape of the forward / data-gradient form: tile columns, K splits (each split a whole number of 16-channel chunks).
-struct ConvShape { int TC, TRB, KS, kcs; unsigned gx, gy, gz; dim3 grid; size_t out_elems; };
+// Launch shape of the forward / data-gradient form: tile columns, channel tiles per block, K splits (each split a whole number of 16-channel chunks).
+static int g_conv_two_tiles = 0;
+void set_conv_two_tiles(int v) { g_conv_two_tiles = v; }
+static bool conv_two_tiles() { return g_conv_two_tiles != 0; }
+struct ConvShape { int TC, TRB, NM, KS, kcs; unsigned gx, gy, gz; dim3 grid; size_t out_elems; };
 static ConvShape conv_shape(int B, int CK, int M, int ho, int wo) {
   ConvShape s;
   s.TC = wo >= 48 ? 64 : 32; s.TRB = wo >= 48 ? 4 : 8;
   const long long tiles = (long long)ceil_div(wo, s.TC)*ceil_div(ho, s.TRB)*B;
-  const long long base = tiles*(M/32);
+  s.NM = (M % 64 == 0 && tiles*(M/64) >= 256 && conv_two_tiles()) ? 2 : 1;   // two channel tiles over one patch where that still leaves a block per CU
+  const long long base = tiles*(M/(32*s.NM));
   const int KC = CK >> 4;
   int ks = 1;
   if (base < 384) ks = (int)std::min<long long>(std::max(KC/2, 1), (512 + base - 1)/base);   // under 1.5 blocks per CU: split K, at least two chunks per split
   s.kcs = ceil_div(KC, ks); s.KS = ceil_div(KC, s.kcs);
   s.gx = ceil_div(wo, s.TC); s.gy = ceil_div(ho, s.TRB); s.gz = B;
-  s.grid = dim3(8*(unsigned)ceil_div((long long)s.gx*s.gy*s.gz*(M/32)*s.KS, 8ll));
+  s.grid = dim3(8*(unsigned)ceil_div((long long)s.gx*s.gy*s.gz*(M/(32*s.NM))*s.KS, 8ll));
   s.out_elems = (size_t)B*M*ho*wo;
   return s;
 }
@@ -787,8 +796,11 @@ static void launch_conv_form(const void* in, const void* wp, void* out, float* s
   const uint4* wq = (const uint4*)wp;
   const T* i_ = (const T*)in;
   T* dst = s.KS > 1 ? reinterpret_cast<T*>(split_ws) : (T*)out;    // (the kernel writes a split's partial output as fp32 whatever T)
-  if (s.TC == 64) hipLaunchKernelGGL((k_conv_mfma<64, P, BWD, T, T>), s.grid, dim3(256), 0, st, i_, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
-  else hipLaunchKernelGGL((k_conv_mfma<32, P, BWD, T, T>), s.grid, dim3(256), 0, st, i_, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
+  if (s.NM == 2) {
+    if (s.TC == 64) hipLaunchKernelGGL((k_conv_mfma<64, P, BWD, T, T, 2>), s.grid, dim3(512), 0, st, i_, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
+    else hipLaunchKernelGGL((k_conv_mfma<32, P, BWD, T, T, 2>), s.grid, dim3(512), 0, st, i_, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
+  } else if (s.TC == 64) hipLaunchKernelGGL((k_conv_mfma<64, P, BWD, T, T, 1>), s.grid, dim3(256), 0, st, i_, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
+  else hipLaunchKernelGGL((k_conv_mfma<32, P, BWD, T, T, 1>), s.grid, dim3(256), 0, st, i_, wq, dst, CK, M, hi, wi, ho, wo, s.KS, s.kcs, s.out_elems, s.gx, s.gy, s.gz);
   if (s.KS > 1) {
     const size_t n4 = s.out_elems/4;                              // (B M ho wo is a multiple of 4: M is a multiple of 32)
     hipLaunchKernelGGL((k_conv_split_sum<T>), dim3((unsigned)((n4 + 255)/256)), dim3(256), 0, st, split_ws, (T*)out, n4, s.KS);

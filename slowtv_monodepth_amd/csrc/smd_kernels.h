@@ -271,6 +271,7 @@ hipError_t launch_conv_thin_bwd_wgt(const float* xp, const float* gy, float* g_w
 hipError_t launch_conv_thin_bwd_data(const float* gy, const float* wgt, float* g_xp, int B, int C, int h, int w, hipStream_t st);
 // smd_conv_mfma.hip: the wide decoder convolutions on the bf16 matrix cores, fp32 operands split into `pieces` bf16 pieces (3: fp32-class results)
 size_t conv_mfma_packed_elems(int C, int CO, int pieces);
+void set_conv_two_tiles(int v);     // launch-shape knob of the forward / data-gradient form (smd_api.hip: conv_two_tiles)
 size_t conv_mfma_wgrad_partials(int B, int C, int CO, int h, int w);
 hipError_t launch_conv_mfma_pack(const float* w, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, hipStream_t st);
 size_t conv_mfma_fwd_split_elems(int B, int C, int CO, int h, int w);     // floats of K-split partial outputs the forward / the data gradient wants (0: none)

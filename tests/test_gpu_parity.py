@@ -1167,6 +1167,11 @@ def test_conv3x3_mfma_kernel(F, B, C, CO, h, w):
     for nm, a, r in zip(('g_xp', 'g_weight'), L, R): assert rel_to_max(a.grad.double(), r.grad) <= 2e-6, (nm, rel_to_max(a.grad.double(), r.grad))
     y2 = F.conv3x3_mfma(xp, wt)                                   # deterministic: the same bits on a second call
     assert torch.equal(y2, y.detach())
+    from slowtv_monodepth_amd import _lib                          # ... and with two channel tiles over one staged patch (launch-shape knob, default off)
+    try:
+        _lib.set_knob('conv_two_tiles', 1)
+        assert torch.equal(F.conv3x3_mfma(xp, wt), y.detach())
+    finally: _lib.reset_knobs()
     L = [xp.clone(), wt.clone().requires_grad_(True)]
     F.conv3x3_mfma(L[0], L[1]).backward(gy)                          # only the weights ask for a gradient, and only the input
     assert rel_to_max(L[1].grad.double(), R[1].grad) <= 2e-6
