@@ -402,33 +402,35 @@ __global__ __launch_bounds__(256) void k_conv_split_sum(const float* __restrict_
 // ---- weight gradient ----
 // g_w[co][c][tap] = sum over samples and pixels of g_y[co][y][x] xp[c][y + ky][x + kx]: per tap a GEMM with M = output channels, N = input channels,
 // K = pixels.  Both operands want 8 consecutive K per lane = 8 consecutive pixels of a row of one channel: the tensors' own (NCHW) order.  A K step is 16
-// pixels of a row (lane group g: pixels 8 g .. 8 g + 7); A = g_y, B = the padded input shifted by the tap — the shift by kx is a funnel shift of the five
-// dwords a lane reads (kx = 0: dwords 0-3, kx = 2: dwords 1-4, kx = 1: v_alignbit of neighbours), so one aligned ds_read_b128 + b32 per (ky, piece)
-// serves three taps.  A wave owns ONE pair (tile of 32 output channels, tile of 32 input channels) and all nine taps: 9 x 16 accumulator registers.
-// A block of four waves = COT x CT such pairs (x KS = 4 / (COT CT) waves per pair that split a row's two K steps) walks down a strip of 32 columns:
-// per row it needs one new row of g_y and one new row of the padded input (rows y .. y + 2 sit in a ring of four slots), requested from memory before
-// the row's MFMAs and split + filed after them: one barrier per row.  The block leaves its sums as one set of partials [tap][co][c];
-// k_conv_wgrad_finalize adds the blocks' sets in fp64 in block order (deterministic, as everywhere in this library).
-template <int COT, int CT>
+// pixels of a row (lane group g: pixels 8 g .. + 7); A = g_y, B = the padded input shifted by the tap — the shift by kx is a funnel shift of the five
+// dwords a lane reads (kx = 0: dwords 0-3, kx = 2: dwords 1-4, kx = 1: v_alignbit of neighbours).  A wave owns ONE pair (tile of 32 output channels, tile
+// of 32 input channels) and all nine taps: 9 x 16 accumulator registers.
+// The row loop runs over INPUT rows: input row r meets g_y rows r, r - 1, r - 2 as the taps' rows ky = 0, 1, 2 — so the block keeps a ring of four g_y rows
+// (small: 32 channels) and only TWO slots of the input row (64 channels: this row, and the next one being filed), an input row's fragments are read once
+// and serve three ky (15 LDS reads per 54 MFMAs), and 60 KB of LDS leave room for two blocks per CU.  A block = 32 output x 64 input channels, four waves =
+// 2 input-channel tiles x the 2 K steps of a 32-column strip; per row it requests one new row of each operand before the row's MFMAs and splits + files
+// them after, one barrier per row.  The block leaves its sums as one set of partials [tap][co][c]; k_conv_wgrad_finalize adds the blocks' sets in fp64 in
+// block order (deterministic, as everywhere in this library).
+// (First form, round 6: the ring held four INPUT rows of 64-128 channels — 93-143 KB, one block per CU, a lane's five dwords read per ky: 193 us at cfg 2's
+// 96 -> 32 layer, the bf16 pipe 37 % busy, 64 % of the LDS cycles bank conflicts of the fifth-dword read.)
 struct WgradTile {
-  static constexpr int COB = 32*COT, CB = 32*CT, KS = 4/(COT*CT);
-  static constexpr int XROW = 20, XCH = 4*XROW + 4;     // dwords: a row slot = 40 bf16 (34 used), a channel = 4 slots + 16 bytes (336 B = 16 x 21: odd, the 16 lanes of a ds_read_b128 group cover all banks)
-  static constexpr int GROW = 16, GCH = 2*GROW + 4;     // dwords: a row slot = 32 bf16, a channel = 2 slots + 16 bytes (144 B = 16 x 9)
+  static constexpr int COB = 32, CB = 64;
+  static constexpr int XROW = 20, XCH = 2*XROW + 4;     // dwords: a row slot = 40 bf16 (34 used), a channel = 2 slots + 16 bytes (176 B = 16 x 11: odd, the 16 lanes of a ds_read_b128 group cover all banks)
+  static constexpr int GROW = 16, GCH = 4*GROW + 4;     // dwords: a row slot = 32 bf16, a channel = 4 slots + 16 bytes (272 B = 16 x 17)
 };
 
-template <int COT, int CT, int P, typename TI>
-__global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const TI* __restrict__ xp, const TI* __restrict__ gy, float* __restrict__ partial,
+template <int P, typename TI>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_mfma(const TI* __restrict__ xp, const TI* __restrict__ gy, float* __restrict__ partial,
                                                          int C, int CO, int h, int w, int rows_per_block) {
-  using T = WgradTile<COT, CT>;
-  constexpr int COB = T::COB, CB = T::CB, KS = T::KS, XROW = T::XROW, XCH = T::XCH, GROW = T::GROW, GCH = T::GCH, NPROD = n_products(P);
-  static_assert(KS == 1 || KS == 2, "waves per pair");
+  using T = WgradTile;
+  constexpr int COB = T::COB, CB = T::CB, XROW = T::XROW, XCH = T::XCH, GROW = T::GROW, GCH = T::GCH, NPROD = n_products(P);
   constexpr int kXs = P*CB*XCH, kGs = P*COB*GCH;
-  constexpr int kRed = (KS == 2) ? 2*144*64 : 0;          // the second wave of a pair parks its accumulators
+  constexpr int kRed = 2*144*64;                          // the second wave of a pair parks its accumulators
   __shared__ __attribute__((aligned(16))) unsigned lds[(kXs + kGs) > kRed ? (kXs + kGs) : kRed];
   unsigned* const xs = lds;
   unsigned* const gs = lds + kXs;
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, g = lane >> 5;
-  const int cot = wv % COT, ct = (wv/COT) % CT, ks = wv/(COT*CT);
+  const int ct = wv & 1, ks = wv >> 1;                    // this wave's input-channel tile and K step (columns 16 ks + 8 g .. + 7)
   const int CGRP = (C + CB - 1)/CB, COGRP = CO/COB;
   const int cg = blockIdx.z % CGRP, cog = (blockIdx.z/CGRP) % COGRP, b = blockIdx.z/(CGRP*COGRP);
   const int x0 = blockIdx.x*32, ybeg = blockIdx.y*rows_per_block, nrows = min(rows_per_block, h - ybeg);
@@ -496,73 +498,62 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_mfma(const TI* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // fill: padded rows ybeg .. ybeg + 2 and g_y's row ybeg
-  for (int r = 0; r < 3; ++r) { load_x(ybeg + r); file_x(r); }
+  // step i = 0 .. nrows + 1 works on padded input row ybeg + i (slot i & 1) against g_y rows ybeg + i - ky (ring slot (i - ky) & 3), ky = 0, 1, 2, where they
+  // are rows of this block; g_y rows at or past ybeg + nrows are filed as zeros (load_g), so only the steps before the block's first rows need a guard
+  load_x(ybeg); file_x(0);
   load_g(ybeg); file_g(0);
   __syncthreads();
-
-  for (int it = 0; it < nrows; ++it) {
-    const int y = ybeg + it;
-    load_x(y + 3);
-    load_g(y + 1);
-    const int gslot = it & 1;
+  for (int i = 0; i < nrows + 2; ++i) {
+    load_x(ybeg + i + 1);
+    load_g(ybeg + i + 1);
+    bf16x8 Bx[3][P];
 #pragma unroll
-    for (int s = 0; s < 2/KS; ++s) {
-      const int xsi = (KS == 2) ? ks : s;                         // K step: columns 16 xsi + 8 g .. + 7
+    for (int p = 0; p < P; ++p) {
+      const uint4* q = reinterpret_cast<const uint4*>(&xs[(p*CB + ct*32 + j)*XCH + (i & 1)*XROW + ks*8 + g*4]);
+      const uint4 d = q[0];
+      const unsigned d4 = q[1].x;
+      Bx[0][p] = as_frag(d);
+      Bx[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16), __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(d4, d.w, 16)});
+      Bx[2][p] = as_frag(uint4{d.y, d.z, d.w, d4});
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      if (i - ky < 0) continue;                                   // (wave-uniform: the block's first two steps)
       bf16x8 A[P];
 #pragma unroll
-      for (int p = 0; p < P; ++p) A[p] = as_frag(*reinterpret_cast<const uint4*>(&gs[(p*COB + cot*32 + j)*GCH + gslot*GROW + xsi*8 + g*4]));
+      for (int p = 0; p < P; ++p) A[p] = as_frag(*reinterpret_cast<const uint4*>(&gs[(p*COB + j)*GCH + ((i - ky) & 3)*GROW + ks*8 + g*4]));
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int slot = (it + ky) & 3;
-        bf16x8 Bx[3][P];
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const unsigned* q = &xs[(p*CB + ct*32 + j)*XCH + slot*XROW + xsi*8 + g*4];
-          const uint4 d = *reinterpret_cast<const uint4*>(q);
-          const unsigned d4 = reinterpret_cast<const uint4*>(q)[1].x;   // the fifth dword as part of an aligned 16-byte read: as a ds_read_b32 its 32-lane groups meet 4-way on the
-                                                                        // 32 banks that instruction sees (channel stride 84 dwords = 20 mod 32: 64 % of this kernel's LDS cycles were conflicts)
-          Bx[0][p] = as_frag(d);
-          Bx[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16), __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(d4, d.w, 16)});
-          Bx[2][p] = as_frag(uint4{d.y, d.z, d.w, d4});
-        }
-#pragma unroll
-        for (int t = 0; t < NPROD; ++t)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) acc[ky*3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[prod_a(P, t)], Bx[kx][prod_b(P, t)], acc[ky*3 + kx], 0, 0, 0);
-      }
+        for (int kx = 0; kx < 3; ++kx) acc[ky*3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[prod_a(P, t)], Bx[kx][prod_b(P, t)], acc[ky*3 + kx], 0, 0, 0);
     }
-    file_x((it + 3) & 3);
-    file_g((it + 1) & 1);
+    file_x((i + 1) & 1);
+    file_g((i + 1) & 3);
     __syncthreads();
   }
 
-  // D[row = co][column = c] of tap t
-  if constexpr (KS == 2) {
-    float* red = reinterpret_cast<float*>(lds);                   // (everybody is past the last barrier of the loop: the ring is free)
-    if (ks == 1) {
+  // D[row = co][column = c] of tap t: the two K-step waves of a pair meet in LDS
+  float* red = reinterpret_cast<float*>(lds);                     // (everybody is past the last barrier of the loop: the rings are free)
+  if (ks == 1) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((cot + COT*ct)*144 + t*16 + r)*64 + lane] = acc[t][r];
-    }
-    __syncthreads();
-    if (ks == 0) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] += red[((cot + COT*ct)*144 + t*16 + r)*64 + lane];
-    }
+      for (int r = 0; r < 16; ++r) red[(ct*144 + t*16 + r)*64 + lane] = acc[t][r];
   }
+  __syncthreads();
   if (ks == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] += red[(ct*144 + t*16 + r)*64 + lane];
     const size_t blk = ((size_t)b*gridDim.y + blockIdx.y)*gridDim.x + blockIdx.x;
-    const int c = (cg*CT + ct)*32 + j;
+    const int c = (cg*2 + ct)*32 + j;
     if (c < C) {
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = (cog*COT + cot)*32 + (r & 3) + 8*(r >> 2) + 4*g;
+          const int co = cog*32 + (r & 3) + 8*(r >> 2) + 4*g;
           partial[((blk*9 + t)*CO + co)*C + c] = acc[t][r];
         }
     }
@@ -705,14 +696,12 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_finalize(const float* __rest
 }
 
 // ---- launch shapes ----
-static inline int wgrad_ct(int C, int CO) { return (CO % 64 == 0) ? 2 : (C > 64 ? 4 : 2); }      // pairs per block: 2 x 2 (64 output channels and up), 1 x 4, 1 x 2 (two waves per pair)
-static inline int wgrad_cot(int C, int CO) { return (CO % 64 == 0) ? 2 : 1; }
 static void wgrad_shape(int B, int C, int CO, int h, int w, dim3& grid, int& rows) {
-  const int CB = 32*wgrad_ct(C, CO), COB = 32*wgrad_cot(C, CO);
-  const int strips = ceil_div(w, 32), base = strips*B*ceil_div(C, CB)*(CO/COB);
-  const int groups = std::max(1, std::min(256/std::max(base, 1), ceil_div(h, 4)));   // one block per CU (its ring takes most of the LDS): one generation of equal blocks where the layer allows
+  const int strips = ceil_div(w, 32), base = strips*B*ceil_div(C, 64)*(CO/32);
+  const int groups = std::max(1, std::min(512/std::max(base, 1), ceil_div(h, 12)));  // two blocks per CU: about one generation of equal blocks where the layer allows; at least
+                                                                                      // twelve rows per block (a block runs two steps more than it has rows, then reduces and writes 9 x 32 x 64 sums)
   rows = ceil_div(h, groups);
-  grid = dim3(strips, ceil_div(h, rows), B*ceil_div(C, CB)*(CO/COB));
+  grid = dim3(strips, ceil_div(h, rows), B*ceil_div(C, 64)*(CO/32));
 }
 static void wgrad16_shape(int B, int C, int h, int w, dim3& grid, int& rows) {
   const int strips = ceil_div(w, 32), NC = C >> 4;
@@ -846,10 +835,7 @@ static void launch_wgrad(const void* xp_, const void* gy_, float* partial, int B
     return;
   }
   wgrad_shape(B, C, CO, h, w, grid, rows);
-  const int cot = wgrad_cot(C, CO), ct = wgrad_ct(C, CO);
-  if (cot == 2) hipLaunchKernelGGL((k_conv_wgrad_mfma<2, 2, P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
-  else if (ct == 4) hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 4, P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
-  else hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 2, P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+  hipLaunchKernelGGL((k_conv_wgrad_mfma<P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
 }
 hipError_t launch_conv_mfma_bwd_wgt(const void* xp, const void* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
 #define SMD_CALL(P, T) launch_wgrad<P, T>(xp, gy, partial, B, C, CO, h, w, st)
