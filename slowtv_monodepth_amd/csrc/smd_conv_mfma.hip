@@ -560,122 +560,135 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_mfma(const TI* __restrict
   }
 }
 
-// Sixteen output channels (the thin last stage): the same GEMM on `v_mfma_f32_16x16x32_bf16` — a K step is 32 pixels of a row (lane group q: pixels 8 q .. + 7),
-// A = g_y (16 channels), B = the padded input shifted by the tap, one 16 x 16 accumulator tile per tap.  Both operands want 8 consecutive pixels of one channel
-// per lane — the tensors' own order — so nothing is staged: a lane loads ITS fragment's pixels straight from memory (32 B of g_y, 40 B of the input: every
-// channel row of the strip is read in whole 128-byte runs), splits them in registers, and a WAVE streams down its rows on its own: no LDS, no barrier.  The
-// input's rows y, y + 1, y + 2 serve the taps' three rows, so their split fragments sit in a rolling window of three slots (the row loop is unrolled by three:
-// every slot a compile-time register set) and each row costs ONE new input row and one g_y row (about 110 vector instructions beside its 54 MFMAs).  HBM-bound
-// (128 B per pixel for 2304 multiply-adds at 6/16 of the f32 MFMA's time).  A block = four waves stacked vertically; their sums meet in LDS and leave as one
-// set [tap][co][c].  (First version, round 6: tiles of 32 x 4 pixels staged through LDS with two barriers per tile: 198 us at cfg 2 where the f32 MFMA kernel
-// of smd_conv_thin.hip takes 114.)
-// the row loop of one wave.  EDGE (the strip reaches past the image's right edge): element loads with clamped columns; otherwise a lane's 10 (input) / 8 (g_y)
-// consecutive pixels as 16- and 8-byte loads.  Two instantiations, chosen once per block: a branch around a load inside the loop makes the compiler lose
-// count of the loads in flight (every wait becomes vmcnt(0) and the prefetch is gone), and one load instruction per element costs the texture path 16
-// channel rows x 4 lanes each (18 of them per row: slower than the LDS-staged version).
-template <int P, typename R, bool EDGE>
-__device__ __forceinline__ void wgrad16_rows(const R* __restrict__ xsrc, const R* __restrict__ gsrc, int xa, int ybeg, int yend, int h, int w, int H, int W, f32x4v (&acc)[9]) {
-  constexpr int NPROD = n_products(P);
-  typedef R R4 __attribute__((ext_vector_type(4), aligned(sizeof(R))));
-  typedef R R2 __attribute__((ext_vector_type(2), aligned(sizeof(R))));
-  bf16x8 Bw[3][3][P];                                             // [window slot][kx][piece]
-  auto load_x = [&](int yy, R (&v)[10]) {                         // padded row yy, columns xa .. xa + 9 (clamped: what lies past the image meets zeros of g_y)
-    const R* rowp = xsrc + (size_t)min(yy, H - 1)*W;
-    if constexpr (!EDGE) {
-      const R4 a = *reinterpret_cast<const R4*>(rowp + xa), b4 = *reinterpret_cast<const R4*>(rowp + xa + 4);
-      const R2 c2 = *reinterpret_cast<const R2*>(rowp + xa + 8);
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b4[0]; v[5] = b4[1]; v[6] = b4[2]; v[7] = b4[3]; v[8] = c2[0]; v[9] = c2[1];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 10; ++e) v[e] = rowp[min(xa + e, W - 1)];
-    }
-  };
-  auto split_x = [&](const R (&v)[10], bf16x8 (&dst)[3][P]) {
-    unsigned d[5][P];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) split_pair<P>(v[2*k], v[2*k + 1], d[k]);
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      dst[0][p] = as_frag(uint4{d[0][p], d[1][p], d[2][p], d[3][p]});
-      dst[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(d[1][p], d[0][p], 16), __builtin_amdgcn_alignbit(d[2][p], d[1][p], 16),
-                                __builtin_amdgcn_alignbit(d[3][p], d[2][p], 16), __builtin_amdgcn_alignbit(d[4][p], d[3][p], 16)});
-      dst[2][p] = as_frag(uint4{d[1][p], d[2][p], d[3][p], d[4][p]});
-    }
-  };
-  auto load_g = [&](int y, R (&v)[8]) {                           // (rows are inside the image: the block's range ends at h; columns past it: zeros, those pixels add nothing)
-    const R* rowp = gsrc + (size_t)y*w;
-    if constexpr (!EDGE) {
-      const R4 a = *reinterpret_cast<const R4*>(rowp + xa), b4 = *reinterpret_cast<const R4*>(rowp + xa + 4);
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b4[0]; v[5] = b4[1]; v[6] = b4[2]; v[7] = b4[3];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const R t = rowp[min(xa + e, w - 1)]; v[e] = xa + e < w ? t : R(0); }
-    }
-  };
-  R xv[10], gv[8];
-  load_x(ybeg, xv); split_x(xv, Bw[0]);
-  load_x(ybeg + 1, xv); split_x(xv, Bw[1]);
-  load_x(ybeg + 2, xv); load_g(ybeg, gv);                         // the first row's own requests
-  // row y uses window slots (y - ybeg + ky) % 3; the new input row y + 2 goes to slot (y - ybeg + 2) % 3; the next row's requests (unconditional: the last
-  // one re-reads a clamped row) fly under this row's MFMAs
-  auto row = [&](int y, auto S0) {
-    constexpr int s0 = decltype(S0)::value;
-    split_x(xv, Bw[(s0 + 2) % 3]);
-    bf16x8 A[P];
-    {
-      unsigned d[4][P];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) split_pair<P>(gv[2*k], gv[2*k + 1], d[k]);
-#pragma unroll
-      for (int p = 0; p < P; ++p) A[p] = as_frag(uint4{d[0][p], d[1][p], d[2][p], d[3][p]});
-    }
-    load_x(y + 3, xv); load_g(min(y + 1, h - 1), gv);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int t = 0; t < NPROD; ++t)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-          acc[ky*3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[prod_a(P, t)], Bw[(s0 + ky) % 3][kx][prod_b(P, t)], acc[ky*3 + kx], 0, 0, 0);
-  };
-  for (int y = ybeg; y < yend; y += 3) {
-    row(y, std::integral_constant<int, 0>{});
-    if (y + 1 < yend) row(y + 1, std::integral_constant<int, 1>{});
-    if (y + 2 < yend) row(y + 2, std::integral_constant<int, 2>{});
-  }
-}
-
-template <int P, typename TI>
-__global__ __launch_bounds__(256) void k_conv16_wgrad_mfma(const TI* __restrict__ xp, const TI* __restrict__ gy, float* __restrict__ partial, int C, int h, int w, int rows) {
-  typedef typename RawOf<TI>::type R;
-  __shared__ float red[4*9*4*64];
+// Sixteen output channels (the thin last stage): the same structure on `v_mfma_f32_16x16x32_bf16` — a K step is 32 pixels of a row (lane group q: pixels
+// 8 q .. + 7), A = g_y (16 channels), B = the padded input shifted by the tap, one 16 x 16 accumulator tile per tap (36 registers).  A block walks down a strip of
+// 64 columns: 2 K steps per row x NC tiles of 16 input channels = 2 NC waves; ring of four g_y rows + two slots of the input row in LDS (40-54 KB: three or four
+// blocks per CU, ~100 registers), one barrier per row.  HBM-bound (128-192 B per pixel for 2304-4608 multiply-adds at 6/16 of the f32 MFMA's time).
+// (Earlier forms, round 6, 16 -> 16 at 192x640 / 32 -> 16 at 96x320: tiles of 32 x 4 pixels staged through LDS with two barriers per tile 198 / 277 us; fragments
+// straight from memory with a rolling register window 138 / 77 — a quarter wave of a fragment load touches 16 channel rows; the f32-MFMA kernel 112 / 76.)
+template <int NC, int P, typename TI>
+__global__ __launch_bounds__(128*NC) void k_conv16_wgrad_mfma(const TI* __restrict__ xp, const TI* __restrict__ gy, float* __restrict__ partial, int h, int w, int rows_per_block) {
+  constexpr int C = 16*NC, NT = 128*NC, NPROD = n_products(P);
+  constexpr int XROW = 36, XCH = 2*XROW + 4;            // dwords: a row slot = 72 bf16 (66 used), a channel = 2 slots + 16 bytes (304 B = 16 x 19)
+  constexpr int GROW = 32, GCH = 4*GROW + 4;            // dwords: a row slot = 64 bf16, a channel = 4 slots + 16 bytes (528 B = 16 x 33)
+  constexpr int kXs = P*C*XCH, kGs = P*16*GCH, kRed = NC*36*64;
+  __shared__ __attribute__((aligned(16))) unsigned lds[(kXs + kGs) > kRed ? (kXs + kGs) : kRed];
+  unsigned* const xs = lds;
+  unsigned* const gs = lds + kXs;
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-  const int NC = C >> 4, nc = blockIdx.z % NC, b = blockIdx.z/NC;
-  const int x0 = blockIdx.x*32, W = w + 2, H = h + 2;
-  const int rw = (rows + 3)/4;                                    // rows per wave
-  const int ybeg = blockIdx.y*rows + wv*rw, yend = min(min(ybeg + rw, (int)(blockIdx.y + 1)*rows), h);
-  const R* gsrc = reinterpret_cast<const R*>(gy) + ((size_t)b*16 + j)*h*w;               // this lane's g_y channel
-  const R* xsrc = reinterpret_cast<const R*>(xp) + ((size_t)b*C + nc*16 + j)*H*W;       // this lane's input channel
-  const int xa = x0 + 8*q;                                        // first pixel of this lane's K slots
+  const int nc = wv >> 1, ks = wv & 1;                   // this wave's input-channel tile and K step (columns 32 ks + 8 q .. + 7)
+  const int x0 = blockIdx.x*64, ybeg = blockIdx.y*rows_per_block, nrows = min(rows_per_block, h - ybeg), b = blockIdx.z;
+  const int W = w + 2, H = h + 2;
+  typedef typename RawOf<TI>::type R;
+  const R* xsrc = reinterpret_cast<const R*>(xp) + (size_t)b*C*H*W;
+  const R* gsrc = reinterpret_cast<const R*>(gy) + (size_t)b*16*h*w;
+
+  constexpr int XITEMS = C*33, XTRIPS = (XITEMS + NT - 1)/NT;   // an item = two adjacent columns of one channel's row (66 columns)
+  constexpr int GITEMS = 16*32, GTRIPS = GITEMS/NT;
+  static_assert(GITEMS % NT == 0, "g_y items per thread");
+  R xv[XTRIPS][2], gv[GTRIPS][2];
+  auto load_x = [&](int yy) {
+    yy = min(yy, H - 1);
+#pragma unroll
+    for (int t = 0; t < XTRIPS; ++t) {
+      const int item = min(t*NT + (int)threadIdx.x, XITEMS - 1);
+      const int c = item/33, pr = item - c*33;
+      const R* rowp = xsrc + ((size_t)c*H + yy)*W;
+      xv[t][0] = rowp[min(x0 + 2*pr, W - 1)];
+      xv[t][1] = rowp[min(x0 + 2*pr + 1, W - 1)];
+    }
+  };
+  auto file_x = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < XTRIPS; ++t) {
+      const int item = t*NT + (int)threadIdx.x;
+      if (item < XITEMS) {
+        const int c = item/33, pr = item - c*33;
+        unsigned pk[P];
+        split_pair<P>(xv[t][0], xv[t][1], pk);
+#pragma unroll
+        for (int p = 0; p < P; ++p) xs[(p*C + c)*XCH + slot*XROW + pr] = pk[p];
+      }
+    }
+  };
+  auto load_g = [&](int y) {                                      // beyond the image or the block's rows: zeros, those pixels add nothing
+#pragma unroll
+    for (int t = 0; t < GTRIPS; ++t) {
+      const int item = t*NT + (int)threadIdx.x;
+      const int co = item >> 5, pr = item & 31;
+      const int xa = x0 + 2*pr;
+      const bool yok = y < ybeg + nrows;
+      const R* rowp = gsrc + ((size_t)co*h + (yok ? y : 0))*w;
+      gv[t][0] = (yok && xa < w) ? rowp[xa] : R(0);
+      gv[t][1] = (yok && xa + 1 < w) ? rowp[xa + 1] : R(0);
+    }
+  };
+  auto file_g = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < GTRIPS; ++t) {
+      const int item = t*NT + (int)threadIdx.x;
+      const int co = item >> 5, pr = item & 31;
+      unsigned pk[P];
+      split_pair<P>(gv[t][0], gv[t][1], pk);
+#pragma unroll
+      for (int p = 0; p < P; ++p) gs[(p*16 + co)*GCH + slot*GROW + pr] = pk[p];
+    }
+  };
+
   f32x4v acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  if (ybeg < yend) {
-    if (x0 + 34 <= W && x0 + 32 <= w) wgrad16_rows<P, R, false>(xsrc, gsrc, xa, ybeg, yend, h, w, H, W, acc);
-    else wgrad16_rows<P, R, true>(xsrc, gsrc, xa, ybeg, yend, h, w, H, W, acc);
-  }
-  // D[row = co 4 q + v][column = c j] of tap t: the four waves' sums meet in LDS, added in wave order
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) red[((wv*9 + t)*4 + v)*64 + lane] = acc[t][v];
+
+  // step i = 0 .. nrows + 1 works on padded input row ybeg + i (slot i & 1) against g_y rows ybeg + i - ky (ring slot (i - ky) & 3), as in k_conv_wgrad_mfma
+  load_x(ybeg); file_x(0);
+  load_g(ybeg); file_g(0);
   __syncthreads();
-  const size_t blk = ((size_t)b*gridDim.y + blockIdx.y)*gridDim.x + blockIdx.x;
-  for (int e = threadIdx.x; e < 9*4*64; e += 256) {
-    const float sum = (red[e] + red[9*256 + e]) + (red[2*9*256 + e] + red[3*9*256 + e]);
-    const int l = e & 63, v = (e >> 6) & 3, t = e >> 8;
-    const int co = (l >> 4)*4 + v, c = nc*16 + (l & 15);
-    partial[((blk*9 + t)*16 + co)*C + c] = sum;
+  for (int i = 0; i < nrows + 2; ++i) {
+    load_x(ybeg + i + 1);
+    load_g(ybeg + i + 1);
+    bf16x8 Bx[3][P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint4* qp = reinterpret_cast<const uint4*>(&xs[(p*C + nc*16 + j)*XCH + (i & 1)*XROW + ks*16 + q*4]);
+      const uint4 d = qp[0];
+      const unsigned d4 = qp[1].x;
+      Bx[0][p] = as_frag(d);
+      Bx[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16), __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(d4, d.w, 16)});
+      Bx[2][p] = as_frag(uint4{d.y, d.z, d.w, d4});
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      if (i - ky < 0) continue;                                   // (wave-uniform: the block's first two steps)
+      bf16x8 A[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) A[p] = as_frag(*reinterpret_cast<const uint4*>(&gs[(p*16 + j)*GCH + ((i - ky) & 3)*GROW + ks*16 + q*4]));
+#pragma unroll
+      for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky*3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[prod_a(P, t)], Bx[kx][prod_b(P, t)], acc[ky*3 + kx], 0, 0, 0);
+    }
+    file_x((i + 1) & 1);
+    file_g((i + 1) & 3);
+    __syncthreads();
+  }
+  // D[row = co 4 q + v][column = c j] of tap t: the two K-step waves of a channel tile meet in LDS
+  float* red = reinterpret_cast<float*>(lds);                     // (everybody is past the last barrier of the loop: the rings are free)
+  if (ks == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[(nc*36 + t*4 + v)*64 + lane] = acc[t][v];
+  }
+  __syncthreads();
+  if (ks == 0) {
+    const size_t blk = ((size_t)b*gridDim.y + blockIdx.y)*gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int co = 4*q + v, c = nc*16 + j;
+        partial[((blk*9 + t)*16 + co)*C + c] = acc[t][v] + red[(nc*36 + t*4 + v)*64 + lane];
+      }
   }
 }
 
@@ -704,11 +717,11 @@ static void wgrad_shape(int B, int C, int CO, int h, int w, dim3& grid, int& row
   grid = dim3(strips, ceil_div(h, rows), B*ceil_div(C, 64)*(CO/32));
 }
 static void wgrad16_shape(int B, int C, int h, int w, dim3& grid, int& rows) {
-  const int strips = ceil_div(w, 32), NC = C >> 4;
-  const long long units = (long long)strips*B*NC;                 // (strip, sample, input-channel tile) columns of waves; about eight waves per SIMD-pair: 1024 blocks
-  const int groups = (int)std::max(1ll, std::min<long long>(ceil_div(h, 8), (1024 + units - 1)/units));   // at least two rows per wave
+  const int strips = ceil_div(w, 64);
+  const long long units = (long long)strips*B;                    // strips of 64 columns; about four blocks per CU, at least twelve rows per block
+  const int groups = (int)std::max(1ll, std::min<long long>(ceil_div(h, 12), (1024 + units - 1)/units));
   rows = ceil_div(h, groups);
-  grid = dim3(strips, ceil_div(h, rows), B*NC);
+  grid = dim3(strips, ceil_div(h, rows), B);
 }
 size_t conv_mfma_wgrad_partials(int B, int C, int CO, int h, int w) {
   dim3 grid; int rows;
@@ -831,7 +844,8 @@ static void launch_wgrad(const void* xp_, const void* gy_, float* partial, int B
   dim3 grid; int rows;
   if (CO == 16) {
     wgrad16_shape(B, C, h, w, grid, rows);
-    hipLaunchKernelGGL((k_conv16_wgrad_mfma<P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, h, w, rows);
+    if (C == 16) hipLaunchKernelGGL((k_conv16_wgrad_mfma<1, P, T>), grid, dim3(128), 0, st, xp, gy, partial, h, w, rows);
+    else hipLaunchKernelGGL((k_conv16_wgrad_mfma<2, P, T>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows);
     return;
   }
   wgrad_shape(B, C, CO, h, w, grid, rows);
