@@ -55,11 +55,12 @@ def report(lines, key, what, unit):
 
 print('\nDecoder convolutions (round 6), produced by scripts/dev/conv_isa_stats.py\n')
 L = isa('smd_conv_mfma.hip')
-report(L, '_ZN3smd11k_conv_mfmaILi64ELi3ELb0EffEE', 'k_conv_mfma<64, 3, false, float, float>  (wide forward, fp32 tensors, three pieces: 4 rows x 64 columns x 32 output channels per block; a chunk = 16 channels x 9 taps)', 'one K chunk of one wave: 9 taps x 2 pixel tiles x 6 products = 108 MFMA')
-report(L, '_ZN3smd11k_conv_mfmaILi64ELi3ELb1EffEE', 'k_conv_mfma<64, 3, true, float, float>   (wide data gradient)', 'one K chunk')
-report(L, '_ZN3smd11k_conv_mfmaILi64ELi1ELb0E14__hip_bfloat16S1_EE', 'k_conv_mfma<64, 1, false, bf16, bf16>    (wide forward, bf16 tensors, one piece)', 'one K chunk: 18 MFMA')
+report(L, '_ZN3smd11k_conv_mfmaILi64ELi3ELb0EffLi1EE', 'k_conv_mfma<64, 3, false, float, float>  (wide forward, fp32 tensors, three pieces: 4 rows x 64 columns x 32 output channels per block; a chunk = 16 channels x 9 taps)', 'one K chunk of one wave: 9 taps x 2 pixel tiles x 6 products = 108 MFMA')
+report(L, '_ZN3smd11k_conv_mfmaILi64ELi3ELb1EffLi1EE', 'k_conv_mfma<64, 3, true, float, float>   (wide data gradient)', 'one K chunk')
+report(L, '_ZN3smd11k_conv_mfmaILi64ELi1ELb0E14__hip_bfloat16S1_Li1EE', 'k_conv_mfma<64, 1, false, bf16, bf16>    (wide forward, bf16 tensors, one piece)', 'one K chunk: 18 MFMA')
 report(L, '_ZN3smd13k_conv16_mfmaILi1ELi3ELb0EffEE', 'k_conv16_mfma<1, 3, false, float, float> (thin forward 16 -> 16: 16x16x32 MFMA, two taps per K step, weights in registers; no loop — one chunk)', 'the whole tile: 5 K steps x 4 rows x 6 products = 120 MFMA')
-report(L, '_ZN3smd17k_conv_wgrad_mfmaILi1ELi4ELi3EfEE', 'k_conv_wgrad_mfma<1, 4, 3, float>        (wide weight gradient, 32 output x 128 input channels per block, ring of input rows)', 'one image row of one wave: 2 K steps x 9 taps x 6 products = 108 MFMA')
-report(L, '_ZN3smd19k_conv16_wgrad_mfmaILi3EfEE', 'k_conv16_wgrad_mfma<3, float>            (thin weight gradient: fragments straight from memory, rolling window; the loop is three rows)', 'three image rows of one wave: 3 x 54 MFMA')
+report(L, '_ZN3smd17k_conv_wgrad_mfmaILi3EfEE', 'k_conv_wgrad_mfma<3, float>              (wide weight gradient, 32 output x 64 input channels per block; loop over INPUT rows, ring of four g_y rows + two input slots)', 'one input row of one wave (its K step of 32 columns, one tile of 32 input channels): 3 ky x 3 kx x 6 products = 54 MFMA')
+report(L, '_ZN3smd19k_conv16_wgrad_mfmaILi1ELi3EfEE', 'k_conv16_wgrad_mfma<1, 3, float>         (thin weight gradient 16 -> 16: the same structure on 16x16x32, strips of 64 columns)', 'one input row of one wave')
+report(L, '_ZN3smd19k_conv16_wgrad_mfmaILi2ELi3EfEE', 'k_conv16_wgrad_mfma<2, 3, float>         (thin weight gradient 32 -> 16)', 'one input row of one wave')
 T = isa('smd_conv_thin.hip')
 report(T, '_ZN3smd11k_thin_mfmaILi16ELi1ELb0EEE', 'k_thin_mfma<16, 1, false>                (round 5, f32 MFMA 16x16x4: the comparison)', 'the whole tile')
