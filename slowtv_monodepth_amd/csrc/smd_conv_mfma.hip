@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void k_conv_split_sum(const float* __restrict_
 // and serve three ky (15 LDS reads per 54 MFMAs), and 60 KB of LDS leave room for two blocks per CU.  A block = 32 output x 64 input channels, four waves =
 // 2 input-channel tiles x the 2 K steps of a 32-column strip; per row it requests one new row of each operand before the row's MFMAs and splits + files
 // them after, one barrier per row.  The block leaves its sums as one set of partials [tap][co][c]; k_conv_wgrad_finalize adds the blocks' sets in fp64 in
-// block order (deterministic, as everywhere in this library).
+// a fixed order (deterministic, as everywhere in this library).
 // (First form, round 6: the ring held four INPUT rows of 64-128 channels — 93-143 KB, one block per CU, a lane's five dwords read per ky: 193 us at cfg 2's
 // 96 -> 32 layer, the bf16 pipe 37 % busy, 64 % of the LDS cycles bank conflicts of the fifth-dword read.)
 struct WgradTile {
@@ -692,21 +692,169 @@ __global__ __launch_bounds__(128*NC) void k_conv16_wgrad_mfma(const TI* __restri
   }
 }
 
-// partial[t][tap][co][c] -> g_w[co][c][tap]: a block = 64 weights x 4 waves that take every fourth block's sums (fp64), added in wave order
-__global__ __launch_bounds__(256) void k_conv_wgrad_finalize(const float* __restrict__ partial, unsigned T, int CO, int C, float* __restrict__ g_w) {
+// The thin weight gradient for fp32 tensors, fourth form: the rows reach LDS by LDS-DMA (`buffer_load_dword ... lds`: no staging registers, so a ring of D rows
+// costs LDS only and D - 1 rows are in flight per block), RAW; a wave reads its own slice of a row — 10 columns of its input channel, 8 of its g_y channel — and
+// splits it in registers (every element is split by exactly one wave of its channel tile; the g_y slice again by each of the NC tiles), keeps the g_y fragments
+// of the two rows before in registers for ky = 1, 2.  The third form issued a row's loads at the top of a step and filed them at its bottom: one row (8 KB) in
+// flight per block, 3.3 us per row step at 16 -> 16 (the MFMAs of a step are 0.4 us).  One barrier per row, no vector-memory wait but the in-order counter.
+// A slot = [C input channels][68 dwords: 66 columns + 2] [16 g_y channels][68: 64 columns + 4] (+ one dummy piece where the pieces do not divide among the waves);
+// channel stride 272 B = 16 x 17.  Pieces outside the image (columns past the row, g_y rows past the block) carry an out-of-range offset / an empty resource:
+// the DMA writes zeros.
+template <int NC, int P>
+__global__ __launch_bounds__(128*NC) void k_conv16_wgrad_dma(const float* __restrict__ xp, const float* __restrict__ gy, float* __restrict__ partial, int h, int w, int rows_per_block) {
+  constexpr int C = 16*NC, NW = 2*NC, NPROD = n_products(P), CS = 68, D = 4;
+  constexpr int XDW = C*CS, GDW = 16*CS, NPX = XDW/64, NPG = GDW/64, NX = (NPX + NW - 1)/NW, NG = (NPG + NW - 1)/NW, NDMA = NX + NG, SLOT = XDW + GDW + 64;
+  static_assert(XDW % 64 == 0 && GDW % 64 == 0, "whole DMA pieces per region");
+  static_assert((D - 2)*NDMA < 64, "the waits below are immediates of six bits");
+  constexpr int kRed = NC*36*64;
+  __shared__ __attribute__((aligned(16))) unsigned lds[(D*SLOT) > kRed ? (D*SLOT) : kRed];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+  const int nc = wv >> 1, ks = wv & 1;
+  const int x0 = blockIdx.x*64, ybeg = blockIdx.y*rows_per_block, nrows = min(rows_per_block, h - ybeg), b = blockIdx.z;
+  const int W = w + 2, H = h + 2, nsteps = nrows + 2;
+  const rsrc_t rs_x = make_rsrc(xp + (size_t)b*C*H*W, (size_t)C*H*W*4), rs_g = make_rsrc(gy + (size_t)b*16*h*w, (size_t)16*h*w*4);
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned*)lds);
+
+  // this wave's pieces of a row: input piece n is piece k = n NW + wv of the slot's input region (dword k 64 + lane), likewise for g_y; a wave whose last
+  // piece does not exist sends it (out-of-range offsets: zeros) to the slot's 256 spare bytes, so that every wave has NX + NG loads in flight per row
+  unsigned vx[NX], vg[NG];
+#pragma unroll
+  for (int n = 0; n < NX; ++n) {
+    const int k = n*NW + wv, d = k*64 + lane, c = d/CS, col = d - c*CS;
+    vx[n] = (k < NPX && col < 66 && x0 + col < W) ? (unsigned)((c*H)*W + x0 + col)*4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    const int k = n*NW + wv, d = k*64 + lane, co = d/CS, col = d - co*CS;
+    vg[n] = (k < NPG && col < 64 && x0 + col < w) ? (unsigned)((co*h)*w + x0 + col)*4u : 0x80000000u;
+  }
+  auto dma = [&](const rsrc_t& rs, unsigned v, unsigned so, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v), "s"(rs), "s"(so), "s"(dst) : "memory");
+  };
+  auto issue = [&](int r) {                                      // row r of the block -> slot r % D   (g_y rows past the block's: a valid row, unused)
+    const unsigned base = lds0 + (unsigned)((r % D)*SLOT*4);
+    const unsigned sx = (unsigned)min(ybeg + r, H - 1)*(unsigned)W*4u, sg = (unsigned)min(ybeg + r, h - 1)*(unsigned)w*4u;
+#pragma unroll
+    for (int n = 0; n < NX; ++n) { const int k = n*NW + wv; dma(rs_x, vx[n], sx, base + (unsigned)(k < NPX ? k*256 : (XDW + GDW)*4)); }
+#pragma unroll
+    for (int n = 0; n < NG; ++n) { const int k = n*NW + wv; dma(rs_g, vg[n], sg, base + (unsigned)(k < NPG ? XDW*4 + k*256 : (XDW + GDW)*4)); }
+  };
+
+  f32x4v acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  bf16x8 A[3][P];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int p = 0; p < P; ++p) A[r][p] = as_frag(uint4{0u, 0u, 0u, 0u});
+
+  // step i: padded input row ybeg + i (slot i % D) against g_y rows ybeg + i - ky: this row's fragments (a0) and the two rows' before (a1, a2)
+  auto step = [&](int i, bf16x8 (&a0)[P], const bf16x8 (&a1)[P], const bf16x8 (&a2)[P]) {
+    // this wave's pieces of row i have landed (the rows requested after it may be in flight: D - 2 of them, fewer at the block's end)
+    const int after = min(D - 2, nsteps - 1 - i);
+    if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2*NDMA) : "memory");
+    else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                             // ... and everybody's; nobody reads slot (i - 1) % D any more
+    asm volatile("" ::: "memory");
+    if (i + D - 1 < nsteps) issue(i + D - 1);
+    const float* slot = reinterpret_cast<const float*>(lds) + (i % D)*SLOT;
+    const float* xr = slot + (nc*16 + j)*CS + ks*32 + q*8;
+    const float* gr = slot + XDW + j*CS + ks*32 + q*8;
+    const float4 x0v = *reinterpret_cast<const float4*>(xr), x1v = *reinterpret_cast<const float4*>(xr + 4);
+    const float2 x2v = *reinterpret_cast<const float2*>(xr + 8);
+    const float4 g0v = *reinterpret_cast<const float4*>(gr), g1v = *reinterpret_cast<const float4*>(gr + 4);
+    unsigned px[5][P], pg[4][P];
+    split_pair<P>(x0v.x, x0v.y, px[0]); split_pair<P>(x0v.z, x0v.w, px[1]); split_pair<P>(x1v.x, x1v.y, px[2]); split_pair<P>(x1v.z, x1v.w, px[3]); split_pair<P>(x2v.x, x2v.y, px[4]);
+    split_pair<P>(g0v.x, g0v.y, pg[0]); split_pair<P>(g0v.z, g0v.w, pg[1]); split_pair<P>(g1v.x, g1v.y, pg[2]); split_pair<P>(g1v.z, g1v.w, pg[3]);
+    bf16x8 Bx[3][P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      Bx[0][p] = as_frag(uint4{px[0][p], px[1][p], px[2][p], px[3][p]});
+      Bx[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(px[1][p], px[0][p], 16), __builtin_amdgcn_alignbit(px[2][p], px[1][p], 16),
+                               __builtin_amdgcn_alignbit(px[3][p], px[2][p], 16), __builtin_amdgcn_alignbit(px[4][p], px[3][p], 16)});
+      Bx[2][p] = as_frag(uint4{px[1][p], px[2][p], px[3][p], px[4][p]});
+      a0[p] = as_frag(i < nrows ? uint4{pg[0][p], pg[1][p], pg[2][p], pg[3][p]} : uint4{0u, 0u, 0u, 0u});   // (past the block's rows: nothing to add)
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const bf16x8 (&a)[P] = ky == 0 ? a0 : ky == 1 ? a1 : a2;
+#pragma unroll
+      for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky*3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[prod_a(P, t)], Bx[kx][prod_b(P, t)], acc[ky*3 + kx], 0, 0, 0);
+    }
+  };
+
+  static_assert(D == 4, "the waits above");
+#pragma unroll
+  for (int r = 0; r < D - 1; ++r) issue(r);                       // (nsteps >= 3)
+  for (int i = 0; i < nsteps; i += 3) {
+    step(i, A[0], A[2], A[1]);
+    if (i + 1 < nsteps) step(i + 1, A[1], A[0], A[2]);
+    if (i + 2 < nsteps) step(i + 2, A[2], A[1], A[0]);
+  }
+  __syncthreads();                                                // the ring is free
+  float* red = reinterpret_cast<float*>(lds);
+  if (ks == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[(nc*36 + t*4 + v)*64 + lane] = acc[t][v];
+  }
+  __syncthreads();
+  if (ks == 0) {
+    const size_t blk = ((size_t)b*gridDim.y + blockIdx.y)*gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int co = 4*q + v, c = nc*16 + j;
+        partial[((blk*9 + t)*16 + co)*C + c] = acc[t][v] + red[(nc*36 + t*4 + v)*64 + lane];
+      }
+  }
+}
+
+// partial[t][tap][co][c] -> g_w[co][c][tap], fp64, fixed order.  Many blocks' sums for few weights (the thin stage: T = 960 sets of 2304): two launches —
+// (1) a block = 64 weights x one of G slices of the T sets, its four waves every fourth set of the slice, added in wave order -> slice[g][i] (fp64, behind the
+// partials in the workspace); (2) the G slices in order.  (One launch of ceil(n / 64) blocks over all T sets — 36 blocks reading 8.8 MB — took 67 us beside a
+// 47 us kernel.)  Few sets (T < 64: the coarse levels, up to 1.2 M weights): G = 1 and the first launch writes g_w itself.
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void k_conv_wgrad_finalize(const float* __restrict__ partial, unsigned T, unsigned G, int CO, int C, double* __restrict__ slice, float* __restrict__ g_w) {
   __shared__ double part[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = CO*C*9, i = blockIdx.x*64 + lane;
+  const unsigned g = blockIdx.y, t0 = (unsigned)(((unsigned long long)T*g)/G), t1 = (unsigned)(((unsigned long long)T*(g + 1))/G);
   double s = 0.0;
-  if (i < n) for (unsigned t = wv; t < T; t += 4) s += (double)partial[(size_t)t*n + i];
+  if (i < n) for (unsigned t = t0 + wv; t < t1; t += 4) s += (double)partial[(size_t)t*n + i];
   part[wv][lane] = s;
   __syncthreads();
   if (wv == 0 && i < n) {
     const double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    const int c = i % C, co = (i/C) % CO, tap = i/(C*CO);
-    g_w[((size_t)co*C + c)*9 + tap] = (float)tot;
+    if (DIRECT) { const int c = i % C, co = (i/C) % CO, tap = i/(C*CO); g_w[((size_t)co*C + c)*9 + tap] = (float)tot; }
+    else slice[(size_t)g*n + i] = tot;
   }
 }
+__global__ __launch_bounds__(256) void k_conv_wgrad_finalize2(const double* __restrict__ slice, unsigned G, int CO, int C, float* __restrict__ g_w) {
+  const int n = CO*C*9, i = blockIdx.x*256 + threadIdx.x;
+  if (i >= n) return;
+  double tot = 0.0;
+  unsigned g = 0;
+  for (; g + 8 <= G; g += 8) {                                     // eight loads in flight, added in order
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = slice[(size_t)(g + k)*n + i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += v[k];
+  }
+  for (; g < G; ++g) tot += slice[(size_t)g*n + i];
+  const int c = i % C, co = (i/C) % CO, tap = i/(C*CO);
+  g_w[((size_t)co*C + c)*9 + tap] = (float)tot;
+}
+static unsigned wgrad_slices(unsigned T) { return T < 64 ? 1u : std::min(32u, T/16); }
 
 // ---- launch shapes ----
 static void wgrad_shape(int B, int C, int CO, int h, int w, dim3& grid, int& rows) {
@@ -718,16 +866,17 @@ static void wgrad_shape(int B, int C, int CO, int h, int w, dim3& grid, int& row
 }
 static void wgrad16_shape(int B, int C, int h, int w, dim3& grid, int& rows) {
   const int strips = ceil_div(w, 64);
-  const long long units = (long long)strips*B;                    // strips of 64 columns; about four blocks per CU, at least twelve rows per block
-  const int groups = (int)std::max(1ll, std::min<long long>(ceil_div(h, 12), (1024 + units - 1)/units));
+  const long long units = (long long)strips*B, slots = C == 16 ? 1024 : 768;   // strips of 64 columns; ONE generation of blocks (four / three per CU), at least twelve rows per block
+  const int groups = (int)std::max(1ll, std::min<long long>(ceil_div(h, 12), slots/units));
   rows = ceil_div(h, groups);
   grid = dim3(strips, ceil_div(h, rows), B);
 }
+// floats of workspace: the blocks' partial sums, then the finalize's fp64 slices
 size_t conv_mfma_wgrad_partials(int B, int C, int CO, int h, int w) {
   dim3 grid; int rows;
-  if (CO == 16) { wgrad16_shape(B, C, h, w, grid, rows); return (size_t)grid.x*grid.y*B*9*16*C; }
-  wgrad_shape(B, C, CO, h, w, grid, rows);
-  return (size_t)grid.x*grid.y*B*9*CO*C;
+  if (CO == 16) wgrad16_shape(B, C, h, w, grid, rows); else wgrad_shape(B, C, CO, h, w, grid, rows);
+  const size_t T = (size_t)grid.x*grid.y*B, n = (size_t)9*CO*C;
+  return T*n + 2*(size_t)wgrad_slices((unsigned)T)*n;           // (T n is even: n = 9 CO C with CO even)
 }
 static size_t thin_packed_elems(int C, int pieces) { return (size_t)(C >> 4)*5*pieces*512; }
 size_t conv_mfma_packed_elems(int C, int CO, int pieces) { return std::max((size_t)CO*C*9*pieces, CO == 16 ? thin_packed_elems(C, pieces) : (size_t)0); }
@@ -844,8 +993,13 @@ static void launch_wgrad(const void* xp_, const void* gy_, float* partial, int B
   dim3 grid; int rows;
   if (CO == 16) {
     wgrad16_shape(B, C, h, w, grid, rows);
-    if (C == 16) hipLaunchKernelGGL((k_conv16_wgrad_mfma<1, P, T>), grid, dim3(128), 0, st, xp, gy, partial, h, w, rows);
-    else hipLaunchKernelGGL((k_conv16_wgrad_mfma<2, P, T>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows);
+    if constexpr (std::is_same<T, float>::value) {                  // fp32 tensors: the LDS-DMA form
+      if (C == 16) hipLaunchKernelGGL((k_conv16_wgrad_dma<1, P>), grid, dim3(128), 0, st, xp, gy, partial, h, w, rows);
+      else hipLaunchKernelGGL((k_conv16_wgrad_dma<2, P>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows);
+    } else {
+      if (C == 16) hipLaunchKernelGGL((k_conv16_wgrad_mfma<1, P, T>), grid, dim3(128), 0, st, xp, gy, partial, h, w, rows);
+      else hipLaunchKernelGGL((k_conv16_wgrad_mfma<2, P, T>), grid, dim3(256), 0, st, xp, gy, partial, h, w, rows);
+    }
     return;
   }
   wgrad_shape(B, C, CO, h, w, grid, rows);
@@ -857,7 +1011,14 @@ hipError_t launch_conv_mfma_bwd_wgt(const void* xp, const void* gy, float* g_w, 
 #undef SMD_CALL
   dim3 grid; int rows;
   if (CO == 16) wgrad16_shape(B, C, h, w, grid, rows); else wgrad_shape(B, C, CO, h, w, grid, rows);
-  hipLaunchKernelGGL(k_conv_wgrad_finalize, dim3(ceil_div(CO*C*9, 64)), dim3(256), 0, st, partial, (unsigned)(grid.x*grid.y*B), CO, C, g_w);
+  const unsigned T = grid.x*grid.y*(unsigned)B, G = wgrad_slices(T);
+  const int n = CO*C*9;
+  double* slice = reinterpret_cast<double*>(partial + (size_t)T*n);
+  if (G == 1) hipLaunchKernelGGL(k_conv_wgrad_finalize<true>, dim3(ceil_div(n, 64), 1), dim3(256), 0, st, partial, T, 1u, CO, C, slice, g_w);
+  else {
+    hipLaunchKernelGGL(k_conv_wgrad_finalize<false>, dim3(ceil_div(n, 64), G), dim3(256), 0, st, partial, T, G, CO, C, slice, g_w);
+    hipLaunchKernelGGL(k_conv_wgrad_finalize2, dim3(ceil_div(n, 256)), dim3(256), 0, st, slice, G, CO, C, g_w);
+  }
   return hipGetLastError();
 }
 
