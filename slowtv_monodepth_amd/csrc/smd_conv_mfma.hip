@@ -560,6 +560,138 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_mfma(const TI* __restrict
   }
 }
 
+// The same block for fp32 tensors with the rows brought in by LDS-DMA (see k_conv16_wgrad_dma below, where the form was built): a ring of four RAW rows —
+// [64 input channels][36 dwords: 34 columns + 2][32 g_y channels][36: 32 columns + 4], 13.8 KB a slot — three rows in flight per block instead of one; a wave
+// splits its own slice of a row at fragment read (10 columns of its input channel, 8 of its g_y channel, the latter also split by the other channel tile's wave)
+// and keeps the g_y fragments of the two rows before in registers.
+template <int P>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_dma(const float* __restrict__ xp, const float* __restrict__ gy, float* __restrict__ partial,
+                                                        int C, int CO, int h, int w, int rows_per_block) {
+  constexpr int COB = 32, CB = 64, NW = 4, NPROD = n_products(P), CS = 36, D = 4;
+  constexpr int XDW = CB*CS, GDW = COB*CS, NPX = XDW/64, NPG = GDW/64, NX = (NPX + NW - 1)/NW, NG = (NPG + NW - 1)/NW, NDMA = NX + NG, SLOT = XDW + GDW + 64;
+  static_assert(XDW % 64 == 0 && GDW % 64 == 0 && (D - 2)*NDMA < 64 && D == 4, "DMA pieces and waits");
+  constexpr int kRing = D*SLOT, kTab = NW*NDMA*64, kRed = 2*144*64;
+  __shared__ __attribute__((aligned(16))) unsigned lds[(kRing + kTab) > kRed ? (kRing + kTab) : kRed];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, g = lane >> 5;
+  const int ct = wv & 1, ks = wv >> 1;
+  const int CGRP = (C + CB - 1)/CB, COGRP = CO/COB;
+  const int cg = blockIdx.z % CGRP, cog = (blockIdx.z/CGRP) % COGRP, b = blockIdx.z/(CGRP*COGRP);
+  const int x0 = blockIdx.x*32, ybeg = blockIdx.y*rows_per_block, nrows = min(rows_per_block, h - ybeg), nsteps = nrows + 2;
+  const int W = w + 2, H = h + 2;
+  const rsrc_t rs_x = make_rsrc(xp + (size_t)b*C*H*W, (size_t)C*H*W*4), rs_g = make_rsrc(gy + ((size_t)b*CO + (size_t)cog*COB)*h*w, (size_t)COB*h*w*4);
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned*)lds);
+  auto dma = [&](const rsrc_t& rs, unsigned v, unsigned so, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v), "s"(rs), "s"(so), "s"(dst) : "memory");
+  };
+  // piece k of a region = its dwords k 64 .. + 63; this wave takes pieces n NW + wv (a piece that does not exist: zeros into the slot's spare 256 bytes).
+  // A lane's offset of a piece does not depend on the row: computed once, kept in LDS behind the ring (the accumulators leave no registers for 14 of them, and
+  // recomputing them costs every row more vector instructions than splitting its operands), read back by the lane that wrote it — no synchronisation.
+  unsigned* const tab = lds + kRing + wv*(NDMA*64) + lane;
+#pragma unroll
+  for (int n = 0; n < NX; ++n) {
+    const int k = n*NW + wv, d = k*64 + lane, ch = d/CS, col = d - ch*CS, c = cg*CB + ch;
+    tab[n*64] = (k < NPX && col < 34 && x0 + col < W && c < C) ? (unsigned)((c*H)*W + x0 + col)*4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    const int k = n*NW + wv, d = k*64 + lane, co = d/CS, col = d - co*CS;
+    tab[(NX + n)*64] = (k < NPG && col < 32 && x0 + col < w) ? (unsigned)((co*h)*w + x0 + col)*4u : 0x80000000u;
+  }
+  auto issue = [&](int r) {
+    const unsigned base = lds0 + (unsigned)((r % D)*SLOT*4);
+    const unsigned sx = (unsigned)min(ybeg + r, H - 1)*(unsigned)W*4u, sg = (unsigned)min(ybeg + r, h - 1)*(unsigned)w*4u;
+    unsigned v[NDMA];
+#pragma unroll
+    for (int n = 0; n < NDMA; ++n) v[n] = tab[n*64];
+#pragma unroll
+    for (int n = 0; n < NX; ++n) { const int k = n*NW + wv; dma(rs_x, v[n], sx, base + (unsigned)(k < NPX ? k*256 : (XDW + GDW)*4)); }
+#pragma unroll
+    for (int n = 0; n < NG; ++n) { const int k = n*NW + wv; dma(rs_g, v[NX + n], sg, base + (unsigned)(k < NPG ? XDW*4 + k*256 : (XDW + GDW)*4)); }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  bf16x8 A[3][P];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int p = 0; p < P; ++p) A[r][p] = as_frag(uint4{0u, 0u, 0u, 0u});
+
+  auto step = [&](int i, bf16x8 (&a0)[P], const bf16x8 (&a1)[P], const bf16x8 (&a2)[P]) {
+    const int after = min(D - 2, nsteps - 1 - i);
+    if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2*NDMA) : "memory");
+    else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (i + D - 1 < nsteps) issue(i + D - 1);
+    const float* slot = reinterpret_cast<const float*>(lds) + (i % D)*SLOT;
+    const float* xr = slot + (ct*32 + j)*CS + ks*16 + g*8;
+    const float* gr = slot + XDW + j*CS + ks*16 + g*8;
+    const float4 x0v = *reinterpret_cast<const float4*>(xr), x1v = *reinterpret_cast<const float4*>(xr + 4);
+    const float2 x2v = *reinterpret_cast<const float2*>(xr + 8);
+    const float4 g0v = *reinterpret_cast<const float4*>(gr), g1v = *reinterpret_cast<const float4*>(gr + 4);
+    unsigned px[5][P], pg[4][P];
+    split_pair<P>(x0v.x, x0v.y, px[0]); split_pair<P>(x0v.z, x0v.w, px[1]); split_pair<P>(x1v.x, x1v.y, px[2]); split_pair<P>(x1v.z, x1v.w, px[3]); split_pair<P>(x2v.x, x2v.y, px[4]);
+    split_pair<P>(g0v.x, g0v.y, pg[0]); split_pair<P>(g0v.z, g0v.w, pg[1]); split_pair<P>(g1v.x, g1v.y, pg[2]); split_pair<P>(g1v.z, g1v.w, pg[3]);
+    bf16x8 Bx[3][P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      Bx[0][p] = as_frag(uint4{px[0][p], px[1][p], px[2][p], px[3][p]});
+      Bx[1][p] = as_frag(uint4{__builtin_amdgcn_alignbit(px[1][p], px[0][p], 16), __builtin_amdgcn_alignbit(px[2][p], px[1][p], 16),
+                               __builtin_amdgcn_alignbit(px[3][p], px[2][p], 16), __builtin_amdgcn_alignbit(px[4][p], px[3][p], 16)});
+      Bx[2][p] = as_frag(uint4{px[1][p], px[2][p], px[3][p], px[4][p]});
+      a0[p] = as_frag(i < nrows ? uint4{pg[0][p], pg[1][p], pg[2][p], pg[3][p]} : uint4{0u, 0u, 0u, 0u});
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const bf16x8 (&a)[P] = ky == 0 ? a0 : ky == 1 ? a1 : a2;
+#pragma unroll
+      for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky*3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[prod_a(P, t)], Bx[kx][prod_b(P, t)], acc[ky*3 + kx], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < D - 1; ++r) issue(r);
+  for (int i = 0; i < nsteps; i += 3) {
+    step(i, A[0], A[2], A[1]);
+    if (i + 1 < nsteps) step(i + 1, A[1], A[0], A[2]);
+    if (i + 2 < nsteps) step(i + 2, A[2], A[1], A[0]);
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);
+  if (ks == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(ct*144 + t*16 + r)*64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (ks == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] += red[(ct*144 + t*16 + r)*64 + lane];
+    const size_t blk = ((size_t)b*gridDim.y + blockIdx.y)*gridDim.x + blockIdx.x;
+    const int c = (cg*2 + ct)*32 + j;
+    if (c < C) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cog*32 + (r & 3) + 8*(r >> 2) + 4*g;
+          partial[((blk*9 + t)*CO + co)*C + c] = acc[t][r];
+        }
+    }
+  }
+}
+
 // Sixteen output channels (the thin last stage): the same structure on `v_mfma_f32_16x16x32_bf16` — a K step is 32 pixels of a row (lane group q: pixels
 // 8 q .. + 7), A = g_y (16 channels), B = the padded input shifted by the tap, one 16 x 16 accumulator tile per tap (36 registers).  A block walks down a strip of
 // 64 columns: 2 K steps per row x NC tiles of 16 input channels = 2 NC waves; ring of four g_y rows + two slots of the input row in LDS (40-54 KB: three or four
@@ -1003,7 +1135,8 @@ static void launch_wgrad(const void* xp_, const void* gy_, float* partial, int B
     return;
   }
   wgrad_shape(B, C, CO, h, w, grid, rows);
-  hipLaunchKernelGGL((k_conv_wgrad_mfma<P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+  if constexpr (std::is_same<T, float>::value) hipLaunchKernelGGL((k_conv_wgrad_dma<P>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
+  else hipLaunchKernelGGL((k_conv_wgrad_mfma<P, T>), grid, dim3(256), 0, st, xp, gy, partial, C, CO, h, w, rows);
 }
 hipError_t launch_conv_mfma_bwd_wgt(const void* xp, const void* gy, float* g_w, float* partial, int B, int C, int CO, int h, int w, int pieces, hipStream_t st) {
 #define SMD_CALL(P, T) launch_wgrad<P, T>(xp, gy, partial, B, C, CO, h, w, st)
