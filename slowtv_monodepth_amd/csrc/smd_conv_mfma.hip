@@ -104,7 +104,7 @@ template <int TC> struct ConvTile {
 // vector-memory path per MFMA; measured neutral (128 -> 64 at 48x160: 103.0 vs 104.7 us forward, 108.0 vs 104.7 data gradient; 512 -> 256 at 12x40: 183 vs 171;
 // 128 -> 64 at 24x80 data gradient 42.7 vs 52.3), so the default stays one tile per block.  Same bits either way.
 template <int TC, int P, bool BWD, typename TI, typename TO, int NM>
-__global__ __launch_bounds__(256*NM) void k_conv_mfma(const TI* __restrict__ in_, const uint4* __restrict__ wp, TO* __restrict__ out,
+__global__ __launch_bounds__(256*NM, 2/NM) void k_conv_mfma(const TI* __restrict__ in_, const uint4* __restrict__ wp, TO* __restrict__ out,
                                                    int CK, int M, int hi, int wi, int ho, int wo, int KS, int kc_per_split, size_t split_stride,
                                                    unsigned gx, unsigned gy, unsigned gz) {
   using T = ConvTile<TC>;
@@ -177,9 +177,14 @@ __global__ __launch_bounds__(256*NM) void k_conv_mfma(const TI* __restrict__ in_
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[nt][r] = 0.f; lo[nt][r] = 0.f; }
 
-  // the weights' fragments: a ring of three, requested two taps ahead; the patch's fragments (LDS) one tap ahead.  Nine taps = three turns of the ring:
-  // every position is a compile-time constant.
-  bf16x8 A[3][P], Bf[2][2][P];
+  // the weights' fragments: five slots, requested FOUR taps ahead (tap t of a chunk sits in slot t mod 5; a chunk counts as ten steps, the tenth empty, so the
+  // positions repeat every chunk), and the next patch's staging loads requested after tap 4's fetch.  The counter of outstanding loads retires in order: a wait
+  // for a fragment also waits for every load requested before it.  With a ring of three (two taps ahead) and the staging request at the chunk's start, tap 2's
+  // fragments were requested after the staging loads and the wait for them drained those: the staging latency stood exposed in every chunk.  Now the fragments
+  // of taps 4 .. 8 are requested before the staging loads and every later fetch belongs to the next chunk, whose first wait comes after the staging loads
+  // have been filed anyway: they have four taps to land and are waited for only where they are filed.  (Six slots / nine: 256 registers and 400 / 72 bytes of
+  // spills per lane.)  The patch's fragments (LDS) one tap ahead.
+  bf16x8 A[5][P], Bf[2][2][P];
   const uint4* wq = wp + ((size_t)mg*KC*9*P)*64 + lane;
   auto fetch_a = [&](bf16x8 (&dst)[P], int kc, int tap) {
 #pragma unroll
@@ -196,35 +201,39 @@ __global__ __launch_bounds__(256*NM) void k_conv_mfma(const TI* __restrict__ in_
       for (int p = 0; p < P; ++p) dst[nt][p] = as_frag(tile[buf*kBuf + p*NPIX*2 + slot]);
     }
   };
-
-  if (kc0 < kc1) {
-    request(kc0);
-    fetch_a(A[0], kc0, 0);
-    fetch_a(A[1], kc0, 1);
-    file(0);
-  }
-  __syncthreads();
-  for (int kc = kc0; kc < kc1; ++kc) {
-    const int cur = (kc - kc0) & 1;
-    const bool more = kc + 1 < kc1;
-    if (more) request(kc + 1);                                    // lands during this chunk's MFMAs
+  // one chunk; MORE is compile-time (the last chunk is peeled): no load sits behind a run-time branch, the compiler keeps count of what is outstanding
+  auto chunk = [&](int kc, int cur, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
     read_b(Bf[0], cur, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (tap < 7) fetch_a(A[(tap + 2) % 3], kc, tap + 2);
-      else if (more) fetch_a(A[(tap + 2) % 3], kc + 1, tap - 7);
       if (tap < 8) read_b(Bf[(tap + 1) & 1], cur, tap + 1);
 #pragma unroll
       for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          if (t == NPROD - 1) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap % 3][0], Bf[tap & 1][nt][0], acc[nt], 0, 0, 0);
-          else lo[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap % 3][prod_a(P, t)], Bf[tap & 1][nt][prod_b(P, t)], lo[nt], 0, 0, 0);
+          if (t == NPROD - 1) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap % 5][0], Bf[tap & 1][nt][0], acc[nt], 0, 0, 0);
+          else lo[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap % 5][prod_a(P, t)], Bf[tap & 1][nt][prod_b(P, t)], lo[nt], 0, 0, 0);
         }
+      if (tap <= 4) fetch_a(A[(tap + 4) % 5], kc, tap + 4);
+      else if (MORE && tap >= 6) fetch_a(A[tap - 6], kc + 1, tap - 6);
+      if (MORE && tap == 8) fetch_a(A[3], kc + 1, 3);             // (the empty tenth step's fetch; slot 3 is tap 8's, whose MFMAs have been issued)
+      if (MORE && tap == 4) request(kc + 1);                      // after this chunk's last fetch: lands during taps 5 .. 8
     }
-    if (more) file(cur ^ 1);
+    if (MORE) file(cur ^ 1);
     __syncthreads();                                              // the other patch is complete, and nobody reads this one any more
+  };
+
+  if (kc0 < kc1) {
+    request(kc0);
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) fetch_a(A[tap], kc0, tap);
+    file(0);
   }
+  __syncthreads();
+  int kc = kc0;
+  for (; kc + 1 < kc1; ++kc) chunk(kc, (kc - kc0) & 1, std::true_type{});
+  if (kc < kc1) chunk(kc, (kc - kc0) & 1, std::false_type{});
   // D[row = output channel][column = pixel]: a register is 32 consecutive pixels of one channel per half wave (128-byte runs)
   // (a K split's partial output is always fp32: `out` is then the workspace the splits' sum reads)
   float* dstf = reinterpret_cast<float*>(out) + (size_t)ks*split_stride;
