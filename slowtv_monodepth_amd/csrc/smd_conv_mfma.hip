@@ -94,6 +94,12 @@ __global__ __launch_bounds__(256) void k_conv_pack_w(const float* __restrict__ w
 // fit twice in 68 KB and the MFMA loop touches no vector memory, 158.  What the series says: the limiter is the bytes a CU pulls through its vector-memory path
 // (~10 B/clk for L2 / HBM data: 25 KB of patch per chunk and block = 2.5 k cycles against 3.5 k of MFMAs for 32 output channels) — weight fragments fetched
 // once per block from L2 cost more than four waves' L1-hit copies.  The lever left is arithmetic per staged byte: two or three channel tiles per patch.
+#ifdef SMD_CONV_TRACE   // diagnosis builds only (scripts/dev/conv_trace.py): shader-clock stamps of wave 0 of every block of the forward / data-gradient form
+__device__ unsigned long long g_conv_trace[8192][40];
+#define SMD_CT(slot) do { if (wall == 0 && lid < 8192u && (slot) < 40) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_conv_trace[lid][(slot)] = t_; } } while (0)
+#else
+#define SMD_CT(slot) do { } while (0)
+#endif
 template <int TC> struct ConvTile {
   static constexpr int TRB = (TC == 64) ? 4 : 8;
   static constexpr int PW = TC + 2, PH = TRB + 2, NPIX = PW*PH;
@@ -204,6 +210,8 @@ __global__ __launch_bounds__(256*NM, 2/NM) void k_conv_mfma(const TI* __restrict
   // one chunk; MORE is compile-time (the last chunk is peeled): no load sits behind a run-time branch, the compiler keeps count of what is outstanding
   auto chunk = [&](int kc, int cur, auto more_tag) {
     constexpr bool MORE = decltype(more_tag)::value;
+    [[maybe_unused]] const int cslot = 3 + 4*(kc - kc0);
+    SMD_CT(cslot);
     read_b(Bf[0], cur, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -220,17 +228,23 @@ __global__ __launch_bounds__(256*NM, 2/NM) void k_conv_mfma(const TI* __restrict
       if (MORE && tap == 8) fetch_a(A[3], kc + 1, 3);             // (the empty tenth step's fetch; slot 3 is tap 8's, whose MFMAs have been issued)
       if (MORE && tap == 4) request(kc + 1);                      // after this chunk's last fetch: lands during taps 5 .. 8
     }
+    SMD_CT(cslot + 1);
     if (MORE) file(cur ^ 1);
+    SMD_CT(cslot + 2);
     __syncthreads();                                              // the other patch is complete, and nobody reads this one any more
+    SMD_CT(cslot + 3);
   };
 
+  SMD_CT(0);
   if (kc0 < kc1) {
     request(kc0);
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) fetch_a(A[tap], kc0, tap);
     file(0);
   }
+  SMD_CT(1);
   __syncthreads();
+  SMD_CT(2);
   int kc = kc0;
   for (; kc + 1 < kc1; ++kc) chunk(kc, (kc - kc0) & 1, std::true_type{});
   if (kc < kc1) chunk(kc, (kc - kc0) & 1, std::false_type{});
@@ -251,6 +265,7 @@ __global__ __launch_bounds__(256*NM, 2/NM) void k_conv_mfma(const TI* __restrict
       }
     }
   }
+  SMD_CT(39);
 }
 
 // ---- sixteen output channels (the decoder's thin last stage: 32 -> 16 at half resolution, 16 -> 16 at full resolution) ----
@@ -1165,3 +1180,9 @@ hipError_t launch_conv_mfma_bwd_wgt(const void* xp, const void* gy, float* g_w, 
 }
 
 }  // namespace smd
+
+#ifdef SMD_CONV_TRACE
+extern "C" int smd_debug_conv_trace(unsigned long long* host_out, int blocks) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(smd::g_conv_trace), (size_t)blocks*40*sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
