@@ -59,8 +59,9 @@ report(L, '_ZN3smd11k_conv_mfmaILi64ELi3ELb0EffLi1EE', 'k_conv_mfma<64, 3, false
 report(L, '_ZN3smd11k_conv_mfmaILi64ELi3ELb1EffLi1EE', 'k_conv_mfma<64, 3, true, float, float>   (wide data gradient)', 'one K chunk')
 report(L, '_ZN3smd11k_conv_mfmaILi64ELi1ELb0E14__hip_bfloat16S1_Li1EE', 'k_conv_mfma<64, 1, false, bf16, bf16>    (wide forward, bf16 tensors, one piece)', 'one K chunk: 18 MFMA')
 report(L, '_ZN3smd13k_conv16_mfmaILi1ELi3ELb0EffEE', 'k_conv16_mfma<1, 3, false, float, float> (thin forward 16 -> 16: 16x16x32 MFMA, two taps per K step, weights in registers; no loop — one chunk)', 'the whole tile: 5 K steps x 4 rows x 6 products = 120 MFMA')
-report(L, '_ZN3smd17k_conv_wgrad_mfmaILi3EfEE', 'k_conv_wgrad_mfma<3, float>              (wide weight gradient, 32 output x 64 input channels per block; loop over INPUT rows, ring of four g_y rows + two input slots)', 'one input row of one wave (its K step of 32 columns, one tile of 32 input channels): 3 ky x 3 kx x 6 products = 54 MFMA')
-report(L, '_ZN3smd19k_conv16_wgrad_mfmaILi1ELi3EfEE', 'k_conv16_wgrad_mfma<1, 3, float>         (thin weight gradient 16 -> 16: the same structure on 16x16x32, strips of 64 columns)', 'one input row of one wave')
-report(L, '_ZN3smd19k_conv16_wgrad_mfmaILi2ELi3EfEE', 'k_conv16_wgrad_mfma<2, 3, float>         (thin weight gradient 32 -> 16)', 'one input row of one wave')
+report(L, '_ZN3smd16k_conv_wgrad_dmaILi3EEE', 'k_conv_wgrad_dma<3>                      (wide weight gradient, fp32 tensors: 32 output x 64 input channels per block, loop over INPUT rows, ring of four RAW rows by LDS-DMA, split at fragment read; the loop body is three rows)', 'three input rows of one wave (its K step of 16 columns, one tile of 32 input channels): 3 x 54 MFMA')
+report(L, '_ZN3smd18k_conv16_wgrad_dmaILi1ELi3EEE', 'k_conv16_wgrad_dma<1, 3>                 (thin weight gradient 16 -> 16, fp32 tensors: the same on 16x16x32, strips of 64 columns)', 'three input rows of one wave')
+report(L, '_ZN3smd18k_conv16_wgrad_dmaILi2ELi3EEE', 'k_conv16_wgrad_dma<2, 3>                 (thin weight gradient 32 -> 16)', 'three input rows of one wave')
+report(L, '_ZN3smd17k_conv_wgrad_mfmaILi1E14__hip_bfloat16EE', 'k_conv_wgrad_mfma<1, bf16>               (wide weight gradient, bf16 tensors: rows staged through registers, split + filed after the row\'s MFMAs)', 'one input row of one wave: 9 MFMA')
 T = isa('smd_conv_thin.hip')
 report(T, '_ZN3smd11k_thin_mfmaILi16ELi1ELb0EEE', 'k_thin_mfma<16, 1, false>                (round 5, f32 MFMA 16x16x4: the comparison)', 'the whole tile')
