@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_conv_pack_w(const float* __restrict__ w
 // shift.  The two 16-byte halves of a pixel are swapped where bit 3 of the pixel index is set: the 16-lane groups that serve a ds_read_b128
 // ({0-3, 12-15, 20-27}, ...) then cover all 64 banks instead of colliding two ways.  Two patches: the next chunk's loads are requested before this chunk's
 // MFMAs and filed after them, one barrier per chunk.  The weights come as whole fragments from `k_conv_pack_w`'s image (1 KiB per wave and piece, lane-major:
-// every block reads the same ones, L1 / L2 hits), a ring of three requested two taps ahead.
+// every block reads the same ones, L1 / L2 hits), five slots requested four taps ahead (see below why).
 // What was measured on the way to this form (cfg 2's 96 -> 32 layer at 96x320, MIOpen 217 us; scripts/dev/conv_mfma_check.py, profiles/r06_conv_mfma_*):
 // one load per loop trip, 134 us; every staging load before its first use + the ring, 135 (the pieces — MFMAs alone 59 us, operand reads 40, staging 79-97 —
 // hardly overlap: a CU's one memory pipeline carries the staging loads AND four waves' copies of the weight fragments, 133 KB per chunk and block);
@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void k_conv_pack_w(const float* __restrict__ w
 // wave per SIMD); two producer waves + four MFMA waves per block, 158-174; chunks of 8 channels (two taps per MFMA K step) so that patch AND weight fragments
 // fit twice in 68 KB and the MFMA loop touches no vector memory, 158.  What the series says: the limiter is the bytes a CU pulls through its vector-memory path
 // (~10 B/clk for L2 / HBM data: 25 KB of patch per chunk and block = 2.5 k cycles against 3.5 k of MFMAs for 32 output channels) — weight fragments fetched
-// once per block from L2 cost more than four waves' L1-hit copies.  The lever left is arithmetic per staged byte: two or three channel tiles per patch.
+// once per block from L2 cost more than four waves' L1-hit copies.  Later in the round (profiles/r06_conv_mfma_ablations.txt): the in-order load counter (a fragment wait
+// drained the staging loads: fragments four taps ahead, staging request behind the chunk's last fetch, -5 %), a phase trace (scripts/dev/conv_trace.py), eight waves with
+// the weights in LDS and persistent blocks (both slower).  The lever left is MFMA work per wave and staged byte: two or three channel tiles per patch.
 #ifdef SMD_CONV_TRACE   // diagnosis builds only (scripts/dev/conv_trace.py): shader-clock stamps of wave 0 of every block of the forward / data-gradient form
 __device__ unsigned long long g_conv_trace[8192][40];
 #define SMD_CT(slot) do { if (wall == 0 && lid < 8192u && (slot) < 40) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_conv_trace[lid][(slot)] = t_; } } while (0)
