@@ -1145,7 +1145,7 @@ def test_conv3x3_thin_kernel(F, B, C, h, w):
 
 
 @pytest.mark.parametrize('B,C,CO,h,w', [(2, 16, 32, 5, 7), (2, 48, 64, 9, 70), (1, 32, 32, 33, 65), (2, 96, 32, 13, 100), (2, 32, 96, 7, 33), (2, 64, 128, 4, 20),
-                                         (1, 16, 32, 1, 1), (3, 160, 64, 6, 20), (2, 512, 256, 6, 20), (12, 96, 32, 96, 320), (12, 128, 64, 24, 80),
+                                         (1, 16, 32, 1, 1), (3, 160, 64, 6, 20), (2, 512, 256, 6, 20), (12, 96, 32, 96, 320), (12, 128, 64, 24, 80), (12, 16, 64, 96, 160), (12, 32, 64, 64, 192),
                                          (2, 16, 16, 7, 70), (1, 16, 16, 2, 2), (2, 32, 16, 9, 33), (3, 16, 16, 13, 129), (12, 16, 16, 192, 640), (12, 32, 16, 96, 320)])
 def test_conv3x3_mfma_kernel(F, B, C, CO, h, w):
     """The decoder's wide up-convolutions (src/networks/decoders/monodepth.py:40-50, 71-84) on the bf16 matrix cores with every fp32 operand split exactly
