@@ -319,7 +319,8 @@ int smd_conv3x3_thin_bwd(const float* xp, const float* weight, const float* g_y,
  * thin last stage, CO == 16 with C == 16 or 32 (`ConvELU(cin, 16)`, monodepth.py:45-50: all three operators, on the 16 x 16 x 32 form of the instruction);
  * anything else SMD_E_UNSUPPORTED, nothing launched.  g_xp (B,C,h+2,w+2) is the gradient of the PADDED input.  Every call takes a workspace of
  * smd_conv3x3_mfma_workspace_bytes (the coarse decoder levels — few pixels, thousands of K — split K over blocks and add the splits' outputs in split
- * order; the weight gradient leaves per-block sums that a fixed-order fp64 second stage adds).  Deterministic. */
+ * order; the weight gradient leaves per-block sums that a fixed-order fp64 second stage adds — in slices, whose fp64 sums sit behind the per-block sums in the
+ * same workspace).  Sizes: one sample's xp and one sample's g_y under 2 GiB each, B x ceil(C / 32) x ceil(CO / 32) < 65536 (else SMD_E_INVALID).  Deterministic. */
 size_t smd_conv3x3_mfma_packed_bytes(int C, int CO, int pieces);
 size_t smd_conv3x3_mfma_workspace_bytes(int B, int C, int CO, int h, int w);
 int smd_conv3x3_mfma_pack(const float* weight, void* wp_fwd, void* wp_bwd, int C, int CO, int pieces, void* stream);

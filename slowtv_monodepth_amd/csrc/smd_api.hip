@@ -824,9 +824,10 @@ int smd_conv3x3_thin_fwd(const float* xp, const float* weight, float* y, int B, 
   if (!thin_sizes_ok(B, C, h, w)) return fail(SMD_E_INVALID, "invalid sizes B=%d C=%d h=%d w=%d", B, C, h, w);
   return check_launch(smd::launch_conv_thin_fwd(xp, weight, y, B, C, h, w, (hipStream_t)stream), "conv3x3_thin_fwd");
 }
-static bool mfma_sizes_ok(int B, int C, int CO, int h, int w) {   // grid dimensions below 65536, element counts that int arithmetic inside a plane can hold
+static bool mfma_sizes_ok(int B, int C, int CO, int h, int w) {   // grid dimensions below 65536, element counts that int arithmetic inside a plane can hold,
+  // one sample's activation and gradient under 2 GiB each (the weight gradient's LDS-DMA pieces carry 32-bit byte offsets from the sample's first element)
   return B >= 1 && C >= 1 && CO >= 1 && C <= 4096 && CO <= 4096 && h >= 1 && w >= 1 && h < 32768 && w < 32768 && (long long)(h + 2)*(w + 2) < (1ll << 30) &&
-         (long long)B*((C + 31)/32)*((CO + 31)/32) < 65536;
+         (long long)B*((C + 31)/32)*((CO + 31)/32) < 65536 && (long long)C*(h + 2)*(w + 2) < (1ll << 29) && (long long)CO*h*w < (1ll << 29);
 }
 static bool mfma_fwd_served(int C, int CO) { return (C % 16 == 0 && CO % 32 == 0) || (CO == 16 && (C == 16 || C == 32)); }
 static bool mfma_wgt_served(int C, int CO) { return CO % 32 == 0 || (CO == 16 && (C == 16 || C == 32)); }
