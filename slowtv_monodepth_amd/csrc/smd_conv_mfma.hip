@@ -160,9 +160,8 @@ __global__ __launch_bounds__(256*NM, 2/NM) void k_conv_mfma(const TI* __restrict
       for (int e = 0; e < 8; ++e) v[t][e] = (!BWD || pofs[t] >= 0) ? p[(size_t)e*plane] : R(0);
     }
   };
-  auto file = [&](int buf) {
-#pragma unroll
-    for (int t = 0; t < TRIPS; ++t) {
+  auto file_trip = [&](int buf, int t) {
+    {
       const int item = t*NT + (int)threadIdx.x;
       if (item < ITEMS) {
         const int half = item >= NPIX ? 1 : 0, pix = item - half*NPIX;
@@ -174,6 +173,10 @@ __global__ __launch_bounds__(256*NM, 2/NM) void k_conv_mfma(const TI* __restrict
         for (int p = 0; p < P; ++p) tile[buf*kBuf + p*NPIX*2 + slot] = uint4{pk[0][p], pk[1][p], pk[2][p], pk[3][p]};
       }
     }
+  };
+  auto file = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) file_trip(buf, t);
   };
 
   // the leading product a0 b0 and the five small ones run in accumulators of their own: adding a term 2^-8 or 2^-16 the size of the sum costs a rounding of
@@ -229,9 +232,13 @@ __global__ __launch_bounds__(256*NM, 2/NM) void k_conv_mfma(const TI* __restrict
       else if (MORE && tap >= 6) fetch_a(A[tap - 6], kc + 1, tap - 6);
       if (MORE && tap == 8) fetch_a(A[3], kc + 1, 3);             // (the empty tenth step's fetch; slot 3 is tap 8's, whose MFMAs have been issued)
       if (MORE && tap == 4) request(kc + 1);                      // after this chunk's last fetch: lands during taps 5 .. 8
+      // the next patch is filed trip by trip behind the last taps' MFMAs (its splits run in the matrix pipe's shadow) instead of after them
+      if (MORE && tap >= 6) {
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) if (t*3/TRIPS == tap - 6) file_trip(cur ^ 1, t);
+      }
     }
     SMD_CT(cslot + 1);
-    if (MORE) file(cur ^ 1);
     SMD_CT(cslot + 2);
     __syncthreads();                                              // the other patch is complete, and nobody reads this one any more
     SMD_CT(cslot + 3);
