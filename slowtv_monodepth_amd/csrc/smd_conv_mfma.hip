@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_conv_pack_w(const float* __restrict__ w
 // patch of the 16 channels in LDS — coalesced row pieces, split into the bf16 pieces ONCE per element (it is used by 9 taps x every output channel),
 // filed pixel-major with the 16 channels of a pixel contiguous (32 B per piece): the B operand of a tap is then one ds_read_b128 per lane whatever the tap's
 // shift.  The two 16-byte halves of a pixel are swapped where bit 3 of the pixel index is set: the 16-lane groups that serve a ds_read_b128
-// ({0-3, 12-15, 20-27}, ...) then cover all 64 banks instead of colliding two ways.  Two patches: the next chunk's loads are requested before this chunk's
-// MFMAs and filed after them, one barrier per chunk.  The weights come as whole fragments from `k_conv_pack_w`'s image (1 KiB per wave and piece, lane-major:
+// ({0-3, 12-15, 20-27}, ...) then cover all 64 banks instead of colliding two ways.  Two patches: the next chunk's loads are requested after tap 4's fetch
+// and filed behind the MFMAs of taps 6 - 8, one barrier per chunk.  The weights come as whole fragments from `k_conv_pack_w`'s image (1 KiB per wave and piece, lane-major:
 // every block reads the same ones, L1 / L2 hits), five slots requested four taps ahead (see below why).
 // What was measured on the way to this form (cfg 2's 96 -> 32 layer at 96x320, MIOpen 217 us; scripts/dev/conv_mfma_check.py, profiles/r06_conv_mfma_*):
 // one load per loop trip, 134 us; every staging load before its first use + the ring, 135 (the pieces — MFMAs alone 59 us, operand reads 40, staging 79-97 —
