@@ -237,6 +237,9 @@ __global__ __launch_bounds__(256*NM, 2/NM) void k_conv_mfma(const TI* __restrict
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) if (t*3/TRIPS == tap - 6) file_trip(cur ^ 1, t);
       }
+      // a tap's instructions stay in their tap: left free, the scheduler sinks the fetches of taps 0 - 2 (for taps 4 - 6) behind tap 3's MFMAs and every later
+      // fragment is then requested one tap before its use and waited for with vmcnt(0) — the four taps of distance exist in the source only
+      __builtin_amdgcn_sched_barrier(0);
     }
     SMD_CT(cslot + 1);
     SMD_CT(cslot + 2);
